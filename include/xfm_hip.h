@@ -1,0 +1,137 @@
+/*
+ * xfm_hip.h -- C ABI of libxfm_hip.so, the MI355X (gfx950) kernels of the XFMamba hot path.
+ *
+ * Drop-in boundary.  Every entry point takes plain device pointers,
+ * sizes, element strides and a hipStream_t passed as void*; nothing allocates, nothing
+ * synchronises, all launches are asynchronous on the given stream and graph-capturable.
+ * Return value: 0 on success, a negative XFM_E* code otherwise (xfm_strerror() names it).
+ * The caller (xfmamba_amd/csms6s.py, csm.py, fusion_vmamba.py) owns allocation and autograd.
+ *
+ * What each entry point replaces in the reference (paths relative to XZheng0427/XFMamba):
+ *
+ *   xfm_selective_scan_fwd  <- pybind `fwd(u, delta, A, B, C, D?, delta_bias?, delta_softplus, nrows)`
+ *                              models/selective_scan/csrc/selective_scan/selective_scan.cpp:165-249,
+ *                              reached from models/csms6s.py:81-85 (SelectiveScanCuda.forward)
+ *   xfm_selective_scan_bwd  <- pybind `bwd(u, delta, A, B, C, D?, delta_bias?, dout, x?, delta_softplus, nrows)`
+ *                              selective_scan.cpp:251-362, reached from models/csms6s.py:96-108
+ *   xfm_scan_plan           <- the chunk-count rule `n_chunks = (seqlen + 2048 - 1) / 2048`
+ *                              selective_scan.cpp:225-228 (sizes the saved-state tensor `x`)
+ *   xfm_cross_scan          <- CrossScanTritonF.forward / triton_cross_scan_flex,
+ *                              models/csm_triton.py:403-430, 278-400 (scans=0, channel-first)
+ *   xfm_cross_merge         <- CrossMergeTritonF.forward, models/csm_triton.py:456-483
+ *   xfm_swap_scan           <- SwappingScan_multiview.forward, models/fusion_vmamba.py:189-213
+ *   xfm_ss2d_fwd/_bwd       <- the fused body of SS2Dv2.forward_corev2, models/fusion_vmamba.py:1145-1174
+ *                              (cross_scan_fn -> selective_scan_fn -> cross_merge_fn in one kernel)
+ *
+ * Contracts shared with the reference FFI (selective_scan.cpp:173-221): u, delta, B, C (and
+ * dout unless `out` is fp32) share one dtype in {fp32, fp16, bf16}; A, D, delta_bias are fp32;
+ * the last (sequence) dimension of every tensor has stride 1; dim % n_groups == 0.
+ */
+#ifndef XFM_HIP_H
+#define XFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XFM_ABI_VERSION 1
+
+enum { XFM_F32 = 0, XFM_F16 = 1, XFM_BF16 = 2 };
+
+enum {
+    XFM_OK = 0,
+    XFM_EINVAL = -1,      /* bad size / null pointer / dim % n_groups != 0 */
+    XFM_EDTYPE = -2,      /* unsupported dtype combination */
+    XFM_ELIMIT = -3,      /* size outside what the kernels support (dstate > 256, H*W too large for LDS ...) */
+    XFM_ELAUNCH = -4      /* hipLaunchKernel failed; hipGetLastError() text via xfm_last_hip_error() */
+};
+
+/* Work decomposition chosen for a scan of this shape.  Forward and backward use the same plan,
+ * so `n_chunks` sizes the chunk-state tensor x: (batch, dim, n_chunks, dstate) fp32. */
+typedef struct {
+    int lanes_per_row;  /* 1..64 lanes of a 64-wide wavefront cooperate on one (batch, dim) row */
+    int items;          /* sequence elements per lane per chunk (compile-time variant) */
+    int n_chunks;       /* ceil(seqlen / (lanes_per_row * items)) */
+} xfm_scan_plan_t;
+
+typedef struct {
+    int batch, dim, seqlen, dstate, n_groups;
+    int delta_softplus;   /* bool */
+    int in_dtype;         /* of u, delta, B, C (and du, ddelta, and dout/out unless out_dtype says fp32) */
+    int out_dtype;        /* of out / dout: XFM_F32 ("oflex", csms6s.py:68) or == in_dtype */
+    /* inputs (borrowed, never written) */
+    const void *u, *delta;          /* (batch, dim, seqlen) */
+    const float *A;                 /* (dim, dstate), row stride A_d_stride, dstate stride 1 */
+    const void *B, *C;              /* (batch, n_groups, dstate, seqlen) */
+    const float *D, *delta_bias;    /* (dim) or NULL */
+    int64_t u_batch_stride, u_d_stride;
+    int64_t delta_batch_stride, delta_d_stride;
+    int64_t A_d_stride;
+    int64_t B_batch_stride, B_group_stride, B_dstate_stride;
+    int64_t C_batch_stride, C_group_stride, C_dstate_stride;
+    /* forward output / backward input */
+    void *out;                      /* fwd: (batch, dim, seqlen) out_dtype;  bwd: unused */
+    int64_t out_batch_stride, out_d_stride;
+    float *x;                       /* (batch, dim, n_chunks, dstate) fp32 contiguous; may be NULL iff n_chunks == 1 */
+    /* backward only */
+    const void *dout;               /* (batch, dim, seqlen) out_dtype */
+    int64_t dout_batch_stride, dout_d_stride;
+    void *du, *ddelta;              /* (batch, dim, seqlen) in_dtype, contiguous */
+    float *dA;                      /* (dim, dstate) fp32 contiguous, ZEROED by the caller (accumulated) */
+    float *dB, *dC;                 /* (batch, n_groups, dstate, seqlen) fp32 contiguous, ZEROED by the caller */
+    float *dD, *ddelta_bias;        /* (dim) fp32 ZEROED by the caller, or NULL */
+} xfm_scan_params_t;
+
+int xfm_abi_version(void);
+const char *xfm_strerror(int code);
+const char *xfm_last_hip_error(void);
+
+int xfm_scan_plan(int batch, int dim, int seqlen, int dstate, int n_groups, xfm_scan_plan_t *plan);
+int xfm_selective_scan_fwd(const xfm_scan_params_t *p, void *stream);
+int xfm_selective_scan_bwd(const xfm_scan_params_t *p, void *stream);
+
+/* x: (B, C, H, W) contiguous -> y: (B, 4, C, H*W) contiguous, same dtype.
+ * Route k: 0 row-major, 1 column-major, 2 = reverse of 0, 3 = reverse of 1. */
+int xfm_cross_scan(const void *x, void *y, int B, int C, int H, int W, int dtype, void *stream);
+/* y: (B, 4, C, H*W) contiguous (in_dtype) -> x: (B, C, H*W) contiguous (out_dtype);
+ * x = y0 + flip(y2) + T^-1(y1 + flip(y3)), accumulated in fp32. */
+int xfm_cross_merge(const void *y, void *x, int B, int C, int H, int W, int in_dtype, int out_dtype, void *stream);
+/* x, x2: (B, C, L) contiguous -> out: (B, 2, C, L): out[:,0] = x with even channels from x2,
+ * out[:,1] = x2 with even channels from x. */
+int xfm_swap_scan(const void *x, const void *x2, void *out, int B, int C, int L, int dtype, void *stream);
+
+/*
+ * Fused SS2D core: out[b,d,p] = sum_k scan_k(...)[b,d,pos_k^-1(p)], i.e. cross-scan + 4-direction
+ * selective scan + cross-merge without materialising the (B,4,D,L) intermediates.  All tensors are
+ * in the NATURAL row-major (h*W+w) order of the feature map; direction k traverses them in the
+ * order of route k above.
+ */
+typedef struct {
+    int batch, d_inner, H, W, dstate;
+    int delta_softplus;
+    int in_dtype;          /* of x, dts, Bs, Cs, dx, ddts */
+    int out_dtype;         /* of y / dy */
+    const void *x;         /* (batch, d_inner, H*W) */
+    const void *dts;       /* (batch, 4, d_inner, H*W)   delta pre-activation, natural order */
+    const void *Bs, *Cs;   /* (batch, 4, dstate, H*W)    natural order */
+    const float *A;        /* (4*d_inner, dstate) */
+    const float *D, *delta_bias; /* (4*d_inner) */
+    void *y;               /* (batch, d_inner, H*W) */
+    /* backward */
+    const void *dy;        /* (batch, d_inner, H*W) out_dtype */
+    void *dx;              /* (batch, d_inner, H*W) in_dtype */
+    void *ddts;            /* (batch, 4, d_inner, H*W) in_dtype */
+    float *dBs, *dCs;      /* (batch, 4, dstate, H*W) fp32 ZEROED */
+    float *dA;             /* (4*d_inner, dstate) fp32 ZEROED */
+    float *dD, *ddelta_bias; /* (4*d_inner) fp32 ZEROED */
+} xfm_ss2d_params_t;
+
+int xfm_ss2d_fwd(const xfm_ss2d_params_t *p, void *stream);
+int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XFM_HIP_H */

@@ -1,0 +1,71 @@
+"""CPU checks of the host-side module layer: state_dict compatibility with the reference
+(key names and shapes recorded from the real reference in tests/golden/g5_state_shapes.json),
+checkpoint-format tolerance, and that the modules refuse to run without the HIP path."""
+import pytest
+import torch
+
+from tests.helpers import load_json
+from xfmamba_amd.fusion_vmamba import (Backbone_VSSM, CSSFVSSLayer_v5, Linear2d, ShallowFusionBlock_v4, SS2Dv2,
+                                       VSSBlock, LayerNorm2d)
+from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
+
+
+@pytest.mark.parametrize("ty,kw", [("tiny", {}), ("small", {}), ("base", dict(hidden_dim=1024))])
+def test_state_dict_keys_and_shapes_match_reference(ty, kw):
+    shapes = load_json("g5_state_shapes.json")
+    m = TwoViewXFMambaTop(in_channels=1, outputs=2, type=ty, **kw)
+    sd = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert sd == shapes[ty]
+    assert sum(p.numel() for p in m.parameters()) == shapes[ty + "_nparams"]
+
+
+def test_reference_constructor_defaults():
+    m = TwoViewXFMambaTop(in_channels=1, outputs=3)        # default type is 'small'
+    assert len(m.mamba_feature_extrac.layers[2].blocks) == 15
+    assert m.classifier.head.out_features == 3
+    with pytest.raises(AssertionError):
+        TwoViewXFMambaTop(in_channels=3, outputs=2)
+    blk = ShallowFusionBlock_v4(hidden_dim=32)             # reference default d_state=4
+    assert blk.shallowfuseSS2D.A_logs.shape == (2 * 64, 4)
+    deep = CSSFVSSLayer_v5(hidden_dim=32, depth=1, drop_path=[0.0], attention_downsampling=4)
+    assert deep.blocks[0].self_attention.in_proj.weight.shape == (128, 32)
+
+
+def test_init_statistics_follow_mamba_init():
+    torch.manual_seed(0)
+    op = SS2Dv2(d_model=64, d_state=1, ssm_ratio=1.0, forward_type="v05_noz", channel_first=True, conv_bias=False)
+    assert torch.all(op.A_logs == 0) and torch.all(op.Ds == 1)          # A = -1 for d_state 1
+    dt = torch.nn.functional.softplus(op.dt_projs_bias)
+    assert float(dt.min()) >= 1e-4 - 1e-7 and float(dt.max()) <= 0.1 + 1e-6
+    assert float(op.dt_projs_weight.abs().max()) <= op.dt_rank ** -0.5 + 1e-7
+    assert not hasattr(op.conv2d, "bias") or op.conv2d.bias is None
+    op16 = SS2Dv2(d_model=32, d_state=16, forward_type="v05_noz", channel_first=True)
+    assert torch.allclose(op16.A_logs[5], torch.log(torch.arange(1, 17.0)))
+
+
+def test_linear2d_loads_conv_shaped_weights_and_legacy_names():
+    lin = Linear2d(4, 6, bias=False)
+    lin.load_state_dict({"weight": torch.ones(6, 4, 1, 1)})
+    assert lin.weight.shape == (6, 4)
+    bb = Backbone_VSSM(depths=[1, 1, 1, 1], dims=16, drop_path_rate=0.0, ssm_ratio=1.0)
+    sd = bb.state_dict()
+    legacy = {}
+    for k, v in sd.items():
+        k = k.replace("layers.0.blocks.0.norm.", "layers.0.blocks.0.ln_1.")
+        k = k.replace("layers.0.blocks.0.op.", "layers.0.blocks.0.self_attention.")
+        legacy[k] = v
+    missing = bb.load_state_dict(legacy, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+
+
+def test_unsupported_configurations_raise():
+    with pytest.raises(NotImplementedError):
+        SS2Dv2(d_model=16, forward_type="v052dc_noz", channel_first=True)
+    with pytest.raises(NotImplementedError):
+        VSSBlock(hidden_dim=16, norm_layer=LayerNorm2d, channel_first=True, forward_type="v05_noz", gmlp=True)
+
+
+def test_modules_refuse_cpu_tensors():
+    m = TwoViewXFMambaTop(in_channels=1, outputs=2, type="tiny").eval()
+    with pytest.raises(RuntimeError, match="no CPU path"), torch.no_grad():
+        m(torch.randn(1, 1, 64, 64), torch.randn(1, 1, 64, 64))

@@ -1,0 +1,133 @@
+"""ctypes binding of ``libxfm_hip.so`` (C ABI declared in ``include/xfm_hip.h``).
+
+There is NO fallback: if the shared library is missing or fails to load, every operator of
+this package raises.  PyTorch is used only for device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxfm_hip.so")
+
+XFM_F32, XFM_F16, XFM_BF16 = 0, 1, 2
+_DT = {torch.float32: XFM_F32, torch.float16: XFM_F16, torch.bfloat16: XFM_BF16}
+
+# every symbol include/xfm_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    "xfm_abi_version", "xfm_strerror", "xfm_last_hip_error", "xfm_scan_plan",
+    "xfm_selective_scan_fwd", "xfm_selective_scan_bwd", "xfm_cross_scan", "xfm_cross_merge",
+    "xfm_swap_scan", "xfm_ss2d_fwd", "xfm_ss2d_bwd",
+)
+
+
+class ScanPlan(C.Structure):
+    _fields_ = [("lanes_per_row", C.c_int), ("items", C.c_int), ("n_chunks", C.c_int)]
+
+
+class ScanParams(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int), ("dim", C.c_int), ("seqlen", C.c_int), ("dstate", C.c_int), ("n_groups", C.c_int),
+        ("delta_softplus", C.c_int), ("in_dtype", C.c_int), ("out_dtype", C.c_int),
+        ("u", C.c_void_p), ("delta", C.c_void_p), ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("D", C.c_void_p), ("delta_bias", C.c_void_p),
+        ("u_batch_stride", C.c_int64), ("u_d_stride", C.c_int64),
+        ("delta_batch_stride", C.c_int64), ("delta_d_stride", C.c_int64),
+        ("A_d_stride", C.c_int64),
+        ("B_batch_stride", C.c_int64), ("B_group_stride", C.c_int64), ("B_dstate_stride", C.c_int64),
+        ("C_batch_stride", C.c_int64), ("C_group_stride", C.c_int64), ("C_dstate_stride", C.c_int64),
+        ("out", C.c_void_p), ("out_batch_stride", C.c_int64), ("out_d_stride", C.c_int64),
+        ("x", C.c_void_p),
+        ("dout", C.c_void_p), ("dout_batch_stride", C.c_int64), ("dout_d_stride", C.c_int64),
+        ("du", C.c_void_p), ("ddelta", C.c_void_p),
+        ("dA", C.c_void_p), ("dB", C.c_void_p), ("dC", C.c_void_p), ("dD", C.c_void_p), ("ddelta_bias", C.c_void_p),
+    ]
+
+
+class SS2DParams(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int), ("d_inner", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dstate", C.c_int),
+        ("delta_softplus", C.c_int), ("in_dtype", C.c_int), ("out_dtype", C.c_int),
+        ("x", C.c_void_p), ("dts", C.c_void_p), ("Bs", C.c_void_p), ("Cs", C.c_void_p),
+        ("A", C.c_void_p), ("D", C.c_void_p), ("delta_bias", C.c_void_p),
+        ("y", C.c_void_p),
+        ("dy", C.c_void_p), ("dx", C.c_void_p), ("ddts", C.c_void_p),
+        ("dBs", C.c_void_p), ("dCs", C.c_void_p), ("dA", C.c_void_p), ("dD", C.c_void_p), ("ddelta_bias", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def build(verbose: bool = False) -> None:
+    """Compile libxfm_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"] + ([] if verbose else ["-s"]))
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"xfmamba_amd: HIP extension {LIB_PATH} not built (run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` or `make -C xfmamba_amd/csrc`). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        l.xfm_abi_version.restype = C.c_int
+        l.xfm_strerror.restype = C.c_char_p
+        l.xfm_strerror.argtypes = [C.c_int]
+        l.xfm_last_hip_error.restype = C.c_char_p
+        l.xfm_scan_plan.argtypes = [C.c_int] * 5 + [C.POINTER(ScanPlan)]
+        for fn in (l.xfm_selective_scan_fwd, l.xfm_selective_scan_bwd):
+            fn.argtypes = [C.POINTER(ScanParams), C.c_void_p]
+            fn.restype = C.c_int
+        for fn in (l.xfm_ss2d_fwd, l.xfm_ss2d_bwd):
+            fn.argtypes = [C.POINTER(SS2DParams), C.c_void_p]
+            fn.restype = C.c_int
+        l.xfm_cross_scan.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+        l.xfm_cross_merge.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
+        l.xfm_swap_scan.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+        if l.xfm_abi_version() != 1:
+            raise RuntimeError("xfmamba_amd: libxfm_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise RuntimeError(f"xfmamba_amd: unsupported dtype {dt} (fp32, fp16, bf16 only)") from None
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        l = lib()
+        msg = l.xfm_strerror(rc).decode()
+        if rc == -4:
+            msg += ": " + l.xfm_last_hip_error().decode()
+        raise RuntimeError(f"xfmamba_amd.{what}: {msg}")
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("xfmamba_amd: operands must live on an MI355X device (no CPU path; "
+                               "the CPU oracle under oracle/ is test infrastructure only)")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def scan_plan(batch: int, dim: int, seqlen: int, dstate: int, n_groups: int) -> ScanPlan:
+    plan = ScanPlan()
+    check(lib().xfm_scan_plan(batch, dim, seqlen, dstate, n_groups, C.byref(plan)), "scan_plan")
+    return plan

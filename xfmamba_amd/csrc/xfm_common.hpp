@@ -1,0 +1,52 @@
+// Device-side helpers shared by the gfx950 kernels of libxfm_hip.so.
+// Written for CDNA4 only: 64-lane wavefronts, LDS tiles, no portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "../../include/xfm_hip.h"
+
+namespace xfm {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+using bf16_t = __hip_bfloat16;
+using f16_t = __half;
+
+// ---- scalar load / store with fp32 conversion -------------------------------------------------
+template <typename T> __device__ __forceinline__ float ldf(const T *p);
+template <> __device__ __forceinline__ float ldf<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ldf<f16_t>(const f16_t *p) { return __half2float(*p); }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t *p) {
+    return __uint_as_float(static_cast<uint32_t>(*reinterpret_cast<const uint16_t *>(p)) << 16);
+}
+
+template <typename T> __device__ __forceinline__ void stf(T *p, float v);
+template <> __device__ __forceinline__ void stf<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<f16_t>(f16_t *p, float v) { *p = __float2half(v); }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t *p, float v) { *p = __float2bfloat16(v); }  // RNE, NaN-safe cast
+
+// ---- math ---------------------------------------------------------------------------------------
+// torch.nn.functional.softplus with beta=1, threshold=20 (reference: models/csms6s.py:49-50,
+// selective_scan_fwd_kernel.cuh:131-134).
+__device__ __forceinline__ float softplus20(float x) { return x <= 20.f ? log1pf(__expf(x)) : x; }
+
+// exp(x * A) through the hardware exp2 (v_exp_f32); caller passes A pre-multiplied by log2(e).
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Wave-level LDS hand-off: orders this wave's LDS writes before its later LDS reads (other lanes'
+// data) without a workgroup barrier -- each wave owns a private LDS region.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- host-side error plumbing ------------------------------------------------------------------
+void set_last_hip_error(hipError_t e);
+int check_launch();
+
+}  // namespace xfm

@@ -1,0 +1,72 @@
+"""``TwoViewXFMambaTop`` -- the model the upstream README calls ``dualfusionmambav13``.
+
+Same constructor, ``forward(x_a, x_b)`` and ``state_dict`` keys as ``net_fusionmamba.py:141-210``
+of XZheng0427/XFMamba; the blocks come from ``xfmamba_amd.fusion_vmamba`` and run the HIP
+kernels.  The ablation models of the reference file are out of scope.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .fusion_vmamba import Backbone_VSSM, CSSFVSSLayer_v5, ShallowFusionBlock_v4
+
+__all__ = ["TwoViewXFMambaTop", "ModelWrapper"]
+
+_TRUNKS = {   # net_fusionmamba.py:151-159
+    "small": dict(depths=[2, 2, 15, 2], dims=96, drop_path_rate=0.3, ssm_ratio=2.0),
+    "base": dict(depths=[2, 2, 15, 2], dims=128, drop_path_rate=0.6, ssm_ratio=2.0),
+    "tiny": dict(depths=[2, 2, 8, 2], dims=96, drop_path_rate=0.2, ssm_ratio=1.0),
+}
+
+
+class ModelWrapper(nn.Module):
+    """Feeds a channel-concatenated pair to a two-input model (net_fusionmamba.py:10-26)."""
+
+    def __init__(self, original_model, output_index=0):
+        super().__init__()
+        self.model = original_model
+        self.output_index = output_index
+
+    def forward(self, input_tensor):
+        assert input_tensor.size(1) % 2 == 0, "The channel dimension must be even to split into two inputs."
+        c = input_tensor.size(1) // 2
+        out = self.model(input_tensor[:, :c], input_tensor[:, c:])
+        return out[self.output_index] if isinstance(out, (tuple, list)) else out
+
+
+class TwoViewXFMambaTop(nn.Module):
+    def __init__(self, in_channels, outputs, attention_downsampling=4, hidden_dim=768, depth=1, attn_drop_rate=0.,
+                 d_state=16, drop_path_rate=0.1, pretrained=None, type='small'):
+        super().__init__()
+        assert in_channels == 1, 'in_channels expected to be 1'
+        if type not in _TRUNKS:
+            raise ValueError(f"type must be one of {sorted(_TRUNKS)}")
+        self.mamba_feature_extrac = Backbone_VSSM(pretrained=pretrained, **_TRUNKS[type])
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]
+        self.shallow_mamba_fusion = ShallowFusionBlock_v4(hidden_dim=hidden_dim, attn_drop_rate=attn_drop_rate,
+                                                          d_state=d_state)
+        # depth is hard-wired to 1 upstream whatever `depth` says (net_fusionmamba.py:170-177)
+        self.fusemamba = CSSFVSSLayer_v5(hidden_dim=hidden_dim, depth=1, drop_path=dpr, attn_drop_rate=attn_drop_rate,
+                                         d_state=d_state, attention_downsampling=attention_downsampling)
+        self.final_conv = nn.Conv2d(hidden_dim, hidden_dim, kernel_size=1)
+        self.classifier = nn.Sequential(OrderedDict(avgpool=nn.AdaptiveAvgPool2d(1), flatten=nn.Flatten(1),
+                                                    head=nn.Linear(hidden_dim, outputs)))
+        # The trunk has no cross-sample op (LayerNorm only), so running both views as one batch of 2B
+        # gives the same features as the reference's two sequential calls and halves the launches.
+        self.merge_views = True
+
+    def forward(self, x_a, x_b):
+        x_a = x_a.expand(-1, 3, -1, -1)
+        x_b = x_b.expand(-1, 3, -1, -1)
+        if self.merge_views:
+            z = self.mamba_feature_extrac(torch.cat([x_a, x_b], dim=0), only_last=True)[-1]
+            z_a, z_b = z[: x_a.shape[0]], z[x_a.shape[0]:]
+        else:
+            z_a = self.mamba_feature_extrac(x_a)[3]
+            z_b = self.mamba_feature_extrac(x_b)[3]
+        z_a, z_b = self.shallow_mamba_fusion(z_a, z_b)
+        z = self.fusemamba(z_a, z_b)
+        return self.classifier(self.final_conv(z))
