@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py -- XFMamba-T two-view training step on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + backward (+ RCCL gradient all-reduce for N > 1) + Adam update of
+``TwoViewXFMambaTop(type='tiny')`` on one synthetic batch of 32 two-view samples per GPU
+(2 x 224 x 224, already resident in HBM), bf16 compute (autocast GEMMs, bf16 scan I/O, fp32 scan
+state / norms / master weights / optimizer), model in train() mode with the reference's DropPath.
+Semantics of the step follow the reference loop (libs/training.py:181-195, 1_train_model.py:134-141:
+CrossEntropyLoss, Adam lr 1e-4 wd 1e-5).
+
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant hand-written kernel, timed with HIP
+events on its own launch stream inside the timed region; ``cpu_baseline`` is the CPU oracle
+(faithful restatement of the reference's CPU path, checked against reference goldens) timed on
+this host for BASELINE configs[0].
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="two-view samples per GPU")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--model", default="tiny", choices=["tiny", "small", "base"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--ss2d", default=None, choices=["fused", "unfused"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--drop-path", type=float, default=None, help="override the reference's DropPath rates (e.g. 0)")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch=2, size=224):
+    """Oracle model (pure torch CPU, sequential scan exactly as reference models/csms6s.py:25-68),
+    one fwd+bwd step of BASELINE configs[0]; ~20-30 s of CPU work."""
+    from oracle import xfm_oracle as O
+    from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
+    torch.manual_seed(42)
+    sd = {k: v.detach().clone() for k, v in TwoViewXFMambaTop(1, 2, type="tiny").state_dict().items()}
+    params = {k: v.requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    sd.update(params)
+    xa, xb = torch.randn(batch, 1, size, size), torch.randn(batch, 1, size, size)
+    lab = torch.randint(0, 2, (batch,))
+    t0 = time.perf_counter()
+    out = O.xfmamba_top_ref(sd, xa, xb, True, O.selective_scan_ref)
+    torch.nn.functional.cross_entropy(out, lab).backward()
+    dt = time.perf_counter() - t0
+    return dict(value=batch / dt, unit="two-view samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 fwd+bwd step, XFMamba-T fp32, batch {batch}, 2x{size}x{size} (BASELINE configs[0]); "
+                       f"oracle = restatement of the reference CPU selective-scan path; {dt:.1f} s")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from xfmamba_amd import _lib, fusion_vmamba
+    from xfmamba_amd.dp import GradBuckets, broadcast_parameters
+    from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
+    _lib.lib()                                                   # fail loudly if the HIP extension is missing
+    if a.ss2d:
+        fusion_vmamba.SS2D_MODE = a.ss2d
+
+    torch.manual_seed(42)                                        # libs/config.py:22
+    kw = dict(hidden_dim=1024) if a.model == "base" else {}
+    model = TwoViewXFMambaTop(in_channels=1, outputs=2, type=a.model, **kw).to(dev).train()
+    if a.drop_path is not None:
+        for m in model.modules():
+            if hasattr(m, "drop_prob"):
+                m.drop_prob = a.drop_path
+    if world > 1:
+        broadcast_parameters(model)
+    buckets = GradBuckets(model, bucket_mb=48.0)                 # also makes .grad views of flat buffers
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)   # 1_train_model.py:141
+    crit = torch.nn.CrossEntropyLoss()
+
+    torch.manual_seed(42 + rank)
+    B = a.batch
+    xa = torch.randn(B, 1, a.size, a.size, device=dev)           # synthetic, resident in HBM
+    xb = torch.randn(B, 1, a.size, a.size, device=dev)
+    lab = torch.randint(0, 2, (B,), device=dev)
+    use_bf16 = a.dtype == "bf16"
+
+    def step():
+        buckets.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+            out = model(xa, xb)
+            loss = crit(out.float(), lab)
+        loss.backward()
+        buckets.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    timer = None
+    if not a.no_kernel_timer:
+        timer = _lib.KernelTimer()
+        _lib.set_timer(timer)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(loss.detach()).item(), "loss diverged"
+
+    if rank == 0:
+        value = a.steps * B * world / dt
+        roof = None
+        kernels = {}
+        if timer is not None:
+            kernels = timer.summary()
+            if kernels:
+                name = max(kernels, key=lambda k: kernels[k]["total_ms"])
+                k = kernels[name]
+                ach = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9
+                roof = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, launches=k["launches"],
+                            avg_launch_us=round(k["avg_us"], 2),
+                            algorithmic_bytes_per_launch=int(k["bytes"] / k["launches"]))
+        line = {
+            "metric": "two-view images/sec fwd+bwd, XFMamba-T 224^2, batch 32/GPU",
+            "value": round(value, 2), "unit": "two-view samples/s (1 sample = 2 images)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"XFMamba-{a.model[0].upper()} ({a.dtype}), 2x{a.size}x{a.size}, batch {B}/GPU, "
+                                   f"fwd+bwd+Adam, train mode (BASELINE configs[1])",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "ss2d_mode": fusion_vmamba.SS2D_MODE,
+                       "single_view_images_per_s": round(2 * value, 2)},
+            "roofline": roof,
+            "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
+                            "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1),
+                            "ms_per_step": round(v["total_ms"] / a.steps, 3)} for k, v in kernels.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

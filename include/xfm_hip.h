@@ -20,6 +20,9 @@
  *                              models/csm_triton.py:403-430, 278-400 (scans=0, channel-first)
  *   xfm_cross_merge         <- CrossMergeTritonF.forward, models/csm_triton.py:456-483
  *   xfm_swap_scan           <- SwappingScan_multiview.forward, models/fusion_vmamba.py:189-213
+ *   xfm_dwconv3x3_fwd/_bwd  <- `self.conv2d` (nn.Conv2d(D, D, 3, padding=1, groups=D)) followed by `self.act`
+ *                              (nn.SiLU) in front of every SS2D core: models/fusion_vmamba.py:1198-1201,
+ *                              :594-601, :853-857 (MIOpen depthwise conv + elementwise kernels upstream)
  *   xfm_ss2d_fwd/_bwd       <- the fused body of SS2Dv2.forward_corev2, models/fusion_vmamba.py:1145-1174
  *                              (cross_scan_fn -> selective_scan_fn -> cross_merge_fn in one kernel)
  *
@@ -102,32 +105,50 @@ int xfm_cross_merge(const void *y, void *x, int B, int C, int H, int W, int in_d
  * out[:,1] = x2 with even channels from x. */
 int xfm_swap_scan(const void *x, const void *x2, void *out, int B, int C, int L, int dtype, void *stream);
 
+/* Depthwise 3x3 convolution, padding 1, stride 1, optional bias, optionally fused with SiLU.
+ * x, y, dy, dx: (B, D, H, W) contiguous in `dtype`; weight: (D, 1, 3, 3) fp32; bias: (D) fp32 or NULL.
+ * Backward recomputes the pre-activation; dweight (D*9) and dbias (D) are fp32 and must be ZEROED. */
+int xfm_dwconv3x3_fwd(const void *x, const float *weight, const float *bias, void *y, int B, int D, int H, int W,
+                      int dtype, int silu, void *stream);
+int xfm_dwconv3x3_bwd(const void *x, const float *weight, const float *bias, const void *dy, void *dx, float *dweight,
+                      float *dbias, int B, int D, int H, int W, int dtype, int silu, void *stream);
+
 /*
- * Fused SS2D core: out[b,d,p] = sum_k scan_k(...)[b,d,pos_k^-1(p)], i.e. cross-scan + 4-direction
- * selective scan + cross-merge without materialising the (B,4,D,L) intermediates.  All tensors are
- * in the NATURAL row-major (h*W+w) order of the feature map; direction k traverses them in the
- * order of route k above.
+ * Fused SS2D core: y[b,d,p] = sum_k scan_k(...)[b,d,.] gathered back to position p, i.e.
+ * cross-scan + 4-route selective scan + cross-merge in ONE kernel; the (B,4,D,L) scan inputs /
+ * fp32 scan outputs of the unfused chain never reach HBM.
+ *
+ * Layout contract.  x, y, dy, dx are feature maps in natural row-major order (p = h*W + w).
+ * The per-route tensors dts, Bs, Cs (and their gradients) are stored, per route k, in the order in
+ * which the route's FORWARD sibling walks the map:
+ *     k = 0, 2 : row-major    index t = h*W + w      (route 2 scans this sequence backwards)
+ *     k = 1, 3 : column-major index t = w*H + h      (route 3 scans this sequence backwards)
+ * so every route streams its operands contiguously.  (The host produces routes 1/3 in column-major
+ * order for free by transposing the small x_proj output before dt_proj; xfmamba_amd/fusion_vmamba.py.)
  */
 typedef struct {
     int batch, d_inner, H, W, dstate;
     int delta_softplus;
     int in_dtype;          /* of x, dts, Bs, Cs, dx, ddts */
-    int out_dtype;         /* of y / dy */
+    int out_dtype;         /* of y / dy (fp32 = "oflex") */
     const void *x;         /* (batch, d_inner, H*W) */
-    const void *dts;       /* (batch, 4, d_inner, H*W)   delta pre-activation, natural order */
-    const void *Bs, *Cs;   /* (batch, 4, dstate, H*W)    natural order */
+    const void *dts;       /* (batch, 4, d_inner, H*W)   delta pre-activation, per-route order */
+    const void *Bs, *Cs;   /* (batch, 4, dstate, H*W)    per-route order */
     const float *A;        /* (4*d_inner, dstate) */
     const float *D, *delta_bias; /* (4*d_inner) */
     void *y;               /* (batch, d_inner, H*W) */
+    float *chk;            /* (batch, 4, d_inner, n_chunks, dstate) fp32 chunk states written by fwd, read by
+                              bwd; may be NULL iff xfm_ss2d_plan() says n_chunks == 1 */
     /* backward */
     const void *dy;        /* (batch, d_inner, H*W) out_dtype */
     void *dx;              /* (batch, d_inner, H*W) in_dtype */
-    void *ddts;            /* (batch, 4, d_inner, H*W) in_dtype */
-    float *dBs, *dCs;      /* (batch, 4, dstate, H*W) fp32 ZEROED */
+    void *ddts;            /* (batch, 4, d_inner, H*W) in_dtype, per-route order */
+    float *dBs, *dCs;      /* (batch, 4, dstate, H*W) fp32 ZEROED, per-route order */
     float *dA;             /* (4*d_inner, dstate) fp32 ZEROED */
     float *dD, *ddelta_bias; /* (4*d_inner) fp32 ZEROED */
 } xfm_ss2d_params_t;
 
+int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, xfm_scan_plan_t *plan);
 int xfm_ss2d_fwd(const xfm_ss2d_params_t *p, void *stream);
 int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream);
 

@@ -1,0 +1,136 @@
+"""GPU parity of the module layer: the reference-named
+nn.Modules running the HIP kernels vs golden vectors recorded from the real reference (G4 blocks,
+G5 whole model) -- outputs, input gradients, parameter gradients, BatchNorm buffers."""
+import pytest
+import torch
+
+from oracle.golden_inputs import g5_inputs
+from oracle import xfm_oracle as O
+from tests.helpers import assert_close, load_json, load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _build(kind):
+    from xfmamba_amd import fusion_vmamba as fv
+    if kind == "ss2dv2":
+        return fv.SS2Dv2(d_model=16, d_state=1, ssm_ratio=1.0, dt_rank="auto", conv_bias=False,
+                         forward_type="v05_noz", channel_first=True)
+    if kind == "ss2dv2_r2":
+        return fv.SS2Dv2(d_model=16, d_state=1, ssm_ratio=2.0, dt_rank="auto", conv_bias=False,
+                         forward_type="v05_noz", channel_first=True)
+    if kind == "vssblock":
+        return fv.VSSBlock(hidden_dim=16, drop_path=0.0, norm_layer=fv.LayerNorm2d, channel_first=True,
+                           ssm_d_state=1, ssm_ratio=1.0, ssm_dt_rank="auto", ssm_conv=3, ssm_conv_bias=False,
+                           ssm_init="v0", forward_type="v05_noz", mlp_ratio=4.0)
+    if kind.startswith("shallow"):
+        return fv.ShallowFusionBlock_v4(hidden_dim=32, d_state=16)
+    return fv.FusionBlock_v5(hidden_dim=32, drop_path=0.0, norm_layer=fv.LayerNorm2d, attn_drop_rate=0.0, d_state=16)
+
+
+BLOCKS = [("ss2dv2", False), ("ss2dv2_r2", False), ("vssblock", True), ("shallow_train", True),
+          ("shallow_eval", False), ("deep", True)]
+
+
+@pytest.mark.parametrize("mode", ["unfused", "fused"])
+@pytest.mark.parametrize("tag,training", BLOCKS, ids=[b[0] for b in BLOCKS])
+def test_blocks_match_reference_golden(tag, training, mode):
+    from xfmamba_amd import fusion_vmamba as fv
+    z = load_npz("g4_blocks.npz")
+    old = fv.SS2D_MODE
+    fv.SS2D_MODE = mode
+    try:
+        m = _build(tag)
+        pre = f"{tag}/sd/"
+        m.load_state_dict({k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}, strict=True)
+        m = m.to(DEV).train(training)
+        ins = [torch.from_numpy(z[f"{tag}/in{i}"]).to(DEV).requires_grad_() for i in range(2) if f"{tag}/in{i}" in z.files]
+        out = m(*ins)
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        for i, o in enumerate(outs):
+            ref = torch.from_numpy(z[f"{tag}/out{i}"])
+            assert_close(o.detach().cpu(), ref, 1e-3, 1e-3 * float(ref.abs().max()), f"out{i}")
+        torch.autograd.backward(list(outs), [torch.from_numpy(z[f"{tag}/gout{i}"]).to(DEV) for i in range(len(outs))])
+        for i, t in enumerate(ins):
+            ref = torch.from_numpy(z[f"{tag}/din{i}"])
+            assert_close(t.grad.cpu(), ref, 1e-3, 1e-3 * float(ref.abs().max()), f"din{i}")
+        pre = f"{tag}/grad/"
+        params = dict(m.named_parameters())
+        for k in z.files:
+            if k.startswith(pre):
+                ref = torch.from_numpy(z[k])
+                assert_close(params[k[len(pre):]].grad.cpu(), ref, 1e-3, 1e-3 * float(ref.abs().max()) + 1e-7, k)
+        for k, p in params.items():
+            assert (p.grad is not None) == ((pre + k) in z.files), k
+        pre = f"{tag}/sd_after/"
+        sd = m.state_dict()
+        for k in z.files:
+            if k.startswith(pre):
+                assert_close(sd[k[len(pre):]].float().cpu(), torch.from_numpy(z[k]).float(), 1e-5, 1e-6, k)
+    finally:
+        fv.SS2D_MODE = old
+
+
+def _tiny_with_synth_weights():
+    from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
+    shapes = load_json("g5_state_shapes.json")["tiny"]
+    m = TwoViewXFMambaTop(in_channels=1, outputs=2, type="tiny")
+    m.load_state_dict(O.synth_state_dict(shapes, seed=0), strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("mode", ["unfused", "fused"])
+@pytest.mark.parametrize("merge_views", [True, False])
+def test_model_tiny_fp32_matches_reference_golden(mode, merge_views):
+    """BASELINE config 0 (XFMamba-T, 2x224^2, batch 2, fp32): logits, loss, every parameter gradient."""
+    from xfmamba_amd import fusion_vmamba as fv
+    z = load_npz("g5_model.npz")
+    names = load_json("g5_grad_names.json")
+    old = fv.SS2D_MODE
+    fv.SS2D_MODE = mode
+    try:
+        m = _tiny_with_synth_weights()
+        m.merge_views = merge_views
+        xa, xb, lab = (t.to(DEV) for t in g5_inputs())
+        m.eval()
+        with torch.no_grad():
+            logits = m(xa, xb)
+        ref = torch.from_numpy(z["logits_eval"])
+        assert_close(logits.cpu(), ref, 1e-3, 1e-3 * float(ref.abs().max()), "eval logits")
+        m.train()
+        for mod in m.modules():
+            if hasattr(mod, "drop_prob"):
+                mod.drop_prob = 0.0
+        out = m(xa, xb)
+        ref = torch.from_numpy(z["logits_train"])
+        assert_close(out.detach().cpu(), ref, 1e-3, 1e-3 * float(ref.abs().max()), "train logits")
+        loss = torch.nn.functional.cross_entropy(out, lab)
+        assert abs(float(loss.detach()) - float(z["loss"])) < 1e-3 * max(1.0, float(z["loss"]))
+        loss.backward()
+        params = dict(m.named_parameters())
+        assert sorted(k for k, p in params.items() if p.grad is None) == sorted(names["no_grad"])
+        for k, row in zip(names["grad_names"], z["grad_stats"]):
+            gn = float(params[k].grad.double().norm())
+            assert abs(gn - row[2]) <= 5e-3 * row[2] + 1e-6, (k, gn, row[2])
+        for k in z.files:
+            if k.startswith("grad/"):
+                ref = torch.from_numpy(z[k])
+                assert_close(params[k[5:]].grad.cpu(), ref, 5e-3, 2e-3 * float(ref.abs().max()) + 1e-8, k)
+            if k.startswith("bn_after/"):
+                assert_close(m.state_dict()[k[9:]].cpu(), torch.from_numpy(z[k]), 1e-4, 1e-5, k)
+    finally:
+        fv.SS2D_MODE = old
+
+
+def test_model_tiny_bf16_autocast_within_tolerance():
+    """bf16 compute (autocast GEMMs, bf16 scan I/O with fp32 state): logits within 1e-2 of the fp32
+    reference, relative to the logit scale (BASELINE tolerance for bf16)."""
+    z = load_npz("g5_model.npz")
+    m = _tiny_with_synth_weights().eval()
+    xa, xb, _ = (t.to(DEV) for t in g5_inputs())
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = m(xa, xb)
+    ref = torch.from_numpy(z["logits_eval"])
+    rel = float((logits.float().cpu() - ref).abs().max() / ref.abs().max())
+    assert rel < 1e-2, rel

@@ -137,7 +137,8 @@ def test_selective_scan_full_size_properties():
     y0 = f(u1, torch.zeros_like(Bm))
     assert_close(y0, D[None, :, None] * u1.float(), 1e-6, 1e-6, "D path")
     sub = xfmamba_amd.selective_scan_fn(u1[5:6], delta[5:6], A, Bm[5:6], Cm[5:6], D, bias, True, True)
-    assert torch.equal(sub, y1[5:6])
+    # a batch of 1 gets a different work decomposition (lanes per row), so equality holds to rounding only
+    assert_close(sub, y1[5:6], 1e-5, 1e-5 * float(y1.abs().max()), "batch independence")
     yc = c_scan.scan_fwd_c(u1[5:6, :8].cpu(), delta[5:6, :8].cpu(), A[:8].cpu(), Bm[5:6, :1].cpu(), Cm[5:6, :1].cpu(),
                            D[:8].cpu(), bias[:8].cpu(), True)
     assert_close(y1[5:6, :8].cpu(), yc, 1e-2, 1e-2 * float(yc.abs().max()), "spot rows vs oracle")
@@ -194,3 +195,93 @@ def test_swap_golden_and_passthrough_backward():
     xb = torch.randn(3, 10, 4, 5, device=DEV, dtype=torch.bfloat16)
     xb2 = torch.randn(3, 10, 4, 5, device=DEV, dtype=torch.bfloat16)
     assert torch.equal(xfmamba_amd.SwappingScan_multiview.apply(xb, xb2).cpu(), O.swap_scan_ref(xb.cpu(), xb2.cpu()))
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 56, 56), (2, 192, 28, 28), (3, 40, 14, 14), (5, 33, 7, 7), (1, 6, 96, 96),
+                                   (2, 5, 9, 13)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("has_bias", [False, True])
+def test_dwconv3x3_silu_matches_torch_fp32(shape, dtype, has_bias):
+    """Row a4/a8/a9 front end: act(conv2d(x)) with nn.Conv2d(D,D,3,padding=1,groups=D) + nn.SiLU
+    (reference fusion_vmamba.py:1198-1201).  Checker: the same op in plain PyTorch fp32 on CPU."""
+    from xfmamba_amd.dwconv import dwconv3x3_silu_fn
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(9)
+    B, D, H, W = shape
+    x = torch.randn(*shape, generator=g).to(dtype)
+    w = 0.3 * torch.randn(D, 1, 3, 3, generator=g)
+    b = 0.1 * torch.randn(D, generator=g) if has_bias else None
+    gy = torch.randn(*shape, generator=g).to(dtype)
+    xr = x.float().clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if has_bias else None
+    yr = F.silu(F.conv2d(xr, wr, br, padding=1, groups=D))
+    yr.backward(gy.float())
+    xd = x.to(DEV).requires_grad_()
+    wd = w.to(DEV).requires_grad_()
+    bd = b.to(DEV).requires_grad_() if has_bias else None
+    y = dwconv3x3_silu_fn(xd, wd, bd, True)
+    y.backward(gy.to(DEV))
+    tol = _tol(dtype)
+    assert y.dtype == dtype
+    assert_close(y.float().cpu(), yr.detach(), tol, tol, "y")
+    assert_close(xd.grad.float().cpu(), xr.grad, tol, tol * float(xr.grad.abs().max()), "dx")
+    assert_close(wd.grad.cpu(), wr.grad, tol, tol * float(wr.grad.abs().max()), "dw")
+    if has_bias:
+        assert_close(bd.grad.cpu(), br.grad, tol, tol * float(br.grad.abs().max()), "db")
+
+
+SS2D_SHAPES = [
+    # (B, D, H, W, N, dtype)
+    (2, 96, 56, 56, 1, torch.float32),      # backbone stage 0 (multi-chunk rows)
+    (2, 192, 28, 28, 1, torch.bfloat16),    # stage 1
+    (3, 96, 14, 14, 1, torch.float32),      # stage 2 (4 planes per wavefront)
+    (2, 96, 7, 7, 1, torch.bfloat16),       # stage 3
+    (2, 32, 7, 7, 16, torch.float32),       # deep fusion block shape (N = 16)
+    (1, 16, 12, 9, 4, torch.float32),       # non-square map, odd sizes
+    (1, 8, 96, 96, 1, torch.float32),       # XFMamba-B @384 stage 0 plane
+    (1, 5, 3, 5, 2, torch.float32),         # tile of one plane (D not a multiple of 2)
+]
+
+
+@pytest.mark.parametrize("shape", SS2D_SHAPES, ids=[f"B{s[0]}D{s[1]}H{s[2]}W{s[3]}N{s[4]}{str(s[5])[6:]}" for s in SS2D_SHAPES])
+def test_fused_ss2d_matches_oracle_chain(shape):
+    """xfm_ss2d_fwd/_bwd == cross_merge(selective_scan(cross_scan(.))) of the oracle (reference chain
+    models/fusion_vmamba.py:1145-1174), forward and all gradients."""
+    from xfmamba_amd.ss2d import ss2d_core_fn, to_route_order
+    Bt, D, H, W, N, dt = shape
+    L = H * W
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(Bt, D, H, W, generator=g).to(dt)
+    dts = (0.5 * torch.rand(Bt, 4, D, L, generator=g)).to(dt)          # natural order per route
+    Bs = torch.randn(Bt, 4, N, L, generator=g).to(dt)
+    Cs = torch.randn(Bt, 4, N, L, generator=g).to(dt)
+    A = -0.5 * torch.rand(4 * D, N, generator=g) - 0.05
+    Dp = torch.randn(4 * D, generator=g)
+    bias = 0.5 * torch.rand(4 * D, generator=g)
+    gy = torch.randn(Bt, D, L, generator=g)
+
+    def route(t):   # natural (B,4,C,L) -> what route k sees in its walking order, incl. reversal for k=2,3
+        return torch.stack([O.cross_scan_ref(t[:, k].reshape(Bt, -1, H, W))[:, k] for k in range(4)], dim=1)
+
+    leaves = [t.float().clone().requires_grad_() for t in (x, dts, A, Bs, Cs, Dp, bias)]
+    xr, dr, Ar, Br, Cr, Dr_, br = leaves
+    ys = c_scan.selective_scan_c(O.cross_scan_ref(xr).reshape(Bt, -1, L), route(dr).reshape(Bt, -1, L), Ar,
+                                 route(Br), route(Cr), Dr_, br, True, True)
+    y_ref = O.cross_merge_ref(ys.view(Bt, 4, D, H, W))
+    y_ref.backward(gy)
+
+    hx = x.to(DEV).requires_grad_()
+    hd = to_route_order(dts, H, W).to(DEV).requires_grad_()
+    hB = to_route_order(Bs, H, W).to(DEV).requires_grad_()
+    hC = to_route_order(Cs, H, W).to(DEV).requires_grad_()
+    hA, hD, hb = (t.to(DEV).requires_grad_() for t in (A, Dp, bias))
+    y = ss2d_core_fn(hx.view(Bt, D, L), hd, hA, hB, hC, hD, hb, H, W)
+    y.backward(gy.to(DEV))
+    tol = _tol(dt)
+    assert_close(y.cpu(), y_ref.detach(), tol, tol * float(y_ref.abs().max()), "y")
+    pairs = [("dx", hx.grad, xr.grad), ("ddts", hd.grad, to_route_order(dr.grad, H, W)),
+             ("dA", hA.grad, Ar.grad), ("dBs", hB.grad, to_route_order(Br.grad, H, W)),
+             ("dCs", hC.grad, to_route_order(Cr.grad, H, W)), ("dD", hD.grad, Dr_.grad), ("dbias", hb.grad, br.grad)]
+    for name, got, ref in pairs:
+        assert_close(got.float().cpu(), ref, tol, tol * (float(ref.abs().max()) + 1e-6), name)

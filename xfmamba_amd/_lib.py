@@ -21,7 +21,7 @@ _DT = {torch.float32: XFM_F32, torch.float16: XFM_F16, torch.bfloat16: XFM_BF16}
 SYMBOLS = (
     "xfm_abi_version", "xfm_strerror", "xfm_last_hip_error", "xfm_scan_plan",
     "xfm_selective_scan_fwd", "xfm_selective_scan_bwd", "xfm_cross_scan", "xfm_cross_merge",
-    "xfm_swap_scan", "xfm_ss2d_fwd", "xfm_ss2d_bwd",
+    "xfm_swap_scan", "xfm_dwconv3x3_fwd", "xfm_dwconv3x3_bwd", "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd",
 )
 
 
@@ -54,7 +54,7 @@ class SS2DParams(C.Structure):
         ("delta_softplus", C.c_int), ("in_dtype", C.c_int), ("out_dtype", C.c_int),
         ("x", C.c_void_p), ("dts", C.c_void_p), ("Bs", C.c_void_p), ("Cs", C.c_void_p),
         ("A", C.c_void_p), ("D", C.c_void_p), ("delta_bias", C.c_void_p),
-        ("y", C.c_void_p),
+        ("y", C.c_void_p), ("chk", C.c_void_p),
         ("dy", C.c_void_p), ("dx", C.c_void_p), ("ddts", C.c_void_p),
         ("dBs", C.c_void_p), ("dCs", C.c_void_p), ("dA", C.c_void_p), ("dD", C.c_void_p), ("ddelta_bias", C.c_void_p),
     ]
@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
         l.xfm_strerror.argtypes = [C.c_int]
         l.xfm_last_hip_error.restype = C.c_char_p
         l.xfm_scan_plan.argtypes = [C.c_int] * 5 + [C.POINTER(ScanPlan)]
+        l.xfm_ss2d_plan.argtypes = [C.c_int] * 5 + [C.POINTER(ScanPlan)]
         for fn in (l.xfm_selective_scan_fwd, l.xfm_selective_scan_bwd):
             fn.argtypes = [C.POINTER(ScanParams), C.c_void_p]
             fn.restype = C.c_int
@@ -90,6 +91,8 @@ def lib() -> C.CDLL:
         l.xfm_cross_scan.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
         l.xfm_cross_merge.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         l.xfm_swap_scan.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+        l.xfm_dwconv3x3_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]
+        l.xfm_dwconv3x3_bwd.argtypes = [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_void_p]
         if l.xfm_abi_version() != 1:
             raise RuntimeError("xfmamba_amd: libxfm_hip.so ABI version mismatch")
         _lib = l
@@ -125,6 +128,54 @@ def stream_ptr() -> int:
 
 def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
+
+
+# ---- optional per-kernel timing (bench.py): HIP events on the stream the kernel is launched on ----
+class KernelTimer:
+    """Collects (start, end) HIP events and algorithmic bytes per launch, keyed by kernel family."""
+
+    def __init__(self):
+        self.records = {}
+
+    def add(self, name, start, end, nbytes):
+        self.records.setdefault(name, []).append((start, end, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            out[name] = dict(launches=len(recs), total_ms=sum(ms), avg_us=1e3 * sum(ms) / len(recs),
+                             bytes=sum(b for _, _, b in recs))
+        return out
+
+
+_TIMER = None
+
+
+def set_timer(t):
+    global _TIMER
+    _TIMER = t
+
+
+class timed:
+    """``with timed(name, nbytes): launch`` -- free when no timer is installed."""
+    __slots__ = ("name", "nbytes", "s")
+
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes, self.s = name, nbytes, None
+
+    def __enter__(self):
+        if _TIMER is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *exc):
+        if self.s is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            _TIMER.add(self.name, self.s, e, self.nbytes)
+        return False
 
 
 def scan_plan(batch: int, dim: int, seqlen: int, dstate: int, n_groups: int) -> ScanPlan:

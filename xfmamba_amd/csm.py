@@ -22,7 +22,7 @@ def _scan(x: torch.Tensor) -> torch.Tensor:
     B, C, H, W = x.shape
     x = x.contiguous()
     y = torch.empty((B, 4, C, H * W), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _lib.timed("cross_scan", 5 * x.numel() * x.element_size()):
         _lib.check(_lib.lib().xfm_cross_scan(x.data_ptr(), y.data_ptr(), B, C, H, W, _lib.dtype_code(x.dtype),
                                              _lib.stream_ptr()), "cross_scan")
     return y
@@ -35,7 +35,7 @@ def _merge(ys: torch.Tensor, H: int, W: int, out_dtype=None) -> torch.Tensor:
     ys = ys.contiguous()
     out_dtype = out_dtype or ys.dtype
     x = torch.empty((B, C, H * W), dtype=out_dtype, device=ys.device)
-    with torch.cuda.device(ys.device):
+    with torch.cuda.device(ys.device), _lib.timed("cross_merge", ys.numel() * ys.element_size() + x.numel() * x.element_size()):
         _lib.check(_lib.lib().xfm_cross_merge(ys.data_ptr(), x.data_ptr(), B, C, H, W, _lib.dtype_code(ys.dtype),
                                               _lib.dtype_code(out_dtype), _lib.stream_ptr()), "cross_merge")
     return x

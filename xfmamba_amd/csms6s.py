@@ -82,7 +82,9 @@ class SelectiveScanHip(torch.autograd.Function):
         _fill_common(p, u, delta, A, B, C, D, delta_bias, delta_softplus, out_dtype)
         p.out, p.out_batch_stride, p.out_d_stride = out.data_ptr(), out.stride(0), out.stride(1)
         p.x = _lib.ptr(x)
-        with torch.cuda.device(u.device):
+        isz, osz = u.element_size(), out.element_size()
+        nbytes = Bt * KD * L * (2 * isz + osz) + 2 * Bt * K * N * L * isz + KD * (N + 2) * 4
+        with torch.cuda.device(u.device), _lib.timed("selective_scan_fwd", nbytes):
             _lib.check(_lib.lib().xfm_selective_scan_fwd(ctypes.byref(p), _lib.stream_ptr()), "selective_scan_fwd")
         ctx.delta_softplus = bool(delta_softplus)
         ctx.out_dtype = out_dtype
@@ -110,7 +112,11 @@ class SelectiveScanHip(torch.autograd.Function):
         p.dout, p.dout_batch_stride, p.dout_d_stride = dout.data_ptr(), dout.stride(0), dout.stride(1)
         p.du, p.ddelta = du.data_ptr(), ddelta.data_ptr()
         p.dA, p.dB, p.dC, p.dD, p.ddelta_bias = dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), _lib.ptr(dD), _lib.ptr(dbias)
-        with torch.cuda.device(dev):
+        Bt, KD, L = u.shape
+        K, N = B.shape[1], B.shape[2]
+        isz, osz = u.element_size(), dout.element_size()
+        nbytes = Bt * KD * L * (4 * isz + osz) + 2 * Bt * K * N * L * (isz + 4) + 2 * KD * (N + 2) * 4
+        with torch.cuda.device(dev), _lib.timed("selective_scan_bwd", nbytes):
             _lib.check(_lib.lib().xfm_selective_scan_bwd(ctypes.byref(p), _lib.stream_ptr()), "selective_scan_bwd")
         return du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, dbias, None, None, None
 

@@ -14,7 +14,7 @@
 // Global <-> register traffic goes through a per-wave LDS transposition tile: HBM is always
 // touched with lanes along the contiguous sequence axis, and each lane then picks its C
 // consecutive elements with an odd LDS stride (bank-conflict free).
-#include "xfm_common.hpp"
+#include "scan_core.hpp"
 
 namespace xfm {
 
@@ -25,73 +25,6 @@ struct ScanArgs {
     int dim_per_group;
     int lds_floats_per_wave;
 };
-
-// ---------------------------------------------------------------------------------------------
-// per-wave tile <-> register transposition
-// buf layout: element j of row g lives at lane' = g*LPR + j/C, slot j%C -> buf[lane'*PC + slot]
-// ---------------------------------------------------------------------------------------------
-template <typename T, int C>
-__device__ __forceinline__ void tile_load(float *buf, const T *base, int64_t row_stride, int G, int lg_lpr, int s0,
-                                          int L, int lane, float (&v)[C]) {
-    constexpr int PC = C | 1;
-    const int SL = C << lg_lpr;
-    for (int g = 0; g < G; ++g) {
-        const T *row = base + (int64_t)g * row_stride;
-        for (int j = lane; j < SL; j += 64) {
-            const int t = s0 + j;
-            const float val = t < L ? ldf<T>(row + t) : 0.f;
-            const int q = j / C;
-            buf[((g << lg_lpr) + q) * PC + (j - q * C)] = val;
-        }
-    }
-    wave_sync();
-#pragma unroll
-    for (int jj = 0; jj < C; ++jj) v[jj] = buf[lane * PC + jj];
-    wave_sync();
-}
-
-template <typename T, int C>
-__device__ __forceinline__ void tile_store(float *buf, T *base, int64_t row_stride, int G, int lg_lpr, int s0, int L,
-                                           int lane, const float (&v)[C]) {
-    constexpr int PC = C | 1;
-    const int SL = C << lg_lpr;
-#pragma unroll
-    for (int jj = 0; jj < C; ++jj) buf[lane * PC + jj] = v[jj];
-    wave_sync();
-    for (int g = 0; g < G; ++g) {
-        T *row = base + (int64_t)g * row_stride;
-        for (int j = lane; j < SL; j += 64) {
-            const int t = s0 + j;
-            const int q = j / C;
-            if (t < L) stf<T>(row + t, buf[((g << lg_lpr) + q) * PC + (j - q * C)]);
-        }
-    }
-    wave_sync();
-}
-
-// Segmented inclusive scan of affine maps over the LPR lanes of a row, ascending lane order.
-// (P,S) represents h -> P*h + S; on return lane i holds the composition of lanes 0..i.
-__device__ __forceinline__ void seg_scan_up(float &P, float &S, int i, int LPR) {
-    for (int d = 1; d < LPR; d <<= 1) {
-        const float Pp = __shfl_up(P, d, LPR);
-        const float Sp = __shfl_up(S, d, LPR);
-        if (i >= d) {
-            S = fmaf(P, Sp, S);
-            P *= Pp;
-        }
-    }
-}
-// Same in descending lane order: lane i holds the composition of lanes LPR-1..i (later lanes first).
-__device__ __forceinline__ void seg_scan_down(float &P, float &S, int i, int LPR) {
-    for (int d = 1; d < LPR; d <<= 1) {
-        const float Pn = __shfl_down(P, d, LPR);
-        const float Sn = __shfl_down(S, d, LPR);
-        if (i + d < LPR) {
-            S = fmaf(P, Sn, S);
-            P *= Pn;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // forward
@@ -129,8 +62,8 @@ __global__ void __launch_bounds__(256) scan_fwd_kernel(const ScanArgs a) {
         const int s0 = seg * SL;
         const int t0 = s0 + i * C;
         float u[C], dl[C], y[C];
-        tile_load<Tin, C>(buf, u_t, p.u_d_stride, G, lg, s0, L, lane, u);
-        tile_load<Tin, C>(buf, d_t, p.delta_d_stride, G, lg, s0, L, lane, dl);
+        tile_load<Tin, C>(buf, u_t, p.u_d_stride, G, lg, s0, L, lane, lane, u);
+        tile_load<Tin, C>(buf, d_t, p.delta_d_stride, G, lg, s0, L, lane, lane, dl);
 #pragma unroll
         for (int jj = 0; jj < C; ++jj) {
             const bool valid = t0 + jj < L;
@@ -176,7 +109,7 @@ __global__ void __launch_bounds__(256) scan_fwd_kernel(const ScanArgs a) {
         }
 #pragma unroll
         for (int jj = 0; jj < C; ++jj) y[jj] = fmaf(Dr, u[jj], y[jj]);
-        tile_store<Tout, C>(buf, o_t, p.out_d_stride, G, lg, s0, L, lane, y);
+        tile_store<Tout, C>(buf, o_t, p.out_d_stride, G, lg, s0, L, lane, lane, y);
     }
 }
 
@@ -223,9 +156,9 @@ __global__ void __launch_bounds__(256) scan_bwd_kernel(const ScanArgs a) {
         const int s0 = seg * SL;
         const int t0 = s0 + i * C;
         float u[C], dl[C], go[C], s1[C], s2[C];
-        tile_load<Tin, C>(buf, u_t, p.u_d_stride, G, lg, s0, L, lane, u);
-        tile_load<Tin, C>(buf, d_t, p.delta_d_stride, G, lg, s0, L, lane, dl);
-        tile_load<Tout, C>(buf, g_t, p.dout_d_stride, G, lg, s0, L, lane, go);
+        tile_load<Tin, C>(buf, u_t, p.u_d_stride, G, lg, s0, L, lane, lane, u);
+        tile_load<Tin, C>(buf, d_t, p.delta_d_stride, G, lg, s0, L, lane, lane, dl);
+        tile_load<Tout, C>(buf, g_t, p.dout_d_stride, G, lg, s0, L, lane, lane, go);
 #pragma unroll
         for (int jj = 0; jj < C; ++jj) {
             const bool valid = t0 + jj < L;
@@ -313,8 +246,8 @@ __global__ void __launch_bounds__(256) scan_bwd_kernel(const ScanArgs a) {
             dD_acc = fmaf(go[jj], u[jj], dD_acc);
             dbias_acc += (t0 + jj < L) ? ddl : 0.f;
         }
-        tile_store<Tin, C>(buf, du_t, (int64_t)L, G, lg, s0, L, lane, du);
-        tile_store<Tin, C>(buf, dd_t, (int64_t)L, G, lg, s0, L, lane, dd);
+        tile_store<Tin, C>(buf, du_t, (int64_t)L, G, lg, s0, L, lane, lane, du);
+        tile_store<Tin, C>(buf, dd_t, (int64_t)L, G, lg, s0, L, lane, lane, dd);
     }
     for (int off = 1; off < LPR; off <<= 1) {
         dD_acc += __shfl_xor(dD_acc, off, 64);

@@ -1,0 +1,114 @@
+"""Batch-sharded data parallelism for the XFMamba hot path: gradients only, over RCCL/xGMI.
+
+The reference has no distributed code; this is new work required by
+BASELINE.json's north star.  One process per GPU, identical replicas, per-rank batches.
+
+Design for MI355X's point-to-point xGMI fabric (7 links per GPU): few, LARGE collectives.
+Gradients live in a handful of flat fp32 buckets (each parameter's ``.grad`` is a view into its
+bucket, so there is no pack/unpack copy); a bucket's all-reduce is issued on a side stream as soon
+as the last of its gradients has been accumulated, overlapping the rest of the backward pass.
+Parameters that never receive a gradient (``outnorm0-2``, ``Cross_SS2Dv5.in_proj``; SURVEY.md
+section 8(a)) keep zero gradients on every rank, so their bucket is simply flushed at
+``finish()``.  BatchNorm statistics of the shallow fusion block stay per-rank (the reference has
+no SyncBN); ``broadcast_buffers`` is offered for checkpoint time.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["GradBuckets", "broadcast_parameters", "broadcast_buffers"]
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    for p in module.parameters():
+        dist.broadcast(p.data, src)
+
+
+def broadcast_buffers(module: torch.nn.Module, src: int = 0) -> None:
+    for b in module.buffers():
+        dist.broadcast(b, src)
+
+
+class GradBuckets:
+    """Flat gradient buckets with overlap-capable all-reduce (average)."""
+
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, process_group=None, overlap: bool = True):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        params.reverse()                                   # gradients become ready roughly in reverse order
+        cap = int(bucket_mb * (1 << 20) / 4)
+        self.buckets: List[torch.Tensor] = []
+        self._bucket_of = {}
+        cur: List[torch.nn.Parameter] = []
+        cur_n = 0
+        groups = []
+        for p in params:
+            if cur and cur_n + p.numel() > cap:
+                groups.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            groups.append(cur)
+        for bi, grp in enumerate(groups):
+            flat = torch.zeros(sum(p.numel() for p in grp), dtype=torch.float32, device=grp[0].device)
+            off = 0
+            for p in grp:
+                p.grad = flat[off:off + p.numel()].view_as(p)     # .grad is a view: no packing copy
+                off += p.numel()
+                self._bucket_of[p] = bi
+            self.buckets.append(flat)
+        self._pending = [len(g) for g in groups]
+        self._sizes = [len(g) for g in groups]
+        self._launched = [False] * len(groups)
+        self._work = []
+        self.overlap = overlap and self.world > 1
+        self._stream = None
+        if self.overlap:
+            if self.buckets and self.buckets[0].is_cuda:
+                self._stream = torch.cuda.Stream()
+            for p in params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # ---- backward-time hook -----------------------------------------------------------------
+    def _on_grad(self, p):
+        bi = self._bucket_of[p]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        if self._launched[bi] or self.world == 1:
+            return
+        self._launched[bi] = True
+        flat = self.buckets[bi]
+        if self._stream is not None:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                flat.div_(self.world)
+                self._work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            flat.div_(self.world)
+            self._work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    # ---- call after loss.backward() ------------------------------------------------------------
+    def finish(self):
+        """Flush buckets whose parameters did not all fire (unused parameters) and wait."""
+        if self.world > 1:
+            for bi in range(len(self.buckets)):
+                self._launch(bi)
+            for w in self._work:
+                w.wait()
+            if self._stream is not None:
+                torch.cuda.current_stream().wait_stream(self._stream)
+        self._work.clear()
+        self._pending = list(self._sizes)
+        self._launched = [False] * len(self.buckets)
+
+    def zero_grad(self):
+        for flat in self.buckets:
+            flat.zero_()

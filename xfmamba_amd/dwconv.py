@@ -1,0 +1,56 @@
+"""Depthwise 3x3 convolution fused with SiLU -- the ``conv2d`` -> ``act`` pair of every SS2D block.
+
+Replaces ``self.act(self.conv2d(x))`` (reference ``models/fusion_vmamba.py:1198-1201``, ``:594-601``,
+``:853-857``; ``nn.Conv2d(D, D, 3, padding=1, groups=D)`` + ``nn.SiLU``) with ``xfm_dwconv3x3_fwd/_bwd``.
+The parameters stay where the reference keeps them (``conv2d.weight`` (D,1,3,3), ``conv2d.bias``).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = ["dwconv3x3_silu_fn", "DWConv3x3SiLUHip"]
+
+
+class DWConv3x3SiLUHip(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias, silu):
+        _lib.require_cuda(x, weight, bias)
+        B, D, H, W = x.shape
+        if weight.shape != (D, 1, 3, 3):
+            raise RuntimeError("dwconv3x3: weight must be (D, 1, 3, 3)")
+        x = x.contiguous()
+        w = weight.float().contiguous()
+        b = None if bias is None else bias.float().contiguous()
+        y = torch.empty_like(x)
+        nbytes = 2 * x.numel() * x.element_size()
+        with torch.cuda.device(x.device), _lib.timed("dwconv3x3_fwd", nbytes):
+            _lib.check(_lib.lib().xfm_dwconv3x3_fwd(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), B, D, H, W,
+                                                    _lib.dtype_code(x.dtype), int(silu), _lib.stream_ptr()), "dwconv3x3_fwd")
+        ctx.silu = int(silu)
+        ctx.wdtype = weight.dtype
+        ctx.save_for_backward(x, w, b)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        B, D, H, W = x.shape
+        dy = dy.contiguous().to(x.dtype)
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(b) if b is not None else None
+        nbytes = 3 * x.numel() * x.element_size()
+        with torch.cuda.device(x.device), _lib.timed("dwconv3x3_bwd", nbytes):
+            _lib.check(_lib.lib().xfm_dwconv3x3_bwd(x.data_ptr(), w.data_ptr(), _lib.ptr(b), dy.data_ptr(), dx.data_ptr(),
+                                                    dw.data_ptr(), _lib.ptr(db), B, D, H, W, _lib.dtype_code(x.dtype),
+                                                    ctx.silu, _lib.stream_ptr()), "dwconv3x3_bwd")
+        return dx, dw.to(ctx.wdtype), (None if db is None else db.to(ctx.wdtype)), None
+
+
+def dwconv3x3_silu_fn(x, weight, bias=None, silu=True):
+    """x (B,D,H,W), weight (D,1,3,3), bias (D,)|None -> silu(conv(x) + bias) in x's dtype."""
+    return DWConv3x3SiLUHip.apply(x, weight, bias, silu)

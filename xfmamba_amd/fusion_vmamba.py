@@ -33,9 +33,10 @@ import torch.nn.functional as F
 
 from .csm import SwappingMerge_multiview, SwappingScan_multiview, cross_merge_fn, cross_scan_fn
 from .csms6s import selective_scan_fn
+from .dwconv import dwconv3x3_silu_fn
 from .ss2d import ss2d_core_fn
 
-SS2D_MODE = "unfused"        # "fused" | "unfused"
+SS2D_MODE = "fused"          # "fused" | "unfused"
 
 
 def trunc_normal_(t, std=0.02):
@@ -164,6 +165,14 @@ class mamba_init:
 # ---------------------------------------------------------------------------------------------
 # SS2D core shared by the backbone block and the deep fusion block
 # ---------------------------------------------------------------------------------------------
+def _dwconv_act(conv: nn.Conv2d, act: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """``act(conv(x))``; the 3x3 depthwise + SiLU case every reference block uses runs on the fused HIP kernel."""
+    if (isinstance(act, nn.SiLU) and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1)
+            and conv.groups == conv.in_channels == conv.out_channels):
+        return dwconv3x3_silu_fn(x, conv.weight, conv.bias, True)
+    return act(conv(x))
+
+
 def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_override=None):
     """x: (B, D, H, W) -> (y: (B, D, H*W) fp32, Cs in the layout of the active mode).
 
@@ -176,19 +185,27 @@ def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_
     As = -A_logs.float().exp()
     Dsf = Ds.float()
     bias = dt_projs_bias.reshape(-1).float()
+    cd = x.dtype
     if SS2D_MODE == "fused":
-        # projections in natural order: one dense GEMM for x_proj of all K routes, one grouped for dt_proj
-        x_dbl = F.conv1d(x.reshape(B, D, L), x_proj_weight.reshape(-1, D, 1))            # (B, K*(R+2N), L)
-        x_dbl = x_dbl.view(B, K, R + 2 * N, L)
-        dts = F.conv1d(x_dbl[:, :, :R].reshape(B, K * R, L), dt_projs_weight.reshape(K * D, R, 1), groups=K)
+        # x_proj of all K routes as ONE dense GEMM on the map in natural order (route k's projection of
+        # the permuted sequence is the permuted projection).  Routes 1/3 walk columns, so their slice of
+        # the small x_dbl tensor is transposed to column-major here; dt_proj (batched GEMM) then emits
+        # dts for those routes directly in the order the kernel walks them -- the big (B,4,D,L) tensor is
+        # written once, contiguous per route, and never permuted.
+        C2 = R + 2 * N
+        x_dbl = torch.matmul(x_proj_weight.reshape(K * C2, D).to(cd), x.reshape(B, D, L))     # (B, K*C2, L)
+        x_dbl = x_dbl.view(B, 2, 2, C2, H, W)                                                  # k = 2*rev + col
+        x_dbl = torch.stack([x_dbl[:, :, 0].flatten(-2), x_dbl[:, :, 1].transpose(-1, -2).flatten(-2)], dim=2)
+        x_dbl = x_dbl.view(B, K, C2, L)
+        dts = torch.matmul(dt_projs_weight.to(cd), x_dbl[:, :, :R])                            # (B, K, D, L)
         Bs = x_dbl[:, :, R:R + N].contiguous()
         Cs = x_dbl[:, :, R + N:].contiguous() if Cs_override is None else Cs_override
-        y = ss2d_core_fn(x.reshape(B, D, L), dts.view(B, K, D, L), As, Bs, Cs, Dsf, bias, H, W)
+        y = ss2d_core_fn(x.reshape(B, D, L), dts, As, Bs, Cs, Dsf, bias, H, W)
         return y, Cs
     xs = cross_scan_fn(x, in_channel_first=True, out_channel_first=True, scans=0)           # (B, 4, D, L)
-    x_dbl = F.conv1d(xs.view(B, -1, L), x_proj_weight.reshape(-1, D, 1), groups=K).view(B, K, -1, L)
+    x_dbl = torch.matmul(x_proj_weight.to(cd), xs)                                          # (B, K, R+2N, L)
     dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
-    dts = F.conv1d(dts.reshape(B, -1, L), dt_projs_weight.reshape(K * D, R, 1), groups=K)
+    dts = torch.matmul(dt_projs_weight.to(cd), dts).view(B, -1, L)
     Bs = Bs.contiguous()
     Cs = Cs.contiguous() if Cs_override is None else Cs_override
     ys = selective_scan_fn(xs.view(B, -1, L), dts, As, Bs, Cs, Dsf, bias, True, True, None)
@@ -262,9 +279,8 @@ class SS2Dv2(nn.Module):
                 z = self.act(z)
         if not self.channel_first:
             x = x.permute(0, 3, 1, 2).contiguous()
-        if self.with_dconv:
-            x = self.conv2d(x)
-        y = self.out_act(self.forward_core(self.act(x)))
+        x = _dwconv_act(self.conv2d, self.act, x) if self.with_dconv else self.act(x)
+        y = self.out_act(self.forward_core(x))
         if z is not None:
             y = y * z
         return self.dropout(self.out_proj(y))
@@ -502,8 +518,11 @@ class ShallowFuse_SS2Dv4(nn.Module):
     def forward(self, x: torch.Tensor, x2: torch.Tensor):
         xp = self.in_proj(x).permute(0, 3, 1, 2).contiguous()
         x2p = self.in_proj(x2).permute(0, 3, 1, 2).contiguous()
-        xc, x2c = (self.conv2d(xp), self.conv2d(x2p)) if self.with_dconv else (xp, x2p)
-        y1, y2 = self.forward_corev2(self.act(xc), self.act(x2c))
+        if self.with_dconv:
+            xc, x2c = _dwconv_act(self.conv2d, self.act, xp), _dwconv_act(self.conv2d, self.act, x2p)
+        else:
+            xc, x2c = self.act(xp), self.act(x2p)
+        y1, y2 = self.forward_corev2(xc, x2c)
         y1, y2 = self.out_act(y1), self.out_act(y2)
         b, d = xp.shape[:2]
         gate1 = self.fc1(self.avg_pool(xp).view(b, d)).view(b, 1, 1, d)
@@ -583,7 +602,7 @@ class Cross_SS2Dv5(nn.Module):
 
         def prep(t):
             t = t.permute(0, 3, 1, 2).contiguous()
-            return self.act(self.conv2d(t) if self.with_dconv else t)
+            return _dwconv_act(self.conv2d, self.act, t) if self.with_dconv else self.act(t)
 
         y, y2, y_fuse = self.forward_corev2(prep(x), prep(x2), prep(x_fuse))
         return self.dropout(self.out_proj(y * z + y2 * z + y_fuse * z))
