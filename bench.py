@@ -54,6 +54,10 @@ def cpu_baseline(batch=2, size=224):
     one fwd+bwd step of BASELINE configs[0]; ~20-30 s of CPU work."""
     from oracle import xfm_oracle as O
     from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
+    # The sequential scan is thousands of tiny ops: more threads than ~16 only add contention (measured:
+    # 250 s/step with torch's default 128 threads on the GPU host vs ~25 s with 8-16).
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, ncpu)))
     torch.manual_seed(42)
     sd = {k: v.detach().clone() for k, v in TwoViewXFMambaTop(1, 2, type="tiny").state_dict().items()}
     params = {k: v.requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}

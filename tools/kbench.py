@@ -1,0 +1,92 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the hand-written kernels at the BASELINE shapes (XFMamba-T, batch 32 x 2 views).
+
+    python tools/kbench.py [--only ss2d] [--force kind,lg,items,pli]   (XFM_SS2D_FORCE plan override)
+
+Prints per-kernel time (HIP events on the launch stream, median of repeats), algorithmic GB/s
+(SURVEY.md 8(d) byte counts) and the fraction of the 8 TB/s HBM peak.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        e.synchronize()
+        ts.append(s.elapsed_time(e) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--force", default=None)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--batch", type=int, default=64)
+    a = ap.parse_args()
+    if a.force:
+        os.environ["XFM_SS2D_FORCE"] = a.force
+    from xfmamba_amd import _lib
+    from xfmamba_amd.ss2d import SS2DCoreHip
+    from xfmamba_amd.dwconv import DWConv3x3SiLUHip
+    import ctypes
+    dt = dict(bf16=torch.bfloat16, fp32=torch.float32)[a.dtype]
+    dev = "cuda"
+    B = a.batch
+    shapes = [("stage0", B, 96, 56, 1), ("stage1", B, 192, 28, 1), ("stage2", B, 384, 14, 1), ("stage3", B, 768, 7, 1),
+              ("deep", B // 2, 1536, 7, 16)]
+    print(f"{'kernel':28s} {'us':>9s} {'GB/s':>8s} {'%HBM':>6s}  plan")
+    for name, Bt, D, H, N in shapes:
+        if a.only and a.only not in "ss2d" and a.only not in name:
+            continue
+        L = H * H
+        x = torch.randn(Bt, D, L, device=dev).to(dt)
+        dts = (0.5 * torch.rand(Bt, 4, D, L, device=dev)).to(dt)
+        Bs = torch.randn(Bt, 4, N, L, device=dev).to(dt)
+        Cs = torch.randn(Bt, 4, N, L, device=dev).to(dt)
+        A = -torch.rand(4 * D, N, device=dev) - 0.1
+        Dp = torch.randn(4 * D, device=dev)
+        bias = 0.1 * torch.rand(4 * D, device=dev)
+        plan = _lib.ScanPlan()
+        _lib.lib().xfm_ss2d_plan(Bt, D, H, H, N, ctypes.byref(plan))
+        ptxt = f"lpr={plan.lanes_per_row} items={plan.items} chunks={plan.n_chunks}"
+        isz = x.element_size()
+        fb = Bt * D * L * (5 * isz + 4) + 2 * Bt * 4 * N * L * isz
+        bb = Bt * D * L * (10 * isz + 4) + 2 * Bt * 4 * N * L * (isz + 4)
+        xr = x.clone().requires_grad_()
+        dr = dts.clone().requires_grad_()
+        y = SS2DCoreHip.apply(xr, dr, A, Bs, Cs, Dp, bias, H, H)
+        gy = torch.randn_like(y)
+        t = timeit(lambda: SS2DCoreHip.apply(x, dts, A, Bs, Cs, Dp, bias, H, H))
+        print(f"{'ss2d_fwd ' + name:28s} {t:9.1f} {fb / t / 1e3:8.1f} {fb / t / 1e3 / 80:6.2f}  {ptxt}")
+        t = timeit(lambda: torch.autograd.grad(y, (xr, dr), gy, retain_graph=True))
+        print(f"{'ss2d_bwd ' + name:28s} {t:9.1f} {bb / t / 1e3:8.1f} {bb / t / 1e3 / 80:6.2f}")
+        if N == 1 and (not a.only or a.only in "dwconv"):
+            x4 = x.view(Bt, D, H, H)
+            w = torch.randn(D, 1, 3, 3, device=dev)
+            t = timeit(lambda: DWConv3x3SiLUHip.apply(x4, w, None, True))
+            nb = 2 * x.numel() * isz
+            print(f"{'dwconv_fwd ' + name:28s} {t:9.1f} {nb / t / 1e3:8.1f} {nb / t / 1e3 / 80:6.2f}")
+            x4r = x4.clone().requires_grad_()
+            y4 = DWConv3x3SiLUHip.apply(x4r, w, None, True)
+            g4 = torch.randn_like(y4)
+            t = timeit(lambda: torch.autograd.grad(y4, x4r, g4, retain_graph=True))
+            nb = 3 * x.numel() * isz
+            print(f"{'dwconv_bwd ' + name:28s} {t:9.1f} {nb / t / 1e3:8.1f} {nb / t / 1e3 / 80:6.2f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -32,7 +32,13 @@ template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t *p, float v) { *p
 // ---- math ---------------------------------------------------------------------------------------
 // torch.nn.functional.softplus with beta=1, threshold=20 (reference: models/csms6s.py:49-50,
 // selective_scan_fwd_kernel.cuh:131-134).
-__device__ __forceinline__ float softplus20(float x) { return x <= 20.f ? log1pf(__expf(x)) : x; }
+// Hardware exp2/log2 plus a 3-term series where 1+z would lose the small z (relative error < 1e-5).
+__device__ __forceinline__ float softplus20(float x) {
+    const float z = __expf(x);
+    const float series = z * fmaf(z, fmaf(z, 0.33333334f, -0.5f), 1.0f);   // log1p(z), |z| < 2^-5
+    const float sp = z < 0.03125f ? series : __logf(1.0f + z);
+    return x <= 20.f ? sp : x;
+}
 
 // exp(x * A) through the hardware exp2 (v_exp_f32); caller passes A pre-multiplied by log2(e).
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
