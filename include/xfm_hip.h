@@ -148,7 +148,8 @@ typedef struct {
     float *dD, *ddelta_bias; /* (4*d_inner) fp32 ZEROED */
 } xfm_ss2d_params_t;
 
-int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, xfm_scan_plan_t *plan);
+/* The chunking (and so the size of chk) depends on the I/O dtype: 16-byte vectors per lane where rows allow. */
+int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, int in_dtype, xfm_scan_plan_t *plan);
 int xfm_ss2d_fwd(const xfm_ss2d_params_t *p, void *stream);
 int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream);
 

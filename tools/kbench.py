@@ -61,7 +61,7 @@ def main():
         Dp = torch.randn(4 * D, device=dev)
         bias = 0.1 * torch.rand(4 * D, device=dev)
         plan = _lib.ScanPlan()
-        _lib.lib().xfm_ss2d_plan(Bt, D, H, H, N, ctypes.byref(plan))
+        _lib.lib().xfm_ss2d_plan(Bt, D, H, H, N, _lib.dtype_code(dt), ctypes.byref(plan))
         ptxt = f"lpr={plan.lanes_per_row} items={plan.items} chunks={plan.n_chunks}"
         isz = x.element_size()
         fb = Bt * D * L * (5 * isz + 4) + 2 * Bt * 4 * N * L * isz

@@ -81,7 +81,7 @@ def lib() -> C.CDLL:
         l.xfm_strerror.argtypes = [C.c_int]
         l.xfm_last_hip_error.restype = C.c_char_p
         l.xfm_scan_plan.argtypes = [C.c_int] * 5 + [C.POINTER(ScanPlan)]
-        l.xfm_ss2d_plan.argtypes = [C.c_int] * 5 + [C.POINTER(ScanPlan)]
+        l.xfm_ss2d_plan.argtypes = [C.c_int] * 6 + [C.POINTER(ScanPlan)]
         for fn in (l.xfm_selective_scan_fwd, l.xfm_selective_scan_bwd):
             fn.argtypes = [C.POINTER(ScanParams), C.c_void_p]
             fn.restype = C.c_int

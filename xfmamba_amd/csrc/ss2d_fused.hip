@@ -11,7 +11,7 @@ static const size_t kLdsPerCU = 160 * 1024;
 static inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
 
 // One decomposition serves forward and backward (they share the chunk-state layout `chk`).
-static int plan_ss2d(int batch, int D, int H, int W, int N, Plan2 *out) {
+static int plan_ss2d(int batch, int D, int H, int W, int N, int in_dtype, Plan2 *out) {
     if (batch <= 0 || D <= 0 || H <= 0 || W <= 0 || N <= 0) return XFM_EINVAL;
     if (N > 256 || (int64_t)H * W >= 65536) return XFM_ELIMIT;
     const int L = H * W;
@@ -19,6 +19,85 @@ static int plan_ss2d(int batch, int D, int H, int W, int N, Plan2 *out) {
     // tuning hook (tools/kbench.py): XFM_SS2D_FORCE="kind,lg,items,pli" restricts the search
     int f_kind = -1, f_lg = -1, f_items = -1, f_pli = -1;
     if (const char *env = getenv("XFM_SS2D_FORCE")) sscanf(env, "%d,%d,%d,%d", &f_kind, &f_lg, &f_items, &f_pli);
+    out->psz = (int)PSZ;
+    const int sz = in_dtype == XFM_F32 ? 4 : 2;
+    // ---- lean variant for d_state == 1 (ss2d_lean.hpp): rows are whole vectors, PPT planes per tile
+    if ((f_kind < 0 || f_kind == 3) && N == 1 && L % 4 == 0 && W > 1) {
+        const int c = (sz == 2 && L % 8 == 0) ? 8 : 4;
+        const int nseg = (L + 64 * c - 1) / (64 * c);
+        int ppt = 1;
+        for (int q = 1; q <= D; ++q)
+            if (D % q == 0 && (int64_t)q * L <= 3200) ppt = q;
+        if (f_lg > 0 && D % f_lg == 0) ppt = f_lg;                     // (tuning hook: "lg" field = planes per tile)
+        const size_t PL = (size_t)ppt * L;
+        const size_t fwd_blk = 2 * PL * sz + 4 * PL * sizeof(float);
+        const size_t bwd_blk = 4 * PL * sz + 2 * PL * sizeof(float) + (size_t)8 * L * sizeof(float);
+        if (fwd_blk <= kLdsPerCU && bwd_blk <= kLdsPerCU) {
+            out->lg = 6;
+            out->items = c;
+            out->n_chunks = nseg;
+            out->kind = 3;
+            out->ppt = ppt;
+            out->bc_floats = 0;
+            out->psz = L;
+            out->lds_fwd_block = fwd_blk;
+            out->lds_bwd_block = bwd_blk;
+            out->lds_fwd_floats = out->lds_bwd_floats = 0;
+            out->waves_fwd = out->waves_bwd = 4;
+            const int tiles_pb = D / ppt;
+            const int resident = (int)std::max<size_t>(1, kLdsPerCU / bwd_blk);
+            int pli = (int)((int64_t)batch * tiles_pb / ((int64_t)256 * resident * 2));
+            if (pli < 1) pli = 1;
+            if (pli > tiles_pb) pli = tiles_pb;
+            if (f_pli > 0) pli = std::min(f_pli, tiles_pb);
+            while (tiles_pb % pli) --pli;
+            out->pli = pli;
+            return XFM_OK;
+        }
+    }
+    if (f_kind == 3) return XFM_ELIMIT;
+    // ---- direct variant: chunk = one 16-byte vector, planes in both layouts (ss2d_direct.hpp)
+    if ((f_kind < 0 || f_kind == 2) && ((int64_t)L * sz) % 4 == 0) {
+        const int c = 16 / sz;
+        const int chunks = (L + c - 1) / c;
+        int lg = 0;
+        while (lg < 6 && (1 << lg) < chunks) ++lg;
+        if (f_lg >= 0) lg = f_lg;
+        while (lg < 6 && (D % (64 >> lg) || (64 >> lg) * N > 2048)) ++lg;
+        const int G = 64 >> lg;
+        if (D % G == 0 && G * N <= 2048) {
+            const int nseg = (chunks + (1 << lg) - 1) >> lg;
+            const size_t pe = (size_t)(L + c - 1) / c * c, GP = (size_t)G * pe;
+            const size_t bcf = (N > 1 && nseg == 1 && (size_t)2 * N * L <= 4096) ? up4((size_t)2 * N * L) : 0;
+            const size_t fw = up4(GP + up4((size_t)G * N) + bcf);
+            const size_t bw = up4(up4((size_t)G * N) + bcf + (size_t)2 * N * L);
+            const size_t fwd_blk = (2 * GP * sz + 15) / 16 * 16 + 4 * fw * sizeof(float);
+            const size_t bwd_blk = (4 * GP * sz + 15) / 16 * 16 + 2 * GP * sizeof(float) + 4 * bw * sizeof(float);
+            if (fwd_blk <= kLdsPerCU && bwd_blk <= kLdsPerCU) {
+                out->lg = lg;
+                out->items = c;
+                out->n_chunks = nseg;
+                out->kind = 2;
+                out->bc_floats = (int)bcf;
+                out->psz = (int)pe;
+                out->lds_fwd_floats = fw;
+                out->lds_bwd_floats = bw;
+                out->lds_fwd_block = fwd_blk;
+                out->lds_bwd_block = bwd_blk;
+                out->waves_fwd = out->waves_bwd = 4;
+                const int tiles_pb = D / G;
+                const int resident = (int)std::max<size_t>(1, kLdsPerCU / bwd_blk);
+                int pli = (int)((int64_t)batch * tiles_pb / ((int64_t)256 * resident * 2));
+                if (pli < 1) pli = 1;
+                if (pli > tiles_pb) pli = tiles_pb;
+                if (f_pli > 0) pli = std::min(f_pli, tiles_pb);
+                while (tiles_pb % pli) --pli;
+                out->pli = pli;
+                return XFM_OK;
+            }
+        }
+    }
+    if (f_kind == 2) return XFM_ELIMIT;
     for (int kind = 1; kind >= 0; --kind) {
         if (f_kind >= 0 && kind != f_kind) continue;
         double best = 1e300;
@@ -103,7 +182,7 @@ int ss2d_launch_raw(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bwd
     const size_t lds = bwd ? pl.lds_bwd_block : pl.lds_fwd_block;
     unsigned grid;
     dim3 block;
-    if (pl.kind == 1) {
+    if (pl.kind >= 1) {
         grid = (unsigned)((int64_t)a.p.batch * ((tiles_pb + pl.pli - 1) / pl.pli));
         block = dim3(256);
     } else {
@@ -122,6 +201,28 @@ int ss2d_launch_raw(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bwd
     return check_launch();
 }
 
+int ss2d_launch_lean(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bwd, hipStream_t s) {
+    const xfm_ss2d_params_t &p = a.p;
+    LeanArgs la;
+    la.x = p.x; la.dts = p.dts; la.Bs = p.Bs; la.Cs = p.Cs;
+    la.A = p.A; la.D = p.D; la.bias = p.delta_bias;
+    la.y = p.y; la.chk = p.chk; la.dy = p.dy; la.dx = p.dx; la.ddts = p.ddts;
+    la.dBs = p.dBs; la.dCs = p.dCs; la.dA = p.dA; la.dD = p.dD; la.dbias = p.ddelta_bias;
+    la.batch = p.batch; la.D_ = p.d_inner; la.H = p.H; la.W = p.W; la.L = p.H * p.W;
+    la.nseg = pl.n_chunks; la.ppt = pl.ppt; la.pli = pl.pli; la.softplus = p.delta_softplus;
+    la.magicW = a.magicW;
+    const size_t lds = bwd ? pl.lds_bwd_block : pl.lds_fwd_block;
+    const unsigned grid = (unsigned)((int64_t)p.batch * (p.d_inner / pl.ppt / pl.pli));
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    void *kargs[] = {&la};
+    const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, lds, s);
+    if (e != hipSuccess) {
+        set_last_hip_error(e);
+        return XFM_ELAUNCH;
+    }
+    return check_launch();
+}
+
 static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream) {
     if (!p || !p->x || !p->dts || !p->Bs || !p->Cs || !p->A || !p->D || !p->delta_bias) return XFM_EINVAL;
     if (!bwd && !p->y) return XFM_EINVAL;
@@ -130,7 +231,7 @@ static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream) {
     if (p->in_dtype < 0 || p->in_dtype > 2) return XFM_EDTYPE;
     if (p->out_dtype != XFM_F32) return XFM_EDTYPE;          // the fused core always emits fp32 ("oflex")
     Plan2 pl;
-    int rc = plan_ss2d(p->batch, p->d_inner, p->H, p->W, p->dstate, &pl);
+    int rc = plan_ss2d(p->batch, p->d_inner, p->H, p->W, p->dstate, p->in_dtype, &pl);
     if (rc) return rc;
     if (pl.n_chunks > 1 && !p->chk) return XFM_EINVAL;
     SS2DArgs a;
@@ -138,12 +239,14 @@ static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream) {
     a.lg_lpr = pl.lg;
     a.n_chunks = pl.n_chunks;
     a.PW = p->W | 1;
-    a.PSZ = (int)up4((size_t)p->H * a.PW);
+    a.PSZ = pl.psz;
     a.lds_floats_per_wave = (int)(bwd ? pl.lds_bwd_floats : pl.lds_fwd_floats);
     a.waves_per_block = bwd ? pl.waves_bwd : pl.waves_fwd;
     a.kind = pl.kind;
     a.pli = pl.pli;
     a.bc_floats = pl.bc_floats;
+    a.dbg = 0;
+    if (const char *env = getenv("XFM_SS2D_DBG")) a.dbg = atoi(env);
     a.magicW = (uint32_t)((0x100000000ull + p->W - 1) / p->W);
     hipStream_t s = (hipStream_t)stream;
     switch (p->in_dtype) {
@@ -157,10 +260,11 @@ static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream) {
 }  // namespace xfm
 
 extern "C" {
-int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, xfm_scan_plan_t *plan) {
+int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, int in_dtype, xfm_scan_plan_t *plan) {
     if (!plan) return XFM_EINVAL;
+    if (in_dtype < 0 || in_dtype > 2) return XFM_EDTYPE;
     xfm::Plan2 pl;
-    const int rc = xfm::plan_ss2d(batch, d_inner, H, W, dstate, &pl);
+    const int rc = xfm::plan_ss2d(batch, d_inner, H, W, dstate, in_dtype, &pl);
     if (rc) return rc;
     plan->lanes_per_row = 1 << pl.lg;
     plan->items = pl.items;

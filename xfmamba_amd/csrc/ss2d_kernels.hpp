@@ -37,6 +37,7 @@ struct SS2DArgs {
     int kind;                    // see above
     int pli;                     // kind 1: consecutive plane tiles handled by one workgroup
     int bc_floats;               // per-wave LDS region holding B,C of the route for all states (0: none)
+    int dbg;                     // timing-only switches (XFM_SS2D_DBG): 1 skip sweeps, 2 skip plane loads, 4 skip merge
     uint32_t magicW;             // ceil(2^32 / W): e / W == __umulhi(e, magicW) for e < 2^16
 };
 
@@ -724,10 +725,19 @@ __global__ void __launch_bounds__(256) ss2d_bwd_wpr_kernel(const SS2DArgs a) {
     }
 }
 
+}  // namespace xfm
+
+#include "ss2d_direct.hpp"
+#include "ss2d_lean.hpp"
+
+namespace xfm {
+
 // launch plan shared by the host code and the per-dtype translation units
 struct Plan2 {
     int lg, items, n_chunks;
-    int kind, pli, bc_floats;
+    int kind, pli, bc_floats;                    // kind 2 = direct (ss2d_direct.hpp), kind 3 = lean d_state==1 (ss2d_lean.hpp)
+    int ppt;                                     // kind 3: planes per tile
+    int psz;                                     // plane size: floats incl. pitch (kind 0/1) or elements (kind 2)
     size_t lds_fwd_floats, lds_bwd_floats;       // per wave (kind 0) / per wave beyond the shared planes (kind 1)
     size_t lds_fwd_block, lds_bwd_block;         // dynamic LDS bytes per workgroup
     int waves_fwd, waves_bwd;                    // waves per workgroup
@@ -737,6 +747,7 @@ template <typename Tin, typename Tout>
 int ss2d_dispatch(const SS2DArgs &a, const Plan2 &pl, bool bwd, hipStream_t s);
 
 int ss2d_launch_raw(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bwd, hipStream_t s);
+int ss2d_launch_lean(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bwd, hipStream_t s);
 
 template <typename Tin, typename Tout, int C, bool N1>
 static int ss2d_launch(const SS2DArgs &a, const Plan2 &pl, bool bwd, hipStream_t s) {
@@ -751,6 +762,18 @@ static int ss2d_launch(const SS2DArgs &a, const Plan2 &pl, bool bwd, hipStream_t
 template <typename Tin, typename Tout>
 static int ss2d_dispatch_impl(const SS2DArgs &a, const Plan2 &pl, bool bwd, hipStream_t s) {
     const bool n1 = a.p.dstate == 1;
+    if (pl.kind == 3) {
+        const void *fn;
+        if (pl.items == 8) fn = bwd ? (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 8> : (const void *)ss2d_fwd_lean_kernel<Tin, Tout, 8>;
+        else fn = bwd ? (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 4> : (const void *)ss2d_fwd_lean_kernel<Tin, Tout, 4>;
+        return ss2d_launch_lean(fn, a, pl, bwd, s);
+    }
+    if (pl.kind == 2) {
+        const void *fn;
+        if (n1) fn = bwd ? (const void *)ss2d_bwd_direct_kernel<Tin, Tout, true> : (const void *)ss2d_fwd_direct_kernel<Tin, Tout, true>;
+        else fn = bwd ? (const void *)ss2d_bwd_direct_kernel<Tin, Tout, false> : (const void *)ss2d_fwd_direct_kernel<Tin, Tout, false>;
+        return ss2d_launch_raw(fn, a, pl, bwd, s);
+    }
     switch (pl.items) {
         case 4: return n1 ? ss2d_launch<Tin, Tout, 4, true>(a, pl, bwd, s) : ss2d_launch<Tin, Tout, 4, false>(a, pl, bwd, s);
         case 7: return n1 ? ss2d_launch<Tin, Tout, 7, true>(a, pl, bwd, s) : ss2d_launch<Tin, Tout, 7, false>(a, pl, bwd, s);

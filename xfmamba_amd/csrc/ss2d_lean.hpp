@@ -1,0 +1,458 @@
+// ss2d_lean.hpp -- instruction-lean fused SS2D kernels for the backbone case d_state == 1
+// (92 % of the scan elements of XFMamba).
+//
+// Same algorithm and layout contract as ss2d_direct.hpp (chunk = one aligned vector per lane, planes in
+// LDS in row-major AND transposed order, wave-per-route workgroups, private dB/dC accumulators), but
+// written against the instruction count the first profiles exposed (profiles/r01_*): 85 VALU
+// lane-instructions per (element, route) of which < 20 % were maths.  Changes:
+//   * the route direction is a template parameter, so reversal is register renaming, not selects;
+//   * rows are a whole number of vectors (L % C == 0): no per-element validity masks, no tail paths;
+//   * the wave scan runs on DPP (row_shr / row_bcast) instead of ds_bpermute shuffles, the chunk carry
+//     lives in a register (lane broadcast) instead of LDS, stores are predicated not branched;
+//   * a tile is PPT planes (not 64/LPR): small maps amortise the two workgroup barriers per tile;
+//   * 32-bit offsets from per-route base pointers computed once.
+#pragma once
+
+namespace xfm {
+
+struct LeanArgs {
+    // tensors (layout contract of include/xfm_hip.h)
+    const void *x, *dts, *Bs, *Cs;
+    const float *A, *D, *bias;
+    void *y;
+    float *chk;
+    const void *dy;
+    void *dx, *ddts;
+    float *dBs, *dCs, *dA, *dD, *dbias;
+    int batch, D_, H, W, L;
+    int nseg;        // chunks per row = ceil(L / (64*C))
+    int ppt;         // planes per tile (staged together in LDS)
+    int pli;         // tiles per workgroup
+    int softplus;
+    uint32_t magicW;
+};
+
+// ---- DPP helpers -------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118;
+constexpr int kRowShl1 = 0x101, kRowShl2 = 0x102, kRowShl4 = 0x104, kRowShl8 = 0x108;
+constexpr int kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+constexpr int kWaveShr1 = 0x138, kWaveShl1 = 0x130;
+
+// Inclusive scan of affine maps h -> P*h + S over the 64 lanes, ascending.  Lanes without a source keep
+// their value (DPP `old` operand = identity map contribution).
+__device__ __forceinline__ void wave_scan_up(float &P, float &S) {
+#define XFM_STEP_UP(CTRL, MASK)                                   \
+    {                                                             \
+        const float Pp = dpp_mov<CTRL, MASK>(1.f, P);             \
+        const float Sp = dpp_mov<CTRL, MASK>(0.f, S);             \
+        S = fmaf(P, Sp, S);                                       \
+        P *= Pp;                                                  \
+    }
+    XFM_STEP_UP(kRowShr1, 0xf)
+    XFM_STEP_UP(kRowShr2, 0xf)
+    XFM_STEP_UP(kRowShr4, 0xf)
+    XFM_STEP_UP(kRowShr8, 0xf)
+    XFM_STEP_UP(kRowBcast15, 0xa)
+    XFM_STEP_UP(kRowBcast31, 0xc)
+#undef XFM_STEP_UP
+}
+
+// Same, descending (lane i composes lanes 63..i).  No row_bcast in this direction: the two cross-row
+// steps use readlane broadcasts of the row totals.
+__device__ __forceinline__ void wave_scan_down(float &P, float &S, int lane) {
+#define XFM_STEP_DN(CTRL)                                         \
+    {                                                             \
+        const float Pn = dpp_mov<CTRL>(1.f, P);                   \
+        const float Sn = dpp_mov<CTRL>(0.f, S);                   \
+        S = fmaf(P, Sn, S);                                       \
+        P *= Pn;                                                  \
+    }
+    XFM_STEP_DN(kRowShl1)
+    XFM_STEP_DN(kRowShl2)
+    XFM_STEP_DN(kRowShl4)
+    XFM_STEP_DN(kRowShl8)
+#undef XFM_STEP_DN
+    // row r (lanes 16r..16r+15) now holds suffixes within the row; fold in the rows above it
+    const float P1 = __shfl(P, 16), S1 = __shfl(S, 16), P2 = __shfl(P, 32), S2 = __shfl(S, 32), P3 = __shfl(P, 48),
+                S3 = __shfl(S, 48);
+    // totals of rows 1..3 = values at their first lanes (suffix over the whole row)
+    const float T3S = S3, T3P = P3;
+    const float T2S = fmaf(P2, T3S, S2), T2P = P2 * T3P;          // rows 2..3
+    const float T1S = fmaf(P1, T2S, S1), T1P = P1 * T2P;          // rows 1..3
+    const int r = lane >> 4;
+    const float Pa = r == 0 ? T1P : (r == 1 ? T2P : (r == 2 ? T3P : 1.f));
+    const float Sa = r == 0 ? T1S : (r == 1 ? T2S : (r == 2 ? T3S : 0.f));
+    S = fmaf(P, Sa, S);
+    P *= Pa;
+}
+
+template <typename T, int C> struct VecIO;
+template <typename T> struct VecIO<T, 8> {   // 8 x 16-bit = 16 bytes
+    using V = uint4;
+    static __device__ __forceinline__ V zero() { return make_uint4(0, 0, 0, 0); }
+    static __device__ __forceinline__ void unpack(const V &v, float *f) { unpack16<T>(v, f); }
+    static __device__ __forceinline__ V pack(const float *f) { return pack16<T>(f); }
+};
+template <typename T> struct VecIO<T, 4> {   // 4 x 16-bit = 8 bytes, or 4 x fp32 = 16 bytes
+    using V = typename std::conditional<sizeof(T) == 4, uint4, uint2>::type;
+    static __device__ __forceinline__ V zero() { return V{}; }
+    static __device__ __forceinline__ void unpack(const V &v, float *f) {
+        if constexpr (sizeof(T) == 4) {
+            unpack16<T>(v, f);
+        } else {
+            float t[8];
+            unpack16<T>(make_uint4(v.x, v.y, 0, 0), t);
+            f[0] = t[0]; f[1] = t[1]; f[2] = t[2]; f[3] = t[3];
+        }
+    }
+    static __device__ __forceinline__ V pack(const float *f) {
+        if constexpr (sizeof(T) == 4) {
+            return pack16<T>(f);
+        } else {
+            const float t[8] = {f[0], f[1], f[2], f[3], 0.f, 0.f, 0.f, 0.f};
+            const uint4 q = pack16<T>(t);
+            return make_uint2(q.x, q.y);
+        }
+    }
+};
+
+// register order <-> physical order
+template <int C, bool REV> __device__ __forceinline__ void to_traversal(const float *phys, float *reg) {
+#pragma unroll
+    for (int j = 0; j < C; ++j) reg[j] = phys[REV ? C - 1 - j : j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, one route over one plane.  xq: this route's LDS plane (type Tin), yq: private fp32 LDS plane.
+// ---------------------------------------------------------------------------------------------
+template <typename Tin, int C, bool REV>
+__device__ __forceinline__ void lean_fwd_plane(const LeanArgs &a, const Tin *__restrict__ dts_row,
+                                               const Tin *__restrict__ Brow, const Tin *__restrict__ Crow,
+                                               float *__restrict__ chk_row, const float A2, const float Dr,
+                                               const float bias, const Tin *xq, float *yq, const int lane) {
+    using IO = VecIO<Tin, C>;
+    using V = typename IO::V;
+    const int L = a.L, nseg = a.nseg;
+    const int ci = REV ? 63 - lane : lane;
+    float hc = 0.f;                                   // state entering the current chunk row-wide
+    int s0 = REV ? (nseg - 1) * 64 * C : 0;
+    const int sstep = REV ? -64 * C : 64 * C;
+    int tp0 = s0 + ci * C;
+    V rd = IO::zero(), rb = IO::zero(), rc = IO::zero();
+    if (tp0 < L) {
+        rd = *reinterpret_cast<const V *>(dts_row + tp0);
+        rb = *reinterpret_cast<const V *>(Brow + tp0);
+        rc = *reinterpret_cast<const V *>(Crow + tp0);
+    }
+    for (int s = 0; s < nseg; ++s) {
+        const bool live = tp0 < L;
+        float ph[C], dl[C], Bv[C], Cv[C], u[C];
+        IO::unpack(rd, ph); to_traversal<C, REV>(ph, dl);
+        IO::unpack(rb, ph); to_traversal<C, REV>(ph, Bv);
+        IO::unpack(rc, ph); to_traversal<C, REV>(ph, Cv);
+        V xv = IO::zero();
+        if (live) xv = *reinterpret_cast<const V *>(xq + tp0);
+        IO::unpack(xv, ph); to_traversal<C, REV>(ph, u);
+        // prefetch the next chunk
+        const int tpn = tp0 + sstep;
+        if (s + 1 < nseg && tpn < L && tpn >= 0) {
+            rd = *reinterpret_cast<const V *>(dts_row + tpn);
+            rb = *reinterpret_cast<const V *>(Brow + tpn);
+            rc = *reinterpret_cast<const V *>(Crow + tpn);
+        }
+        float av[C], bb[C];
+        float P = 1.f, S = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            float v = dl[j] + bias;
+            if (a.softplus) v = softplus20(v);
+            v = live ? v : 0.f;                       // dead lanes: identity map (a = 1, b = 0)
+            av[j] = exp2_fast(v * A2);
+            bb[j] = v * u[j] * Bv[j];
+            S = fmaf(av[j], S, bb[j]);
+            P *= av[j];
+        }
+        wave_scan_up(P, S);
+        // exclusive prefix: map of lanes 0..lane-1, applied to the row carry
+        const float Pe = dpp_mov<kWaveShr1>(1.f, P), Se = dpp_mov<kWaveShr1>(0.f, S);
+        float h = fmaf(Pe, hc, Se);
+        hc = fmaf(__shfl(P, 63), hc, __shfl(S, 63));  // state after this chunk row = inclusive map of lane 63
+        float y[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            h = fmaf(av[j], h, bb[j]);
+            y[j] = fmaf(Cv[j], h, Dr * u[j]);
+        }
+        if (nseg > 1 && lane == 63) chk_row[s] = hc;
+        if (live) {
+            float yo[C];
+            to_traversal<C, REV>(y, yo);              // the map is an involution: traversal -> physical
+#pragma unroll
+            for (int q = 0; q < C; q += 4) *reinterpret_cast<float4 *>(yq + tp0 + q) = make_float4(yo[q], yo[q + 1], yo[q + 2], yo[q + 3]);
+        }
+        tp0 = tpn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, one route over one plane
+// ---------------------------------------------------------------------------------------------
+template <typename Tin, int C, bool REV>
+__device__ __forceinline__ void lean_bwd_plane(const LeanArgs &a, const Tin *__restrict__ dts_row,
+                                               Tin *__restrict__ ddts_row, const Tin *__restrict__ Brow,
+                                               const Tin *__restrict__ Crow, const float *__restrict__ chk_row,
+                                               const float An, const float Dr, const float bias, const Tin *xq,
+                                               const Tin *gq, float *dxq, float *accB, float *accC, float &dA_acc,
+                                               float &dD_acc, float &dbias_acc, const int lane) {
+    using IO = VecIO<Tin, C>;
+    using V = typename IO::V;
+    const int L = a.L, nseg = a.nseg;
+    const float A2 = An * kLog2e;
+    const int ci = REV ? 63 - lane : lane;
+    float Ec = 0.f;                                   // E flowing in from the chunk row processed before (later in the route)
+    const int sstep = REV ? 64 * C : -64 * C;         // chunks are walked against the route
+    int tp0 = (REV ? 0 : (nseg - 1) * 64 * C) + ci * C;
+    V rd = IO::zero(), rb = IO::zero(), rc = IO::zero();
+    if (tp0 < L) {
+        rd = *reinterpret_cast<const V *>(dts_row + tp0);
+        rb = *reinterpret_cast<const V *>(Brow + tp0);
+        rc = *reinterpret_cast<const V *>(Crow + tp0);
+    }
+    for (int s = nseg - 1; s >= 0; --s) {
+        const bool live = tp0 < L;
+        float ph[C], dl[C], Bv[C], Cv[C], u[C], go[C];
+        IO::unpack(rd, ph); to_traversal<C, REV>(ph, dl);
+        IO::unpack(rb, ph); to_traversal<C, REV>(ph, Bv);
+        IO::unpack(rc, ph); to_traversal<C, REV>(ph, Cv);
+        V xv = IO::zero(), gv = IO::zero();
+        if (live) {
+            xv = *reinterpret_cast<const V *>(xq + tp0);
+            gv = *reinterpret_cast<const V *>(gq + tp0);
+        }
+        IO::unpack(xv, ph); to_traversal<C, REV>(ph, u);
+        IO::unpack(gv, ph); to_traversal<C, REV>(ph, go);
+        const int tpn = tp0 + sstep;
+        if (s > 0 && tpn < L && tpn >= 0) {
+            rd = *reinterpret_cast<const V *>(dts_row + tpn);
+            rb = *reinterpret_cast<const V *>(Brow + tpn);
+            rc = *reinterpret_cast<const V *>(Crow + tpn);
+        }
+        float av[C], bb[C], cg[C];
+        float P = 1.f, S = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            float v = dl[j] + bias;
+            if (a.softplus) v = softplus20(v);
+            v = live ? v : 0.f;
+            dl[j] = v;
+            av[j] = exp2_fast(v * A2);
+            bb[j] = v * u[j] * Bv[j];
+            cg[j] = Cv[j] * go[j];
+            S = fmaf(av[j], S, bb[j]);
+            P *= av[j];
+        }
+        float R = 0.f;
+#pragma unroll
+        for (int j = C - 1; j >= 0; --j) R = av[j] * (cg[j] + R);
+        float P2 = P;
+        wave_scan_up(P, S);
+        const float hin0 = (s > 0) ? chk_row[s - 1] : 0.f;          // state entering this chunk row (uniform)
+        const float Pe = dpp_mov<kWaveShr1>(1.f, P), Se = dpp_mov<kWaveShr1>(0.f, S);
+        float hh = fmaf(Pe, hin0, Se);
+        wave_scan_down(P2, R, lane);
+        const float Pn = dpp_mov<kWaveShl1>(1.f, P2), Rn = dpp_mov<kWaveShl1>(0.f, R);
+        float E = fmaf(Pn, Ec, Rn);
+        Ec = fmaf(__shfl(P2, 0), Ec, __shfl(R, 0));                 // E leaving this chunk row = inclusive map of lane 0
+        float h[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            hh = fmaf(av[j], hh, bb[j]);
+            h[j] = hh;
+        }
+        float du[C], dd[C], dBv[C], dCv[C];
+#pragma unroll
+        for (int j = C - 1; j >= 0; --j) {
+            const float dh = cg[j] + E;
+            E = av[j] * dh;
+            const float ah = h[j] - bb[j];
+            const float s1 = dh * Bv[j];
+            const float s2 = dh * An * ah;
+            dA_acc = fmaf(dh * dl[j], ah, dA_acc);
+            dBv[j] = dh * dl[j] * u[j];
+            dCv[j] = go[j] * h[j];
+            du[j] = fmaf(dl[j], s1, Dr * go[j]);
+            float ddl = fmaf(u[j], s1, s2);
+            if (a.softplus) ddl *= (dl[j] <= 20.f) ? 1.f - __expf(-dl[j]) : 1.f;
+            dd[j] = ddl;
+            dD_acc = fmaf(go[j], u[j], dD_acc);
+            dbias_acc += live ? ddl : 0.f;              // (a dead lane still carries dh*A*h through s2)
+        }
+        if (live) {
+            float t[C];
+            to_traversal<C, REV>(dd, t);
+            *reinterpret_cast<V *>(ddts_row + tp0) = IO::pack(t);
+            to_traversal<C, REV>(du, t);
+#pragma unroll
+            for (int q = 0; q < C; ++q) atomicAdd(dxq + tp0 + q, t[q]);      // 2 route-waves share this plane
+            to_traversal<C, REV>(dBv, t);
+#pragma unroll
+            for (int q = 0; q < C; q += 4) {
+                float4 v = *reinterpret_cast<float4 *>(accB + tp0 + q);
+                v.x += t[q]; v.y += t[q + 1]; v.z += t[q + 2]; v.w += t[q + 3];
+                *reinterpret_cast<float4 *>(accB + tp0 + q) = v;
+            }
+            to_traversal<C, REV>(dCv, t);
+#pragma unroll
+            for (int q = 0; q < C; q += 4) {
+                float4 v = *reinterpret_cast<float4 *>(accC + tp0 + q);
+                v.x += t[q]; v.y += t[q + 1]; v.z += t[q + 2]; v.w += t[q + 3];
+                *reinterpret_cast<float4 *>(accC + tp0 + q) = v;
+            }
+        }
+        tp0 = tpn;
+    }
+}
+
+// natural + transposed LDS copies of PPT planes (source type S in HBM, LDS type T)
+template <typename S, typename T, int VS>
+__device__ __forceinline__ void lean_planes_load(T *nat, T *tr, const S *src, int nplanes, int L, int H, int W,
+                                                 uint32_t magicW) {
+    using IO = VecIO<S, VS>;
+    const int nvec = L / VS;                           // L % VS == 0 guaranteed by the plan
+    for (int pl = 0; pl < nplanes; ++pl) {
+        const S *pg = src + (int64_t)pl * L;
+        for (int v = threadIdx.x; v < nvec; v += 256) {
+            const int e0 = v * VS;
+            float f[VS];
+            IO::unpack(*reinterpret_cast<const typename IO::V *>(pg + e0), f);
+            int h = (int)__umulhi((uint32_t)e0, magicW), w = e0 - h * W;
+#pragma unroll
+            for (int q = 0; q < VS; ++q) {
+                const T val = from_float<T>(f[q]);
+                nat[pl * L + e0 + q] = val;
+                tr[pl * L + w * H + h] = val;
+                if (++w == W) {
+                    w = 0;
+                    ++h;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels: wave w owns route {0,2,1,3}[w]; LDS (forward):  xN | xT (Tin, PPT planes) | 4 x y planes (fp32)
+//                                         LDS (backward): xN | xT | gN | gT (Tin) | dxN | dxT (fp32) | 4 x (accB|accC)
+// ---------------------------------------------------------------------------------------------
+template <typename Tin, typename Tout, int C>
+__global__ void __launch_bounds__(256) ss2d_fwd_lean_kernel(const LeanArgs a) {
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = a.L, H = a.H, W = a.W, D = a.D_, PL = a.ppt * L;
+    const int tiles_pb = D / a.ppt;
+    const int groups_pb = tiles_pb / a.pli;
+    const int b = blockIdx.x / groups_pb, tg = blockIdx.x - b * groups_pb;
+    Tin *xN = reinterpret_cast<Tin *>(smem), *xT = xN + PL;
+    float *Y = smem + (2 * (size_t)PL * sizeof(Tin)) / 4;            // 4 planes-sets of PL floats
+    const bool col = wave >> 1, rev = wave & 1;
+    const int k = (wave & 1) * 2 + (wave >> 1);
+    const Tin *xq = col ? xT : xN;
+    float *yq = Y + (size_t)wave * PL;
+    const int64_t route = (int64_t)b * 4 + k;
+    const Tin *Brow = (const Tin *)a.Bs + route * L, *Crow = (const Tin *)a.Cs + route * L;
+    for (int it = 0; it < a.pli; ++it) {
+        const int d0 = (tg * a.pli + it) * a.ppt;
+        const int64_t po = ((int64_t)b * D + d0) * L;
+        __syncthreads();
+        lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
+        __syncthreads();
+        for (int pl = 0; pl < a.ppt; ++pl) {
+            const int d = d0 + pl, row = k * D + d;
+            const Tin *dts_row = (const Tin *)a.dts + (route * D + d) * L;
+            float *chk_row = a.chk + (route * D + d) * a.nseg;
+            const float A2 = a.A[row] * kLog2e, Dr = a.D[row], bias = a.bias[row];
+            if (rev) lean_fwd_plane<Tin, C, true>(a, dts_row, Brow, Crow, chk_row, A2, Dr, bias, xq + pl * L, yq + pl * L, lane);
+            else lean_fwd_plane<Tin, C, false>(a, dts_row, Brow, Crow, chk_row, A2, Dr, bias, xq + pl * L, yq + pl * L, lane);
+        }
+        __syncthreads();
+        Tout *yo = (Tout *)a.y + po;
+        const float *Y0 = Y, *Y1 = Y + PL, *Y2 = Y + 2 * PL, *Y3 = Y + 3 * PL;
+        for (int pl = 0; pl < a.ppt; ++pl)
+            for (int e = threadIdx.x; e < L; e += 256) {
+                const int h = (int)__umulhi((uint32_t)e, a.magicW), w = e - h * W;
+                const int n_ = pl * L + e, t_ = pl * L + w * H + h;
+                stf<Tout>(yo + (int64_t)pl * L + e, (Y0[n_] + Y1[n_]) + (Y2[t_] + Y3[t_]));   // fixed order
+            }
+    }
+}
+
+template <typename Tin, typename Tout, int C>
+__global__ void __launch_bounds__(256) ss2d_bwd_lean_kernel(const LeanArgs a) {
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = a.L, H = a.H, W = a.W, D = a.D_, PL = a.ppt * L;
+    const int tiles_pb = D / a.ppt;
+    const int groups_pb = tiles_pb / a.pli;
+    const int b = blockIdx.x / groups_pb, tg = blockIdx.x - b * groups_pb;
+    Tin *xN = reinterpret_cast<Tin *>(smem), *xT = xN + PL, *gN = xT + PL, *gT = gN + PL;
+    float *dxN = smem + (4 * (size_t)PL * sizeof(Tin)) / 4, *dxT = dxN + PL;
+    float *accB = dxT + PL + (size_t)wave * 2 * L, *accC = accB + L;
+    for (int e = lane; e < 2 * L; e += 64) accB[e] = 0.f;
+    const bool col = wave >> 1, rev = wave & 1;
+    const int k = (wave & 1) * 2 + (wave >> 1);
+    const Tin *xq = col ? xT : xN, *gq = col ? gT : gN;
+    float *dxq = col ? dxT : dxN;
+    const int64_t route = (int64_t)b * 4 + k;
+    const Tin *Brow = (const Tin *)a.Bs + route * L, *Crow = (const Tin *)a.Cs + route * L;
+    for (int it = 0; it < a.pli; ++it) {
+        const int d0 = (tg * a.pli + it) * a.ppt;
+        const int64_t po = ((int64_t)b * D + d0) * L;
+        __syncthreads();
+        lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
+        lean_planes_load<Tout, Tin, 4>(gN, gT, (const Tout *)a.dy + po, a.ppt, L, H, W, a.magicW);
+        for (int e = threadIdx.x; e < 2 * PL; e += 256) dxN[e] = 0.f;
+        __syncthreads();
+        for (int pl = 0; pl < a.ppt; ++pl) {
+            const int d = d0 + pl, row = k * D + d;
+            const int64_t ro = (route * D + d) * L;
+            const float *chk_row = a.chk + (route * D + d) * a.nseg;
+            const float An = a.A[row], Dr = a.D[row], bias = a.bias[row];
+            float dA_acc = 0.f, dD_acc = 0.f, dbias_acc = 0.f;
+            if (rev)
+                lean_bwd_plane<Tin, C, true>(a, (const Tin *)a.dts + ro, (Tin *)a.ddts + ro, Brow, Crow, chk_row, An, Dr, bias,
+                                             xq + pl * L, gq + pl * L, dxq + pl * L, accB, accC, dA_acc, dD_acc, dbias_acc, lane);
+            else
+                lean_bwd_plane<Tin, C, false>(a, (const Tin *)a.dts + ro, (Tin *)a.ddts + ro, Brow, Crow, chk_row, An, Dr, bias,
+                                              xq + pl * L, gq + pl * L, dxq + pl * L, accB, accC, dA_acc, dD_acc, dbias_acc, lane);
+            for (int o = 32; o > 0; o >>= 1) {
+                dA_acc += __shfl_xor(dA_acc, o, 64);
+                dD_acc += __shfl_xor(dD_acc, o, 64);
+                dbias_acc += __shfl_xor(dbias_acc, o, 64);
+            }
+            if (lane == 0) {
+                atomicAdd(a.dA + row, dA_acc);
+                atomicAdd(a.dD + row, dD_acc);
+                atomicAdd(a.dbias + row, dbias_acc);
+            }
+        }
+        __syncthreads();
+        Tin *dxo = (Tin *)a.dx + po;
+        for (int pl = 0; pl < a.ppt; ++pl)
+            for (int e = threadIdx.x; e < L; e += 256) {
+                const int h = (int)__umulhi((uint32_t)e, a.magicW), w = e - h * W;
+                stf<Tin>(dxo + (int64_t)pl * L + e, dxN[pl * L + e] + dxT[pl * L + w * H + h]);
+            }
+    }
+    wave_sync();
+    float *dBg = a.dBs + route * L, *dCg = a.dCs + route * L;
+    for (int e = lane; e < L; e += 64) {
+        atomicAdd(dBg + e, accB[e]);
+        atomicAdd(dCg + e, accC[e]);
+    }
+}
+
+}  // namespace xfm

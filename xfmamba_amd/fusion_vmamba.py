@@ -68,13 +68,9 @@ class Linear2d(nn.Linear):
     """1x1 convolution stored as an (out, in) linear weight (fusion_vmamba.py:42-49)."""
 
     def forward(self, x: torch.Tensor):
-        # A 1x1 convolution on NCHW is W(out,in) @ x(b)(in, H*W): issue it as a (batched) library GEMM on the
-        # planes as they lie, instead of MIOpen's NHWC implicit-GEMM path with its layout transposes.
-        B, _, H, W = x.shape
-        y = torch.matmul(self.weight, x.flatten(2))
-        if self.bias is not None:
-            y = y + self.bias.to(y.dtype)[None, :, None]
-        return y.view(B, -1, H, W)
+        # (measured: issuing this as a broadcast matmul on the NCHW planes is slower than MIOpen's implicit GEMM
+        # here -- 65.6 vs 56.8 ms/step -- so the library convolution stays)
+        return F.conv2d(x, self.weight[:, :, None, None], self.bias)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         k = prefix + "weight"

@@ -27,9 +27,9 @@ def to_route_order(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return torch.stack([t[:, :, 0].flatten(-2), t[:, :, 1].transpose(-1, -2).flatten(-2)], dim=2).view(B, K, C, L)
 
 
-def _plan(Bt, Dm, H, W, N):
+def _plan(Bt, Dm, H, W, N, dtype):
     plan = _lib.ScanPlan()
-    _lib.check(_lib.lib().xfm_ss2d_plan(Bt, Dm, H, W, N, ctypes.byref(plan)), "ss2d_plan")
+    _lib.check(_lib.lib().xfm_ss2d_plan(Bt, Dm, H, W, N, _lib.dtype_code(dtype), ctypes.byref(plan)), "ss2d_plan")
     return plan
 
 
@@ -56,7 +56,7 @@ class SS2DCoreHip(torch.autograd.Function):
             raise RuntimeError("ss2d_core: x, dts, Bs, Cs must share one dtype")
         x, dts, Bs, Cs = x.contiguous(), dts.contiguous(), Bs.contiguous(), Cs.contiguous()
         A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
-        plan = _plan(Bt, Dm, H, W, N)
+        plan = _plan(Bt, Dm, H, W, N, x.dtype)
         chk = (torch.empty((Bt, 4, Dm, plan.n_chunks, N), dtype=torch.float32, device=x.device)
                if plan.n_chunks > 1 else None)
         y = torch.empty((Bt, Dm, L), dtype=torch.float32, device=x.device)   # oflex: fp32 out
