@@ -14,6 +14,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 
+def time_raw(cfn, params, reps=30, warm=3):
+    """Back-to-back launches of one C-ABI entry point between two events (no Python work in between)."""
+    import ctypes
+    from xfmamba_amd import _lib
+    st = _lib.stream_ptr()
+    for _ in range(warm):
+        _lib.check(cfn(ctypes.byref(params), st), "kbench")
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        cfn(ctypes.byref(params), st)
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) * 1e3 / reps
+
+
 def timeit(fn, reps=20, warm=3):
     for _ in range(warm):
         fn()
@@ -66,13 +83,21 @@ def main():
         isz = x.element_size()
         fb = Bt * D * L * (5 * isz + 4) + 2 * Bt * 4 * N * L * isz
         bb = Bt * D * L * (10 * isz + 4) + 2 * Bt * 4 * N * L * (isz + 4)
-        xr = x.clone().requires_grad_()
-        dr = dts.clone().requires_grad_()
-        y = SS2DCoreHip.apply(xr, dr, A, Bs, Cs, Dp, bias, H, H)
+        from xfmamba_amd import ss2d as S2
+        chk = torch.empty((Bt, 4, D, max(plan.n_chunks, 1), N), dtype=torch.float32, device=dev)
+        y = torch.empty((Bt, D, L), dtype=torch.float32, device=dev)
         gy = torch.randn_like(y)
-        t = timeit(lambda: SS2DCoreHip.apply(x, dts, A, Bs, Cs, Dp, bias, H, H))
+        dx, ddts = torch.empty_like(x), torch.empty_like(dts)
+        dBs = torch.zeros(Bs.shape, dtype=torch.float32, device=dev)
+        dCs = torch.zeros_like(dBs)
+        dA, dD, dbias = torch.zeros_like(A), torch.zeros_like(Dp), torch.zeros_like(bias)
+        p = _lib.SS2DParams()
+        S2._fill(p, x, dts, A, Bs, Cs, Dp, bias, H, H, torch.float32, chk)
+        p.y, p.dy, p.dx, p.ddts = y.data_ptr(), gy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
+        p.dBs, p.dCs, p.dA, p.dD, p.ddelta_bias = dBs.data_ptr(), dCs.data_ptr(), dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
+        t = time_raw(_lib.lib().xfm_ss2d_fwd, p)
         print(f"{'ss2d_fwd ' + name:28s} {t:9.1f} {fb / t / 1e3:8.1f} {fb / t / 1e3 / 80:6.2f}  {ptxt}")
-        t = timeit(lambda: torch.autograd.grad(y, (xr, dr), gy, retain_graph=True))
+        t = time_raw(_lib.lib().xfm_ss2d_bwd, p)
         print(f"{'ss2d_bwd ' + name:28s} {t:9.1f} {bb / t / 1e3:8.1f} {bb / t / 1e3 / 80:6.2f}")
         if N == 1 and (not a.only or a.only in "dwconv"):
             x4 = x.view(Bt, D, H, H)

@@ -31,13 +31,17 @@ static int plan_ss2d(int batch, int D, int H, int W, int N, int in_dtype, Plan2 
         if (f_lg > 0 && D % f_lg == 0) ppt = f_lg;                     // (tuning hook: "lg" field = planes per tile)
         const size_t PL = (size_t)ppt * L;
         const size_t fwd_blk = 2 * PL * sz + 4 * PL * sizeof(float);
-        const size_t bwd_blk = 4 * PL * sz + 2 * PL * sizeof(float) + (size_t)8 * L * sizeof(float);
+        // registers win for short rows; from ~4 chunks on the LDS accumulators are faster (measured, stage 0: 473 vs 563 us)
+        const bool has_reg = nseg <= 2;
+        const int reg_nseg = (has_reg && !getenv("XFM_SS2D_LDSACC")) ? nseg : 0;
+        const size_t bwd_blk = 8 * PL * sz + (reg_nseg ? 0 : (size_t)8 * L * sizeof(float));
         if (fwd_blk <= kLdsPerCU && bwd_blk <= kLdsPerCU) {
             out->lg = 6;
             out->items = c;
             out->n_chunks = nseg;
             out->kind = 3;
             out->ppt = ppt;
+            out->reg_nseg = reg_nseg;
             out->bc_floats = 0;
             out->psz = L;
             out->lds_fwd_block = fwd_blk;
@@ -211,6 +215,7 @@ int ss2d_launch_lean(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bw
     la.batch = p.batch; la.D_ = p.d_inner; la.H = p.H; la.W = p.W; la.L = p.H * p.W;
     la.nseg = pl.n_chunks; la.ppt = pl.ppt; la.pli = pl.pli; la.softplus = p.delta_softplus;
     la.magicW = a.magicW;
+    la.dbg = a.dbg;
     const size_t lds = bwd ? pl.lds_bwd_block : pl.lds_fwd_block;
     const unsigned grid = (unsigned)((int64_t)p.batch * (p.d_inner / pl.ppt / pl.pli));
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -246,7 +251,11 @@ static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream) {
     a.pli = pl.pli;
     a.bc_floats = pl.bc_floats;
     a.dbg = 0;
-    if (const char *env = getenv("XFM_SS2D_DBG")) a.dbg = atoi(env);
+    if (const char *env = getenv("XFM_SS2D_DBG")) {
+        a.dbg = atoi(env);
+        static int once = 0;
+        if (!once++) fprintf(stderr, "[xfm] ss2d timing switches dbg=%d kind=%d items=%d chunks=%d ppt=%d pli=%d lds=%zu/%zu\n", a.dbg, pl.kind, pl.items, pl.n_chunks, pl.ppt, pl.pli, pl.lds_fwd_block, pl.lds_bwd_block);
+    }
     a.magicW = (uint32_t)((0x100000000ull + p->W - 1) / p->W);
     hipStream_t s = (hipStream_t)stream;
     switch (p->in_dtype) {

@@ -737,6 +737,7 @@ struct Plan2 {
     int lg, items, n_chunks;
     int kind, pli, bc_floats;                    // kind 2 = direct (ss2d_direct.hpp), kind 3 = lean d_state==1 (ss2d_lean.hpp)
     int ppt;                                     // kind 3: planes per tile
+    int reg_nseg;                                // kind 3: chunk count of the register-accumulator variant (0: LDS)
     int psz;                                     // plane size: floats incl. pitch (kind 0/1) or elements (kind 2)
     size_t lds_fwd_floats, lds_bwd_floats;       // per wave (kind 0) / per wave beyond the shared planes (kind 1)
     size_t lds_fwd_block, lds_bwd_block;         // dynamic LDS bytes per workgroup
@@ -764,8 +765,21 @@ static int ss2d_dispatch_impl(const SS2DArgs &a, const Plan2 &pl, bool bwd, hipS
     const bool n1 = a.p.dstate == 1;
     if (pl.kind == 3) {
         const void *fn;
-        if (pl.items == 8) fn = bwd ? (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 8> : (const void *)ss2d_fwd_lean_kernel<Tin, Tout, 8>;
-        else fn = bwd ? (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 4> : (const void *)ss2d_fwd_lean_kernel<Tin, Tout, 4>;
+        if (!bwd) {
+            fn = pl.items == 8 ? (const void *)ss2d_fwd_lean_kernel<Tin, Tout, 8> : (const void *)ss2d_fwd_lean_kernel<Tin, Tout, 4>;
+        } else if (pl.items == 8) {
+            switch (pl.reg_nseg) {                      // dB/dC sums in registers when the chunk count is a built variant
+                case 1: fn = (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 8, 1>; break;
+                case 2: fn = (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 8, 2>; break;
+                default: fn = (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 8, 0>;
+            }
+        } else {
+            switch (pl.reg_nseg) {
+                case 1: fn = (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 4, 1>; break;
+                case 2: fn = (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 4, 2>; break;
+                default: fn = (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 4, 0>;
+            }
+        }
         return ss2d_launch_lean(fn, a, pl, bwd, s);
     }
     if (pl.kind == 2) {

@@ -29,6 +29,7 @@ struct LeanArgs {
     int ppt;         // planes per tile (staged together in LDS)
     int pli;         // tiles per workgroup
     int softplus;
+    int dbg;         // timing-only switches (XFM_SS2D_DBG): 1 skip sweeps, 2 skip plane loads, 4 skip merge/store, 8 skip dB/dC flush
     uint32_t magicW;
 };
 
@@ -36,6 +37,9 @@ struct LeanArgs {
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_mov(float old, float src) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+}
+template <int LANE> __device__ __forceinline__ float bcast_lane(float v) {   // v_readlane_b32: no LDS round trip
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), LANE));
 }
 constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118;
 constexpr int kRowShl1 = 0x101, kRowShl2 = 0x102, kRowShl4 = 0x104, kRowShl8 = 0x108;
@@ -77,8 +81,8 @@ __device__ __forceinline__ void wave_scan_down(float &P, float &S, int lane) {
     XFM_STEP_DN(kRowShl8)
 #undef XFM_STEP_DN
     // row r (lanes 16r..16r+15) now holds suffixes within the row; fold in the rows above it
-    const float P1 = __shfl(P, 16), S1 = __shfl(S, 16), P2 = __shfl(P, 32), S2 = __shfl(S, 32), P3 = __shfl(P, 48),
-                S3 = __shfl(S, 48);
+    const float P1 = bcast_lane<16>(P), S1 = bcast_lane<16>(S), P2 = bcast_lane<32>(P), S2 = bcast_lane<32>(S),
+                P3 = bcast_lane<48>(P), S3 = bcast_lane<48>(S);
     // totals of rows 1..3 = values at their first lanes (suffix over the whole row)
     const float T3S = S3, T3P = P3;
     const float T2S = fmaf(P2, T3S, S2), T2P = P2 * T3P;          // rows 2..3
@@ -129,25 +133,25 @@ template <int C, bool REV> __device__ __forceinline__ void to_traversal(const fl
 // ---------------------------------------------------------------------------------------------
 // forward, one route over one plane.  xq: this route's LDS plane (type Tin), yq: private fp32 LDS plane.
 // ---------------------------------------------------------------------------------------------
+// Operand vectors of the NEXT chunk, in flight while the current one is computed; the stream runs on
+// across planes (consecutive d => next row = this row + L), so plane starts do not expose HBM latency.
+template <typename V> struct LeanPref { V d, b, c; float h; };
+
 template <typename Tin, int C, bool REV>
 __device__ __forceinline__ void lean_fwd_plane(const LeanArgs &a, const Tin *__restrict__ dts_row,
                                                const Tin *__restrict__ Brow, const Tin *__restrict__ Crow,
                                                float *__restrict__ chk_row, const float A2, const float Dr,
-                                               const float bias, const Tin *xq, float *yq, const int lane) {
+                                               const float bias, const Tin *xq, float *yq, const int lane,
+                                               LeanPref<typename VecIO<Tin, C>::V> &pf, const bool has_next) {
     using IO = VecIO<Tin, C>;
     using V = typename IO::V;
     const int L = a.L, nseg = a.nseg;
     const int ci = REV ? 63 - lane : lane;
     float hc = 0.f;                                   // state entering the current chunk row-wide
-    int s0 = REV ? (nseg - 1) * 64 * C : 0;
+    const int s0 = REV ? (nseg - 1) * 64 * C : 0;
     const int sstep = REV ? -64 * C : 64 * C;
     int tp0 = s0 + ci * C;
-    V rd = IO::zero(), rb = IO::zero(), rc = IO::zero();
-    if (tp0 < L) {
-        rd = *reinterpret_cast<const V *>(dts_row + tp0);
-        rb = *reinterpret_cast<const V *>(Brow + tp0);
-        rc = *reinterpret_cast<const V *>(Crow + tp0);
-    }
+    V rd = pf.d, rb = pf.b, rc = pf.c;
     for (int s = 0; s < nseg; ++s) {
         const bool live = tp0 < L;
         float ph[C], dl[C], Bv[C], Cv[C], u[C];
@@ -157,12 +161,18 @@ __device__ __forceinline__ void lean_fwd_plane(const LeanArgs &a, const Tin *__r
         V xv = IO::zero();
         if (live) xv = *reinterpret_cast<const V *>(xq + tp0);
         IO::unpack(xv, ph); to_traversal<C, REV>(ph, u);
-        // prefetch the next chunk
+        // prefetch the next chunk (of this plane, or the first chunk of the next plane)
         const int tpn = tp0 + sstep;
-        if (s + 1 < nseg && tpn < L && tpn >= 0) {
-            rd = *reinterpret_cast<const V *>(dts_row + tpn);
-            rb = *reinterpret_cast<const V *>(Brow + tpn);
-            rc = *reinterpret_cast<const V *>(Crow + tpn);
+        if (s + 1 < nseg) {
+            if (tpn < L && tpn >= 0) {
+                rd = *reinterpret_cast<const V *>(dts_row + tpn);
+                rb = *reinterpret_cast<const V *>(Brow + tpn);
+                rc = *reinterpret_cast<const V *>(Crow + tpn);
+            }
+        } else if (has_next && s0 + ci * C < L) {
+            pf.d = *reinterpret_cast<const V *>(dts_row + L + s0 + ci * C);
+            pf.b = *reinterpret_cast<const V *>(Brow + s0 + ci * C);
+            pf.c = *reinterpret_cast<const V *>(Crow + s0 + ci * C);
         }
         float av[C], bb[C];
         float P = 1.f, S = 0.f;
@@ -180,7 +190,7 @@ __device__ __forceinline__ void lean_fwd_plane(const LeanArgs &a, const Tin *__r
         // exclusive prefix: map of lanes 0..lane-1, applied to the row carry
         const float Pe = dpp_mov<kWaveShr1>(1.f, P), Se = dpp_mov<kWaveShr1>(0.f, S);
         float h = fmaf(Pe, hc, Se);
-        hc = fmaf(__shfl(P, 63), hc, __shfl(S, 63));  // state after this chunk row = inclusive map of lane 63
+        hc = fmaf(bcast_lane<63>(P), hc, bcast_lane<63>(S));  // state after this chunk row = inclusive map of lane 63
         float y[C];
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -201,27 +211,29 @@ __device__ __forceinline__ void lean_fwd_plane(const LeanArgs &a, const Tin *__r
 // ---------------------------------------------------------------------------------------------
 // backward, one route over one plane
 // ---------------------------------------------------------------------------------------------
-template <typename Tin, int C, bool REV>
+// NSEG > 0: the chunk loop is unrolled and the route's dB/dC sums over the planes of the workgroup live in
+// registers (rB/rC[NSEG][C]); NSEG == 0: runtime chunk count, sums in the wave-private LDS accumulators.
+template <typename Tin, int C, bool REV, int NSEG>
 __device__ __forceinline__ void lean_bwd_plane(const LeanArgs &a, const Tin *__restrict__ dts_row,
                                                Tin *__restrict__ ddts_row, const Tin *__restrict__ Brow,
                                                const Tin *__restrict__ Crow, const float *__restrict__ chk_row,
                                                const float An, const float Dr, const float bias, const Tin *xq,
-                                               const Tin *gq, float *dxq, float *accB, float *accC, float &dA_acc,
-                                               float &dD_acc, float &dbias_acc, const int lane) {
+                                               const Tin *gq, Tin *dxq, float *accB, float *accC,
+                                               float (&rB)[NSEG ? NSEG : 1][C], float (&rC)[NSEG ? NSEG : 1][C],
+                                               float &dA_acc, float &dD_acc, float &dbias_acc, const int lane,
+                                               LeanPref<typename VecIO<Tin, C>::V> &pf, const bool has_next) {
     using IO = VecIO<Tin, C>;
     using V = typename IO::V;
-    const int L = a.L, nseg = a.nseg;
+    const int L = a.L, nseg = NSEG ? NSEG : a.nseg;
     const float A2 = An * kLog2e;
     const int ci = REV ? 63 - lane : lane;
     float Ec = 0.f;                                   // E flowing in from the chunk row processed before (later in the route)
     const int sstep = REV ? 64 * C : -64 * C;         // chunks are walked against the route
-    int tp0 = (REV ? 0 : (nseg - 1) * 64 * C) + ci * C;
-    V rd = IO::zero(), rb = IO::zero(), rc = IO::zero();
-    if (tp0 < L) {
-        rd = *reinterpret_cast<const V *>(dts_row + tp0);
-        rb = *reinterpret_cast<const V *>(Brow + tp0);
-        rc = *reinterpret_cast<const V *>(Crow + tp0);
-    }
+    const int tpf = (REV ? 0 : (nseg - 1) * 64 * C) + ci * C;
+    int tp0 = tpf;
+    V rd = pf.d, rb = pf.b, rc = pf.c;
+    float hin_next = pf.h;                            // chunk state entering chunk s (prefetched like the vectors)
+#pragma unroll 1
     for (int s = nseg - 1; s >= 0; --s) {
         const bool live = tp0 < L;
         float ph[C], dl[C], Bv[C], Cv[C], u[C], go[C];
@@ -236,17 +248,29 @@ __device__ __forceinline__ void lean_bwd_plane(const LeanArgs &a, const Tin *__r
         IO::unpack(xv, ph); to_traversal<C, REV>(ph, u);
         IO::unpack(gv, ph); to_traversal<C, REV>(ph, go);
         const int tpn = tp0 + sstep;
-        if (s > 0 && tpn < L && tpn >= 0) {
-            rd = *reinterpret_cast<const V *>(dts_row + tpn);
-            rb = *reinterpret_cast<const V *>(Brow + tpn);
-            rc = *reinterpret_cast<const V *>(Crow + tpn);
+        const float hin0 = hin_next;
+        if (s > 0) {
+            if (tpn < L && tpn >= 0) {
+                rd = *reinterpret_cast<const V *>(dts_row + tpn);
+                rb = *reinterpret_cast<const V *>(Brow + tpn);
+                rc = *reinterpret_cast<const V *>(Crow + tpn);
+            }
+            hin_next = (s > 1) ? chk_row[s - 2] : 0.f;
+        } else if (has_next) {
+            if (tpf < L) {
+                pf.d = *reinterpret_cast<const V *>(dts_row + L + tpf);
+                pf.b = *reinterpret_cast<const V *>(Brow + tpf);
+                pf.c = *reinterpret_cast<const V *>(Crow + tpf);
+            }
+            pf.h = (nseg > 1) ? chk_row[nseg + nseg - 2] : 0.f;       // next plane's row of chk, entry of its last chunk
         }
-        float av[C], bb[C], cg[C];
+        float av[C], bb[C], cg[C], sg[C];
         float P = 1.f, S = 0.f;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             float v = dl[j] + bias;
-            if (a.softplus) v = softplus20(v);
+            sg[j] = 1.f;
+            if (a.softplus) v = softplus20_sig(v, sg[j]);
             v = live ? v : 0.f;
             dl[j] = v;
             av[j] = exp2_fast(v * A2);
@@ -260,13 +284,12 @@ __device__ __forceinline__ void lean_bwd_plane(const LeanArgs &a, const Tin *__r
         for (int j = C - 1; j >= 0; --j) R = av[j] * (cg[j] + R);
         float P2 = P;
         wave_scan_up(P, S);
-        const float hin0 = (s > 0) ? chk_row[s - 1] : 0.f;          // state entering this chunk row (uniform)
         const float Pe = dpp_mov<kWaveShr1>(1.f, P), Se = dpp_mov<kWaveShr1>(0.f, S);
         float hh = fmaf(Pe, hin0, Se);
         wave_scan_down(P2, R, lane);
         const float Pn = dpp_mov<kWaveShl1>(1.f, P2), Rn = dpp_mov<kWaveShl1>(0.f, R);
         float E = fmaf(Pn, Ec, Rn);
-        Ec = fmaf(__shfl(P2, 0), Ec, __shfl(R, 0));                 // E leaving this chunk row = inclusive map of lane 0
+        Ec = fmaf(bcast_lane<0>(P2), Ec, bcast_lane<0>(R));                 // E leaving this chunk row = inclusive map of lane 0
         float h[C];
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -286,7 +309,7 @@ __device__ __forceinline__ void lean_bwd_plane(const LeanArgs &a, const Tin *__r
             dCv[j] = go[j] * h[j];
             du[j] = fmaf(dl[j], s1, Dr * go[j]);
             float ddl = fmaf(u[j], s1, s2);
-            if (a.softplus) ddl *= (dl[j] <= 20.f) ? 1.f - __expf(-dl[j]) : 1.f;
+            ddl *= sg[j];                               // d softplus / d raw (1 when softplus is off or linear)
             dd[j] = ddl;
             dD_acc = fmaf(go[j], u[j], dD_acc);
             dbias_acc += live ? ddl : 0.f;              // (a dead lane still carries dh*A*h through s2)
@@ -296,21 +319,34 @@ __device__ __forceinline__ void lean_bwd_plane(const LeanArgs &a, const Tin *__r
             to_traversal<C, REV>(dd, t);
             *reinterpret_cast<V *>(ddts_row + tp0) = IO::pack(t);
             to_traversal<C, REV>(du, t);
+            *reinterpret_cast<V *>(dxq + tp0) = IO::pack(t);                  // this route's private dx plane
+            if constexpr (NSEG > 0) {
+                // one rolled loop body; the chunk index only selects which register set receives the sums
+                // (values stay in traversal order and are un-permuted once, at the flush)
 #pragma unroll
-            for (int q = 0; q < C; ++q) atomicAdd(dxq + tp0 + q, t[q]);      // 2 route-waves share this plane
-            to_traversal<C, REV>(dBv, t);
+                for (int ss = 0; ss < NSEG; ++ss)
+                    if (ss == s) {
 #pragma unroll
-            for (int q = 0; q < C; q += 4) {
-                float4 v = *reinterpret_cast<float4 *>(accB + tp0 + q);
-                v.x += t[q]; v.y += t[q + 1]; v.z += t[q + 2]; v.w += t[q + 3];
-                *reinterpret_cast<float4 *>(accB + tp0 + q) = v;
-            }
-            to_traversal<C, REV>(dCv, t);
+                        for (int j = 0; j < C; ++j) {
+                            rB[ss][j] += dBv[j];
+                            rC[ss][j] += dCv[j];
+                        }
+                    }
+            } else {
+                to_traversal<C, REV>(dBv, t);
 #pragma unroll
-            for (int q = 0; q < C; q += 4) {
-                float4 v = *reinterpret_cast<float4 *>(accC + tp0 + q);
-                v.x += t[q]; v.y += t[q + 1]; v.z += t[q + 2]; v.w += t[q + 3];
-                *reinterpret_cast<float4 *>(accC + tp0 + q) = v;
+                for (int q = 0; q < C; q += 4) {
+                    float4 v = *reinterpret_cast<float4 *>(accB + tp0 + q);
+                    v.x += t[q]; v.y += t[q + 1]; v.z += t[q + 2]; v.w += t[q + 3];
+                    *reinterpret_cast<float4 *>(accB + tp0 + q) = v;
+                }
+                to_traversal<C, REV>(dCv, t);
+#pragma unroll
+                for (int q = 0; q < C; q += 4) {
+                    float4 v = *reinterpret_cast<float4 *>(accC + tp0 + q);
+                    v.x += t[q]; v.y += t[q + 1]; v.z += t[q + 2]; v.w += t[q + 3];
+                    *reinterpret_cast<float4 *>(accC + tp0 + q) = v;
+                }
             }
         }
         tp0 = tpn;
@@ -330,10 +366,10 @@ __device__ __forceinline__ void lean_planes_load(T *nat, T *tr, const S *src, in
             float f[VS];
             IO::unpack(*reinterpret_cast<const typename IO::V *>(pg + e0), f);
             int h = (int)__umulhi((uint32_t)e0, magicW), w = e0 - h * W;
+            *reinterpret_cast<typename VecIO<T, VS>::V *>(nat + pl * L + e0) = VecIO<T, VS>::pack(f);
 #pragma unroll
             for (int q = 0; q < VS; ++q) {
                 const T val = from_float<T>(f[q]);
-                nat[pl * L + e0 + q] = val;
                 tr[pl * L + w * H + h] = val;
                 if (++w == W) {
                     w = 0;
@@ -364,21 +400,36 @@ __global__ void __launch_bounds__(256) ss2d_fwd_lean_kernel(const LeanArgs a) {
     float *yq = Y + (size_t)wave * PL;
     const int64_t route = (int64_t)b * 4 + k;
     const Tin *Brow = (const Tin *)a.Bs + route * L, *Crow = (const Tin *)a.Cs + route * L;
+    using V = typename VecIO<Tin, C>::V;
+    LeanPref<V> pf;
+    pf.d = pf.b = pf.c = VecIO<Tin, C>::zero();
+    pf.h = 0.f;
+    {   // first chunk of the first plane of this workgroup
+        const int tpf = (rev ? (a.nseg - 1) * 64 * C : 0) + (rev ? 63 - lane : lane) * C;
+        if (tpf < L) {
+            pf.d = *reinterpret_cast<const V *>((const Tin *)a.dts + (route * D + (int64_t)tg * a.pli * a.ppt) * L + tpf);
+            pf.b = *reinterpret_cast<const V *>(Brow + tpf);
+            pf.c = *reinterpret_cast<const V *>(Crow + tpf);
+        }
+    }
+    const int n_planes = a.pli * a.ppt;
     for (int it = 0; it < a.pli; ++it) {
         const int d0 = (tg * a.pli + it) * a.ppt;
         const int64_t po = ((int64_t)b * D + d0) * L;
         __syncthreads();
-        lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
+        if (!(a.dbg & 2)) lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
         __syncthreads();
-        for (int pl = 0; pl < a.ppt; ++pl) {
+        for (int pl = 0; pl < ((a.dbg & 1) ? 0 : a.ppt); ++pl) {
             const int d = d0 + pl, row = k * D + d;
             const Tin *dts_row = (const Tin *)a.dts + (route * D + d) * L;
             float *chk_row = a.chk + (route * D + d) * a.nseg;
             const float A2 = a.A[row] * kLog2e, Dr = a.D[row], bias = a.bias[row];
-            if (rev) lean_fwd_plane<Tin, C, true>(a, dts_row, Brow, Crow, chk_row, A2, Dr, bias, xq + pl * L, yq + pl * L, lane);
-            else lean_fwd_plane<Tin, C, false>(a, dts_row, Brow, Crow, chk_row, A2, Dr, bias, xq + pl * L, yq + pl * L, lane);
+            const bool has_next = it * a.ppt + pl + 1 < n_planes;
+            if (rev) lean_fwd_plane<Tin, C, true>(a, dts_row, Brow, Crow, chk_row, A2, Dr, bias, xq + pl * L, yq + pl * L, lane, pf, has_next);
+            else lean_fwd_plane<Tin, C, false>(a, dts_row, Brow, Crow, chk_row, A2, Dr, bias, xq + pl * L, yq + pl * L, lane, pf, has_next);
         }
         __syncthreads();
+        if (a.dbg & 4) continue;
         Tout *yo = (Tout *)a.y + po;
         const float *Y0 = Y, *Y1 = Y + PL, *Y2 = Y + 2 * PL, *Y3 = Y + 3 * PL;
         for (int pl = 0; pl < a.ppt; ++pl)
@@ -390,7 +441,7 @@ __global__ void __launch_bounds__(256) ss2d_fwd_lean_kernel(const LeanArgs a) {
     }
 }
 
-template <typename Tin, typename Tout, int C>
+template <typename Tin, typename Tout, int C, int NSEG>
 __global__ void __launch_bounds__(256) ss2d_bwd_lean_kernel(const LeanArgs a) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -398,36 +449,62 @@ __global__ void __launch_bounds__(256) ss2d_bwd_lean_kernel(const LeanArgs a) {
     const int tiles_pb = D / a.ppt;
     const int groups_pb = tiles_pb / a.pli;
     const int b = blockIdx.x / groups_pb, tg = blockIdx.x - b * groups_pb;
-    Tin *xN = reinterpret_cast<Tin *>(smem), *xT = xN + PL, *gN = xT + PL, *gT = gN + PL;
-    float *dxN = smem + (4 * (size_t)PL * sizeof(Tin)) / 4, *dxT = dxN + PL;
-    float *accB = dxT + PL + (size_t)wave * 2 * L, *accC = accB + L;
-    for (int e = lane; e < 2 * L; e += 64) accB[e] = 0.f;
+    // LDS: xN | xT | gN | gT | 4 private dx planes (all Tin, PPT planes each) | [NSEG == 0: 4 x (accB | accC) fp32]
+    Tin *xN = reinterpret_cast<Tin *>(smem), *xT = xN + PL, *gN = xT + PL, *gT = gN + PL, *DX = gT + PL;
+    float *accB = smem + (8 * (size_t)PL * sizeof(Tin)) / 4 + (size_t)wave * 2 * L, *accC = accB + L;
+    if (NSEG == 0)
+        for (int e = lane; e < 2 * L; e += 64) accB[e] = 0.f;
+    float rB[NSEG ? NSEG : 1][C], rC[NSEG ? NSEG : 1][C];
+#pragma unroll
+    for (int s = 0; s < (NSEG ? NSEG : 1); ++s)
+#pragma unroll
+        for (int j = 0; j < C; ++j) rB[s][j] = rC[s][j] = 0.f;
     const bool col = wave >> 1, rev = wave & 1;
     const int k = (wave & 1) * 2 + (wave >> 1);
     const Tin *xq = col ? xT : xN, *gq = col ? gT : gN;
-    float *dxq = col ? dxT : dxN;
+    Tin *dxq = DX + (size_t)wave * PL;
     const int64_t route = (int64_t)b * 4 + k;
     const Tin *Brow = (const Tin *)a.Bs + route * L, *Crow = (const Tin *)a.Cs + route * L;
+    using V = typename VecIO<Tin, C>::V;
+    const int nseg = NSEG ? NSEG : a.nseg;
+    LeanPref<V> pf;
+    pf.d = pf.b = pf.c = VecIO<Tin, C>::zero();
+    pf.h = 0.f;
+    {   // last chunk (in route order) of the first plane of this workgroup
+        const int tpf = (rev ? 0 : (nseg - 1) * 64 * C) + (rev ? 63 - lane : lane) * C;
+        const int64_t r0 = route * D + (int64_t)tg * a.pli * a.ppt;
+        if (tpf < L) {
+            pf.d = *reinterpret_cast<const V *>((const Tin *)a.dts + r0 * L + tpf);
+            pf.b = *reinterpret_cast<const V *>(Brow + tpf);
+            pf.c = *reinterpret_cast<const V *>(Crow + tpf);
+        }
+        if (nseg > 1) pf.h = a.chk[r0 * nseg + nseg - 2];
+    }
+    const int n_planes = a.pli * a.ppt;
     for (int it = 0; it < a.pli; ++it) {
         const int d0 = (tg * a.pli + it) * a.ppt;
         const int64_t po = ((int64_t)b * D + d0) * L;
         __syncthreads();
-        lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
-        lean_planes_load<Tout, Tin, 4>(gN, gT, (const Tout *)a.dy + po, a.ppt, L, H, W, a.magicW);
-        for (int e = threadIdx.x; e < 2 * PL; e += 256) dxN[e] = 0.f;
+        if (!(a.dbg & 2)) {
+            lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
+            lean_planes_load<Tout, Tin, 4>(gN, gT, (const Tout *)a.dy + po, a.ppt, L, H, W, a.magicW);
+        }
         __syncthreads();
-        for (int pl = 0; pl < a.ppt; ++pl) {
+        for (int pl = 0; pl < ((a.dbg & 1) ? 0 : a.ppt); ++pl) {
             const int d = d0 + pl, row = k * D + d;
             const int64_t ro = (route * D + d) * L;
-            const float *chk_row = a.chk + (route * D + d) * a.nseg;
+            const float *chk_row = a.chk + (route * D + d) * nseg;
             const float An = a.A[row], Dr = a.D[row], bias = a.bias[row];
             float dA_acc = 0.f, dD_acc = 0.f, dbias_acc = 0.f;
+            const bool has_next = it * a.ppt + pl + 1 < n_planes;
             if (rev)
-                lean_bwd_plane<Tin, C, true>(a, (const Tin *)a.dts + ro, (Tin *)a.ddts + ro, Brow, Crow, chk_row, An, Dr, bias,
-                                             xq + pl * L, gq + pl * L, dxq + pl * L, accB, accC, dA_acc, dD_acc, dbias_acc, lane);
+                lean_bwd_plane<Tin, C, true, NSEG>(a, (const Tin *)a.dts + ro, (Tin *)a.ddts + ro, Brow, Crow, chk_row, An, Dr,
+                                                   bias, xq + pl * L, gq + pl * L, dxq + pl * L, accB, accC, rB, rC, dA_acc,
+                                                   dD_acc, dbias_acc, lane, pf, has_next);
             else
-                lean_bwd_plane<Tin, C, false>(a, (const Tin *)a.dts + ro, (Tin *)a.ddts + ro, Brow, Crow, chk_row, An, Dr, bias,
-                                              xq + pl * L, gq + pl * L, dxq + pl * L, accB, accC, dA_acc, dD_acc, dbias_acc, lane);
+                lean_bwd_plane<Tin, C, false, NSEG>(a, (const Tin *)a.dts + ro, (Tin *)a.ddts + ro, Brow, Crow, chk_row, An, Dr,
+                                                    bias, xq + pl * L, gq + pl * L, dxq + pl * L, accB, accC, rB, rC, dA_acc,
+                                                    dD_acc, dbias_acc, lane, pf, has_next);
             for (int o = 32; o > 0; o >>= 1) {
                 dA_acc += __shfl_xor(dA_acc, o, 64);
                 dD_acc += __shfl_xor(dD_acc, o, 64);
@@ -440,18 +517,45 @@ __global__ void __launch_bounds__(256) ss2d_bwd_lean_kernel(const LeanArgs a) {
             }
         }
         __syncthreads();
+        if (a.dbg & 4) continue;
         Tin *dxo = (Tin *)a.dx + po;
+        const Tin *X0 = DX, *X1 = DX + PL, *X2 = DX + 2 * PL, *X3 = DX + 3 * PL;
         for (int pl = 0; pl < a.ppt; ++pl)
             for (int e = threadIdx.x; e < L; e += 256) {
                 const int h = (int)__umulhi((uint32_t)e, a.magicW), w = e - h * W;
-                stf<Tin>(dxo + (int64_t)pl * L + e, dxN[pl * L + e] + dxT[pl * L + w * H + h]);
+                const int n_ = pl * L + e, t_ = pl * L + w * H + h;
+                stf<Tin>(dxo + (int64_t)pl * L + e, (ldf<Tin>(X0 + n_) + ldf<Tin>(X1 + n_)) + (ldf<Tin>(X2 + t_) + ldf<Tin>(X3 + t_)));
             }
     }
     wave_sync();
+    if (a.dbg & 8) return;
     float *dBg = a.dBs + route * L, *dCg = a.dCs + route * L;
-    for (int e = lane; e < L; e += 64) {
-        atomicAdd(dBg + e, accB[e]);
-        atomicAdd(dCg + e, accC[e]);
+    if constexpr (NSEG > 0) {
+        // registers hold [traversal chunk s][traversal element j] of this lane.  Atomics are only fast when a
+        // wave instruction covers contiguous bytes (MI355X_MICROARCH.md, "Global float atomics"), so the sums
+        // are first laid out by position in LDS (the plane region is free now: 4 waves x L floats fit in it).
+        __syncthreads();
+        float *stage = smem + (size_t)wave * L;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int s = 0; s < NSEG; ++s) {
+                const int tp0 = (rev ? NSEG - 1 - s : s) * 64 * C + (rev ? 63 - lane : lane) * C;
+                if (tp0 < L) {
+#pragma unroll
+                    for (int j = 0; j < C; ++j) stage[tp0 + (rev ? C - 1 - j : j)] = pass ? rC[s][j] : rB[s][j];
+                }
+            }
+            wave_sync();
+            float *dst = pass ? dCg : dBg;
+            for (int e = lane; e < L; e += 64) atomicAdd(dst + e, stage[e]);
+            wave_sync();
+        }
+    } else {
+        for (int e = lane; e < L; e += 64) {
+            atomicAdd(dBg + e, accB[e]);
+            atomicAdd(dCg + e, accC[e]);
+        }
     }
 }
 

@@ -32,12 +32,22 @@ template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t *p, float v) { *p
 // ---- math ---------------------------------------------------------------------------------------
 // torch.nn.functional.softplus with beta=1, threshold=20 (reference: models/csms6s.py:49-50,
 // selective_scan_fwd_kernel.cuh:131-134).
-// Hardware exp2/log2 plus a 3-term series where 1+z would lose the small z (relative error < 1e-5).
-__device__ __forceinline__ float softplus20(float x) {
-    const float z = __expf(x);
+// Hardware exp2/log2 (v_exp_f32 / v_log_f32, no denormal fix-ups: e^x underflowing to 0 is exact enough
+// here) plus a 3-term series where 1+z would lose the small z (relative error < 1e-5).
+// Optionally also returns d softplus / dx = sigmoid(x) = z / (1 + z) (one v_rcp_f32, no second exp).
+__device__ __forceinline__ float softplus20_sig(float x, float &sig) {
+    const float z = __builtin_amdgcn_exp2f(x * kLog2e);
+    const float zp1 = 1.0f + z;
     const float series = z * fmaf(z, fmaf(z, 0.33333334f, -0.5f), 1.0f);   // log1p(z), |z| < 2^-5
-    const float sp = z < 0.03125f ? series : __logf(1.0f + z);
-    return x <= 20.f ? sp : x;
+    const float lg = __builtin_amdgcn_logf(zp1) * 0.6931471805599453f;
+    const float sp = z < 0.03125f ? series : lg;
+    const bool lin = x > 20.f;
+    sig = lin ? 1.0f : z * __builtin_amdgcn_rcpf(zp1);
+    return lin ? x : sp;
+}
+__device__ __forceinline__ float softplus20(float x) {
+    float s;
+    return softplus20_sig(x, s);
 }
 
 // exp(x * A) through the hardware exp2 (v_exp_f32); caller passes A pre-multiplied by log2(e).
