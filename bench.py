@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--drop-path", type=float, default=None, help="override the reference's DropPath rates (e.g. 0)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     return ap.parse_args()
 
 
@@ -103,7 +104,9 @@ def main():
     if world > 1:
         broadcast_parameters(model)
     buckets = GradBuckets(model, bucket_mb=48.0)                 # also makes .grad views of flat buffers
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)   # 1_train_model.py:141
+    use_graph = (not a.no_graph) and world == 1     # (captured RCCL collectives: not exercised yet -> eager for N > 1)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True,     # 1_train_model.py:141
+                           capturable=use_graph)
     crit = torch.nn.CrossEntropyLoss()
 
     torch.manual_seed(42 + rank)
@@ -128,19 +131,58 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the whole step (fwd + bwd + Adam) as ONE hipGraph: ~2800 launches per step are replayed by the
+    # runtime instead of being issued one by one from Python ("HIP graphs instead of a tracing compiler")
+    graph = None
+    loss_static = None
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(3, min(a.warmup, 5))):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss_static = step()
+        except Exception as e:                       # noqa: BLE001  (report and fall back to eager launches)
+            print(f"[bench] graph capture failed, running eager: {type(e).__name__}: {e}", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+            return loss_static
+        return step()
+
     for _ in range(a.warmup):
-        step()
+        run_step()
     timer = None
-    if not a.no_kernel_timer:
+    if not a.no_kernel_timer and graph is None:
         timer = _lib.KernelTimer()
         _lib.set_timer(timer)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = step()
+        loss = run_step()
     fence()
     dt = time.perf_counter() - t0
     _lib.set_timer(None)
+    if graph is not None and not a.no_kernel_timer:
+        # per-kernel HIP-event timing cannot live inside a captured graph: the same step is run eagerly, with
+        # events around every hand-written launch, right after the timed region (not part of `value`)
+        timer = _lib.KernelTimer()
+        _lib.set_timer(timer)
+        ksteps = min(a.steps, 5)
+        for _ in range(ksteps):
+            step()
+        torch.cuda.synchronize()
+        _lib.set_timer(None)
+    else:
+        ksteps = a.steps
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -173,7 +215,8 @@ def main():
             "roofline": roof,
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                             "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1),
-                            "ms_per_step": round(v["total_ms"] / a.steps, 3)} for k, v in kernels.items()},
+                            "ms_per_step": round(v["total_ms"] / ksteps, 3)} for k, v in kernels.items()},
+            "launch_mode": "hipGraph" if graph is not None else "eager",
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -23,6 +23,8 @@
  *   xfm_dwconv3x3_fwd/_bwd  <- `self.conv2d` (nn.Conv2d(D, D, 3, padding=1, groups=D)) followed by `self.act`
  *                              (nn.SiLU) in front of every SS2D core: models/fusion_vmamba.py:1198-1201,
  *                              :594-601, :853-857 (MIOpen depthwise conv + elementwise kernels upstream)
+ *   xfm_layernorm2d_fwd/_bwd <- LayerNorm2d.forward = permute -> F.layer_norm -> permute on NCHW maps,
+ *                              models/fusion_vmamba.py:52-57 (block norms, out_norm of SS2Dv2, patch-embed/downsample norms)
  *   xfm_ss2d_fwd/_bwd       <- the fused body of SS2Dv2.forward_corev2, models/fusion_vmamba.py:1145-1174
  *                              (cross_scan_fn -> selective_scan_fn -> cross_merge_fn in one kernel)
  *
@@ -112,6 +114,15 @@ int xfm_dwconv3x3_fwd(const void *x, const float *weight, const float *bias, voi
                       int dtype, int silu, void *stream);
 int xfm_dwconv3x3_bwd(const void *x, const float *weight, const float *bias, const void *dy, void *dx, float *dweight,
                       float *dbias, int B, int D, int H, int W, int dtype, int silu, void *stream);
+
+/* LayerNorm over C of x (B, C, L) [NCHW with L = H*W], eps inside the rsqrt, affine weight/bias (C) fp32 (bias may
+ * be NULL).  y may be a narrower dtype than x (the consumer GEMM's).  mean / rstd: (B, L) fp32, written by fwd and
+ * read by bwd.  bwd: dx in x_dtype; dweight / dbias fp32, ZEROED by the caller (dbias may be NULL). */
+int xfm_layernorm2d_fwd(const void *x, const float *weight, const float *bias, void *y, float *mean, float *rstd, int B,
+                        int C, int L, float eps, int x_dtype, int y_dtype, void *stream);
+int xfm_layernorm2d_bwd(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,
+                        void *dx, float *dweight, float *dbias, int B, int C, int L, int x_dtype, int y_dtype,
+                        void *stream);
 
 /*
  * Fused SS2D core: y[b,d,p] = sum_k scan_k(...)[b,d,.] gathered back to position p, i.e.

@@ -285,3 +285,32 @@ def test_fused_ss2d_matches_oracle_chain(shape):
              ("dCs", hC.grad, to_route_order(Cr.grad, H, W)), ("dD", hD.grad, Dr_.grad), ("dbias", hb.grad, br.grad)]
     for name, got, ref in pairs:
         assert_close(got.float().cpu(), ref, tol, tol * (float(ref.abs().max()) + 1e-6), name)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 56, 56), (3, 192, 28, 28), (2, 384, 14, 14), (5, 768, 7, 7), (1, 33, 5, 9)])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16)])
+def test_layernorm2d_matches_torch_fp32(shape, xdt, ydt):
+    """LayerNorm2d (reference fusion_vmamba.py:52-57: permute -> F.layer_norm -> permute) vs plain PyTorch fp32."""
+    from xfmamba_amd.layernorm2d import layernorm2d_fn
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(4)
+    B, C, H, W = shape
+    x = (torch.randn(*shape, generator=g) * 2 + 0.5).to(xdt)
+    w = 1 + 0.2 * torch.randn(C, generator=g)
+    b = 0.1 * torch.randn(C, generator=g)
+    gy = torch.randn(*shape, generator=g).to(ydt)
+    xr = x.float().clone().requires_grad_()
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.layer_norm(xr.permute(0, 2, 3, 1), (C,), wr, br, 1e-5).permute(0, 3, 1, 2)
+    yr.backward(gy.float())
+    xd = x.to(DEV).requires_grad_()
+    wd, bd = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = layernorm2d_fn(xd, wd, bd, 1e-5, ydt)
+    y.backward(gy.to(DEV))
+    tol = 1e-3 if (xdt == torch.float32 and ydt == torch.float32) else 1e-2
+    assert y.dtype == ydt and xd.grad.dtype == xdt
+    assert_close(y.float().cpu(), yr.detach(), tol, tol * float(yr.abs().max()), "y")
+    assert_close(xd.grad.float().cpu(), xr.grad, tol, tol * float(xr.grad.abs().max()), "dx")
+    assert_close(wd.grad.cpu(), wr.grad, tol, tol * float(wr.grad.abs().max()), "dw")
+    assert_close(bd.grad.cpu(), br.grad, tol, tol * float(br.grad.abs().max()), "db")

@@ -1,0 +1,180 @@
+// layernorm2d.hip -- LayerNorm over the channel axis of an NCHW tensor, in place of the reference's
+// permute -> F.layer_norm -> permute (LayerNorm2d, models/fusion_vmamba.py:52-57).
+//
+// The reference pays two layout copies around a library LayerNorm; here lanes run along the contiguous
+// H*W axis (coalesced 256-byte rows per wavefront), the four waves of a workgroup split the channels, and
+// the per-position statistics are combined through LDS.  Forward: mean pass, centred-variance pass,
+// normalise pass (the 2nd/3rd read hit L2).  Backward: one kernel for dx (same tiling), one for the
+// per-channel dweight/dbias reductions (planes are contiguous per channel, so those are plain streaming
+// sums + one atomic per workgroup).  HBM-bound: algorithmic bytes = 1 read + 1 write (fwd),
+// 2 reads + 1 write (+ 2 re-reads for dw/db) (bwd).
+#include "xfm_common.hpp"
+
+namespace xfm {
+
+template <typename Tx, typename Ty>
+__global__ void __launch_bounds__(256) ln2d_fwd_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, Ty *__restrict__ y,
+                                                       float *__restrict__ mean, float *__restrict__ rstd, int C,
+                                                       int L, int tiles_pb, float eps) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / tiles_pb, p = (blockIdx.x - b * tiles_pb) * 64 + lane;
+    const bool ok = p < L;
+    const Tx *xb = x + (int64_t)b * C * L + p;
+    float s = 0.f;
+    if (ok)
+        for (int c = wave; c < C; c += 4) s += ldf<Tx>(xb + (int64_t)c * L);
+    red[wave][lane] = s;
+    __syncthreads();
+    const float mu = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    __syncthreads();
+    float v = 0.f;
+    if (ok)
+        for (int c = wave; c < C; c += 4) {
+            const float d = ldf<Tx>(xb + (int64_t)c * L) - mu;
+            v = fmaf(d, d, v);
+        }
+    red[wave][lane] = v;
+    __syncthreads();
+    const float rs = rsqrtf((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C + eps);
+    if (ok) {
+        if (wave == 0) {
+            mean[(int64_t)b * L + p] = mu;
+            rstd[(int64_t)b * L + p] = rs;
+        }
+        Ty *yb = y + (int64_t)b * C * L + p;
+        for (int c = wave; c < C; c += 4) {
+            const float xh = (ldf<Tx>(xb + (int64_t)c * L) - mu) * rs;
+            stf<Ty>(yb + (int64_t)c * L, fmaf(xh, w[c], bias ? bias[c] : 0.f));
+        }
+    }
+}
+
+// dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * w
+template <typename Tx, typename Ty>
+__global__ void __launch_bounds__(256) ln2d_bwd_dx_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                          const Ty *__restrict__ dy, const float *__restrict__ mean,
+                                                          const float *__restrict__ rstd, Tx *__restrict__ dx, int C,
+                                                          int L, int tiles_pb) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / tiles_pb, p = (blockIdx.x - b * tiles_pb) * 64 + lane;
+    const bool ok = p < L;
+    const int64_t o = (int64_t)b * C * L + p;
+    const float mu = ok ? mean[(int64_t)b * L + p] : 0.f, rs = ok ? rstd[(int64_t)b * L + p] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok)
+        for (int c = wave; c < C; c += 4) {
+            const float g = ldf<Ty>(dy + o + (int64_t)c * L) * w[c];
+            const float xh = (ldf<Tx>(x + o + (int64_t)c * L) - mu) * rs;
+            s1 += g;
+            s2 = fmaf(g, xh, s2);
+        }
+    red[0][wave][lane] = s1;
+    red[1][wave][lane] = s2;
+    __syncthreads();
+    const float m1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
+    const float m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
+    if (ok)
+        for (int c = wave; c < C; c += 4) {
+            const float g = ldf<Ty>(dy + o + (int64_t)c * L) * w[c];
+            const float xh = (ldf<Tx>(x + o + (int64_t)c * L) - mu) * rs;
+            stf<Tx>(dx + o + (int64_t)c * L, rs * (g - m1 - xh * m2));
+        }
+}
+
+// dw[c] = sum_{b,p} dy * xhat,  db[c] = sum_{b,p} dy;  one workgroup per (channel, batch slice)
+template <typename Tx, typename Ty>
+__global__ void __launch_bounds__(256) ln2d_bwd_wb_kernel(const Tx *__restrict__ x, const Ty *__restrict__ dy,
+                                                          const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                          float *__restrict__ dw, float *__restrict__ db, int B, int C,
+                                                          int L, int bsplit) {
+    __shared__ float red[2][4];
+    const int c = blockIdx.x / bsplit, sl = blockIdx.x - c * bsplit;
+    const int b0 = (int)((int64_t)B * sl / bsplit), b1 = (int)((int64_t)B * (sl + 1) / bsplit);
+    float a1 = 0.f, a2 = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const int64_t o = ((int64_t)b * C + c) * L;
+        const float *mb = mean + (int64_t)b * L, *rb = rstd + (int64_t)b * L;
+        for (int p = threadIdx.x; p < L; p += 256) {
+            const float g = ldf<Ty>(dy + o + p);
+            a1 = fmaf(g, (ldf<Tx>(x + o + p) - mb[p]) * rb[p], a1);
+            a2 += g;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a1 += __shfl_xor(a1, off, 64);
+        a2 += __shfl_xor(a2, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a1;
+        red[1][threadIdx.x >> 6] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(dw + c, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        if (db) atomicAdd(db + c, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+template <typename Tx, typename Ty>
+static int ln_fwd(const void *x, const float *w, const float *b, void *y, float *mean, float *rstd, int B, int C, int L,
+                  float eps, hipStream_t s) {
+    const int tiles = (L + 63) / 64;
+    hipLaunchKernelGGL((ln2d_fwd_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, b, (Ty *)y, mean,
+                       rstd, C, L, tiles, eps);
+    return check_launch();
+}
+
+template <typename Tx, typename Ty>
+static int ln_bwd(const void *x, const float *w, const void *dy, const float *mean, const float *rstd, void *dx,
+                  float *dw, float *db, int B, int C, int L, hipStream_t s) {
+    const int tiles = (L + 63) / 64;
+    hipLaunchKernelGGL((ln2d_bwd_dx_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, (const Ty *)dy,
+                       mean, rstd, (Tx *)dx, C, L, tiles);
+    int rc = check_launch();
+    if (rc) return rc;
+    int bsplit = 2048 / C;                      // aim at >= ~2048 workgroups
+    if (bsplit < 1) bsplit = 1;
+    if (bsplit > B) bsplit = B;
+    hipLaunchKernelGGL((ln2d_bwd_wb_kernel<Tx, Ty>), dim3(C * bsplit), dim3(256), 0, s, (const Tx *)x, (const Ty *)dy,
+                       mean, rstd, dw, db, B, C, L, bsplit);
+    return check_launch();
+}
+
+}  // namespace xfm
+
+extern "C" {
+
+int xfm_layernorm2d_fwd(const void *x, const float *weight, const float *bias, void *y, float *mean, float *rstd, int B,
+                        int C, int L, float eps, int x_dtype, int y_dtype, void *stream) {
+    using namespace xfm;
+    if (!x || !weight || !y || !mean || !rstd || B <= 0 || C <= 0 || L <= 0) return XFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == XFM_F32 && y_dtype == XFM_F32) return ln_fwd<float, float>(x, weight, bias, y, mean, rstd, B, C, L, eps, s);
+    if (x_dtype == XFM_F32 && y_dtype == XFM_BF16) return ln_fwd<float, bf16_t>(x, weight, bias, y, mean, rstd, B, C, L, eps, s);
+    if (x_dtype == XFM_F32 && y_dtype == XFM_F16) return ln_fwd<float, f16_t>(x, weight, bias, y, mean, rstd, B, C, L, eps, s);
+    if (x_dtype == XFM_BF16 && y_dtype == XFM_BF16) return ln_fwd<bf16_t, bf16_t>(x, weight, bias, y, mean, rstd, B, C, L, eps, s);
+    if (x_dtype == XFM_BF16 && y_dtype == XFM_F32) return ln_fwd<bf16_t, float>(x, weight, bias, y, mean, rstd, B, C, L, eps, s);
+    if (x_dtype == XFM_F16 && y_dtype == XFM_F16) return ln_fwd<f16_t, f16_t>(x, weight, bias, y, mean, rstd, B, C, L, eps, s);
+    if (x_dtype == XFM_F16 && y_dtype == XFM_F32) return ln_fwd<f16_t, float>(x, weight, bias, y, mean, rstd, B, C, L, eps, s);
+    return XFM_EDTYPE;
+}
+
+int xfm_layernorm2d_bwd(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,
+                        void *dx, float *dweight, float *dbias, int B, int C, int L, int x_dtype, int y_dtype,
+                        void *stream) {
+    using namespace xfm;
+    if (!x || !weight || !dy || !mean || !rstd || !dx || !dweight || B <= 0 || C <= 0 || L <= 0) return XFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == XFM_F32 && y_dtype == XFM_F32) return ln_bwd<float, float>(x, weight, dy, mean, rstd, dx, dweight, dbias, B, C, L, s);
+    if (x_dtype == XFM_F32 && y_dtype == XFM_BF16) return ln_bwd<float, bf16_t>(x, weight, dy, mean, rstd, dx, dweight, dbias, B, C, L, s);
+    if (x_dtype == XFM_F32 && y_dtype == XFM_F16) return ln_bwd<float, f16_t>(x, weight, dy, mean, rstd, dx, dweight, dbias, B, C, L, s);
+    if (x_dtype == XFM_BF16 && y_dtype == XFM_BF16) return ln_bwd<bf16_t, bf16_t>(x, weight, dy, mean, rstd, dx, dweight, dbias, B, C, L, s);
+    if (x_dtype == XFM_BF16 && y_dtype == XFM_F32) return ln_bwd<bf16_t, float>(x, weight, dy, mean, rstd, dx, dweight, dbias, B, C, L, s);
+    if (x_dtype == XFM_F16 && y_dtype == XFM_F16) return ln_bwd<f16_t, f16_t>(x, weight, dy, mean, rstd, dx, dweight, dbias, B, C, L, s);
+    if (x_dtype == XFM_F16 && y_dtype == XFM_F32) return ln_bwd<f16_t, float>(x, weight, dy, mean, rstd, dx, dweight, dbias, B, C, L, s);
+    return XFM_EDTYPE;
+}
+}

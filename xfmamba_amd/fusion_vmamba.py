@@ -34,6 +34,7 @@ import torch.nn.functional as F
 from .csm import SwappingMerge_multiview, SwappingScan_multiview, cross_merge_fn, cross_scan_fn
 from .csms6s import selective_scan_fn
 from .dwconv import dwconv3x3_silu_fn
+from .layernorm2d import layernorm2d_fn
 from .ss2d import ss2d_core_fn
 
 SS2D_MODE = "fused"          # "fused" | "unfused"
@@ -82,9 +83,12 @@ class Linear2d(nn.Linear):
 class LayerNorm2d(nn.LayerNorm):
     """LayerNorm over the channel axis of an NCHW tensor (fusion_vmamba.py:52-57)."""
 
-    def forward(self, x: torch.Tensor):
-        y = F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps)
-        return y.permute(0, 3, 1, 2)
+    cast_out = False      # True: under autocast emit the autocast dtype (the consumer is a GEMM that casts anyway)
+
+    def forward(self, x: torch.Tensor, out_dtype=None):
+        if out_dtype is None and self.cast_out and torch.is_autocast_enabled():
+            out_dtype = torch.get_autocast_dtype("cuda")
+        return layernorm2d_fn(x, self.weight, self.bias, self.eps, out_dtype)
 
 
 class Permute(nn.Module):
@@ -268,9 +272,9 @@ class SS2Dv2(nn.Module):
         B, D, H, W = x.shape
         y, _ = _ss2d_core(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs, self.Ds, self.dt_projs_bias)
         y = y.view(B, -1, H, W)
-        if not self.channel_first:
-            y = y.permute(0, 2, 3, 1)
-        return self.out_norm(y).to(x.dtype)
+        if self.channel_first:
+            return self.out_norm(y, out_dtype=x.dtype)          # LayerNorm2d kernel emits x's dtype directly
+        return self.out_norm(y.permute(0, 2, 3, 1)).to(x.dtype)
 
     def forward(self, x: torch.Tensor, **kwargs):
         x = self.in_proj(x)
@@ -302,12 +306,16 @@ class VSSBlock(nn.Module):
         self.post_norm = post_norm
         if self.ssm_branch:
             self.norm = norm_layer(hidden_dim)
+            if isinstance(self.norm, LayerNorm2d):
+                self.norm.cast_out = not post_norm               # feeds in_proj (a GEMM)
             self.op = SS2Dv2(d_model=hidden_dim, d_state=ssm_d_state, ssm_ratio=ssm_ratio, dt_rank=ssm_dt_rank,
                              act_layer=ssm_act_layer, d_conv=ssm_conv, conv_bias=ssm_conv_bias, dropout=ssm_drop_rate,
                              initialize=ssm_init, forward_type=forward_type, channel_first=channel_first)
         self.drop_path = DropPath(drop_path)
         if self.mlp_branch:
             self.norm2 = norm_layer(hidden_dim)
+            if isinstance(self.norm2, LayerNorm2d):
+                self.norm2.cast_out = not post_norm              # feeds mlp.fc1 (a GEMM)
             self.mlp = Mlp(in_features=hidden_dim, hidden_features=int(hidden_dim * mlp_ratio),
                            act_layer=mlp_act_layer, drop=mlp_drop_rate, channels_first=channel_first)
 

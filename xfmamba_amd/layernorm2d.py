@@ -1,0 +1,62 @@
+"""LayerNorm over the channel axis of NCHW maps on the HIP kernel ``xfm_layernorm2d_fwd/_bwd``.
+
+Replaces the body of the reference's ``LayerNorm2d.forward`` (``models/fusion_vmamba.py:52-57``:
+permute -> ``F.layer_norm`` -> permute).  The output may be emitted directly in a narrower dtype
+(``out_dtype``) when the consumer is a GEMM/conv that would cast it anyway under autocast.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = ["layernorm2d_fn", "LayerNorm2dHip"]
+
+
+class LayerNorm2dHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        _lib.require_cuda(x, weight, bias)
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        x = x.contiguous()
+        w = weight.float().contiguous()
+        b = None if bias is None else bias.float().contiguous()
+        out_dtype = out_dtype or x.dtype
+        y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        mean = torch.empty((B, L), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((B, L), dtype=torch.float32, device=x.device)
+        nbytes = x.numel() * (x.element_size() + y.element_size())
+        with torch.cuda.device(x.device), _lib.timed("layernorm2d_fwd", nbytes):
+            _lib.check(_lib.lib().xfm_layernorm2d_fwd(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), mean.data_ptr(),
+                                                      rstd.data_ptr(), B, C, L, float(eps), _lib.dtype_code(x.dtype),
+                                                      _lib.dtype_code(out_dtype), _lib.stream_ptr()), "layernorm2d_fwd")
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.has_bias = bias is not None
+        ctx.wdtype = weight.dtype
+        ctx.ydtype = out_dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        dy = dy.contiguous()
+        if dy.dtype != ctx.ydtype:
+            dy = dy.to(ctx.ydtype)
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(w) if ctx.has_bias else None
+        nbytes = x.numel() * (2 * x.element_size() + dy.element_size())
+        with torch.cuda.device(x.device), _lib.timed("layernorm2d_bwd", nbytes):
+            _lib.check(_lib.lib().xfm_layernorm2d_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                      dx.data_ptr(), dw.data_ptr(), _lib.ptr(db), B, C, L,
+                                                      _lib.dtype_code(x.dtype), _lib.dtype_code(ctx.ydtype), _lib.stream_ptr()),
+                       "layernorm2d_bwd")
+        return dx, dw.to(ctx.wdtype), (None if db is None else db.to(ctx.wdtype)), None, None
+
+
+def layernorm2d_fn(x, weight, bias, eps=1e-5, out_dtype=None):
+    """x (B, C, H, W) -> LayerNorm over C; statistics in fp32; output dtype ``out_dtype`` or x's."""
+    return LayerNorm2dHip.apply(x, weight, bias, eps, out_dtype)
