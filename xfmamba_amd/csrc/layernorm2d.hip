@@ -84,6 +84,94 @@ __global__ void __launch_bounds__(256) ln2d_bwd_dx_kernel(const Tx *__restrict__
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// register-cached variants: C == CPT * NW.  The workgroup has NW waves (<= 16); lane = position, each thread
+// keeps its CPT channel values in registers, so x (and dy) are read from HBM exactly once.
+// ---------------------------------------------------------------------------------------------
+template <typename Tx, typename Ty, int CPT>
+__global__ void __launch_bounds__(1024) ln2d_fwd_cached_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                               const float *__restrict__ bias, Ty *__restrict__ y,
+                                                               float *__restrict__ mean, float *__restrict__ rstd,
+                                                               int C, int L, int tiles_pb, float eps, int NW) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / tiles_pb, p = (blockIdx.x - b * tiles_pb) * 64 + lane;
+    const bool ok = p < L;
+    const int64_t o = (int64_t)b * C * L + p;
+    float v[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        v[j] = ok ? ldf<Tx>(x + o + (int64_t)(wave + j * NW) * L) : 0.f;
+        s += v[j];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    float mu = 0.f;
+    for (int q = 0; q < NW; ++q) mu += red[q][lane];
+    mu /= (float)C;
+    __syncthreads();
+    float q2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        v[j] -= mu;
+        q2 = fmaf(v[j], v[j], q2);
+    }
+    red[wave][lane] = q2;
+    __syncthreads();
+    float var = 0.f;
+    for (int q = 0; q < NW; ++q) var += red[q][lane];
+    const float rs = rsqrtf(var / (float)C + eps);
+    if (ok) {
+        if (wave == 0) {
+            mean[(int64_t)b * L + p] = mu;
+            rstd[(int64_t)b * L + p] = rs;
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = wave + j * NW;
+            stf<Ty>(y + o + (int64_t)c * L, fmaf(v[j] * rs, w[c], bias ? bias[c] : 0.f));
+        }
+    }
+}
+
+template <typename Tx, typename Ty, int CPT>
+__global__ void __launch_bounds__(1024) ln2d_bwd_dx_cached_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                                  const Ty *__restrict__ dy, const float *__restrict__ mean,
+                                                                  const float *__restrict__ rstd, Tx *__restrict__ dx,
+                                                                  int C, int L, int tiles_pb, int NW) {
+    __shared__ float red[2][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / tiles_pb, p = (blockIdx.x - b * tiles_pb) * 64 + lane;
+    const bool ok = p < L;
+    const int64_t o = (int64_t)b * C * L + p;
+    const float mu = ok ? mean[(int64_t)b * L + p] : 0.f, rs = ok ? rstd[(int64_t)b * L + p] : 0.f;
+    float g[CPT], xh[CPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = wave + j * NW;
+        g[j] = ok ? ldf<Ty>(dy + o + (int64_t)c * L) * w[c] : 0.f;
+        xh[j] = ok ? (ldf<Tx>(x + o + (int64_t)c * L) - mu) * rs : 0.f;
+        s1 += g[j];
+        s2 = fmaf(g[j], xh[j], s2);
+    }
+    red[0][wave][lane] = s1;
+    red[1][wave][lane] = s2;
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+    for (int q = 0; q < NW; ++q) {
+        m1 += red[0][q][lane];
+        m2 += red[1][q][lane];
+    }
+    m1 /= (float)C;
+    m2 /= (float)C;
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) stf<Tx>(dx + o + (int64_t)(wave + j * NW) * L, rs * (g[j] - m1 - xh[j] * m2));
+    }
+}
+
 // dw[c] = sum_{b,p} dy * xhat,  db[c] = sum_{b,p} dy;  one workgroup per (channel, batch slice)
 template <typename Tx, typename Ty>
 __global__ void __launch_bounds__(256) ln2d_bwd_wb_kernel(const Tx *__restrict__ x, const Ty *__restrict__ dy,
@@ -122,8 +210,18 @@ template <typename Tx, typename Ty>
 static int ln_fwd(const void *x, const float *w, const float *b, void *y, float *mean, float *rstd, int B, int C, int L,
                   float eps, hipStream_t s) {
     const int tiles = (L + 63) / 64;
-    hipLaunchKernelGGL((ln2d_fwd_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, b, (Ty *)y, mean,
-                       rstd, C, L, tiles, eps);
+    if (C % 24 == 0 && C / 24 <= 16) {
+        const int NW = C / 24;
+        hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 24>), dim3(B * tiles), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
+                           (Ty *)y, mean, rstd, C, L, tiles, eps, NW);
+    } else if (C % 48 == 0 && C / 48 <= 16) {
+        const int NW = C / 48;
+        hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 48>), dim3(B * tiles), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
+                           (Ty *)y, mean, rstd, C, L, tiles, eps, NW);
+    } else {
+        hipLaunchKernelGGL((ln2d_fwd_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, b, (Ty *)y, mean,
+                           rstd, C, L, tiles, eps);
+    }
     return check_launch();
 }
 
@@ -131,8 +229,18 @@ template <typename Tx, typename Ty>
 static int ln_bwd(const void *x, const float *w, const void *dy, const float *mean, const float *rstd, void *dx,
                   float *dw, float *db, int B, int C, int L, hipStream_t s) {
     const int tiles = (L + 63) / 64;
-    hipLaunchKernelGGL((ln2d_bwd_dx_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, (const Ty *)dy,
-                       mean, rstd, (Tx *)dx, C, L, tiles);
+    if (C % 24 == 0 && C / 24 <= 16) {
+        const int NW = C / 24;
+        hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 24>), dim3(B * tiles), dim3(64 * NW), 0, s, (const Tx *)x, w,
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, tiles, NW);
+    } else if (C % 48 == 0 && C / 48 <= 16) {
+        const int NW = C / 48;
+        hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 48>), dim3(B * tiles), dim3(64 * NW), 0, s, (const Tx *)x, w,
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, tiles, NW);
+    } else {
+        hipLaunchKernelGGL((ln2d_bwd_dx_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, (const Ty *)dy,
+                           mean, rstd, (Tx *)dx, C, L, tiles);
+    }
     int rc = check_launch();
     if (rc) return rc;
     int bsplit = 2048 / C;                      // aim at >= ~2048 workgroups

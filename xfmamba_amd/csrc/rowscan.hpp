@@ -1,0 +1,241 @@
+// rowscan.hpp -- selective scan for SHORT rows (the 7x7 maps of XFMamba: stage 3 of the trunk and both
+// fusion blocks, L = 49, d_state 16 or 1).  Same operator boundary as selective_scan.hip.
+//
+// For L <= 64 a parallel scan along the row wastes the machine: chunks of a few elements, 2*log2(64)
+// cross-lane steps per state, and (in the backward) per-element reductions.  Here ONE LANE OWNS ONE
+// ROW: a wavefront takes 64 consecutive rows of one (batch, group) -- they share B and C -- stages
+// their operands in LDS with coalesced loads (row pitch L = 49 is odd: conflict-free per-lane walks),
+// and every lane runs the recurrence sequentially with the state in registers.  No scan, no shuffles.
+//   forward : t outer, n inner, h[n] in registers.
+//   backward: n outer; a forward pass keeps h_t (L registers), the reverse pass folds dh into per-t
+//             accumulators; dB/dC (a sum over the 64 rows for every (n,t)) go through an LDS transpose
+//             so that lane t sums its column and the atomics of a wave are one contiguous run.
+#pragma once
+
+#include "scan_core.hpp"
+
+namespace xfm {
+
+struct RowScanArgs {
+    xfm_scan_params_t p;
+    int dim_per_group;
+};
+
+template <int LT> constexpr int rs_pad() { return (LT + 3) & ~3; }
+
+// stage one (64 x LT) operand tile: rows r0..r0+63 of tensor `src` -> flat LDS [row*LT + t]
+template <typename T, typename S, int LT>
+__device__ __forceinline__ void rs_stage(T *dst, const S *src, int64_t batch_off, int64_t row_stride, int r0, int lane) {
+    for (int e = lane; e < 64 * LT; e += 64) {
+        const int row = e / LT, t = e - row * LT;
+        const float v = ldf<S>(src + batch_off + (int64_t)(r0 + row) * row_stride + t);
+        if constexpr (sizeof(T) == 4) dst[e] = v;
+        else stf<T>(dst + e, v);
+    }
+}
+
+template <typename Tin, typename Tout, int LT, int NS>
+__global__ void __launch_bounds__(64) rowscan_fwd_kernel(const RowScanArgs a) {
+    constexpr int LP = rs_pad<LT>();
+    extern __shared__ float smem[];
+    const xfm_scan_params_t &p = a.p;
+    const int lane = threadIdx.x;
+    const int tiles_pb = p.dim / 64;
+    const int b = blockIdx.x / tiles_pb, r0 = (blockIdx.x - b * tiles_pb) * 64;
+    const int k = r0 / a.dim_per_group, r = r0 + lane;
+    float *dy = smem;                                   // [64][LT] delta in, y out (in place, lane-private slots)
+    float *Bt = dy + 64 * LT;                           // [NS][LP]
+    float *Ct = Bt + NS * LP;
+    Tin *ut = reinterpret_cast<Tin *>(Ct + NS * LP);    // [64][LT]
+    rs_stage<float, Tin, LT>(dy, (const Tin *)p.delta, (int64_t)b * p.delta_batch_stride, p.delta_d_stride, r0, lane);
+    rs_stage<Tin, Tin, LT>(ut, (const Tin *)p.u, (int64_t)b * p.u_batch_stride, p.u_d_stride, r0, lane);
+    const Tin *Bg = (const Tin *)p.B + (int64_t)b * p.B_batch_stride + (int64_t)k * p.B_group_stride;
+    const Tin *Cg = (const Tin *)p.C + (int64_t)b * p.C_batch_stride + (int64_t)k * p.C_group_stride;
+    for (int e = lane; e < NS * LT; e += 64) {
+        const int n = e / LT, t = e - n * LT;
+        Bt[n * LP + t] = ldf<Tin>(Bg + (int64_t)n * p.B_dstate_stride + t);
+        Ct[n * LP + t] = ldf<Tin>(Cg + (int64_t)n * p.C_dstate_stride + t);
+    }
+    float A2[NS], h[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        A2[n] = p.A[(int64_t)r * p.A_d_stride + n] * kLog2e;
+        h[n] = 0.f;
+    }
+    const float Dr = p.D ? p.D[r] : 0.f, bias = p.delta_bias ? p.delta_bias[r] : 0.f;
+    wave_sync();
+#pragma unroll 1
+    for (int t = 0; t < LT; ++t) {
+        float dl = dy[lane * LT + t] + bias;
+        if (p.delta_softplus) dl = softplus20(dl);
+        const float uu = ldf<Tin>(ut + lane * LT + t);
+        const float du = dl * uu;
+        float y = Dr * uu;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const float av = exp2_fast(dl * A2[n]);
+            h[n] = fmaf(av, h[n], du * Bt[n * LP + t]);       // B, C reads are wave-uniform: LDS broadcast
+            y = fmaf(Ct[n * LP + t], h[n], y);
+        }
+        dy[lane * LT + t] = y;
+    }
+    wave_sync();
+    Tout *ob = (Tout *)p.out + (int64_t)b * p.out_batch_stride;
+    for (int e = lane; e < 64 * LT; e += 64) {
+        const int row = e / LT, t = e - row * LT;
+        stf<Tout>(ob + (int64_t)(r0 + row) * p.out_d_stride + t, dy[e]);
+    }
+}
+
+template <typename Tin, typename Tout, int LT, int NS>
+__global__ void __launch_bounds__(64) rowscan_bwd_kernel(const RowScanArgs a) {
+    constexpr int LP = rs_pad<LT>();
+    extern __shared__ float smem[];
+    const xfm_scan_params_t &p = a.p;
+    const int lane = threadIdx.x;
+    const int tiles_pb = p.dim / 64;
+    const int b = blockIdx.x / tiles_pb, r0 = (blockIdx.x - b * tiles_pb) * 64;
+    const int k = r0 / a.dim_per_group, r = r0 + lane;
+    const int L = LT;
+    float *dl_t = smem;                                 // [64][LT] softplus(delta + bias); later ddelta out
+    float *sc = dl_t + 64 * LT;                         // [LT][64] transpose scratch; later du out
+    float *Bt = sc + 64 * LT;                           // [NS][LP]
+    float *Ct = Bt + NS * LP;
+    Tin *ut = reinterpret_cast<Tin *>(Ct + NS * LP);    // [64][LT]
+    Tin *gt = ut + 64 * LT;                             // [64][LT] dout (kept in the input precision)
+    rs_stage<float, Tin, LT>(dl_t, (const Tin *)p.delta, (int64_t)b * p.delta_batch_stride, p.delta_d_stride, r0, lane);
+    rs_stage<Tin, Tin, LT>(ut, (const Tin *)p.u, (int64_t)b * p.u_batch_stride, p.u_d_stride, r0, lane);
+    rs_stage<Tin, Tout, LT>(gt, (const Tout *)p.dout, (int64_t)b * p.dout_batch_stride, p.dout_d_stride, r0, lane);
+    const Tin *Bg = (const Tin *)p.B + (int64_t)b * p.B_batch_stride + (int64_t)k * p.B_group_stride;
+    const Tin *Cg = (const Tin *)p.C + (int64_t)b * p.C_batch_stride + (int64_t)k * p.C_group_stride;
+    for (int e = lane; e < NS * LT; e += 64) {
+        const int n = e / LT, t = e - n * LT;
+        Bt[n * LP + t] = ldf<Tin>(Bg + (int64_t)n * p.B_dstate_stride + t);
+        Ct[n * LP + t] = ldf<Tin>(Cg + (int64_t)n * p.C_dstate_stride + t);
+    }
+    const float Dr = p.D ? p.D[r] : 0.f, bias = p.delta_bias ? p.delta_bias[r] : 0.f;
+    wave_sync();
+    // own row: raw delta -> softplus (in place), keep nothing else in registers across the state loop
+#pragma unroll 1
+    for (int t = 0; t < LT; ++t) {
+        float v = dl_t[lane * LT + t] + bias;
+        if (p.delta_softplus) v = softplus20(v);
+        dl_t[lane * LT + t] = v;
+    }
+    float h[LT], s1[LT], s2[LT];
+#pragma unroll
+    for (int t = 0; t < LT; ++t) s1[t] = s2[t] = 0.f;
+    float *dBg = p.dB + ((int64_t)b * p.n_groups + k) * NS * L;
+    float *dCg = p.dC + ((int64_t)b * p.n_groups + k) * NS * L;
+#pragma unroll 1
+    for (int n = 0; n < NS; ++n) {
+        const float An = p.A[(int64_t)r * p.A_d_stride + n];
+        const float A2 = An * kLog2e;
+        const float *Bn = Bt + n * LP, *Cn = Ct + n * LP;
+        float hp = 0.f;
+#pragma unroll
+        for (int t = 0; t < LT; ++t) {
+            const float dl = dl_t[lane * LT + t];
+            hp = fmaf(exp2_fast(dl * A2), hp, dl * ldf<Tin>(ut + lane * LT + t) * Bn[t]);
+            h[t] = hp;
+        }
+        float E = 0.f, dA = 0.f;
+#pragma unroll
+        for (int t = LT - 1; t >= 0; --t) {
+            const float dl = dl_t[lane * LT + t];
+            const float uu = ldf<Tin>(ut + lane * LT + t), g = ldf<Tin>(gt + lane * LT + t);
+            const float av = exp2_fast(dl * A2);
+            const float dh = fmaf(Cn[t], g, E);
+            E = av * dh;
+            const float du_ = dl * uu;
+            const float ah = h[t] - du_ * Bn[t];                 // a_t * h_{t-1}
+            s1[t] = fmaf(dh, Bn[t], s1[t]);
+            s2[t] = fmaf(dh * An, ah, s2[t]);
+            dA = fmaf(dh * dl, ah, dA);
+            sc[t * 64 + lane] = dh * du_;                        // dB contribution of this row, transposed
+            h[t] = g * h[t];                                     // dC contribution (h_t is dead after this)
+        }
+        atomicAdd(p.dA + (int64_t)r * NS + n, dA);
+        wave_sync();
+        if (lane < LT) {                                         // lane t sums column t over the 64 rows
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 64; q += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(sc + lane * 64 + q);
+                acc += (v.x + v.y) + (v.z + v.w);
+            }
+            atomicAdd(dBg + n * L + lane, acc);
+        }
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < LT; ++t) sc[t * 64 + lane] = h[t];
+        wave_sync();
+        if (lane < LT) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 64; q += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(sc + lane * 64 + q);
+                acc += (v.x + v.y) + (v.z + v.w);
+            }
+            atomicAdd(dCg + n * L + lane, acc);
+        }
+        wave_sync();
+    }
+    // per-row outputs: du, ddelta (through LDS for coalesced stores), dD, ddelta_bias
+    float dD = 0.f, db = 0.f;
+#pragma unroll
+    for (int t = 0; t < LT; ++t) {
+        const float dl = dl_t[lane * LT + t];
+        const float uu = ldf<Tin>(ut + lane * LT + t), g = ldf<Tin>(gt + lane * LT + t);
+        const float du = fmaf(dl, s1[t], Dr * g);
+        float dd = fmaf(uu, s1[t], s2[t]);
+        if (p.delta_softplus && dl <= 20.f) dd *= 1.f - __expf(-dl);
+        dD = fmaf(g, uu, dD);
+        db += dd;
+        sc[lane * LT + t] = du;
+        dl_t[lane * LT + t] = dd;
+    }
+    if (p.dD) atomicAdd(p.dD + r, dD);
+    if (p.ddelta_bias) atomicAdd(p.ddelta_bias + r, db);
+    wave_sync();
+    Tin *dub = (Tin *)p.du + ((int64_t)b * p.dim + r0) * L;
+    Tin *ddb = (Tin *)p.ddelta + ((int64_t)b * p.dim + r0) * L;
+    for (int e = lane; e < 64 * LT; e += 64) {
+        stf<Tin>(dub + e, sc[e]);
+        stf<Tin>(ddb + e, dl_t[e]);
+    }
+}
+
+template <typename Tin, typename Tout, int LT, int NS>
+static int rowscan_launch(const xfm_scan_params_t &p, bool bwd, hipStream_t s) {
+    constexpr int LP = rs_pad<LT>();
+    RowScanArgs a;
+    a.p = p;
+    a.dim_per_group = p.dim / p.n_groups;
+    const unsigned grid = (unsigned)((int64_t)p.batch * (p.dim / 64));
+    if (bwd) {
+        const size_t lds = (size_t)(2 * 64 * LT + 2 * NS * LP) * sizeof(float) + (size_t)2 * 64 * LT * sizeof(Tin);
+        hipLaunchKernelGGL((rowscan_bwd_kernel<Tin, Tout, LT, NS>), dim3(grid), dim3(64), lds, s, a);
+    } else {
+        const size_t lds = (size_t)(64 * LT + 2 * NS * LP) * sizeof(float) + (size_t)64 * LT * sizeof(Tin);
+        hipLaunchKernelGGL((rowscan_fwd_kernel<Tin, Tout, LT, NS>), dim3(grid), dim3(64), lds, s, a);
+    }
+    return check_launch();
+}
+
+// true if the rowscan kernels cover this call (and then `rc` holds the launch result)
+template <typename Tin, typename Tout>
+static bool rowscan_try(const xfm_scan_params_t &p, bool bwd, hipStream_t s, int *rc) {
+    if (p.seqlen != 49 || (p.dim / p.n_groups) % 64 != 0) return false;
+    if (p.dstate == 16) {
+        *rc = rowscan_launch<Tin, Tout, 49, 16>(p, bwd, s);
+        return true;
+    }
+    if (p.dstate == 1) {
+        *rc = rowscan_launch<Tin, Tout, 49, 1>(p, bwd, s);
+        return true;
+    }
+    return false;
+}
+
+}  // namespace xfm

@@ -15,6 +15,7 @@
 // touched with lanes along the contiguous sequence axis, and each lane then picks its C
 // consecutive elements with an odd LDS stride (bank-conflict free).
 #include "scan_core.hpp"
+#include "rowscan.hpp"
 
 namespace xfm {
 
@@ -345,6 +346,14 @@ static int run(const xfm_scan_params_t *p, bool bwd, void *stream) {
     a.lds_floats_per_wave = 64 * (plan.items | 1) + (64 / plan.lanes_per_row) * p->dstate;
     hipStream_t s = (hipStream_t)stream;
     const bool of32 = p->out_dtype == XFM_F32;
+    {   // short rows (7x7 maps): one lane per row, no scan (rowscan.hpp)
+        int rrc = 0;
+        bool hit = false;
+        if (p->in_dtype == XFM_F32) hit = rowscan_try<float, float>(*p, bwd, s, &rrc);
+        else if (p->in_dtype == XFM_BF16) hit = of32 ? rowscan_try<bf16_t, float>(*p, bwd, s, &rrc) : rowscan_try<bf16_t, bf16_t>(*p, bwd, s, &rrc);
+        else if (p->in_dtype == XFM_F16) hit = of32 ? rowscan_try<f16_t, float>(*p, bwd, s, &rrc) : rowscan_try<f16_t, f16_t>(*p, bwd, s, &rrc);
+        if (hit) return rrc;
+    }
     switch (p->in_dtype) {
         case XFM_F32: return dispatch_items<float, float>(a, plan.items, bwd, s);
         case XFM_F16:

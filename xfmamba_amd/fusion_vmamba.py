@@ -192,7 +192,9 @@ def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_
     Dsf = Ds.float()
     bias = dt_projs_bias.reshape(-1).float()
     cd = x.dtype
-    if SS2D_MODE == "fused":
+    # 7x7 maps (trunk stage 3, both fusion blocks): rows of 49 are too short for a parallel scan to pay; the
+    # operator chain with the one-lane-per-row scan kernel is faster there and the (B,4,D,49) tensors are tiny.
+    if SS2D_MODE == "fused" and L > 64:
         # x_proj of all K routes as ONE dense GEMM on the map in natural order (route k's projection of
         # the permuted sequence is the permuted projection).  Routes 1/3 walk columns, so their slice of
         # the small x_dbl tensor is transposed to column-major here; dt_proj (batched GEMM) then emits
