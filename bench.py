@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--drop-path", type=float, default=None, help="override the reference's DropPath rates (e.g. 0)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
+    ap.add_argument("--no-miopen-find", action="store_true", help="leave MIOpen's default solver heuristics (default: "
+                    "torch.backends.cudnn.benchmark = True, i.e. MIOpen's own find pass during warm-up; +5 %% measured)")
     return ap.parse_args()
 
 
@@ -65,13 +67,17 @@ def cpu_baseline(batch=2, size=224):
     sd.update(params)
     xa, xb = torch.randn(batch, 1, size, size), torch.randn(batch, 1, size, size)
     lab = torch.randint(0, 2, (batch,))
+    nstep = 2
     t0 = time.perf_counter()
-    out = O.xfmamba_top_ref(sd, xa, xb, True, O.selective_scan_ref)
-    torch.nn.functional.cross_entropy(out, lab).backward()
-    dt = time.perf_counter() - t0
+    for _ in range(nstep):
+        for v in params.values():
+            v.grad = None
+        out = O.xfmamba_top_ref(sd, xa, xb, True, O.selective_scan_ref)
+        torch.nn.functional.cross_entropy(out, lab).backward()
+    dt = (time.perf_counter() - t0) / nstep
     return dict(value=batch / dt, unit="two-view samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 fwd+bwd step, XFMamba-T fp32, batch {batch}, 2x{size}x{size} (BASELINE configs[0]); "
-                       f"oracle = restatement of the reference CPU selective-scan path; {dt:.1f} s")
+                sample=f"{nstep} fwd+bwd steps, XFMamba-T fp32, batch {batch}, 2x{size}x{size} (BASELINE configs[0]); "
+                       f"oracle = restatement of the reference CPU selective-scan path; {dt:.1f} s/step")
 
 
 def main():
@@ -94,6 +100,8 @@ def main():
     if a.ss2d:
         fusion_vmamba.SS2D_MODE = a.ss2d
 
+    if not a.no_miopen_find:
+        torch.backends.cudnn.benchmark = True
     torch.manual_seed(42)                                        # libs/config.py:22
     kw = dict(hidden_dim=1024) if a.model == "base" else {}
     model = TwoViewXFMambaTop(in_channels=1, outputs=2, type=a.model, **kw).to(dev).train()
@@ -196,7 +204,9 @@ def main():
         if timer is not None:
             kernels = timer.summary()
             if kernels:
-                name = max(kernels, key=lambda k: kernels[k]["total_ms"])
+                # the north-star kernel: the fused SS2D scan (forward or backward, whichever costs more per step)
+                scan = {k: v for k, v in kernels.items() if k.startswith("ss2d")} or kernels
+                name = max(scan, key=lambda k: scan[k]["total_ms"])
                 k = kernels[name]
                 ach = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9
                 roof = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",

@@ -69,4 +69,7 @@ class TwoViewXFMambaTop(nn.Module):
             z_b = self.mamba_feature_extrac(x_b)[3]
         z_a, z_b = self.shallow_mamba_fusion(z_a, z_b)
         z = self.fusemamba(z_a, z_b)
-        return self.classifier(self.final_conv(z))
+        # the 768->768->outputs head is negligible work: keep it out of autocast so the logits are not quantised
+        # to the 8-bit bf16 mantissa (no effect when autocast is off, i.e. on the fp32 reference path)
+        with torch.autocast("cuda", enabled=False):
+            return self.classifier(self.final_conv(z.float()))
