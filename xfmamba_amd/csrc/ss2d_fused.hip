@@ -30,7 +30,7 @@ static int plan_ss2d(int batch, int D, int H, int W, int N, int in_dtype, Plan2 
             if (D % q == 0 && (int64_t)q * L <= 3200) ppt = q;
         if (f_lg > 0 && D % f_lg == 0) ppt = f_lg;                     // (tuning hook: "lg" field = planes per tile)
         const size_t PL = (size_t)ppt * L;
-        const size_t fwd_blk = 2 * PL * sz + 4 * PL * sizeof(float);
+        const size_t fwd_blk = 6 * PL * sz;
         // registers win for short rows; from ~4 chunks on the LDS accumulators are faster (measured, stage 0: 473 vs 563 us)
         const bool has_reg = nseg <= 2;
         const int reg_nseg = (has_reg && !getenv("XFM_SS2D_LDSACC")) ? nseg : 0;
@@ -49,13 +49,17 @@ static int plan_ss2d(int batch, int D, int H, int W, int N, int in_dtype, Plan2 
             out->lds_fwd_floats = out->lds_bwd_floats = 0;
             out->waves_fwd = out->waves_bwd = 4;
             const int tiles_pb = D / ppt;
-            const int resident = (int)std::max<size_t>(1, kLdsPerCU / bwd_blk);
-            int pli = (int)((int64_t)batch * tiles_pb / ((int64_t)256 * resident * 2));
-            if (pli < 1) pli = 1;
-            if (pli > tiles_pb) pli = tiles_pb;
-            if (f_pli > 0) pli = std::min(f_pli, tiles_pb);
-            while (tiles_pb % pli) --pli;
-            out->pli = pli;
+            auto pick_pli = [&](size_t blk) {      // ~2 rounds of resident workgroups
+                const int resident = (int)std::min<size_t>(8, std::max<size_t>(1, kLdsPerCU / blk));
+                int pli = (int)((int64_t)batch * tiles_pb / ((int64_t)256 * resident * 2));
+                if (pli < 1) pli = 1;
+                if (pli > tiles_pb) pli = tiles_pb;
+                if (f_pli > 0) pli = std::min(f_pli, tiles_pb);
+                while (tiles_pb % pli) --pli;
+                return pli;
+            };
+            out->pli = pick_pli(bwd_blk);          // backward: also the span of the dB/dC accumulation
+            out->pli_fwd = pick_pli(fwd_blk);
             return XFM_OK;
         }
     }
@@ -213,11 +217,11 @@ int ss2d_launch_lean(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bw
     la.y = p.y; la.chk = p.chk; la.dy = p.dy; la.dx = p.dx; la.ddts = p.ddts;
     la.dBs = p.dBs; la.dCs = p.dCs; la.dA = p.dA; la.dD = p.dD; la.dbias = p.ddelta_bias;
     la.batch = p.batch; la.D_ = p.d_inner; la.H = p.H; la.W = p.W; la.L = p.H * p.W;
-    la.nseg = pl.n_chunks; la.ppt = pl.ppt; la.pli = pl.pli; la.softplus = p.delta_softplus;
+    la.nseg = pl.n_chunks; la.ppt = pl.ppt; la.pli = bwd ? pl.pli : pl.pli_fwd; la.softplus = p.delta_softplus;
     la.magicW = a.magicW;
     la.dbg = a.dbg;
     const size_t lds = bwd ? pl.lds_bwd_block : pl.lds_fwd_block;
-    const unsigned grid = (unsigned)((int64_t)p.batch * (p.d_inner / pl.ppt / pl.pli));
+    const unsigned grid = (unsigned)((int64_t)p.batch * (p.d_inner / pl.ppt / la.pli));
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void *kargs[] = {&la};
     const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, lds, s);

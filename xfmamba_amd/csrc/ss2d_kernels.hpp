@@ -737,6 +737,7 @@ struct Plan2 {
     int lg, items, n_chunks;
     int kind, pli, bc_floats;                    // kind 2 = direct (ss2d_direct.hpp), kind 3 = lean d_state==1 (ss2d_lean.hpp)
     int ppt;                                     // kind 3: planes per tile
+    int pli_fwd;                                 // kind 3: tiles per workgroup in the forward (no accumulators to amortise)
     int reg_nseg;                                // kind 3: chunk count of the register-accumulator variant (0: LDS)
     int psz;                                     // plane size: floats incl. pitch (kind 0/1) or elements (kind 2)
     size_t lds_fwd_floats, lds_bwd_floats;       // per wave (kind 0) / per wave beyond the shared planes (kind 1)

@@ -141,7 +141,7 @@ template <typename Tin, int C, bool REV>
 __device__ __forceinline__ void lean_fwd_plane(const LeanArgs &a, const Tin *__restrict__ dts_row,
                                                const Tin *__restrict__ Brow, const Tin *__restrict__ Crow,
                                                float *__restrict__ chk_row, const float A2, const float Dr,
-                                               const float bias, const Tin *xq, float *yq, const int lane,
+                                               const float bias, const Tin *xq, Tin *yq, const int lane,
                                                LeanPref<typename VecIO<Tin, C>::V> &pf, const bool has_next) {
     using IO = VecIO<Tin, C>;
     using V = typename IO::V;
@@ -201,8 +201,7 @@ __device__ __forceinline__ void lean_fwd_plane(const LeanArgs &a, const Tin *__r
         if (live) {
             float yo[C];
             to_traversal<C, REV>(y, yo);              // the map is an involution: traversal -> physical
-#pragma unroll
-            for (int q = 0; q < C; q += 4) *reinterpret_cast<float4 *>(yq + tp0 + q) = make_float4(yo[q], yo[q + 1], yo[q + 2], yo[q + 3]);
+            *reinterpret_cast<V *>(yq + tp0) = IO::pack(yo);   // private plane in the I/O precision (fp32 for fp32 I/O)
         }
         tp0 = tpn;
     }
@@ -392,12 +391,14 @@ __global__ void __launch_bounds__(256) ss2d_fwd_lean_kernel(const LeanArgs a) {
     const int tiles_pb = D / a.ppt;
     const int groups_pb = tiles_pb / a.pli;
     const int b = blockIdx.x / groups_pb, tg = blockIdx.x - b * groups_pb;
+    // LDS: xN | xT | 4 private y plane sets, all in the I/O precision: the per-route partial sums are rounded to
+    // it once before the fixed-order fp32 merge (for 16-bit I/O that keeps 4 workgroups per CU instead of 2)
     Tin *xN = reinterpret_cast<Tin *>(smem), *xT = xN + PL;
-    float *Y = smem + (2 * (size_t)PL * sizeof(Tin)) / 4;            // 4 planes-sets of PL floats
+    Tin *Y = xT + PL;
     const bool col = wave >> 1, rev = wave & 1;
     const int k = (wave & 1) * 2 + (wave >> 1);
     const Tin *xq = col ? xT : xN;
-    float *yq = Y + (size_t)wave * PL;
+    Tin *yq = Y + (size_t)wave * PL;
     const int64_t route = (int64_t)b * 4 + k;
     const Tin *Brow = (const Tin *)a.Bs + route * L, *Crow = (const Tin *)a.Cs + route * L;
     using V = typename VecIO<Tin, C>::V;
@@ -431,12 +432,13 @@ __global__ void __launch_bounds__(256) ss2d_fwd_lean_kernel(const LeanArgs a) {
         __syncthreads();
         if (a.dbg & 4) continue;
         Tout *yo = (Tout *)a.y + po;
-        const float *Y0 = Y, *Y1 = Y + PL, *Y2 = Y + 2 * PL, *Y3 = Y + 3 * PL;
+        const Tin *Y0 = Y, *Y1 = Y + PL, *Y2 = Y + 2 * PL, *Y3 = Y + 3 * PL;
         for (int pl = 0; pl < a.ppt; ++pl)
             for (int e = threadIdx.x; e < L; e += 256) {
                 const int h = (int)__umulhi((uint32_t)e, a.magicW), w = e - h * W;
                 const int n_ = pl * L + e, t_ = pl * L + w * H + h;
-                stf<Tout>(yo + (int64_t)pl * L + e, (Y0[n_] + Y1[n_]) + (Y2[t_] + Y3[t_]));   // fixed order
+                stf<Tout>(yo + (int64_t)pl * L + e,
+                          (ldf<Tin>(Y0 + n_) + ldf<Tin>(Y1 + n_)) + (ldf<Tin>(Y2 + t_) + ldf<Tin>(Y3 + t_)));   // fixed order
             }
     }
 }
