@@ -88,7 +88,8 @@ __global__ void __launch_bounds__(64) rowscan_fwd_kernel(const RowScanArgs a) {
 }
 
 template <typename Tin, typename Tout, int LT, int NS>
-__global__ void __launch_bounds__(64) rowscan_bwd_kernel(const RowScanArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))   // 1 wave/SIMD: whole 512-register file
+rowscan_bwd_kernel(const RowScanArgs a) {
     constexpr int LP = rs_pad<LT>();
     extern __shared__ float smem[];
     const xfm_scan_params_t &p = a.p;
@@ -97,15 +98,12 @@ __global__ void __launch_bounds__(64) rowscan_bwd_kernel(const RowScanArgs a) {
     const int b = blockIdx.x / tiles_pb, r0 = (blockIdx.x - b * tiles_pb) * 64;
     const int k = r0 / a.dim_per_group, r = r0 + lane;
     const int L = LT;
-    float *dl_t = smem;                                 // [64][LT] softplus(delta + bias); later ddelta out
-    float *sc = dl_t + 64 * LT;                         // [LT][64] transpose scratch; later du out
+    // LDS: one (64 x LT) fp32 tile used for staging / transposes / outputs, plus B and C of the group.
+    // The row's own operands live in REGISTERS for the whole state loop (a wave is alone on its SIMD anyway:
+    // the tile keeps occupancy LDS-bound, so the 512-register file is free to use).
+    float *sc = smem;                                   // [64][LT] or [LT][64]
     float *Bt = sc + 64 * LT;                           // [NS][LP]
     float *Ct = Bt + NS * LP;
-    Tin *ut = reinterpret_cast<Tin *>(Ct + NS * LP);    // [64][LT]
-    Tin *gt = ut + 64 * LT;                             // [64][LT] dout (kept in the input precision)
-    rs_stage<float, Tin, LT>(dl_t, (const Tin *)p.delta, (int64_t)b * p.delta_batch_stride, p.delta_d_stride, r0, lane);
-    rs_stage<Tin, Tin, LT>(ut, (const Tin *)p.u, (int64_t)b * p.u_batch_stride, p.u_d_stride, r0, lane);
-    rs_stage<Tin, Tout, LT>(gt, (const Tout *)p.dout, (int64_t)b * p.dout_batch_stride, p.dout_d_stride, r0, lane);
     const Tin *Bg = (const Tin *)p.B + (int64_t)b * p.B_batch_stride + (int64_t)k * p.B_group_stride;
     const Tin *Cg = (const Tin *)p.C + (int64_t)b * p.C_batch_stride + (int64_t)k * p.C_group_stride;
     for (int e = lane; e < NS * LT; e += 64) {
@@ -114,19 +112,38 @@ __global__ void __launch_bounds__(64) rowscan_bwd_kernel(const RowScanArgs a) {
         Ct[n * LP + t] = ldf<Tin>(Cg + (int64_t)n * p.C_dstate_stride + t);
     }
     const float Dr = p.D ? p.D[r] : 0.f, bias = p.delta_bias ? p.delta_bias[r] : 0.f;
+    float dl[LT], du[LT], g[LT];                        // delta' , delta'*u , dout  of this lane's row
+    rs_stage<float, Tin, LT>(sc, (const Tin *)p.delta, (int64_t)b * p.delta_batch_stride, p.delta_d_stride, r0, lane);
     wave_sync();
-    // own row: raw delta -> softplus (in place), keep nothing else in registers across the state loop
-#pragma unroll 1
+#pragma unroll
     for (int t = 0; t < LT; ++t) {
-        float v = dl_t[lane * LT + t] + bias;
+        float v = sc[lane * LT + t] + bias;
         if (p.delta_softplus) v = softplus20(v);
-        dl_t[lane * LT + t] = v;
+        dl[t] = v;
     }
+    wave_sync();
+    rs_stage<float, Tin, LT>(sc, (const Tin *)p.u, (int64_t)b * p.u_batch_stride, p.u_d_stride, r0, lane);
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < LT; ++t) du[t] = sc[lane * LT + t];          // u for now
+    wave_sync();
+    rs_stage<float, Tout, LT>(sc, (const Tout *)p.dout, (int64_t)b * p.dout_batch_stride, p.dout_d_stride, r0, lane);
+    wave_sync();
+    float dD = 0.f;
+#pragma unroll
+    for (int t = 0; t < LT; ++t) {
+        g[t] = sc[lane * LT + t];
+        dD = fmaf(g[t], du[t], dD);
+    }
+    wave_sync();
     float h[LT], s1[LT], s2[LT];
 #pragma unroll
     for (int t = 0; t < LT; ++t) s1[t] = s2[t] = 0.f;
     float *dBg = p.dB + ((int64_t)b * p.n_groups + k) * NS * L;
     float *dCg = p.dC + ((int64_t)b * p.n_groups + k) * NS * L;
+    // s1 accumulates sum_n dh*B, s2 sum_n dh*A*(a*h_prev); u is recovered as du/dl only where needed (final pass)
+#pragma unroll
+    for (int t = 0; t < LT; ++t) du[t] *= dl[t];
 #pragma unroll 1
     for (int n = 0; n < NS; ++n) {
         const float An = p.A[(int64_t)r * p.A_d_stride + n];
@@ -135,25 +152,21 @@ __global__ void __launch_bounds__(64) rowscan_bwd_kernel(const RowScanArgs a) {
         float hp = 0.f;
 #pragma unroll
         for (int t = 0; t < LT; ++t) {
-            const float dl = dl_t[lane * LT + t];
-            hp = fmaf(exp2_fast(dl * A2), hp, dl * ldf<Tin>(ut + lane * LT + t) * Bn[t]);
+            hp = fmaf(exp2_fast(dl[t] * A2), hp, du[t] * Bn[t]);
             h[t] = hp;
         }
         float E = 0.f, dA = 0.f;
 #pragma unroll
         for (int t = LT - 1; t >= 0; --t) {
-            const float dl = dl_t[lane * LT + t];
-            const float uu = ldf<Tin>(ut + lane * LT + t), g = ldf<Tin>(gt + lane * LT + t);
-            const float av = exp2_fast(dl * A2);
-            const float dh = fmaf(Cn[t], g, E);
+            const float av = exp2_fast(dl[t] * A2);
+            const float dh = fmaf(Cn[t], g[t], E);
             E = av * dh;
-            const float du_ = dl * uu;
-            const float ah = h[t] - du_ * Bn[t];                 // a_t * h_{t-1}
+            const float ah = h[t] - du[t] * Bn[t];               // a_t * h_{t-1}
             s1[t] = fmaf(dh, Bn[t], s1[t]);
             s2[t] = fmaf(dh * An, ah, s2[t]);
-            dA = fmaf(dh * dl, ah, dA);
-            sc[t * 64 + lane] = dh * du_;                        // dB contribution of this row, transposed
-            h[t] = g * h[t];                                     // dC contribution (h_t is dead after this)
+            dA = fmaf(dh * dl[t], ah, dA);
+            sc[t * 64 + lane] = dh * du[t];                      // dB contribution of this row, transposed
+            h[t] = g[t] * h[t];                                  // dC contribution (h_t is dead after this)
         }
         atomicAdd(p.dA + (int64_t)r * NS + n, dA);
         wave_sync();
@@ -181,29 +194,28 @@ __global__ void __launch_bounds__(64) rowscan_bwd_kernel(const RowScanArgs a) {
         }
         wave_sync();
     }
-    // per-row outputs: du, ddelta (through LDS for coalesced stores), dD, ddelta_bias
-    float dD = 0.f, db = 0.f;
-#pragma unroll
-    for (int t = 0; t < LT; ++t) {
-        const float dl = dl_t[lane * LT + t];
-        const float uu = ldf<Tin>(ut + lane * LT + t), g = ldf<Tin>(gt + lane * LT + t);
-        const float du = fmaf(dl, s1[t], Dr * g);
-        float dd = fmaf(uu, s1[t], s2[t]);
-        if (p.delta_softplus && dl <= 20.f) dd *= 1.f - __expf(-dl);
-        dD = fmaf(g, uu, dD);
-        db += dd;
-        sc[lane * LT + t] = du;
-        dl_t[lane * LT + t] = dd;
-    }
-    if (p.dD) atomicAdd(p.dD + r, dD);
-    if (p.ddelta_bias) atomicAdd(p.ddelta_bias + r, db);
-    wave_sync();
+    // per-row outputs: du, ddelta (through the LDS tile for coalesced stores), dD, ddelta_bias
+    float db = 0.f;
     Tin *dub = (Tin *)p.du + ((int64_t)b * p.dim + r0) * L;
     Tin *ddb = (Tin *)p.ddelta + ((int64_t)b * p.dim + r0) * L;
-    for (int e = lane; e < 64 * LT; e += 64) {
-        stf<Tin>(dub + e, sc[e]);
-        stf<Tin>(ddb + e, dl_t[e]);
+#pragma unroll
+    for (int t = 0; t < LT; ++t) sc[lane * LT + t] = fmaf(dl[t], s1[t], Dr * g[t]);
+    wave_sync();
+    for (int e = lane; e < 64 * LT; e += 64) stf<Tin>(dub + e, sc[e]);
+    wave_sync();
+    rs_stage<float, Tin, LT>(sc, (const Tin *)p.u, (int64_t)b * p.u_batch_stride, p.u_d_stride, r0, lane);   // u again (cheap)
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < LT; ++t) {
+        float dd = fmaf(sc[lane * LT + t], s1[t], s2[t]);
+        if (p.delta_softplus && dl[t] <= 20.f) dd *= 1.f - __expf(-dl[t]);
+        db += dd;
+        sc[lane * LT + t] = dd;
     }
+    wave_sync();
+    for (int e = lane; e < 64 * LT; e += 64) stf<Tin>(ddb + e, sc[e]);
+    if (p.dD) atomicAdd(p.dD + r, dD);
+    if (p.ddelta_bias) atomicAdd(p.ddelta_bias + r, db);
 }
 
 template <typename Tin, typename Tout, int LT, int NS>
@@ -214,7 +226,7 @@ static int rowscan_launch(const xfm_scan_params_t &p, bool bwd, hipStream_t s) {
     a.dim_per_group = p.dim / p.n_groups;
     const unsigned grid = (unsigned)((int64_t)p.batch * (p.dim / 64));
     if (bwd) {
-        const size_t lds = (size_t)(2 * 64 * LT + 2 * NS * LP) * sizeof(float) + (size_t)2 * 64 * LT * sizeof(Tin);
+        const size_t lds = (size_t)(64 * LT + 2 * NS * LP) * sizeof(float);
         hipLaunchKernelGGL((rowscan_bwd_kernel<Tin, Tout, LT, NS>), dim3(grid), dim3(64), lds, s, a);
     } else {
         const size_t lds = (size_t)(64 * LT + 2 * NS * LP) * sizeof(float) + (size_t)64 * LT * sizeof(Tin);
