@@ -209,8 +209,16 @@ def main():
                 name = max(scan, key=lambda k: scan[k]["total_ms"])
                 k = kernels[name]
                 ach = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9
+                # HBM bytes per launch from the PMC counters of this very command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+                # separate --pmc passes; MI355X_MICROARCH.md "HBM"): measured offline, committed under profiles/
+                traffic = None
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                    traffic = tj.get(name + "_lean_kernel", {}).get("hbm_bytes_per_launch")
+                except Exception:      # noqa: BLE001
+                    pass
                 roof = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, launches=k["launches"],
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, launches=k["launches"],
                             avg_launch_us=round(k["avg_us"], 2),
                             algorithmic_bytes_per_launch=int(k["bytes"] / k["launches"]))
         line = {
