@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--model", default="tiny", choices=["tiny", "small", "base"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--ss2d", default=None, choices=["fused", "unfused"])
+    ap.add_argument("--stream", default=None, choices=["tokens", "planes"], help="residual-stream layout of the trunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--drop-path", type=float, default=None, help="override the reference's DropPath rates (e.g. 0)")
@@ -99,6 +100,8 @@ def main():
     _lib.lib()                                                   # fail loudly if the HIP extension is missing
     if a.ss2d:
         fusion_vmamba.SS2D_MODE = a.ss2d
+    if a.stream:
+        fusion_vmamba.STREAM_LAYOUT = a.stream
 
     if not a.no_miopen_find:
         torch.backends.cudnn.benchmark = True

@@ -72,6 +72,49 @@ def test_blocks_match_reference_golden(tag, training, mode):
         fv.SS2D_MODE = old
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,H", [(96, 56), (192, 28), (384, 14), (768, 7)])
+def test_vss_stage_tokens_stream_matches_planes_and_oracle(C, H, dt):
+    """Two VSSBlocks (DropPath off) at a trunk width: the token-major stream (row LayerNorm + batched-GEMM layout
+    changes) vs the NCHW module path vs the CPU oracle -- output, input gradient, every parameter gradient."""
+    from xfmamba_amd import fusion_vmamba as fv
+    torch.manual_seed(C)
+    blocks = torch.nn.Sequential(*[
+        fv.VSSBlock(hidden_dim=C, drop_path=0.0, norm_layer=fv.LayerNorm2d, channel_first=True, ssm_d_state=1,
+                    ssm_ratio=1.0, ssm_dt_rank="auto", ssm_conv=3, ssm_conv_bias=False, ssm_init="v0",
+                    forward_type="v05_noz", mlp_ratio=4.0) for _ in range(2)]).to(DEV).train()
+    x = torch.randn(2, C, H, H, device=DEV)
+    gy = torch.randn(2, C, H, H, device=DEV)
+    res = {}
+    old = fv.STREAM_LAYOUT
+    try:
+        for layout in ("planes", "tokens"):
+            fv.STREAM_LAYOUT = layout
+            blocks.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+                y = fv._run_blocks(blocks, xi)
+            y.float().backward(gy)
+            res[layout] = (y.detach().float().cpu(), xi.grad.cpu(),
+                           {k: p.grad.detach().cpu().clone() for k, p in blocks.named_parameters()})
+    finally:
+        fv.STREAM_LAYOUT = old
+    sd = {f"b.{k}": v.detach().cpu() for k, v in blocks.state_dict().items()}
+    xr = x.cpu().clone().requires_grad_()
+    pr = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    yr = xr
+    for i in range(2):
+        yr = O.vss_block_ref(pr, f"b.{i}.", yr)
+    yr.backward(gy.cpu())
+    tol = 1e-3 if dt == torch.float32 else 2e-2
+    for layout in ("planes", "tokens"):
+        y, dx, grads = res[layout]
+        assert_close(y, yr.detach(), tol, tol * float(yr.abs().max()), f"{layout} y")
+        assert_close(dx, xr.grad, tol, tol * float(xr.grad.abs().max()), f"{layout} dx")
+        for k, gref in ((k, pr[f"b.{k}"].grad) for k in grads):
+            assert_close(grads[k], gref, 5 * tol, 2 * tol * float(gref.abs().max()) + 1e-7, f"{layout} d{k}")
+
+
 def _tiny_with_synth_weights():
     from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
     shapes = load_json("g5_state_shapes.json")["tiny"]
@@ -80,15 +123,15 @@ def _tiny_with_synth_weights():
     return m.to(DEV)
 
 
-@pytest.mark.parametrize("mode", ["unfused", "fused"])
+@pytest.mark.parametrize("mode,layout", [("unfused", "planes"), ("fused", "planes"), ("fused", "tokens")])
 @pytest.mark.parametrize("merge_views", [True, False])
-def test_model_tiny_fp32_matches_reference_golden(mode, merge_views):
+def test_model_tiny_fp32_matches_reference_golden(mode, layout, merge_views):
     """BASELINE config 0 (XFMamba-T, 2x224^2, batch 2, fp32): logits, loss, every parameter gradient."""
     from xfmamba_amd import fusion_vmamba as fv
     z = load_npz("g5_model.npz")
     names = load_json("g5_grad_names.json")
-    old = fv.SS2D_MODE
-    fv.SS2D_MODE = mode
+    old, old_layout = fv.SS2D_MODE, fv.STREAM_LAYOUT
+    fv.SS2D_MODE, fv.STREAM_LAYOUT = mode, layout
     try:
         m = _tiny_with_synth_weights()
         m.merge_views = merge_views
@@ -120,7 +163,7 @@ def test_model_tiny_fp32_matches_reference_golden(mode, merge_views):
             if k.startswith("bn_after/"):
                 assert_close(m.state_dict()[k[9:]].cpu(), torch.from_numpy(z[k]), 1e-4, 1e-5, k)
     finally:
-        fv.SS2D_MODE = old
+        fv.SS2D_MODE, fv.STREAM_LAYOUT = old, old_layout
 
 
 def test_model_tiny_bf16_autocast_within_tolerance():

@@ -314,3 +314,123 @@ def test_layernorm2d_matches_torch_fp32(shape, xdt, ydt):
     assert_close(xd.grad.float().cpu(), xr.grad, tol, tol * float(xr.grad.abs().max()), "dx")
     assert_close(wd.grad.cpu(), wr.grad, tol, tol * float(wr.grad.abs().max()), "dw")
     assert_close(bd.grad.cpu(), br.grad, tol, tol * float(br.grad.abs().max()), "db")
+
+
+@pytest.mark.parametrize("C", [48, 96, 192, 384, 768, 64, 1024])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["plain", "add", "add_scale"])
+def test_add_layernorm_rows_matches_torch_fp32(C, dt, mode):
+    """x + drop_path(y) followed by LayerNorm (reference fusion_vmamba.py:1325-1337) on the token-major stream vs
+    plain PyTorch fp32: both outputs, both input gradients, dw/db; ragged row count (rows % rows-per-wave != 0)."""
+    from xfmamba_amd.rowln import add_layernorm_rows_fn, layernorm_rows_fn
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C)
+    B, H, W = 3, 5, 7
+    x = torch.randn(B, H, W, C, generator=g) * 2 + 0.5
+    y = torch.randn(B, H, W, C, generator=g).to(dt)
+    sc = torch.tensor([0.0, 1.25, 1.25]) if mode == "add_scale" else None
+    w = 1 + 0.2 * torch.randn(C, generator=g)
+    b = 0.1 * torch.randn(C, generator=g)
+    gh = torch.randn(B, H, W, C, generator=g).to(dt)
+    gres = torch.randn(B, H, W, C, generator=g)
+    xr, yr = x.clone().requires_grad_(), y.float().clone().requires_grad_()
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    sr = xr if mode == "plain" else xr + (yr if sc is None else yr * sc.view(B, 1, 1, 1))
+    hr = F.layer_norm(sr, (C,), wr, br, 1e-5)
+    ((hr * gh.float()).sum() + (0 if mode == "plain" else (sr * gres).sum())).backward()
+    xd, yd = x.to(DEV).requires_grad_(), y.to(DEV).requires_grad_()
+    wd, bd = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    if mode == "plain":
+        h = layernorm_rows_fn(xd, wd, bd, 1e-5, dt)
+        (h.float() * gh.to(DEV).float()).sum().backward()
+    else:
+        xn, h = add_layernorm_rows_fn(xd, yd, None if sc is None else sc.to(DEV), wd, bd, 1e-5, dt)
+        assert xn.dtype == torch.float32
+        assert_close(xn.detach().cpu(), sr.detach(), 1e-6, 1e-6, "x_new")
+        ((h.float() * gh.to(DEV).float()).sum() + (xn * gres.to(DEV)).sum()).backward()
+    tol = 1e-3 if dt == torch.float32 else 1e-2
+    assert h.dtype == dt
+    assert_close(h.float().cpu(), hr.detach(), tol, tol * float(hr.abs().max()), "h")
+    assert_close(xd.grad.cpu(), xr.grad, tol, tol * float(xr.grad.abs().max()), "dx")
+    if mode != "plain":
+        assert yd.grad.dtype == dt
+        assert_close(yd.grad.float().cpu(), yr.grad, tol, tol * float(yr.grad.abs().max()), "dy")
+    assert_close(wd.grad.cpu(), wr.grad, tol, tol * float(wr.grad.abs().max()), "dw")
+    assert_close(bd.grad.cpu(), br.grad, tol, tol * float(br.grad.abs().max()), "db")
+
+
+def test_add_layernorm_rows_many_rows_and_unsupported_width():
+    """Grid-stride path (more row groups than workgroups in the backward) and the loud failure for other widths."""
+    from xfmamba_amd.rowln import layernorm_rows_fn, rows_supported
+    import torch.nn.functional as F
+    C = 96
+    x = torch.randn(8, 112, 112, C, device=DEV)
+    w = (1 + 0.1 * torch.randn(C, device=DEV)).requires_grad_()
+    b = torch.zeros(C, device=DEV).requires_grad_()
+    xr = x.clone().requires_grad_()
+    xd = x.clone().requires_grad_()
+    gh = torch.randn_like(x)
+    h = layernorm_rows_fn(xd, w, b, 1e-5, torch.float32)
+    h.backward(gh)
+    dw, db = w.grad.clone(), b.grad.clone()
+    w.grad = b.grad = None
+    hr = F.layer_norm(xr, (C,), w, b, 1e-5)
+    hr.backward(gh)
+    assert_close(h.detach().cpu(), hr.detach().cpu(), 1e-4, 1e-4, "h")
+    assert_close(xd.grad.cpu(), xr.grad.cpu(), 1e-3, 1e-4, "dx")
+    assert_close(dw.cpu(), w.grad.cpu(), 1e-3, 1e-3 * float(w.grad.abs().max()), "dw")
+    assert_close(db.cpu(), b.grad.cpu(), 1e-3, 1e-3 * float(b.grad.abs().max()), "db")
+    assert not rows_supported(100)
+    with pytest.raises(RuntimeError):
+        layernorm_rows_fn(torch.randn(2, 3, 100, device=DEV), torch.ones(100, device=DEV), None)
+
+
+@pytest.mark.parametrize("rows,C", [(37, 384), (3 * 56 * 56, 384), (1000, 768), (64, 3072), (5, 40), (70000, 96)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_bias_gelu_and_colsum_match_torch_fp32(rows, C, dt):
+    """fc1 bias + exact GELU (reference Mlp, fusion_vmamba.py:135-153) and the bias-gradient column sums."""
+    from xfmamba_amd.mlp_tokens import bias_gelu_fn, colsum_fn
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(rows + C)
+    z = (torch.randn(rows, C, generator=g) * 1.5).to(dt)
+    b = 0.3 * torch.randn(C, generator=g)
+    gy = torch.randn(rows, C, generator=g).to(dt)
+    zr, br = z.float().clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.gelu(zr + br)
+    yr.backward(gy.float())
+    zd, bd = z.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = bias_gelu_fn(zd, bd)
+    y.backward(gy.to(DEV))
+    tol = 1e-3 if dt == torch.float32 else 1e-2
+    assert y.dtype == dt and zd.grad.dtype == dt
+    assert_close(y.float().cpu(), yr.detach(), tol, tol * float(yr.abs().max()), "gelu")
+    assert_close(zd.grad.float().cpu(), zr.grad, tol, tol * float(zr.grad.abs().max()), "dz")
+    assert_close(bd.grad.cpu(), br.grad, tol, tol * float(br.grad.abs().max()) * (1 if dt == torch.float32 else 3), "db")
+    cs = colsum_fn(z.to(DEV))
+    ref = z.double().sum(0)
+    assert_close(cs.cpu(), ref, 1e-4, 1e-4 * float(z.float().abs().sum(0).max()), "colsum")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_mlp_tokens_matches_torch_fp32(dt):
+    from xfmamba_amd.mlp_tokens import mlp_tokens_fn
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    B, H, W, C = 2, 14, 14, 96
+    x = torch.randn(B, H, W, C, generator=g)
+    w1, b1 = 0.1 * torch.randn(4 * C, C, generator=g), 0.1 * torch.randn(4 * C, generator=g)
+    w2, b2 = 0.1 * torch.randn(C, 4 * C, generator=g), 0.1 * torch.randn(C, generator=g)
+    gy = torch.randn(B, H, W, C, generator=g)
+    ref = [t.clone().requires_grad_() for t in (x, w1, b1, w2, b2)]
+    yr = F.linear(F.gelu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])
+    yr.backward(gy)
+    dev = [t.to(DEV).requires_grad_() for t in (x, w1, b1, w2, b2)]
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+        y = mlp_tokens_fn(dev[0].to(dt), *dev[1:])
+    y.float().backward(gy.to(DEV))
+    tol = 1e-3 if dt == torch.float32 else 1e-2
+    assert y.dtype == dt
+    assert_close(y.float().cpu(), yr.detach(), tol, tol * float(yr.abs().max()), "y")
+    for name, a, r in zip(("dx", "dw1", "db1", "dw2", "db2"), dev, ref):
+        assert a.grad.dtype == torch.float32
+        assert_close(a.grad.cpu(), r.grad, tol, 2 * tol * float(r.grad.abs().max()), name)

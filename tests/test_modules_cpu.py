@@ -69,3 +69,38 @@ def test_modules_refuse_cpu_tensors():
     m = TwoViewXFMambaTop(in_channels=1, outputs=2, type="tiny").eval()
     with pytest.raises(RuntimeError, match="no CPU path"), torch.no_grad():
         m(torch.randn(1, 1, 64, 64), torch.randn(1, 1, 64, 64))
+
+
+@pytest.mark.parametrize("in_tokens,out_tokens", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_batched_proj_layouts(in_tokens, out_tokens, bias):
+    """1x1 projection with token- / plane-major operands on either side == einsum over channels (value and grads)."""
+    from xfmamba_amd.proj import batched_proj
+    g = torch.Generator().manual_seed(3)
+    B, L, K, M = 3, 10, 6, 5
+    xp = torch.randn(B, K, L, generator=g, dtype=torch.float64)
+    w = torch.randn(M, K, generator=g, dtype=torch.float64, requires_grad=True)
+    bb = torch.randn(M, generator=g, dtype=torch.float64, requires_grad=True) if bias else None
+    x = (xp.transpose(1, 2).contiguous() if in_tokens else xp.clone()).requires_grad_()
+    y = batched_proj(x, w, bb, in_tokens=in_tokens, out_tokens=out_tokens)
+    xr = xp.clone().requires_grad_()
+    wr = w.detach().clone().requires_grad_()
+    br = bb.detach().clone().requires_grad_() if bias else None
+    yr = torch.einsum("mk,bkl->bml", wr, xr) + (br[None, :, None] if bias else 0)
+    gy = torch.randn(B, M, L, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    y.backward(gy.transpose(1, 2) if out_tokens else gy)
+    assert y.shape == ((B, L, M) if out_tokens else (B, M, L)) and y.is_contiguous()
+    torch.testing.assert_close(y.transpose(1, 2) if out_tokens else y, yr)
+    torch.testing.assert_close(x.grad.transpose(1, 2) if in_tokens else x.grad, xr.grad)
+    torch.testing.assert_close(w.grad, wr.grad)
+    if bias:
+        torch.testing.assert_close(bb.grad, br.grad)
+
+
+def test_drop_path_sample_scale_matches_forward_distribution():
+    from xfmamba_amd.fusion_vmamba import DropPath
+    dp = DropPath(0.25).train()
+    s = dp.sample_scale(4000, "cpu")
+    assert all(min(abs(v), abs(v - 1 / 0.75)) < 1e-6 for v in s.unique().tolist()) and abs(float(s.mean()) - 1.0) < 0.05
+    assert dp.eval().sample_scale(8, "cpu") is None and DropPath(0.0).train().sample_scale(8, "cpu") is None

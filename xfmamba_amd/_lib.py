@@ -21,7 +21,10 @@ _DT = {torch.float32: XFM_F32, torch.float16: XFM_F16, torch.bfloat16: XFM_BF16}
 SYMBOLS = (
     "xfm_abi_version", "xfm_strerror", "xfm_last_hip_error", "xfm_scan_plan",
     "xfm_selective_scan_fwd", "xfm_selective_scan_bwd", "xfm_cross_scan", "xfm_cross_merge",
-    "xfm_swap_scan", "xfm_dwconv3x3_fwd", "xfm_dwconv3x3_bwd", "xfm_layernorm2d_fwd", "xfm_layernorm2d_bwd", "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd",
+    "xfm_swap_scan", "xfm_dwconv3x3_fwd", "xfm_dwconv3x3_bwd", "xfm_layernorm2d_fwd", "xfm_layernorm2d_bwd",
+    "xfm_add_layernorm_rows_supported", "xfm_add_layernorm_rows_bwd_blocks", "xfm_add_layernorm_rows_fwd",
+    "xfm_add_layernorm_rows_bwd", "xfm_colsum_blocks", "xfm_bias_gelu_fwd", "xfm_bias_gelu_bwd", "xfm_colsum",
+    "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd",
 )
 
 
@@ -95,6 +98,14 @@ def lib() -> C.CDLL:
         l.xfm_dwconv3x3_bwd.argtypes = [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_void_p]
         l.xfm_layernorm2d_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_float] + [C.c_int] * 2 + [C.c_void_p]
         l.xfm_layernorm2d_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_void_p]
+        l.xfm_add_layernorm_rows_supported.argtypes = [C.c_int]
+        l.xfm_add_layernorm_rows_bwd_blocks.argtypes = [C.c_int, C.c_int]
+        l.xfm_add_layernorm_rows_fwd.argtypes = [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]
+        l.xfm_add_layernorm_rows_bwd.argtypes = [C.c_void_p] * 12 + [C.c_int] * 4 + [C.c_void_p]
+        l.xfm_colsum_blocks.argtypes = [C.c_longlong, C.c_int, C.c_int]
+        l.xfm_bias_gelu_fwd.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]
+        l.xfm_bias_gelu_bwd.argtypes = [C.c_void_p] * 6 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]
+        l.xfm_colsum.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]
         if l.xfm_abi_version() != 1:
             raise RuntimeError("xfmamba_amd: libxfm_hip.so ABI version mismatch")
         _lib = l

@@ -1,0 +1,339 @@
+// Residual add + DropPath scale + LayerNorm over the channels of a TOKEN-MAJOR (B, H*W, C) stream, one kernel.
+//
+//     x_new = x + scale[b] * y          (the `x = x + self.drop_path(branch)` of VSSBlock._forward,
+//     h     = LayerNorm_C(x_new) * w + b       models/fusion_vmamba.py:1325-1337, fused with the norm that follows)
+//
+// The residual stream x is fp32; y (branch output), h (input of the next GEMM) and their gradients are in the GEMM
+// dtype.  A row of C = 4*G*NV channels is owned by G lanes holding NV float4 each, so a wavefront works on 64/G rows
+// with fully coalesced 16-byte accesses and the row statistics are reduced with cross-lane shuffles only.
+// HBM-bound: fwd reads 4+2 B and writes 4+2 B per element, bwd reads 4+4+2 B and writes 4+2 B.
+#include "xfm_common.hpp"
+
+namespace xfm {
+
+template <typename T> struct Vec4IO;
+template <> struct Vec4IO<float> {
+    static __device__ __forceinline__ float4 ld(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void st(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct Vec4IO<bf16_t> {
+    static __device__ __forceinline__ float4 ld(const bf16_t *p) {
+        const uint2 r = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ uint32_t rne(float f) {     // fp32 -> bf16 bits, round to nearest even
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    static __device__ __forceinline__ void st(bf16_t *p, float4 v) {
+        uint2 r;
+        r.x = rne(v.x) | (rne(v.y) << 16);
+        r.y = rne(v.z) | (rne(v.w) << 16);
+        *reinterpret_cast<uint2 *>(p) = r;
+    }
+};
+
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+struct RowLnArgs {
+    const float *x;         // (rows, C) residual stream in
+    const void *y;          // (rows, C) branch output or null
+    const float *scale;     // (B) per-sample DropPath factor or null
+    const float *w, *b;     // (C); b may be null
+    float *x_new;           // (rows, C) residual stream out (null when y is null: x passes through)
+    void *h;                // (rows, C) normalised output
+    float *mean, *rstd;     // (rows)
+    // backward
+    const void *dh;         // (rows, C)
+    const float *dres;      // (rows, C) gradient arriving on x_new from later consumers, or null
+    float *dx;              // (rows, C) gradient of x (and of x_new)
+    void *dy;               // (rows, C) gradient of y, or null
+    float *part;            // (nblk, 2, C) per-workgroup partial dw / db
+    int rows, rows_per_sample, C;
+    float eps;
+};
+
+template <typename Ty, int G, int NV> __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % G, rsub = lane / G;
+    const int C = a.C;
+    float4 w[NV], bb[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = (k * G + sub) * 4;
+        w[k] = Vec4IO<float>::ld(a.w + c);
+        bb[k] = a.b ? Vec4IO<float>::ld(a.b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const Ty *y = static_cast<const Ty *>(a.y);
+    Ty *h = static_cast<Ty *>(a.h);
+    const float invC = 1.0f / (float)C;
+    for (long rg = (long)blockIdx.x * 4 + wave; rg * RPW < a.rows; rg += (long)gridDim.x * 4) {
+        const long row = rg * RPW + rsub;
+        const bool live = row < a.rows;
+        const long r = live ? row : a.rows - 1;
+        float4 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = Vec4IO<float>::ld(a.x + r * C + (k * G + sub) * 4);
+        if (y) {
+            const float s = a.scale ? a.scale[r / a.rows_per_sample] : 1.0f;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const float4 t = Vec4IO<Ty>::ld(y + r * C + (k * G + sub) * 4);
+                v[k].x = fmaf(s, t.x, v[k].x);
+                v[k].y = fmaf(s, t.y, v[k].y);
+                v[k].z = fmaf(s, t.z, v[k].z);
+                v[k].w = fmaf(s, t.w, v[k].w);
+                if (live) Vec4IO<float>::st(a.x_new + r * C + (k * G + sub) * 4, v[k]);
+            }
+        }
+        float s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s1 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        const float mu = group_sum<G>(s1) * invC;
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            v[k].x -= mu; v[k].y -= mu; v[k].z -= mu; v[k].w -= mu;
+            s2 += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+        }
+        const float rs = rsqrtf(group_sum<G>(s2) * invC + a.eps);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                float4 o;
+                o.x = fmaf(v[k].x * rs, w[k].x, bb[k].x);
+                o.y = fmaf(v[k].y * rs, w[k].y, bb[k].y);
+                o.z = fmaf(v[k].z * rs, w[k].z, bb[k].z);
+                o.w = fmaf(v[k].w * rs, w[k].w, bb[k].w);
+                Vec4IO<Ty>::st(h + r * C + (k * G + sub) * 4, o);
+            }
+            if (sub == 0) {
+                a.mean[r] = mu;
+                a.rstd[r] = rs;
+            }
+        }
+    }
+}
+
+// dx = rstd * (g - mean_C(g) - xhat * mean_C(g * xhat)) + dres,  g = dh * w;  dy = scale[b] * dx.
+// dw / db column sums: per-lane accumulators over the rows a workgroup walks, folded across the workgroup through
+// LDS and written as one partial row per workgroup (summed by rowln_wb_kernel: deterministic, no atomics).
+template <typename Ty, int G, int NV> __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnArgs a) {
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % G, rsub = lane / G;
+    const int C = a.C;
+    float4 w[NV], aw[NV], ab[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        w[k] = Vec4IO<float>::ld(a.w + (k * G + sub) * 4);
+        aw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const Ty *dh = static_cast<const Ty *>(a.dh);
+    Ty *dy = static_cast<Ty *>(a.dy);
+    const float *xin = a.x;                 // x_new saved by the forward
+    const float invC = 1.0f / (float)C;
+    for (long rg = (long)blockIdx.x * 4 + wave; rg * RPW < a.rows; rg += (long)gridDim.x * 4) {
+        const long row = rg * RPW + rsub;
+        const bool live = row < a.rows;
+        const long r = live ? row : a.rows - 1;
+        const float mu = a.mean[r], rs = a.rstd[r];
+        float4 xh[NV], g[NV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const long off = r * C + (k * G + sub) * 4;
+            const float4 xv = Vec4IO<float>::ld(xin + off);
+            float4 d = Vec4IO<Ty>::ld(dh + off);
+            if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            aw[k].x = fmaf(d.x, xh[k].x, aw[k].x); aw[k].y = fmaf(d.y, xh[k].y, aw[k].y);
+            aw[k].z = fmaf(d.z, xh[k].z, aw[k].z); aw[k].w = fmaf(d.w, xh[k].w, aw[k].w);
+            ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
+            g[k] = make_float4(d.x * w[k].x, d.y * w[k].y, d.z * w[k].z, d.w * w[k].w);
+            c1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+            c2 += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+        }
+        c1 = group_sum<G>(c1) * invC;
+        c2 = group_sum<G>(c2) * invC;
+        const float s = (dy && a.scale) ? a.scale[r / a.rows_per_sample] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const long off = r * C + (k * G + sub) * 4;
+            float4 o;
+            o.x = rs * (g[k].x - c1 - xh[k].x * c2);
+            o.y = rs * (g[k].y - c1 - xh[k].y * c2);
+            o.z = rs * (g[k].z - c1 - xh[k].z * c2);
+            o.w = rs * (g[k].w - c1 - xh[k].w * c2);
+            if (a.dres) {
+                const float4 e = Vec4IO<float>::ld(a.dres + off);
+                o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+            }
+            if (live) {
+                Vec4IO<float>::st(a.dx + off, o);
+                if (dy) Vec4IO<Ty>::st(dy + off, make_float4(o.x * s, o.y * s, o.z * s, o.w * s));
+            }
+        }
+    }
+    // fold the RPW row slots of the wave (lanes with equal `sub`), then the 4 waves through LDS
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+#pragma unroll
+        for (int m = G; m < 64; m <<= 1) {
+            aw[k].x += __shfl_xor(aw[k].x, m, 64); aw[k].y += __shfl_xor(aw[k].y, m, 64);
+            aw[k].z += __shfl_xor(aw[k].z, m, 64); aw[k].w += __shfl_xor(aw[k].w, m, 64);
+            ab[k].x += __shfl_xor(ab[k].x, m, 64); ab[k].y += __shfl_xor(ab[k].y, m, 64);
+            ab[k].z += __shfl_xor(ab[k].z, m, 64); ab[k].w += __shfl_xor(ab[k].w, m, 64);
+        }
+    }
+    __shared__ float red[4][2][4 * G * NV];         // [wave][dw|db][channel], C = 4*G*NV
+    if (rsub == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (k * G + sub) * 4;
+            *reinterpret_cast<float4 *>(&red[wave][0][c]) = aw[k];
+            *reinterpret_cast<float4 *>(&red[wave][1][c]) = ab[k];
+        }
+    }
+    __syncthreads();
+    float *part = a.part + (long)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        part[i] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+// dw[c] = sum over workgroups of part[., 0, c]; db likewise.  64 columns (of the 2*C) x 16 row slots per workgroup.
+__global__ __launch_bounds__(1024) void rowln_wb_kernel(const float *part, float *dw, float *db, int nblk, int C) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < 2 * C) {
+        int j = slot;
+        for (; j + 16 < nblk; j += 32) {
+            s0 += part[(long)j * 2 * C + i];
+            s1 += part[(long)(j + 16) * 2 * C + i];
+        }
+        if (j < nblk) s0 += part[(long)j * 2 * C + i];
+    }
+    red[slot][lane] = s0 + s1;
+    __syncthreads();
+    if (slot == 0 && i < 2 * C) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][lane];
+        if (i < C) dw[i] = s;
+        else if (db) db[i - C] = s;
+    }
+}
+
+static bool pick_shape(int C, int &G, int &NV) {
+    for (int nv : {3, 4}) {
+        for (int g : {4, 8, 16, 32, 64}) {
+            if (4 * g * nv == C) {
+                G = g;
+                NV = nv;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+static int fwd_blocks(int rows, int G) {
+    const long rgs = ((long)rows * G + 63) / 64;
+    long nb = (rgs + 3) / 4;
+    if (nb > 8192) nb = 8192;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+template <typename Ty, int NV> static int launch(bool bwd, int G, const RowLnArgs &a, int nblk, hipStream_t s) {
+#define XFM_ROWLN_CASE(GG)                                                                                   \
+    case GG:                                                                                                   \
+        if (bwd) hipLaunchKernelGGL((rowln_bwd_kernel<Ty, GG, NV>), dim3(nblk), dim3(256), 0, s, a);            \
+        else hipLaunchKernelGGL((rowln_fwd_kernel<Ty, GG, NV>), dim3(nblk), dim3(256), 0, s, a);                \
+        break;
+    switch (G) {
+        XFM_ROWLN_CASE(4)
+        XFM_ROWLN_CASE(8)
+        XFM_ROWLN_CASE(16)
+        XFM_ROWLN_CASE(32)
+        XFM_ROWLN_CASE(64)
+    default: return XFM_ELIMIT;
+    }
+#undef XFM_ROWLN_CASE
+    return check_launch();
+}
+
+template <typename Ty> static int launch_nv(bool bwd, int G, int NV, const RowLnArgs &a, int nblk, hipStream_t s) {
+    return NV == 3 ? launch<Ty, 3>(bwd, G, a, nblk, s) : launch<Ty, 4>(bwd, G, a, nblk, s);
+}
+
+}  // namespace xfm
+
+extern "C" {
+
+int xfm_add_layernorm_rows_supported(int C) {
+    int G, NV;
+    return xfm::pick_shape(C, G, NV) ? 1 : 0;
+}
+
+int xfm_add_layernorm_rows_bwd_blocks(int rows, int C) {
+    int G, NV;
+    if (!xfm::pick_shape(C, G, NV) || rows <= 0) return 0;
+    const int nb = xfm::fwd_blocks(rows, G);
+    return nb > 512 ? 512 : nb;
+}
+
+int xfm_add_layernorm_rows_fwd(const float *x, const void *y, const float *scale, const float *weight, const float *bias,
+                               float *x_new, void *h, float *mean, float *rstd, int B, int rows_per_sample, int C,
+                               float eps, int dtype, void *stream) {
+    using namespace xfm;
+    if (!x || !weight || !h || !mean || !rstd || B <= 0 || rows_per_sample <= 0 || C <= 0) return XFM_EINVAL;
+    if (y && !x_new) return XFM_EINVAL;
+    int G, NV;
+    if (!pick_shape(C, G, NV)) return XFM_ELIMIT;
+    RowLnArgs a{};
+    a.x = x; a.y = y; a.scale = scale; a.w = weight; a.b = bias; a.x_new = x_new; a.h = h; a.mean = mean; a.rstd = rstd;
+    a.rows = B * rows_per_sample; a.rows_per_sample = rows_per_sample; a.C = C; a.eps = eps;
+    const int nblk = fwd_blocks(a.rows, G);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == XFM_F32) return launch_nv<float>(false, G, NV, a, nblk, s);
+    if (dtype == XFM_BF16) return launch_nv<bf16_t>(false, G, NV, a, nblk, s);
+    return XFM_EDTYPE;
+}
+
+int xfm_add_layernorm_rows_bwd(const float *x_new, const float *weight, const void *dh, const float *dres,
+                               const float *mean, const float *rstd, const float *scale, float *dx, void *dy,
+                               float *dweight, float *dbias, float *workspace, int B, int rows_per_sample, int C,
+                               int dtype, void *stream) {
+    using namespace xfm;
+    if (!x_new || !weight || !dh || !mean || !rstd || !dx || !dweight || !workspace || B <= 0 || rows_per_sample <= 0)
+        return XFM_EINVAL;
+    int G, NV;
+    if (!pick_shape(C, G, NV)) return XFM_ELIMIT;
+    RowLnArgs a{};
+    a.x = x_new; a.w = weight; a.dh = dh; a.dres = dres; a.mean = const_cast<float *>(mean); a.rstd = const_cast<float *>(rstd); a.scale = scale; a.dx = dx;
+    a.dy = dy; a.part = workspace;
+    a.rows = B * rows_per_sample; a.rows_per_sample = rows_per_sample; a.C = C;
+    const int nblk = xfm_add_layernorm_rows_bwd_blocks(a.rows, C);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (dtype == XFM_F32) rc = launch_nv<float>(true, G, NV, a, nblk, s);
+    else if (dtype == XFM_BF16) rc = launch_nv<bf16_t>(true, G, NV, a, nblk, s);
+    else return XFM_EDTYPE;
+    if (rc != XFM_OK) return rc;
+    hipLaunchKernelGGL(rowln_wb_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, s, workspace, dweight, dbias, nblk, C);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+// Element-wise pieces of the Mlp on the token-major stream (models/fusion_vmamba.py:135-153:
+// fc1 -> act -> drop -> fc2 -> drop) that sit between the library GEMMs:
+//
+//   bias_gelu fwd :  g  = gelu(z + b)                      (z = x @ W1^T from the GEMM, exact erf GELU = nn.GELU())
+//   bias_gelu bwd :  dz = dg * gelu'(z + b),  db = column sums of dz      (one pass; no separate bias reduction)
+//   colsum        :  out[c] = sum over rows of x[., c]      (fc2 / generic bias gradients)
+//
+// (rows, C) row-major; one thread owns one 16-byte channel group and walks rows, so the column sums stay in
+// registers; a workgroup is NT = C / VEC threads wide and R rows deep.  Column sums leave the kernel as one
+// partial row per workgroup and are folded by colsum_finish_kernel (deterministic, no atomics).
+// HBM-bound: 2 tensor passes forward, 3 backward.
+#include "xfm_common.hpp"
+
+namespace xfm {
+
+template <typename T> struct Pack;           // 16-byte vector of T  <->  fp32 lanes
+template <> struct Pack<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void ld(const float *p, float *v) {
+        const float4 r = *reinterpret_cast<const float4 *>(p);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+    static __device__ __forceinline__ void st(float *p, const float *v) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Pack<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void ld(const bf16_t *p, float *v) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(p);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ uint32_t rne(float f) {
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    static __device__ __forceinline__ void st(bf16_t *p, const float *v) {
+        uint4 r;
+        r.x = rne(v[0]) | (rne(v[1]) << 16);
+        r.y = rne(v[2]) | (rne(v[3]) << 16);
+        r.z = rne(v[4]) | (rne(v[5]) << 16);
+        r.w = rne(v[6]) | (rne(v[7]) << 16);
+        *reinterpret_cast<uint4 *>(p) = r;
+    }
+};
+
+constexpr float kInvSqrt2 = 0.70710678118654752f;
+constexpr float kInvSqrt2Pi = 0.3989422804014327f;
+
+struct TokArgs {
+    const void *z;        // (rows, C)
+    const float *bias;    // (C) or null
+    const void *dg;       // (rows, C) backward only
+    void *out;            // g (fwd) / dz (bwd); null for colsum
+    float *part;          // (gridDim.x, C) partial column sums (bwd / colsum)
+    long rows;
+    int C, NT, R;         // NT = C / VEC threads per row, R rows per workgroup pass
+};
+
+// MODE 0: bias_gelu fwd, 1: bias_gelu bwd (+ column sums of dz), 2: column sums of z
+template <typename T, int MODE> __global__ void tokens_kernel(TokArgs a) {
+    constexpr int V = Pack<T>::N;
+    extern __shared__ float red[];                 // (R, C) for the column sums
+    const int t = threadIdx.x % a.NT, rs = threadIdx.x / a.NT;
+    const int c0 = t * V;
+    float b[V], acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        b[i] = (MODE != 2 && a.bias) ? a.bias[c0 + i] : 0.f;
+        acc[i] = 0.f;
+    }
+    const T *z = static_cast<const T *>(a.z);
+    const T *dg = static_cast<const T *>(a.dg);
+    T *out = static_cast<T *>(a.out);
+    for (long r = (long)blockIdx.x * a.R + rs; r < a.rows; r += (long)gridDim.x * a.R) {
+        const long off = r * a.C + c0;
+        float v[V], o[V];
+        Pack<T>::ld(z + off, v);
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float u = v[i] + b[i];
+                o[i] = 0.5f * u * (1.0f + erff(u * kInvSqrt2));
+            }
+            Pack<T>::st(out + off, o);
+        } else if (MODE == 1) {
+            float d[V];
+            Pack<T>::ld(dg + off, d);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float u = v[i] + b[i];
+                const float cdf = 0.5f * (1.0f + erff(u * kInvSqrt2));
+                const float pdf = kInvSqrt2Pi * __expf(-0.5f * u * u);
+                o[i] = d[i] * fmaf(u, pdf, cdf);
+                acc[i] += o[i];
+            }
+            Pack<T>::st(out + off, o);
+        } else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] += v[i];
+        }
+    }
+    if (MODE != 0) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) red[rs * a.C + c0 + i] = acc[i];
+        __syncthreads();
+        float *part = a.part + (long)blockIdx.x * a.C;
+        for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+            float s = 0.f;
+            for (int j = 0; j < a.R; ++j) s += red[j * a.C + c];
+            part[c] = s;
+        }
+    }
+}
+
+// out[c] = sum_j part[j, c].  64 channels x 16 row slots per workgroup: the slots stride through the partial rows
+// (coalesced 256-byte reads, independent loads in flight), then fold through LDS.
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float *part, float *out, int nblk, int C) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        int j = slot;
+        for (; j + 16 < nblk; j += 32) {
+            s0 += part[(long)j * C + c];
+            s1 += part[(long)(j + 16) * C + c];
+        }
+        if (j < nblk) s0 += part[(long)j * C + c];
+    }
+    red[slot][lane] = s0 + s1;
+    __syncthreads();
+    if (slot == 0 && c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][lane];
+        out[c] = s;
+    }
+}
+
+struct TokShape {
+    int NT, R, threads, nblk;
+};
+
+static bool tok_shape(long rows, int C, int vec, bool reduce, TokShape &s) {
+    if (rows <= 0 || C <= 0 || C % vec != 0) return false;
+    s.NT = C / vec;
+    if (s.NT > 1024) return false;
+    s.R = 256 / s.NT;
+    if (s.R < 1) s.R = 1;
+    s.threads = s.NT * s.R;
+    if (reduce && (long)s.R * C * 4 > 64 * 1024) return false;
+    long nb = (rows + s.R - 1) / s.R;
+    const long cap = reduce ? 512 : 16384;
+    s.nblk = (int)(nb > cap ? cap : nb);
+    return true;
+}
+
+template <typename T, int MODE> static int tok_launch(const TokArgs &a0, hipStream_t s) {
+    TokShape sh;
+    if (!tok_shape(a0.rows, a0.C, Pack<T>::N, MODE != 0, sh)) return XFM_ELIMIT;
+    TokArgs a = a0;
+    a.NT = sh.NT;
+    a.R = sh.R;
+    const size_t lds = MODE != 0 ? (size_t)sh.R * a.C * sizeof(float) : 0;
+    hipLaunchKernelGGL((tokens_kernel<T, MODE>), dim3(sh.nblk), dim3(sh.threads), lds, s, a);
+    return check_launch();
+}
+
+}  // namespace xfm
+
+extern "C" {
+
+int xfm_colsum_blocks(long long rows, int C, int dtype) {
+    xfm::TokShape sh;
+    if (!xfm::tok_shape(rows, C, dtype == XFM_F32 ? 4 : 8, true, sh)) return 0;
+    return sh.nblk;
+}
+
+int xfm_bias_gelu_fwd(const void *z, const float *bias, void *g, long long rows, int C, int dtype, void *stream) {
+    using namespace xfm;
+    if (!z || !g || rows <= 0 || C <= 0) return XFM_EINVAL;
+    TokArgs a{};
+    a.z = z; a.bias = bias; a.out = g; a.rows = rows; a.C = C;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == XFM_F32) return tok_launch<float, 0>(a, s);
+    if (dtype == XFM_BF16) return tok_launch<bf16_t, 0>(a, s);
+    return XFM_EDTYPE;
+}
+
+int xfm_bias_gelu_bwd(const void *z, const float *bias, const void *dg, void *dz, float *dbias, float *workspace,
+                      long long rows, int C, int dtype, void *stream) {
+    using namespace xfm;
+    if (!z || !dg || !dz || !dbias || !workspace || rows <= 0 || C <= 0) return XFM_EINVAL;
+    TokArgs a{};
+    a.z = z; a.bias = bias; a.dg = dg; a.out = dz; a.part = workspace; a.rows = rows; a.C = C;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (dtype == XFM_F32) rc = tok_launch<float, 1>(a, s);
+    else if (dtype == XFM_BF16) rc = tok_launch<bf16_t, 1>(a, s);
+    else return XFM_EDTYPE;
+    if (rc != XFM_OK) return rc;
+    const int nblk = xfm_colsum_blocks(rows, C, dtype);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, workspace, dbias, nblk, C);
+    return check_launch();
+}
+
+int xfm_colsum(const void *x, float *out, float *workspace, long long rows, int C, int dtype, void *stream) {
+    using namespace xfm;
+    if (!x || !out || !workspace || rows <= 0 || C <= 0) return XFM_EINVAL;
+    TokArgs a{};
+    a.z = x; a.part = workspace; a.rows = rows; a.C = C;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (dtype == XFM_F32) rc = tok_launch<float, 2>(a, s);
+    else if (dtype == XFM_BF16) rc = tok_launch<bf16_t, 2>(a, s);
+    else return XFM_EDTYPE;
+    if (rc != XFM_OK) return rc;
+    const int nblk = xfm_colsum_blocks(rows, C, dtype);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, workspace, out, nblk, C);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -35,9 +35,17 @@ from .csm import SwappingMerge_multiview, SwappingScan_multiview, cross_merge_fn
 from .csms6s import selective_scan_fn
 from .dwconv import dwconv3x3_silu_fn
 from .layernorm2d import layernorm2d_fn
+from .mlp_tokens import linear_tokens_fn, mlp_tokens_fn
+from .proj import batched_proj
+from .rowln import add_layernorm_rows_fn, layernorm_rows_fn, rows_supported
 from .ss2d import ss2d_core_fn
 
 SS2D_MODE = "fused"          # "fused" | "unfused"
+# Layout of the trunk's residual stream between VSS blocks.  "tokens": (B, H, W, C) fp32 -- LayerNorm (+ residual add
+# + DropPath) is one row kernel, Mlp / in_proj / out_proj are plain hipBLASLt GEMMs, the scan path gets its (B, D, L)
+# planes from in_proj's GEMM epilogue layout.  "planes": NCHW as the reference's channel_first blocks
+# (1x1 convs through MIOpen).  Same parameters, same results.
+STREAM_LAYOUT = "tokens"
 
 
 def trunc_normal_(t, std=0.02):
@@ -60,6 +68,16 @@ class DropPath(nn.Module):
         if keep > 0.0 and self.scale_by_keep:
             mask = mask / keep
         return x * mask
+
+    def sample_scale(self, batch: int, device):
+        """The per-sample factor ``forward`` multiplies by, as a (B,) fp32 vector (None when it is the identity)."""
+        if self.drop_prob == 0.0 or not self.training:
+            return None
+        keep = 1.0 - self.drop_prob
+        mask = torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask = mask / keep
+        return mask
 
     def extra_repr(self):
         return f"drop_prob={self.drop_prob}"
@@ -114,6 +132,14 @@ class Mlp(nn.Module):
 
     def forward(self, x):
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+    def forward_tokens(self, x):
+        """Same Mlp on a token-major (B, H, W, C) tensor: two plain GEMMs (Linear2d weights are (out, in))."""
+        drop = self.drop if self.drop.p > 0.0 else None
+        if isinstance(self.act, nn.GELU) and self.act.approximate == "none":
+            return mlp_tokens_fn(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, drop)
+        x = self.drop(self.act(linear_tokens_fn(x, self.fc1.weight, self.fc1.bias)))
+        return self.drop(linear_tokens_fn(x, self.fc2.weight, self.fc2.bias))
 
 
 class mamba_init:
@@ -201,7 +227,7 @@ def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_
         # dts for those routes directly in the order the kernel walks them -- the big (B,4,D,L) tensor is
         # written once, contiguous per route, and never permuted.
         C2 = R + 2 * N
-        x_dbl = torch.matmul(x_proj_weight.reshape(K * C2, D).to(cd), x.reshape(B, D, L))     # (B, K*C2, L)
+        x_dbl = batched_proj(x.reshape(B, D, L), x_proj_weight.reshape(K * C2, D))             # (B, K*C2, L)
         x_dbl = x_dbl.view(B, 2, 2, C2, H, W)                                                  # k = 2*rev + col
         x_dbl = torch.stack([x_dbl[:, :, 0].flatten(-2), x_dbl[:, :, 1].transpose(-1, -2).flatten(-2)], dim=2)
         x_dbl = x_dbl.view(B, K, C2, L)
@@ -293,6 +319,44 @@ class SS2Dv2(nn.Module):
             y = y * z
         return self.dropout(self.out_proj(y))
 
+    def forward_tokens(self, h: torch.Tensor):
+        """``forward`` for a token-major (B, H, W, C) input / output (channel_first blocks only): in_proj writes the
+        (B, D, L) planes the scan path wants, out_proj reads planes and writes tokens -- layout changes ride on the
+        GEMMs' operand flags."""
+        B, H, W, C = h.shape
+        L = H * W
+        x = batched_proj(h.view(B, L, C), self.in_proj.weight, self.in_proj.bias, in_tokens=True, out_tokens=False)
+        z = None
+        if not self.disable_z:
+            x, z = x.chunk(2, dim=1)
+            if not self.disable_z_act:
+                z = self.act(z)
+        x = x.reshape(B, -1, H, W)
+        x = _dwconv_act(self.conv2d, self.act, x) if self.with_dconv else self.act(x)
+        y = self.out_act(self.forward_core(x)).view(B, -1, L)
+        if z is not None:
+            y = y * z
+        out = batched_proj(y, self.out_proj.weight, self.out_proj.bias, in_tokens=False, out_tokens=True)
+        return self.dropout(out.view(B, H, W, C))
+
+
+def _norm_tokens(norm: nn.LayerNorm, x, pend):
+    """LayerNorm of the token-major stream, folding in a pending ``x += scale * y``.  Returns (x, normalised)."""
+    out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+    if pend is None:
+        return x, layernorm_rows_fn(x, norm.weight, norm.bias, norm.eps, out_dtype)
+    return add_layernorm_rows_fn(x, pend[0], pend[1], norm.weight, norm.bias, norm.eps, out_dtype)
+
+
+def _settle(x, pend):
+    """Apply a pending ``x += scale * y`` with nothing to fuse it into (end of a stage)."""
+    if pend is None:
+        return x
+    y, s = pend
+    if s is not None:
+        y = y * s.view(-1, *([1] * (y.ndim - 1))).to(y.dtype)
+    return x + y
+
 
 class VSSBlock(nn.Module):
     def __init__(self, hidden_dim: int = 0, drop_path: float = 0, norm_layer: nn.Module = nn.LayerNorm,
@@ -327,6 +391,37 @@ class VSSBlock(nn.Module):
         if self.mlp_branch:
             x = x + self.drop_path(self.norm2(self.mlp(x)) if self.post_norm else self.mlp(self.norm2(x)))
         return x
+
+    def tokens_ok(self) -> bool:
+        """Can this block run on the token-major stream (pre-norm LayerNorm2d blocks of a supported width)?"""
+        norms = [m for m in (getattr(self, "norm", None), getattr(self, "norm2", None)) if m is not None]
+        return (not self.post_norm and all(isinstance(m, LayerNorm2d) and rows_supported(m.normalized_shape[0])
+                                           for m in norms)
+                and (not self.ssm_branch or self.op.channel_first))
+
+    def forward_tokens(self, x: torch.Tensor, pend=None):
+        """x: (B, H, W, C) fp32 residual stream; ``pend`` = (y, scale) is a branch output not yet added to it.
+        Every ``x + drop_path(branch)`` is deferred into the LayerNorm kernel that reads the sum next."""
+        B = x.shape[0]
+        if self.ssm_branch:
+            x, h = _norm_tokens(self.norm, x, pend)
+            pend = (self.op.forward_tokens(h), self.drop_path.sample_scale(B, x.device))
+        if self.mlp_branch:
+            x, h = _norm_tokens(self.norm2, x, pend)
+            pend = (self.mlp.forward_tokens(h), self.drop_path.sample_scale(B, x.device))
+        return x, pend
+
+
+def _run_blocks(blocks: nn.Sequential, x: torch.Tensor):
+    """A stage's VSSBlocks on an NCHW map; internally on the token-major stream when ``STREAM_LAYOUT == "tokens"``."""
+    if (STREAM_LAYOUT != "tokens" or not x.is_cuda or len(blocks) == 0
+            or not all(isinstance(b, VSSBlock) and b.tokens_ok() for b in blocks)):
+        return blocks(x)
+    t = x.permute(0, 2, 3, 1).float().contiguous()
+    pend = None
+    for b in blocks:
+        t, pend = b.forward_tokens(t, pend)
+    return _settle(t, pend).permute(0, 3, 1, 2).contiguous()
 
 
 class VSSM(nn.Module):
@@ -401,7 +496,7 @@ class VSSM(nn.Module):
     def forward(self, x: torch.Tensor):
         x = self.patch_embed(x)
         for layer in self.layers:
-            x = layer(x)
+            x = layer.downsample(_run_blocks(layer.blocks, x))
         return self.classifier(x)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
@@ -465,7 +560,7 @@ class Backbone_VSSM(VSSM):
         outs = []
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
-            o = layer.blocks(x)
+            o = _run_blocks(layer.blocks, x)
             x = layer.downsample(o)
             if i in self.out_indices and (not only_last or i == last):
                 outs.append(getattr(self, f"outnorm{i}")(o).contiguous())

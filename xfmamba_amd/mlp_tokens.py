@@ -1,0 +1,114 @@
+"""Mlp of a VSS block on the token-major stream: library GEMMs + the HIP kernels ``xfm_bias_gelu_fwd/_bwd`` and
+``xfm_colsum`` for everything between them (``models/fusion_vmamba.py:135-153``: fc1 -> GELU -> drop -> fc2 -> drop).
+
+fc1's bias add and the exact GELU are one pass; the backward pass of that kernel also emits fc1's bias gradient, and
+fc2's bias gradient is a column-sum kernel -- no framework reductions are left on the path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .proj import split_k_wgrad
+
+__all__ = ["bias_gelu_fn", "colsum_fn", "linear_tokens_fn", "mlp_tokens_fn"]
+
+
+def _rows(t):
+    C = t.shape[-1]
+    return t.numel() // C, C
+
+
+def colsum_fn(x: torch.Tensor) -> torch.Tensor:
+    """Sum over all axes but the last of a contiguous tensor -> (C,) fp32."""
+    _lib.require_cuda(x)
+    x = x.contiguous()
+    rows, C = _rows(x)
+    lib = _lib.lib()
+    code = _lib.dtype_code(x.dtype)
+    nblk = lib.xfm_colsum_blocks(rows, C, code)
+    if nblk <= 0:
+        raise RuntimeError(f"xfmamba_amd: colsum does not support width {C} / dtype {x.dtype}")
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(nblk * C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _lib.timed("colsum", x.numel() * x.element_size()):
+        _lib.check(lib.xfm_colsum(x.data_ptr(), out.data_ptr(), ws.data_ptr(), rows, C, code, _lib.stream_ptr()), "colsum")
+    return out
+
+
+class BiasGeluHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, bias):
+        _lib.require_cuda(z, bias)
+        z = z.contiguous()
+        rows, C = _rows(z)
+        b = None if bias is None else bias.float().contiguous()
+        g = torch.empty_like(z)
+        with torch.cuda.device(z.device), _lib.timed("bias_gelu_fwd", 2 * z.numel() * z.element_size()):
+            _lib.check(_lib.lib().xfm_bias_gelu_fwd(z.data_ptr(), _lib.ptr(b), g.data_ptr(), rows, C,
+                                                    _lib.dtype_code(z.dtype), _lib.stream_ptr()), "bias_gelu_fwd")
+        ctx.save_for_backward(z, b)
+        ctx.bdtype = None if bias is None else bias.dtype
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        z, b = ctx.saved_tensors
+        rows, C = _rows(z)
+        lib = _lib.lib()
+        code = _lib.dtype_code(z.dtype)
+        dg = dg.contiguous() if dg.dtype == z.dtype else dg.to(z.dtype).contiguous()
+        dz = torch.empty_like(z)
+        db = torch.empty(C, dtype=torch.float32, device=z.device)
+        ws = torch.empty(lib.xfm_colsum_blocks(rows, C, code) * C, dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device), _lib.timed("bias_gelu_bwd", 3 * z.numel() * z.element_size()):
+            _lib.check(lib.xfm_bias_gelu_bwd(z.data_ptr(), _lib.ptr(b), dg.data_ptr(), dz.data_ptr(), db.data_ptr(),
+                                             ws.data_ptr(), rows, C, code, _lib.stream_ptr()), "bias_gelu_bwd")
+        return dz, (None if ctx.bdtype is None else db.to(ctx.bdtype))
+
+
+def bias_gelu_fn(z, bias=None):
+    """``gelu(z + bias)`` (exact erf form, ``nn.GELU()``), bias over the last axis."""
+    return BiasGeluHip.apply(z, bias)
+
+
+class LinearTokens(torch.autograd.Function):
+    """``F.linear`` on (..., K) tokens whose bias gradient comes from the column-sum kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        cd = x.dtype
+        w = weight.to(cd)
+        y = torch.nn.functional.linear(x, w, None if bias is None else bias.to(cd))
+        ctx.save_for_backward(x, w)
+        ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        wdtype, bdtype = ctx.meta
+        dy = dy.contiguous() if dy.dtype == w.dtype else dy.to(w.dtype).contiguous()
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy2, w).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = split_k_wgrad(dy2, x2).to(wdtype)
+        if bdtype is not None and ctx.needs_input_grad[2]:
+            db = colsum_fn(dy2).to(bdtype)
+        return dx, dw, db
+
+
+def linear_tokens_fn(x, weight, bias=None):
+    return LinearTokens.apply(x, weight, bias)
+
+
+def mlp_tokens_fn(x, w1, b1, w2, b2, drop=None):
+    """fc2(drop(gelu(fc1(x)))) on token-major ``x`` (..., C); weights are the (out, in) Linear2d / nn.Linear weights."""
+    z = linear_tokens_fn(x, w1, None)
+    g = bias_gelu_fn(z, b1)
+    if drop is not None:
+        g = drop(g)
+    y = linear_tokens_fn(g, w2, b2)
+    return y if drop is None else drop(y)

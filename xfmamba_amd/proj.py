@@ -1,0 +1,106 @@
+"""Channel projections (1x1 convolutions) as batched library GEMMs that change the activation layout for free.
+
+The trunk keeps its residual stream TOKEN-major, (B, H*W, C): LayerNorm and the Mlp GEMMs then run on plain
+row-major matrices.  The scan path wants PLANES, (B, D, H*W).  ``batched_proj`` evaluates ``y[b] = W @ x[b]`` with
+either operand layout on either side; the transposition is a BLAS operand flag (a strided view handed to
+``torch.bmm``), so no activation is ever copied or permuted: in_proj reads tokens and writes planes, out_proj reads
+planes and writes tokens, x_proj stays on planes.  This replaces ``Linear2d.forward`` = ``F.conv2d`` with a 1x1
+kernel (``models/fusion_vmamba.py:42-45``), for which MIOpen transposes NCHW <-> NHWC around an implicit GEMM.
+Weight gradients are per-sample partial products (fp32) summed over the batch.
+"""
+from __future__ import annotations
+
+import torch
+
+__all__ = ["batched_proj", "split_k_wgrad"]
+
+_F32_OUT = [None]      # does torch.bmm accept out_dtype on this build?  probed once
+
+
+def _bmm_f32(a, b):
+    if a.dtype not in (torch.bfloat16, torch.float16):
+        return torch.bmm(a, b)
+    if _F32_OUT[0] is None:
+        try:
+            r = torch.bmm(a, b, out_dtype=torch.float32)
+            _F32_OUT[0] = True
+            return r
+        except (TypeError, RuntimeError):
+            _F32_OUT[0] = False
+    if _F32_OUT[0]:
+        return torch.bmm(a, b, out_dtype=torch.float32)
+    return torch.bmm(a, b).float()
+
+
+def _k_slices(rows: int, target: int = 2048, cap: int = 128) -> int:
+    """Number of equal row slices (a divisor of ``rows``) whose length is closest to ``target``."""
+    want = max(1, min(cap, rows // target))
+    best = 1
+    for s in range(1, min(cap, rows) + 1):
+        if rows % s == 0 and abs(s - want) < abs(best - want):
+            best = s
+    return best
+
+
+def split_k_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """``dy2^T @ x2`` for tall operands (rows, M), (rows, K) -> (M, K) fp32.
+
+    A weight gradient contracts over every token (rows = B*H*W up to 2e5) into a small (M, K) result; handed to the
+    GEMM library as one product it runs on the handful of workgroups that tile (M, K).  Cut into row slices it is a
+    batched GEMM that fills the chip, with fp32 partial products summed afterwards."""
+    dy2, x2 = dy2.contiguous(), x2.contiguous()
+    rows = dy2.shape[0]
+    S = _k_slices(rows)
+    if S == 1:
+        return _bmm_f32(dy2.t().unsqueeze(0), x2.unsqueeze(0))[0]
+    return _bmm_f32(dy2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0)
+
+
+class BatchedProj(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, in_tokens, out_tokens):
+        # x: (B, L, K) tokens or (B, K, L) planes; weight (M, K); result (B, L, M) tokens or (B, M, L) planes
+        x = x.contiguous()
+        B = x.shape[0]
+        cd = x.dtype
+        w = weight.to(cd)
+        M, K = w.shape
+        if out_tokens:
+            xt = x if in_tokens else x.transpose(1, 2)                       # (B, L, K)
+            y = torch.bmm(xt, w.t().unsqueeze(0).expand(B, K, M))            # (B, L, M)
+            if bias is not None:
+                y = y + bias.to(cd)
+        else:
+            xp = x.transpose(1, 2) if in_tokens else x                       # (B, K, L)
+            y = torch.bmm(w.unsqueeze(0).expand(B, M, K), xp)                # (B, M, L)
+            if bias is not None:
+                y = y + bias.to(cd)[:, None]
+        ctx.save_for_backward(x, w)
+        ctx.meta = (in_tokens, out_tokens, weight.dtype, bias is not None and bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        in_tokens, out_tokens, wdtype, bdtype = ctx.meta
+        B = x.shape[0]
+        M, K = w.shape
+        dy = dy.contiguous() if dy.dtype == w.dtype else dy.to(w.dtype).contiguous()
+        dyp = dy.transpose(1, 2) if out_tokens else dy                        # (B, M, L)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if in_tokens:
+                dx = torch.bmm(dyp.transpose(1, 2), w.unsqueeze(0).expand(B, M, K))          # (B, L, K)
+            else:
+                dx = torch.bmm(w.t().unsqueeze(0).expand(B, K, M), dyp)                      # (B, K, L)
+        if ctx.needs_input_grad[1]:
+            xt = x if in_tokens else x.transpose(1, 2)                                        # (B, L, K)
+            dw = _bmm_f32(dyp, xt).sum(0).to(wdtype)                                          # (M, K)
+        if bdtype is not False and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 1) if out_tokens else (0, 2), dtype=torch.promote_types(dy.dtype, torch.float32)).to(bdtype)
+        return dx, dw, db, None, None
+
+
+def batched_proj(x, weight, bias=None, in_tokens=False, out_tokens=False):
+    """``y[b] = weight @ x[b]`` (+ bias) over the channel axis, reading / writing token- or plane-major tensors."""
+    return BatchedProj.apply(x, weight, bias, in_tokens, out_tokens)

@@ -1,0 +1,124 @@
+"""Residual add + DropPath + LayerNorm on a token-major (B, H, W, C) stream: ``xfm_add_layernorm_rows_fwd/_bwd``.
+
+``add_layernorm_rows_fn(x, y, scale, weight, bias)`` returns ``(x + scale[b] * y, LayerNorm_C(x + scale[b] * y))`` --
+the ``x = x + self.drop_path(branch(x))`` of ``VSSBlock._forward`` (``models/fusion_vmamba.py:1325-1337``) together
+with the norm that reads the sum next -- in one pass over HBM; ``layernorm_rows_fn`` is the plain norm.  The residual
+stream is fp32; ``y`` and the normalised output are in ``out_dtype`` (the consumer GEMM's dtype under autocast).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = ["add_layernorm_rows_fn", "layernorm_rows_fn", "rows_supported"]
+
+
+def rows_supported(C: int) -> bool:
+    return bool(_lib.lib().xfm_add_layernorm_rows_supported(int(C)))
+
+
+def _fwd(x, y, scale, w, b, eps, out_dtype):
+    B, C = x.shape[0], x.shape[-1]
+    rps = x.numel() // (B * C)
+    h = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    x_new = torch.empty_like(x) if y is not None else None
+    mean = torch.empty(B * rps, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    nbytes = x.numel() * (4 + h.element_size() + (0 if y is None else 4 + y.element_size()))
+    with torch.cuda.device(x.device), _lib.timed("add_layernorm_rows_fwd", nbytes):
+        _lib.check(_lib.lib().xfm_add_layernorm_rows_fwd(
+            x.data_ptr(), _lib.ptr(y), _lib.ptr(scale), w.data_ptr(), _lib.ptr(b), _lib.ptr(x_new), h.data_ptr(),
+            mean.data_ptr(), rstd.data_ptr(), B, rps, C, float(eps), _lib.dtype_code(out_dtype), _lib.stream_ptr()),
+            "add_layernorm_rows_fwd")
+    return x_new, h, mean, rstd
+
+
+def _bwd(x_new, w, dh, dres, mean, rstd, scale, want_dy, has_bias, dtype):
+    B, C = x_new.shape[0], x_new.shape[-1]
+    rps = x_new.numel() // (B * C)
+    lib = _lib.lib()
+    dx = torch.empty_like(x_new)
+    dy = torch.empty(x_new.shape, dtype=dtype, device=x_new.device) if want_dy else None
+    dw = torch.empty_like(w)
+    db = torch.empty_like(w) if has_bias else None
+    ws = torch.empty(2 * C * lib.xfm_add_layernorm_rows_bwd_blocks(B * rps, C), dtype=torch.float32, device=x_new.device)
+    nbytes = x_new.numel() * (8 + dh.element_size() + (0 if dres is None else 4) + (dy.element_size() if want_dy else 0))
+    with torch.cuda.device(x_new.device), _lib.timed("add_layernorm_rows_bwd", nbytes):
+        _lib.check(lib.xfm_add_layernorm_rows_bwd(
+            x_new.data_ptr(), w.data_ptr(), dh.data_ptr(), _lib.ptr(dres), mean.data_ptr(), rstd.data_ptr(),
+            _lib.ptr(scale), dx.data_ptr(), _lib.ptr(dy), dw.data_ptr(), _lib.ptr(db), ws.data_ptr(), B, rps, C,
+            _lib.dtype_code(dtype), _lib.stream_ptr()), "add_layernorm_rows_bwd")
+    return dx, dy, dw, db
+
+
+def _prep(x, weight, bias, out_dtype):
+    _lib.require_cuda(x, weight, bias)
+    if x.dtype != torch.float32:
+        raise RuntimeError("xfmamba_amd: the token-major residual stream is fp32")
+    out_dtype = out_dtype or x.dtype
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"xfmamba_amd: add_layernorm_rows emits fp32 or bf16, not {out_dtype}")
+    w = weight.float().contiguous()
+    b = None if bias is None else bias.float().contiguous()
+    return x.contiguous(), w, b, out_dtype
+
+
+class LayerNormRowsHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        x, w, b, out_dtype = _prep(x, weight, bias, out_dtype)
+        _, h, mean, rstd = _fwd(x, None, None, w, b, eps, out_dtype)
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.meta = (bias is not None, weight.dtype, out_dtype)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, w, mean, rstd = ctx.saved_tensors
+        has_bias, wdtype, dtype = ctx.meta
+        dh = dh.contiguous() if dh.dtype == dtype else dh.to(dtype).contiguous()
+        dx, _, dw, db = _bwd(x, w, dh, None, mean, rstd, None, False, has_bias, dtype)
+        return dx, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None
+
+
+class AddLayerNormRowsHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, scale, weight, bias, eps, out_dtype):
+        x, w, b, out_dtype = _prep(x, weight, bias, out_dtype)
+        _lib.require_cuda(y)
+        ctx.ydtype = y.dtype
+        y = y.contiguous() if y.dtype == out_dtype else y.to(out_dtype).contiguous()
+        if y.shape != x.shape:
+            raise RuntimeError(f"xfmamba_amd: residual {tuple(x.shape)} vs branch {tuple(y.shape)}")
+        s = None if scale is None else scale.float().contiguous()
+        x_new, h, mean, rstd = _fwd(x, y, s, w, b, eps, out_dtype)
+        ctx.save_for_backward(x_new, w, mean, rstd, s)
+        ctx.meta = (bias is not None, weight.dtype, out_dtype)
+        return x_new, h
+
+    @staticmethod
+    def backward(ctx, dres, dh):
+        x_new, w, mean, rstd, s = ctx.saved_tensors
+        has_bias, wdtype, dtype = ctx.meta
+        if dh is None:                       # the norm output was not used: only the sum carries a gradient
+            dx = dres
+            dy = dres if s is None else dres * s.view(-1, *([1] * (dres.ndim - 1)))
+            return dx, dy.to(ctx.ydtype), None, None, None, None, None
+        dh = dh.contiguous() if dh.dtype == dtype else dh.to(dtype).contiguous()
+        if dres is not None:
+            dres = dres.float().contiguous()
+        dx, dy, dw, db = _bwd(x_new, w, dh, dres, mean, rstd, s, True, has_bias, dtype)
+        if dy.dtype != ctx.ydtype:
+            dy = dy.to(ctx.ydtype)
+        return dx, dy, None, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None
+
+
+def layernorm_rows_fn(x, weight, bias, eps=1e-5, out_dtype=None):
+    """LayerNorm over the last axis of a contiguous fp32 (B, ..., C) tensor; output in ``out_dtype`` (fp32 / bf16)."""
+    return LayerNormRowsHip.apply(x, weight, bias, eps, out_dtype)
+
+
+def add_layernorm_rows_fn(x, y, scale, weight, bias, eps=1e-5, out_dtype=None):
+    """``x_new = x + scale[b] * y`` (scale (B,) or None) and ``LayerNorm(x_new)``: returns ``(x_new, h)``."""
+    return AddLayerNormRowsHip.apply(x, y, scale, weight, bias, eps, out_dtype)
