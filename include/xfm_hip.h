@@ -127,23 +127,26 @@ int xfm_layernorm2d_bwd(const void *x, const float *weight, const void *dy, cons
 /* Residual add + DropPath scale + LayerNorm over C of a TOKEN-MAJOR stream (rows = B*rows_per_sample tokens of C
  * channels, contiguous), one pass:   x_new = x + scale[b]*y ;  h = LayerNorm_C(x_new)*weight + bias.
  * Replaces `x = x + self.drop_path(branch(x))` followed by the next `self.norm2(x)` / `self.norm(x)` of
- * VSSBlock._forward (models/fusion_vmamba.py:1325-1337).  x, x_new, mean, rstd, weight, bias fp32; y, h (and dh, dy)
- * in `dtype` (XFM_F32 or XFM_BF16).  y == NULL: plain LayerNorm of x (x_new unused).  scale: (B) fp32 or NULL (= 1).
+ * VSSBlock._forward (models/fusion_vmamba.py:1325-1337).  x_new, mean, rstd, weight, bias fp32; y, h (and dh, dy)
+ * in `dtype` (XFM_F32 or XFM_BF16).  y == NULL: plain LayerNorm of x (x_new unused; x and dx in `x_dtype`, fp32 or
+ * bf16 -- e.g. a convolution's bf16 output); with y, x must be fp32.  scale: (B) fp32 or NULL (= 1).
  * Supported C: 4*G*NV with G in {4,8,16,32,64}, NV in {3,4} (48..768 by doubling, 64..1024 by doubling); otherwise
  * XFM_ELIMIT (`xfm_add_layernorm_rows_supported` tells).
  * bwd: dh = gradient of h, dres = gradient arriving on x_new from its other consumers (fp32, or NULL);
  * dx = gradient of x (== gradient of x_new), dy = scale[b]*dx in `dtype` (NULL when the forward had no y);
- * dweight / dbias (C) fp32 are OVERWRITTEN (dbias may be NULL); workspace: 2*C*xfm_add_layernorm_rows_bwd_blocks()
- * floats.  x_new: the forward's x_new (or its x when y was NULL). */
+ * dweight / dbias (C) fp32 are OVERWRITTEN (dbias may be NULL); workspace: 3*C*xfm_add_layernorm_rows_bwd_blocks()
+ * floats.  pre_bias (C, fp32, only with y == NULL): added to x before the norm -- the bias of the convolution that
+ * produced x (patch-embed / downsample convs, models/fusion_vmamba.py:1504-1538), whose gradient dpre_bias (the column
+ * sums of dx) then comes out of the same backward pass.  x_new: the forward's x_new (or its x when y was NULL). */
 int xfm_add_layernorm_rows_supported(int C);
 int xfm_add_layernorm_rows_bwd_blocks(int rows, int C);
-int xfm_add_layernorm_rows_fwd(const float *x, const void *y, const float *scale, const float *weight, const float *bias,
-                               float *x_new, void *h, float *mean, float *rstd, int B, int rows_per_sample, int C,
-                               float eps, int dtype, void *stream);
-int xfm_add_layernorm_rows_bwd(const float *x_new, const float *weight, const void *dh, const float *dres,
-                               const float *mean, const float *rstd, const float *scale, float *dx, void *dy,
-                               float *dweight, float *dbias, float *workspace, int B, int rows_per_sample, int C,
-                               int dtype, void *stream);
+int xfm_add_layernorm_rows_fwd(const void *x, const void *y, const float *scale, const float *pre_bias,
+                               const float *weight, const float *bias, float *x_new, void *h, float *mean, float *rstd, int B, int rows_per_sample, int C,
+                               float eps, int x_dtype, int dtype, void *stream);
+int xfm_add_layernorm_rows_bwd(const void *x_new, const float *pre_bias, const float *weight, const void *dh,
+                               const float *dres, const float *mean, const float *rstd, const float *scale, void *dx,
+                               void *dy, float *dweight, float *dbias, float *dpre_bias, float *workspace, int B, int rows_per_sample, int C,
+                               int x_dtype, int dtype, void *stream);
 
 /* Element-wise pieces of the Mlp (models/fusion_vmamba.py:135-153, fc1 -> GELU -> fc2) between the library GEMMs, on
  * (rows, C) row-major token-major activations in `dtype` (XFM_F32 / XFM_BF16; C % 4 resp. % 8 == 0, C <= 8192):

@@ -434,3 +434,29 @@ def test_mlp_tokens_matches_torch_fp32(dt):
     for name, a, r in zip(("dx", "dw1", "db1", "dw2", "db2"), dev, ref):
         assert a.grad.dtype == torch.float32
         assert_close(a.grad.cpu(), r.grad, tol, 2 * tol * float(r.grad.abs().max()), name)
+
+
+@pytest.mark.parametrize("C,xdt,hdt", [(48, torch.bfloat16, torch.bfloat16), (96, torch.bfloat16, torch.float32),
+                                       (192, torch.float32, torch.float32), (768, torch.bfloat16, torch.float32)])
+def test_layernorm_rows_with_conv_bias_and_bf16_input(C, xdt, hdt):
+    """LayerNorm(conv_out + conv_bias) on tokens (patch-embed / downsample, fusion_vmamba.py:1504-1538): the bias add
+    and its gradient live in the norm kernel; the convolution output may arrive in bf16."""
+    from xfmamba_amd.rowln import layernorm_rows_fn
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C + 1)
+    x = (torch.randn(4, 9, 11, C, generator=g) * 2).to(xdt)
+    pb = torch.randn(C, generator=g)
+    w = 1 + 0.2 * torch.randn(C, generator=g)
+    b = 0.1 * torch.randn(C, generator=g)
+    gh = torch.randn(4, 9, 11, C, generator=g).to(hdt)
+    ref = [t.clone().requires_grad_() for t in (x.float(), pb, w, b)]
+    hr = F.layer_norm(ref[0] + ref[1], (C,), ref[2], ref[3], 1e-5)
+    hr.backward(gh.float())
+    dev = [t.to(DEV).requires_grad_() for t in (x, pb, w, b)]
+    h = layernorm_rows_fn(dev[0], dev[2], dev[3], 1e-5, hdt, dev[1])
+    h.backward(gh.to(DEV))
+    tol = 1e-3 if (xdt == torch.float32 and hdt == torch.float32) else 1e-2
+    assert h.dtype == hdt and dev[0].grad.dtype == xdt
+    assert_close(h.float().cpu(), hr.detach(), tol, tol * float(hr.abs().max()), "h")
+    for name, a, r in zip(("dx", "dpre_bias", "dw", "db"), dev, ref):
+        assert_close(a.grad.float().cpu(), r.grad, tol, 2 * tol * float(r.grad.abs().max()), name)

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--top", type=int, default=70)
     ap.add_argument("--shapes", action="store_true")
+    ap.add_argument("--width", type=int, default=60)
     ap.add_argument("--stack", action="store_true")
     ap.add_argument("--find", action="store_true", help="MIOpen find mode (as bench.py)")
     a = ap.parse_args()
@@ -62,7 +63,7 @@ def main():
     print(f"total self device time {tot / 1e3:.2f} ms")
     for e in rows[:a.top]:
         shp = str(e.input_shapes)[:150] if a.shapes else ""
-        print(f"{e.self_device_time_total / 1e3:8.3f} ms  n={e.count:4d}  {e.key[:60]:60s} {shp}")
+        print(f"{e.self_device_time_total / 1e3:8.3f} ms  n={e.count:4d}  {e.key[:a.width]:{a.width}s} {shp}")
         if a.stack and e.stack:
             for s in e.stack[:6]:
                 if "xfmamba_amd" in s or "bench" in s:

@@ -100,8 +100,8 @@ def lib() -> C.CDLL:
         l.xfm_layernorm2d_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_void_p]
         l.xfm_add_layernorm_rows_supported.argtypes = [C.c_int]
         l.xfm_add_layernorm_rows_bwd_blocks.argtypes = [C.c_int, C.c_int]
-        l.xfm_add_layernorm_rows_fwd.argtypes = [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]
-        l.xfm_add_layernorm_rows_bwd.argtypes = [C.c_void_p] * 12 + [C.c_int] * 4 + [C.c_void_p]
+        l.xfm_add_layernorm_rows_fwd.argtypes = [C.c_void_p] * 10 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
+        l.xfm_add_layernorm_rows_bwd.argtypes = [C.c_void_p] * 14 + [C.c_int] * 5 + [C.c_void_p]
         l.xfm_colsum_blocks.argtypes = [C.c_longlong, C.c_int, C.c_int]
         l.xfm_bias_gelu_fwd.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]
         l.xfm_bias_gelu_bwd.argtypes = [C.c_void_p] * 6 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]

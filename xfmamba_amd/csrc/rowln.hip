@@ -42,24 +42,26 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
 }
 
 struct RowLnArgs {
-    const float *x;         // (rows, C) residual stream in
+    const void *x;          // (rows, C) residual stream in (fp32; bf16 allowed when y is null)
     const void *y;          // (rows, C) branch output or null
     const float *scale;     // (B) per-sample DropPath factor or null
     const float *w, *b;     // (C); b may be null
+    const float *pre_bias;  // (C) or null: added to x before the norm (a convolution's bias), y must be null
+    int nparts;             // 2 (dw, db) or 3 (+ d pre_bias) partial rows per workgroup
     float *x_new;           // (rows, C) residual stream out (null when y is null: x passes through)
     void *h;                // (rows, C) normalised output
     float *mean, *rstd;     // (rows)
     // backward
     const void *dh;         // (rows, C)
     const float *dres;      // (rows, C) gradient arriving on x_new from later consumers, or null
-    float *dx;              // (rows, C) gradient of x (and of x_new)
+    void *dx;               // (rows, C) gradient of x (and of x_new), in x's dtype
     void *dy;               // (rows, C) gradient of y, or null
     float *part;            // (nblk, 2, C) per-workgroup partial dw / db
     int rows, rows_per_sample, C;
     float eps;
 };
 
-template <typename Ty, int G, int NV> __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
+template <typename Tx, typename Ty, int G, int NV> __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % G, rsub = lane / G;
@@ -72,15 +74,23 @@ template <typename Ty, int G, int NV> __global__ __launch_bounds__(256) void row
         bb[k] = a.b ? Vec4IO<float>::ld(a.b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const Ty *y = static_cast<const Ty *>(a.y);
+    const Tx *x = static_cast<const Tx *>(a.x);
     Ty *h = static_cast<Ty *>(a.h);
     const float invC = 1.0f / (float)C;
+    float4 pb[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        pb[k] = a.pre_bias ? Vec4IO<float>::ld(a.pre_bias + (k * G + sub) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (long rg = (long)blockIdx.x * 4 + wave; rg * RPW < a.rows; rg += (long)gridDim.x * 4) {
         const long row = rg * RPW + rsub;
         const bool live = row < a.rows;
         const long r = live ? row : a.rows - 1;
         float4 v[NV];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = Vec4IO<float>::ld(a.x + r * C + (k * G + sub) * 4);
+        for (int k = 0; k < NV; ++k) {
+            v[k] = Vec4IO<Tx>::ld(x + r * C + (k * G + sub) * 4);
+            v[k].x += pb[k].x; v[k].y += pb[k].y; v[k].z += pb[k].z; v[k].w += pb[k].w;
+        }
         if (y) {
             const float s = a.scale ? a.scale[r / a.rows_per_sample] : 1.0f;
 #pragma unroll
@@ -125,21 +135,24 @@ template <typename Ty, int G, int NV> __global__ __launch_bounds__(256) void row
 // dx = rstd * (g - mean_C(g) - xhat * mean_C(g * xhat)) + dres,  g = dh * w;  dy = scale[b] * dx.
 // dw / db column sums: per-lane accumulators over the rows a workgroup walks, folded across the workgroup through
 // LDS and written as one partial row per workgroup (summed by rowln_wb_kernel: deterministic, no atomics).
-template <typename Ty, int G, int NV> __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnArgs a) {
+template <typename Tx, typename Ty, int G, int NV> __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnArgs a) {
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % G, rsub = lane / G;
     const int C = a.C;
-    float4 w[NV], aw[NV], ab[NV];
+    float4 w[NV], aw[NV], ab[NV], ap[NV], pb[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         w[k] = Vec4IO<float>::ld(a.w + (k * G + sub) * 4);
+        pb[k] = a.pre_bias ? Vec4IO<float>::ld(a.pre_bias + (k * G + sub) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         aw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         ab[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ap[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const Ty *dh = static_cast<const Ty *>(a.dh);
     Ty *dy = static_cast<Ty *>(a.dy);
-    const float *xin = a.x;                 // x_new saved by the forward
+    const Tx *xin = static_cast<const Tx *>(a.x);      // x_new saved by the forward
+    Tx *dxo = static_cast<Tx *>(a.dx);
     const float invC = 1.0f / (float)C;
     for (long rg = (long)blockIdx.x * 4 + wave; rg * RPW < a.rows; rg += (long)gridDim.x * 4) {
         const long row = rg * RPW + rsub;
@@ -151,10 +164,11 @@ template <typename Ty, int G, int NV> __global__ __launch_bounds__(256) void row
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const long off = r * C + (k * G + sub) * 4;
-            const float4 xv = Vec4IO<float>::ld(xin + off);
+            const float4 xv = Vec4IO<Tx>::ld(xin + off);
             float4 d = Vec4IO<Ty>::ld(dh + off);
             if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
-            xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            xh[k] = make_float4((xv.x + pb[k].x - mu) * rs, (xv.y + pb[k].y - mu) * rs, (xv.z + pb[k].z - mu) * rs,
+                                (xv.w + pb[k].w - mu) * rs);
             aw[k].x = fmaf(d.x, xh[k].x, aw[k].x); aw[k].y = fmaf(d.y, xh[k].y, aw[k].y);
             aw[k].z = fmaf(d.z, xh[k].z, aw[k].z); aw[k].w = fmaf(d.w, xh[k].w, aw[k].w);
             ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
@@ -178,7 +192,8 @@ template <typename Ty, int G, int NV> __global__ __launch_bounds__(256) void row
                 o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
             }
             if (live) {
-                Vec4IO<float>::st(a.dx + off, o);
+                ap[k].x += o.x; ap[k].y += o.y; ap[k].z += o.z; ap[k].w += o.w;
+                Vec4IO<Tx>::st(dxo + off, o);
                 if (dy) Vec4IO<Ty>::st(dy + off, make_float4(o.x * s, o.y * s, o.z * s, o.w * s));
             }
         }
@@ -192,47 +207,54 @@ template <typename Ty, int G, int NV> __global__ __launch_bounds__(256) void row
             aw[k].z += __shfl_xor(aw[k].z, m, 64); aw[k].w += __shfl_xor(aw[k].w, m, 64);
             ab[k].x += __shfl_xor(ab[k].x, m, 64); ab[k].y += __shfl_xor(ab[k].y, m, 64);
             ab[k].z += __shfl_xor(ab[k].z, m, 64); ab[k].w += __shfl_xor(ab[k].w, m, 64);
+            ap[k].x += __shfl_xor(ap[k].x, m, 64); ap[k].y += __shfl_xor(ap[k].y, m, 64);
+            ap[k].z += __shfl_xor(ap[k].z, m, 64); ap[k].w += __shfl_xor(ap[k].w, m, 64);
         }
     }
-    __shared__ float red[4][2][4 * G * NV];         // [wave][dw|db][channel], C = 4*G*NV
+    __shared__ float red[4][3][4 * G * NV];         // [wave][dw|db|dpre][channel], C = 4*G*NV
     if (rsub == 0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = (k * G + sub) * 4;
             *reinterpret_cast<float4 *>(&red[wave][0][c]) = aw[k];
             *reinterpret_cast<float4 *>(&red[wave][1][c]) = ab[k];
+            *reinterpret_cast<float4 *>(&red[wave][2][c]) = ap[k];
         }
     }
     __syncthreads();
-    float *part = a.part + (long)blockIdx.x * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float *part = a.part + (long)blockIdx.x * a.nparts * C;
+    for (int i = threadIdx.x; i < a.nparts * C; i += 256) {
         const int which = i / C, c = i - which * C;
         part[i] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
     }
 }
 
-// dw[c] = sum over workgroups of part[., 0, c]; db likewise.  64 columns (of the 2*C) x 16 row slots per workgroup.
-__global__ __launch_bounds__(1024) void rowln_wb_kernel(const float *part, float *dw, float *db, int nblk, int C) {
+// dw[c] = sum over workgroups of part[., 0, c]; db and d pre_bias likewise.  64 columns (of the nparts*C) x 16 row
+// slots per workgroup.
+__global__ __launch_bounds__(1024) void rowln_wb_kernel(const float *part, float *dw, float *db, float *dpre, int nblk,
+                                                         int C, int nparts) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
+    const int W = nparts * C;
     float s0 = 0.f, s1 = 0.f;
-    if (i < 2 * C) {
+    if (i < W) {
         int j = slot;
         for (; j + 16 < nblk; j += 32) {
-            s0 += part[(long)j * 2 * C + i];
-            s1 += part[(long)(j + 16) * 2 * C + i];
+            s0 += part[(long)j * W + i];
+            s1 += part[(long)(j + 16) * W + i];
         }
-        if (j < nblk) s0 += part[(long)j * 2 * C + i];
+        if (j < nblk) s0 += part[(long)j * W + i];
     }
     red[slot][lane] = s0 + s1;
     __syncthreads();
-    if (slot == 0 && i < 2 * C) {
+    if (slot == 0 && i < W) {
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[k][lane];
         if (i < C) dw[i] = s;
-        else if (db) db[i - C] = s;
+        else if (i < 2 * C) { if (db) db[i - C] = s; }
+        else if (dpre) dpre[i - 2 * C] = s;
     }
 }
 
@@ -256,11 +278,12 @@ static int fwd_blocks(int rows, int G) {
     return (int)(nb < 1 ? 1 : nb);
 }
 
-template <typename Ty, int NV> static int launch(bool bwd, int G, const RowLnArgs &a, int nblk, hipStream_t s) {
+template <typename Tx, typename Ty, int NV>
+static int launch(bool bwd, int G, const RowLnArgs &a, int nblk, hipStream_t s) {
 #define XFM_ROWLN_CASE(GG)                                                                                   \
     case GG:                                                                                                   \
-        if (bwd) hipLaunchKernelGGL((rowln_bwd_kernel<Ty, GG, NV>), dim3(nblk), dim3(256), 0, s, a);            \
-        else hipLaunchKernelGGL((rowln_fwd_kernel<Ty, GG, NV>), dim3(nblk), dim3(256), 0, s, a);                \
+        if (bwd) hipLaunchKernelGGL((rowln_bwd_kernel<Tx, Ty, GG, NV>), dim3(nblk), dim3(256), 0, s, a);        \
+        else hipLaunchKernelGGL((rowln_fwd_kernel<Tx, Ty, GG, NV>), dim3(nblk), dim3(256), 0, s, a);            \
         break;
     switch (G) {
         XFM_ROWLN_CASE(4)
@@ -274,8 +297,14 @@ template <typename Ty, int NV> static int launch(bool bwd, int G, const RowLnArg
     return check_launch();
 }
 
-template <typename Ty> static int launch_nv(bool bwd, int G, int NV, const RowLnArgs &a, int nblk, hipStream_t s) {
-    return NV == 3 ? launch<Ty, 3>(bwd, G, a, nblk, s) : launch<Ty, 4>(bwd, G, a, nblk, s);
+static int launch_any(bool bwd, int x_dtype, int dtype, int G, int NV, const RowLnArgs &a, int nblk, hipStream_t s) {
+#define XFM_ROWLN_DT(TX, TY) (NV == 3 ? launch<TX, TY, 3>(bwd, G, a, nblk, s) : launch<TX, TY, 4>(bwd, G, a, nblk, s))
+    if (x_dtype == XFM_F32 && dtype == XFM_F32) return XFM_ROWLN_DT(float, float);
+    if (x_dtype == XFM_F32 && dtype == XFM_BF16) return XFM_ROWLN_DT(float, bf16_t);
+    if (x_dtype == XFM_BF16 && dtype == XFM_F32) return XFM_ROWLN_DT(bf16_t, float);
+    if (x_dtype == XFM_BF16 && dtype == XFM_BF16) return XFM_ROWLN_DT(bf16_t, bf16_t);
+#undef XFM_ROWLN_DT
+    return XFM_EDTYPE;
 }
 
 }  // namespace xfm
@@ -294,45 +323,41 @@ int xfm_add_layernorm_rows_bwd_blocks(int rows, int C) {
     return nb > 512 ? 512 : nb;
 }
 
-int xfm_add_layernorm_rows_fwd(const float *x, const void *y, const float *scale, const float *weight, const float *bias,
-                               float *x_new, void *h, float *mean, float *rstd, int B, int rows_per_sample, int C,
-                               float eps, int dtype, void *stream) {
+int xfm_add_layernorm_rows_fwd(const void *x, const void *y, const float *scale, const float *pre_bias,
+                               const float *weight, const float *bias, float *x_new, void *h, float *mean, float *rstd, int B, int rows_per_sample, int C,
+                               float eps, int x_dtype, int dtype, void *stream) {
     using namespace xfm;
     if (!x || !weight || !h || !mean || !rstd || B <= 0 || rows_per_sample <= 0 || C <= 0) return XFM_EINVAL;
-    if (y && !x_new) return XFM_EINVAL;
+    if (y && (!x_new || x_dtype != XFM_F32 || pre_bias)) return XFM_EINVAL;
     int G, NV;
     if (!pick_shape(C, G, NV)) return XFM_ELIMIT;
     RowLnArgs a{};
-    a.x = x; a.y = y; a.scale = scale; a.w = weight; a.b = bias; a.x_new = x_new; a.h = h; a.mean = mean; a.rstd = rstd;
+    a.x = x; a.y = y; a.scale = scale; a.pre_bias = pre_bias; a.w = weight; a.b = bias; a.x_new = x_new; a.h = h; a.mean = mean; a.rstd = rstd;
     a.rows = B * rows_per_sample; a.rows_per_sample = rows_per_sample; a.C = C; a.eps = eps;
     const int nblk = fwd_blocks(a.rows, G);
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == XFM_F32) return launch_nv<float>(false, G, NV, a, nblk, s);
-    if (dtype == XFM_BF16) return launch_nv<bf16_t>(false, G, NV, a, nblk, s);
-    return XFM_EDTYPE;
+    return launch_any(false, x_dtype, dtype, G, NV, a, nblk, (hipStream_t)stream);
 }
 
-int xfm_add_layernorm_rows_bwd(const float *x_new, const float *weight, const void *dh, const float *dres,
-                               const float *mean, const float *rstd, const float *scale, float *dx, void *dy,
-                               float *dweight, float *dbias, float *workspace, int B, int rows_per_sample, int C,
-                               int dtype, void *stream) {
+int xfm_add_layernorm_rows_bwd(const void *x_new, const float *pre_bias, const float *weight, const void *dh,
+                               const float *dres, const float *mean, const float *rstd, const float *scale, void *dx,
+                               void *dy, float *dweight, float *dbias, float *dpre_bias, float *workspace, int B, int rows_per_sample, int C,
+                               int x_dtype, int dtype, void *stream) {
     using namespace xfm;
     if (!x_new || !weight || !dh || !mean || !rstd || !dx || !dweight || !workspace || B <= 0 || rows_per_sample <= 0)
         return XFM_EINVAL;
     int G, NV;
     if (!pick_shape(C, G, NV)) return XFM_ELIMIT;
     RowLnArgs a{};
-    a.x = x_new; a.w = weight; a.dh = dh; a.dres = dres; a.mean = const_cast<float *>(mean); a.rstd = const_cast<float *>(rstd); a.scale = scale; a.dx = dx;
+    a.x = x_new; a.pre_bias = pre_bias; a.nparts = dpre_bias ? 3 : 2; a.w = weight; a.dh = dh; a.dres = dres; a.mean = const_cast<float *>(mean); a.rstd = const_cast<float *>(rstd); a.scale = scale; a.dx = dx;
     a.dy = dy; a.part = workspace;
     a.rows = B * rows_per_sample; a.rows_per_sample = rows_per_sample; a.C = C;
     const int nblk = xfm_add_layernorm_rows_bwd_blocks(a.rows, C);
     hipStream_t s = (hipStream_t)stream;
-    int rc;
-    if (dtype == XFM_F32) rc = launch_nv<float>(true, G, NV, a, nblk, s);
-    else if (dtype == XFM_BF16) rc = launch_nv<bf16_t>(true, G, NV, a, nblk, s);
-    else return XFM_EDTYPE;
+    if ((dy || dres) && x_dtype != XFM_F32) return XFM_EINVAL;
+    const int rc = launch_any(true, x_dtype, dtype, G, NV, a, nblk, s);
     if (rc != XFM_OK) return rc;
-    hipLaunchKernelGGL(rowln_wb_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, s, workspace, dweight, dbias, nblk, C);
+    hipLaunchKernelGGL(rowln_wb_kernel, dim3((a.nparts * C + 63) / 64), dim3(1024), 0, s, workspace, dweight, dbias,
+                       dpre_bias, nblk, C, a.nparts);
     return check_launch();
 }
 

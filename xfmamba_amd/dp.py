@@ -4,13 +4,14 @@ The reference has no distributed code; this is new work re
 BASELINE.json's north star.  One process per GPU, identical replicas, per-rank batches.
 
 Design for MI355X's point-to-point xGMI fabric (7 links per GPU): few, LARGE collectives.
-Gradients live in a handful of flat fp32 buckets (each parameter's ``.grad`` is a view into its
-bucket, so there is no pack/unpack copy); a bucket's all-reduce is issued on a side stream as soon
-as the last of its gradients has been accumulated, overlapping the rest of the backward pass.
-Parameters that never receive a gradient (``outnorm0-2``, ``Cross_SS2Dv5.in_proj``; SURVEY.md
-section 8(a)) keep zero gradients on every rank, so their bucket is simply flushed at
-``finish()``.  BatchNorm statistics of the shallow fusion block stay per-rank (the reference has
-no SyncBN); ``broadcast_buffers`` is offered for checkpoint time.
+Autograd writes every gradient into a fresh tensor (``zero_grad`` drops the old ones, so there is neither a
+zero-fill nor an accumulate kernel per parameter); when the last gradient of a bucket has arrived the bucket is
+packed with ONE multi-tensor copy into a flat fp32 buffer, the parameters' ``.grad`` are re-pointed at views of that
+buffer, and the bucket's all-reduce is issued on a side stream, overlapping the rest of the backward pass.
+With a single process nothing is packed at all.  Parameters that never receive a gradient (``outnorm0-2``,
+``Cross_SS2Dv5.in_proj``) are the same on every rank: their slots are zero-filled at
+``finish()``.  BatchNorm statistics of the shallow fusion block stay per-rank (the reference has no SyncBN);
+``broadcast_buffers`` is offered for checkpoint time.
 """
 from __future__ import annotations
 
@@ -33,45 +34,49 @@ def broadcast_buffers(module: torch.nn.Module, src: int = 0) -> None:
 
 
 class GradBuckets:
-    """Flat gradient buckets with overlap-capable all-reduce (average)."""
+    """Gradient buckets with overlap-capable all-reduce (average)."""
 
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, process_group=None, overlap: bool = True):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        params = [p for p in module.parameters() if p.requires_grad]
-        params.reverse()                                   # gradients become ready roughly in reverse order
-        cap = int(bucket_mb * (1 << 20) / 4)
+        self.params = [p for p in module.parameters() if p.requires_grad]
         self.buckets: List[torch.Tensor] = []
+        self._groups: List[List[torch.nn.Parameter]] = []
+        self._views: List[List[torch.Tensor]] = []
         self._bucket_of = {}
+        self._work = []
+        self._stream = None
+        self.overlap = overlap and self.world > 1
+        if self.world == 1:
+            return
+        order = list(reversed(self.params))                # gradients become ready roughly in reverse order
+        cap = int(bucket_mb * (1 << 20) / 4)
         cur: List[torch.nn.Parameter] = []
         cur_n = 0
-        groups = []
-        for p in params:
+        for p in order:
             if cur and cur_n + p.numel() > cap:
-                groups.append(cur)
+                self._groups.append(cur)
                 cur, cur_n = [], 0
             cur.append(p)
             cur_n += p.numel()
         if cur:
-            groups.append(cur)
-        for bi, grp in enumerate(groups):
+            self._groups.append(cur)
+        for bi, grp in enumerate(self._groups):
             flat = torch.zeros(sum(p.numel() for p in grp), dtype=torch.float32, device=grp[0].device)
-            off = 0
+            views, off = [], 0
             for p in grp:
-                p.grad = flat[off:off + p.numel()].view_as(p)     # .grad is a view: no packing copy
+                views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
                 self._bucket_of[p] = bi
             self.buckets.append(flat)
-        self._pending = [len(g) for g in groups]
-        self._sizes = [len(g) for g in groups]
-        self._launched = [False] * len(groups)
-        self._work = []
-        self.overlap = overlap and self.world > 1
-        self._stream = None
+            self._views.append(views)
+        self._sizes = [len(g) for g in self._groups]
+        self._pending = list(self._sizes)
+        self._launched = [False] * len(self._groups)
         if self.overlap:
-            if self.buckets and self.buckets[0].is_cuda:
+            if self.buckets[0].is_cuda:
                 self._stream = torch.cuda.Stream()
-            for p in params:
+            for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     # ---- backward-time hook -----------------------------------------------------------------
@@ -82,10 +87,17 @@ class GradBuckets:
             self._launch(bi)
 
     def _launch(self, bi):
-        if self._launched[bi] or self.world == 1:
+        if self._launched[bi]:
             return
         self._launched[bi] = True
-        flat = self.buckets[bi]
+        flat, grp, views = self.buckets[bi], self._groups[bi], self._views[bi]
+        have = [(v, p.grad) for v, p in zip(views, grp) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])      # one multi-tensor pack
+        for v, p in zip(views, grp):
+            if p.grad is None:
+                v.zero_()                                   # never-used parameter: same on every rank
+            p.grad = v
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
@@ -98,17 +110,19 @@ class GradBuckets:
     # ---- call after loss.backward() ------------------------------------------------------------
     def finish(self):
         """Flush buckets whose parameters did not all fire (unused parameters) and wait."""
-        if self.world > 1:
-            for bi in range(len(self.buckets)):
-                self._launch(bi)
-            for w in self._work:
-                w.wait()
-            if self._stream is not None:
-                torch.cuda.current_stream().wait_stream(self._stream)
+        if self.world == 1:
+            return
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        for w in self._work:
+            w.wait()
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
         self._work.clear()
         self._pending = list(self._sizes)
         self._launched = [False] * len(self.buckets)
 
     def zero_grad(self):
-        for flat in self.buckets:
-            flat.zero_()
+        """Drop the gradients: the next backward pass assigns fresh tensors instead of accumulating."""
+        for p in self.params:
+            p.grad = None

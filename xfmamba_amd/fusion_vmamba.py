@@ -412,16 +412,51 @@ class VSSBlock(nn.Module):
         return x, pend
 
 
-def _run_blocks(blocks: nn.Sequential, x: torch.Tensor):
-    """A stage's VSSBlocks on an NCHW map; internally on the token-major stream when ``STREAM_LAYOUT == "tokens"``."""
-    if (STREAM_LAYOUT != "tokens" or not x.is_cuda or len(blocks) == 0
-            or not all(isinstance(b, VSSBlock) and b.tokens_ok() for b in blocks)):
-        return blocks(x)
-    t = x.permute(0, 2, 3, 1).float().contiguous()
+def _blocks_tokens_ok(blocks) -> bool:
+    return len(blocks) > 0 and all(isinstance(b, VSSBlock) and b.tokens_ok() for b in blocks)
+
+
+def _blocks_tokens(blocks, t):
+    """VSSBlocks of a stage on the token-major stream; the last residual add is settled here."""
     pend = None
     for b in blocks:
         t, pend = b.forward_tokens(t, pend)
-    return _settle(t, pend).permute(0, 3, 1, 2).contiguous()
+    return _settle(t, pend)
+
+
+def _run_blocks(blocks: nn.Sequential, x: torch.Tensor):
+    """A stage's VSSBlocks on an NCHW map; internally on the token-major stream when ``STREAM_LAYOUT == "tokens"``."""
+    if STREAM_LAYOUT != "tokens" or not x.is_cuda or not _blocks_tokens_ok(blocks):
+        return blocks(x)
+    t = x.permute(0, 2, 3, 1).float().contiguous()
+    return _blocks_tokens(blocks, t).permute(0, 3, 1, 2).contiguous()
+
+
+def _conv_ln_tokens(conv: nn.Conv2d, norm: nn.Module, t: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    """``norm(conv(t))`` on a token-major (B, H, W, C) tensor -> (B, H', W', C').  The convolution is handed to
+    MIOpen as a channels_last map (its implicit-GEMM kernels are NHWC-native, so no NCHW<->NHWC transposes run around
+    them) WITHOUT its bias: the bias is added inside the LayerNorm kernel, whose backward pass also returns its
+    gradient -- no per-channel reduction over the convolution output is left to the framework."""
+    fused = isinstance(norm, LayerNorm2d)
+    y = F.conv2d(t.permute(0, 3, 1, 2), conv.weight, None if fused else conv.bias, conv.stride, conv.padding,
+                 conv.dilation, conv.groups)
+    y = y.permute(0, 2, 3, 1)
+    y = y if y.is_contiguous() else y.contiguous()
+    if not fused:
+        return y if out_dtype is None else y.to(out_dtype)
+    if y.dtype not in (torch.float32, torch.bfloat16):
+        y = y.float()
+    return layernorm_rows_fn(y, norm.weight, norm.bias, norm.eps, out_dtype, conv.bias)
+
+
+def _ln_tokens(norm: nn.Module, t: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    if isinstance(norm, nn.Identity):
+        return t if out_dtype is None else t.to(out_dtype)
+    return layernorm_rows_fn(t, norm.weight, norm.bias, norm.eps, out_dtype)
+
+
+def _norm_tokens_ok(norm: nn.Module) -> bool:
+    return isinstance(norm, nn.Identity) or (isinstance(norm, LayerNorm2d) and rows_supported(norm.normalized_shape[0]))
 
 
 class VSSM(nn.Module):
@@ -493,7 +528,43 @@ class VSSM(nn.Module):
         return nn.Sequential(nn.Identity(), nn.Conv2d(dim, out_dim, kernel_size=3, stride=2, padding=1),
                              nn.Identity(), norm_layer(out_dim))
 
+    # ---- token-major trunk: patch embedding, stages and downsampling without ever leaving (B, H, W, C) ----------
+    def tokens_trunk_ok(self, x: torch.Tensor) -> bool:
+        if STREAM_LAYOUT != "tokens" or not x.is_cuda:
+            return False
+        pe = self.patch_embed
+        ok = (len(pe) == 8 and isinstance(pe[0], nn.Conv2d) and isinstance(pe[5], nn.Conv2d)
+              and _norm_tokens_ok(pe[2]) and _norm_tokens_ok(pe[7]))
+        for layer in self.layers:
+            ok = ok and _blocks_tokens_ok(layer.blocks)
+            d = layer.downsample
+            ok = ok and (isinstance(d, nn.Identity) or (len(d) == 4 and isinstance(d[1], nn.Conv2d)
+                                                         and _norm_tokens_ok(d[3])))
+        return ok
+
+    def stem_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """patch_embed (conv s2 -> LN -> GELU -> conv s2 -> LN) -> fp32 tokens (B, H/4, W/4, C0)."""
+        pe = self.patch_embed
+        act_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+        t = x.permute(0, 2, 3, 1).contiguous()                  # (B, H, W, 3): a channels_last image
+        t = pe[4](_conv_ln_tokens(pe[0], pe[2], t, act_dtype))  # norm output feeds GELU -> conv: the conv's dtype
+        return _conv_ln_tokens(pe[5], pe[7], t, torch.float32)
+
+    def stage_tokens(self, i: int, t: torch.Tensor):
+        """Stage i on tokens: returns (stage output, downsampled input of stage i+1 or None)."""
+        layer = self.layers[i]
+        o = _blocks_tokens(layer.blocks, t)
+        if isinstance(layer.downsample, nn.Identity):
+            return o, None
+        return o, _conv_ln_tokens(layer.downsample[1], layer.downsample[3], o, torch.float32)
+
     def forward(self, x: torch.Tensor):
+        if self.tokens_trunk_ok(x):
+            t = self.stem_tokens(x)
+            for i in range(len(self.layers)):
+                o, t = self.stage_tokens(i, t)
+            x = o.permute(0, 3, 1, 2)
+            return self.classifier(x)
         x = self.patch_embed(x)
         for layer in self.layers:
             x = layer.downsample(_run_blocks(layer.blocks, x))
@@ -556,9 +627,17 @@ class Backbone_VSSM(VSSM):
     def forward(self, x, only_last: bool = False):
         """``only_last=True`` skips the out-norms whose results ``TwoViewXFMambaTop`` discards
         (outnorm0-2, net_fusionmamba.py:200-201); values of the last output are unchanged."""
+        last = len(self.layers) - 1
+        if self.tokens_trunk_ok(x) and all(_norm_tokens_ok(getattr(self, f"outnorm{i}")) for i in self.out_indices):
+            t = self.stem_tokens(x)
+            outs = []
+            for i in range(len(self.layers)):
+                o, t = self.stage_tokens(i, t)
+                if i in self.out_indices and (not only_last or i == last):
+                    outs.append(_ln_tokens(getattr(self, f"outnorm{i}"), o, torch.float32).permute(0, 3, 1, 2).contiguous())
+            return outs if len(self.out_indices) else o.permute(0, 3, 1, 2).contiguous()
         x = self.patch_embed(x)
         outs = []
-        last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
             o = _run_blocks(layer.blocks, x)
             x = layer.downsample(o)

@@ -18,23 +18,24 @@ def rows_supported(C: int) -> bool:
     return bool(_lib.lib().xfm_add_layernorm_rows_supported(int(C)))
 
 
-def _fwd(x, y, scale, w, b, eps, out_dtype):
+def _fwd(x, y, scale, w, b, eps, out_dtype, pre=None):
     B, C = x.shape[0], x.shape[-1]
     rps = x.numel() // (B * C)
     h = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     x_new = torch.empty_like(x) if y is not None else None
     mean = torch.empty(B * rps, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    nbytes = x.numel() * (4 + h.element_size() + (0 if y is None else 4 + y.element_size()))
+    nbytes = x.numel() * (x.element_size() + h.element_size() + (0 if y is None else 4 + y.element_size()))
     with torch.cuda.device(x.device), _lib.timed("add_layernorm_rows_fwd", nbytes):
         _lib.check(_lib.lib().xfm_add_layernorm_rows_fwd(
-            x.data_ptr(), _lib.ptr(y), _lib.ptr(scale), w.data_ptr(), _lib.ptr(b), _lib.ptr(x_new), h.data_ptr(),
-            mean.data_ptr(), rstd.data_ptr(), B, rps, C, float(eps), _lib.dtype_code(out_dtype), _lib.stream_ptr()),
+            x.data_ptr(), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(pre), w.data_ptr(), _lib.ptr(b), _lib.ptr(x_new), h.data_ptr(),
+            mean.data_ptr(), rstd.data_ptr(), B, rps, C, float(eps), _lib.dtype_code(x.dtype), _lib.dtype_code(out_dtype),
+            _lib.stream_ptr()),
             "add_layernorm_rows_fwd")
     return x_new, h, mean, rstd
 
 
-def _bwd(x_new, w, dh, dres, mean, rstd, scale, want_dy, has_bias, dtype):
+def _bwd(x_new, w, dh, dres, mean, rstd, scale, want_dy, has_bias, dtype, pre=None):
     B, C = x_new.shape[0], x_new.shape[-1]
     rps = x_new.numel() // (B * C)
     lib = _lib.lib()
@@ -42,20 +43,22 @@ def _bwd(x_new, w, dh, dres, mean, rstd, scale, want_dy, has_bias, dtype):
     dy = torch.empty(x_new.shape, dtype=dtype, device=x_new.device) if want_dy else None
     dw = torch.empty_like(w)
     db = torch.empty_like(w) if has_bias else None
-    ws = torch.empty(2 * C * lib.xfm_add_layernorm_rows_bwd_blocks(B * rps, C), dtype=torch.float32, device=x_new.device)
-    nbytes = x_new.numel() * (8 + dh.element_size() + (0 if dres is None else 4) + (dy.element_size() if want_dy else 0))
+    dpre = torch.empty_like(w) if pre is not None else None
+    ws = torch.empty(3 * C * lib.xfm_add_layernorm_rows_bwd_blocks(B * rps, C), dtype=torch.float32, device=x_new.device)
+    nbytes = x_new.numel() * (2 * x_new.element_size() + dh.element_size() + (0 if dres is None else 4)
+                              + (dy.element_size() if want_dy else 0))
     with torch.cuda.device(x_new.device), _lib.timed("add_layernorm_rows_bwd", nbytes):
         _lib.check(lib.xfm_add_layernorm_rows_bwd(
-            x_new.data_ptr(), w.data_ptr(), dh.data_ptr(), _lib.ptr(dres), mean.data_ptr(), rstd.data_ptr(),
-            _lib.ptr(scale), dx.data_ptr(), _lib.ptr(dy), dw.data_ptr(), _lib.ptr(db), ws.data_ptr(), B, rps, C,
-            _lib.dtype_code(dtype), _lib.stream_ptr()), "add_layernorm_rows_bwd")
-    return dx, dy, dw, db
+            x_new.data_ptr(), _lib.ptr(pre), w.data_ptr(), dh.data_ptr(), _lib.ptr(dres), mean.data_ptr(), rstd.data_ptr(),
+            _lib.ptr(scale), dx.data_ptr(), _lib.ptr(dy), dw.data_ptr(), _lib.ptr(db), _lib.ptr(dpre), ws.data_ptr(), B, rps, C,
+            _lib.dtype_code(x_new.dtype), _lib.dtype_code(dtype), _lib.stream_ptr()), "add_layernorm_rows_bwd")
+    return dx, dy, dw, db, dpre
 
 
-def _prep(x, weight, bias, out_dtype):
+def _prep(x, weight, bias, out_dtype, need_f32=False):
     _lib.require_cuda(x, weight, bias)
-    if x.dtype != torch.float32:
-        raise RuntimeError("xfmamba_amd: the token-major residual stream is fp32")
+    if x.dtype != torch.float32 and (need_f32 or x.dtype != torch.bfloat16):
+        raise RuntimeError(f"xfmamba_amd: token-major LayerNorm input must be fp32 (bf16 without a residual add), not {x.dtype}")
     out_dtype = out_dtype or x.dtype
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError(f"xfmamba_amd: add_layernorm_rows emits fp32 or bf16, not {out_dtype}")
@@ -66,26 +69,28 @@ def _prep(x, weight, bias, out_dtype):
 
 class LayerNormRowsHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, out_dtype):
+    def forward(ctx, x, weight, bias, eps, out_dtype, pre_bias):
         x, w, b, out_dtype = _prep(x, weight, bias, out_dtype)
-        _, h, mean, rstd = _fwd(x, None, None, w, b, eps, out_dtype)
-        ctx.save_for_backward(x, w, mean, rstd)
-        ctx.meta = (bias is not None, weight.dtype, out_dtype)
+        pre = None if pre_bias is None else pre_bias.float().contiguous()
+        _, h, mean, rstd = _fwd(x, None, None, w, b, eps, out_dtype, pre)
+        ctx.save_for_backward(x, w, mean, rstd, pre)
+        ctx.meta = (bias is not None, weight.dtype, out_dtype, None if pre_bias is None else pre_bias.dtype)
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        x, w, mean, rstd = ctx.saved_tensors
-        has_bias, wdtype, dtype = ctx.meta
+        x, w, mean, rstd, pre = ctx.saved_tensors
+        has_bias, wdtype, dtype, pdtype = ctx.meta
         dh = dh.contiguous() if dh.dtype == dtype else dh.to(dtype).contiguous()
-        dx, _, dw, db = _bwd(x, w, dh, None, mean, rstd, None, False, has_bias, dtype)
-        return dx, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None
+        dx, _, dw, db, dpre = _bwd(x, w, dh, None, mean, rstd, None, False, has_bias, dtype, pre)
+        return (dx, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None,
+                (None if dpre is None else dpre.to(pdtype)))
 
 
 class AddLayerNormRowsHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, scale, weight, bias, eps, out_dtype):
-        x, w, b, out_dtype = _prep(x, weight, bias, out_dtype)
+        x, w, b, out_dtype = _prep(x, weight, bias, out_dtype, need_f32=True)
         _lib.require_cuda(y)
         ctx.ydtype = y.dtype
         y = y.contiguous() if y.dtype == out_dtype else y.to(out_dtype).contiguous()
@@ -108,15 +113,16 @@ class AddLayerNormRowsHip(torch.autograd.Function):
         dh = dh.contiguous() if dh.dtype == dtype else dh.to(dtype).contiguous()
         if dres is not None:
             dres = dres.float().contiguous()
-        dx, dy, dw, db = _bwd(x_new, w, dh, dres, mean, rstd, s, True, has_bias, dtype)
+        dx, dy, dw, db, _ = _bwd(x_new, w, dh, dres, mean, rstd, s, True, has_bias, dtype)
         if dy.dtype != ctx.ydtype:
             dy = dy.to(ctx.ydtype)
         return dx, dy, None, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None
 
 
-def layernorm_rows_fn(x, weight, bias, eps=1e-5, out_dtype=None):
-    """LayerNorm over the last axis of a contiguous fp32 (B, ..., C) tensor; output in ``out_dtype`` (fp32 / bf16)."""
-    return LayerNormRowsHip.apply(x, weight, bias, eps, out_dtype)
+def layernorm_rows_fn(x, weight, bias, eps=1e-5, out_dtype=None, pre_bias=None):
+    """LayerNorm over the last axis of a contiguous fp32 / bf16 (B, ..., C) tensor; output in ``out_dtype``.
+    ``pre_bias`` (C,) is added to ``x`` first (the bias of the convolution that produced ``x``)."""
+    return LayerNormRowsHip.apply(x, weight, bias, eps, out_dtype, pre_bias)
 
 
 def add_layernorm_rows_fn(x, y, scale, weight, bias, eps=1e-5, out_dtype=None):
