@@ -107,6 +107,17 @@ int xfm_cross_merge(const void *y, void *x, int B, int C, int H, int W, int in_d
  * out[:,1] = x2 with even channels from x. */
 int xfm_swap_scan(const void *x, const void *x2, void *out, int B, int C, int L, int dtype, void *stream);
 
+/* Route split of the x_proj output and its adjoint.  x_proj of all four routes is ONE dense GEMM on the map in natural
+ * order (replaces the per-route `einsum("b k d l, k c d -> b k c l")` on the cross-scanned copies,
+ * models/fusion_vmamba.py:1150-1153); xd: (B, 4, R+2N, H*W) holds route k = 2*rev + col in channels [k*(R+2N), ...).
+ * split: xr (B,4,R,L) = dt_proj input, Bs / Cs (B,4,N,L), planes of the column routes (k odd) transposed to column-major
+ * -- the layout contract of xfm_ss2d_fwd.  merge: gradient of xd from dxr (`dtype`) and the fp32 dBs / dCs accumulators
+ * of xfm_ss2d_bwd. */
+int xfm_ss2d_route_split(const void *xd, void *xr, void *Bs, void *Cs, int B, int R, int N, int H, int W, int dtype,
+                         void *stream);
+int xfm_ss2d_route_merge(const void *dxr, const float *dBs, const float *dCs, void *dxd, int B, int R, int N, int H,
+                         int W, int dtype, void *stream);
+
 /* Depthwise 3x3 convolution, padding 1, stride 1, optional bias, optionally fused with SiLU.
  * x, y, dy, dx: (B, D, H, W) contiguous in `dtype`; weight: (D, 1, 3, 3) fp32; bias: (D) fp32 or NULL.
  * Backward recomputes the pre-activation; dweight (D*9) and dbias (D) are fp32 and must be ZEROED. */

@@ -460,3 +460,38 @@ def test_layernorm_rows_with_conv_bias_and_bf16_input(C, xdt, hdt):
     assert_close(h.float().cpu(), hr.detach(), tol, tol * float(hr.abs().max()), "h")
     for name, a, r in zip(("dx", "dpre_bias", "dw", "db"), dev, ref):
         assert_close(a.grad.float().cpu(), r.grad, tol, 2 * tol * float(r.grad.abs().max()), name)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 56, 56, 1), (3, 192, 28, 28, 1), (2, 384, 14, 14, 1), (2, 64, 10, 6, 2)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_ss2d_proj_core_matches_operator_chain(shape, dt):
+    """Route split + dt_proj + fused scan as one node (xfm_ss2d_route_split/_merge inside) vs the same maths spelled
+    with framework ops around ss2d_core_fn (to_route_order + matmul): output and every gradient."""
+    from xfmamba_amd.ss2d import ss2d_core_fn, ss2d_proj_core_fn, to_route_order
+    B, D, H, W, N = shape
+    L, K = H * W, 4
+    R = max(1, D // 16)
+    C2 = R + 2 * N
+    g = torch.Generator().manual_seed(B * D + H)
+    x = torch.randn(B, D, L, generator=g).to(dt)
+    xd = (0.5 * torch.randn(B, K * C2, L, generator=g)).to(dt)
+    dtw = torch.randn(K, D, R, generator=g) * R ** -0.5
+    A = -torch.rand(K * D, N, generator=g) - 0.1
+    Dp = torch.randn(K * D, generator=g)
+    bias = 0.1 * torch.rand(K * D, generator=g)
+    gy = torch.randn(B, D, L, generator=g)
+    outs = []
+    for fused in (False, True):
+        t = [v.to(DEV).requires_grad_() for v in (x, xd, dtw, A, Dp, bias)]
+        if fused:
+            y = ss2d_proj_core_fn(t[0], t[1], t[2], t[3], t[4], t[5], H, W)
+        else:
+            r = to_route_order(t[1].view(B, K, C2, L), H, W)
+            dts = torch.matmul(t[2].to(dt), r[:, :, :R])
+            y = ss2d_core_fn(t[0], dts, t[3], r[:, :, R:R + N].contiguous(), r[:, :, R + N:].contiguous(), t[4], t[5], H, W)
+        y.backward(gy.to(DEV))
+        outs.append([y.detach()] + [v.grad for v in t])
+    tol = 1e-4 if dt == torch.float32 else 1e-2
+    for name, a, b in zip(("y", "dx", "dx_dbl", "ddt_w", "dA", "dD", "dbias"), outs[1], outs[0]):
+        assert a.dtype == b.dtype, name
+        assert_close(a.float().cpu(), b.float().cpu(), tol, tol * float(b.float().abs().max()) + 1e-7, name)

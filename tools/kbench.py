@@ -66,6 +66,37 @@ def main():
     shapes = [("stage0", B, 96, 56, 1), ("stage1", B, 192, 28, 1), ("stage2", B, 384, 14, 1), ("stage3", B, 768, 7, 1),
               ("deep", B // 2, 1536, 7, 16)]
     print(f"{'kernel':28s} {'us':>9s} {'GB/s':>8s} {'%HBM':>6s}  plan")
+    if not a.only or a.only in "rowscan":
+        from xfmamba_amd import csms6s
+        for name, Bt, KD, N in (("rowscan fusion", B // 2, 6144, 16), ("rowscan stage3", B, 3072, 1)):
+            L, K = 49, 4
+            u = torch.randn(Bt, KD, L, device=dev).to(dt)
+            delta = (0.5 * torch.rand(Bt, KD, L, device=dev)).to(dt)
+            Bm = torch.randn(Bt, K, N, L, device=dev).to(dt)
+            Cm = torch.randn(Bt, K, N, L, device=dev).to(dt)
+            A = -torch.rand(KD, N, device=dev) - 0.1
+            Dp = torch.randn(KD, device=dev)
+            bias = 0.1 * torch.rand(KD, device=dev)
+            p = _lib.ScanParams()
+            csms6s._fill_common(p, u, delta, A, Bm, Cm, Dp, bias, True, torch.float32)
+            out = torch.empty(Bt, KD, L, device=dev)
+            p.out, p.out_batch_stride, p.out_d_stride = out.data_ptr(), out.stride(0), out.stride(1)
+            plan = _lib.scan_plan(Bt, KD, L, N, K)
+            xs = torch.empty(Bt, KD, max(plan.n_chunks, 1), N, device=dev)
+            p.x = xs.data_ptr()
+            dout = torch.randn_like(out)
+            du, dd = torch.empty_like(u), torch.empty_like(delta)
+            dA, dBm, dCm = torch.zeros_like(A), torch.zeros(Bt, K, N, L, device=dev), torch.zeros(Bt, K, N, L, device=dev)
+            dD, db = torch.zeros_like(Dp), torch.zeros_like(bias)
+            p.dout, p.dout_batch_stride, p.dout_d_stride = dout.data_ptr(), dout.stride(0), dout.stride(1)
+            p.du, p.ddelta = du.data_ptr(), dd.data_ptr()
+            p.dA, p.dB, p.dC, p.dD, p.ddelta_bias = dA.data_ptr(), dBm.data_ptr(), dCm.data_ptr(), dD.data_ptr(), db.data_ptr()
+            isz = u.element_size()
+            fb, bb = Bt * KD * L * (2 * isz + 4), Bt * KD * L * (4 * isz + 4)
+            t = time_raw(_lib.lib().xfm_selective_scan_fwd, p)
+            print(f"{'scan_fwd ' + name:28s} {t:9.1f} {fb / t / 1e3:8.1f} {fb / t / 1e3 / 80:6.2f}")
+            t = time_raw(_lib.lib().xfm_selective_scan_bwd, p)
+            print(f"{'scan_bwd ' + name:28s} {t:9.1f} {bb / t / 1e3:8.1f} {bb / t / 1e3 / 80:6.2f}")
     for name, Bt, D, H, N in shapes:
         if a.only and a.only not in "ss2d" and a.only not in name:
             continue

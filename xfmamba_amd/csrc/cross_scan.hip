@@ -127,9 +127,98 @@ static int launch_merge(const void *y, void *x, int B, int C, int H, int W, hipS
     return check_launch();
 }
 
+// ---- route split / merge of the x_proj output ------------------------------------------------------------------
+// x_proj is evaluated once on the map in natural order (the projection commutes with the route permutations); this
+// kernel hands its (B, 4, R+2N, H*W) result to the consumers in the layout contract of xfm_ss2d_fwd: three contiguous
+// tensors dt-input (B,4,R,L), Bs (B,4,N,L), Cs (B,4,N,L), with the planes of the column routes (k odd) transposed to
+// column-major.  One workgroup per (b, k, c) plane; transposition through a padded LDS tile.
+template <typename Ts, typename Td>
+__device__ __forceinline__ void plane_move(const Ts *src, Td *dst, int R0, int C0, bool transpose, float *tile) {
+    const int L = R0 * C0;
+    if (!transpose) {
+        for (int e = threadIdx.x; e < L; e += blockDim.x) stf<Td>(dst + e, ldf<Ts>(src + e));
+        return;
+    }
+    const int pitch = C0 + 1;
+    for (int e = threadIdx.x; e < L; e += blockDim.x) {
+        const int r = e / C0, c = e - r * C0;
+        tile[r * pitch + c] = ldf<Ts>(src + e);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < L; e += blockDim.x) {     // (R0 x C0) row-major -> (C0 x R0) row-major
+        const int c = e / R0, r = e - c * R0;
+        stf<Td>(dst + e, tile[r * pitch + c]);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) route_split_kernel(const T *xd, T *xr, T *Bs, T *Cs, int R, int N, int H, int W) {
+    extern __shared__ float tile[];
+    const int C2 = R + 2 * N, L = H * W;
+    const int c = blockIdx.x % C2, bk = blockIdx.x / C2, k = bk & 3;
+    const T *src = xd + (int64_t)blockIdx.x * L;
+    T *dst = c < R ? xr + ((int64_t)bk * R + c) * L
+                   : (c < R + N ? Bs + ((int64_t)bk * N + (c - R)) * L : Cs + ((int64_t)bk * N + (c - R - N)) * L);
+    plane_move<T, T>(src, dst, H, W, (k & 1) != 0, tile);
+}
+
+// adjoint: gradients arrive as dt-input grad (T), dBs / dCs (fp32 accumulators of the scan backward)
+template <typename T>
+__global__ void __launch_bounds__(256) route_merge_kernel(const T *dxr, const float *dBs, const float *dCs, T *dxd, int R,
+                                                          int N, int H, int W) {
+    extern __shared__ float tile[];
+    const int C2 = R + 2 * N, L = H * W;
+    const int c = blockIdx.x % C2, bk = blockIdx.x / C2, k = bk & 3;
+    T *dst = dxd + (int64_t)blockIdx.x * L;
+    const bool tr = (k & 1) != 0;
+    if (c < R) plane_move<T, T>(dxr + ((int64_t)bk * R + c) * L, dst, W, H, tr, tile);
+    else if (c < R + N) plane_move<float, T>(dBs + ((int64_t)bk * N + (c - R)) * L, dst, W, H, tr, tile);
+    else plane_move<float, T>(dCs + ((int64_t)bk * N + (c - R - N)) * L, dst, W, H, tr, tile);
+}
+
+template <typename T>
+static int launch_route(bool merge, const void *a, const void *b, const void *c, void *d, void *e, void *f, int B, int R,
+                        int N, int H, int W, hipStream_t s) {
+    const size_t lds = (size_t)(H > W ? H : W) * ((H > W ? W : H) + 1) * sizeof(float) + (size_t)(H + W) * sizeof(float);
+    if (lds > 64 * 1024) return XFM_ELIMIT;
+    const dim3 grid((unsigned)((int64_t)B * 4 * (R + 2 * N)));
+    if (merge)
+        hipLaunchKernelGGL((route_merge_kernel<T>), grid, dim3(256), lds, s, (const T *)a, (const float *)b,
+                           (const float *)c, (T *)d, R, N, H, W);
+    else
+        hipLaunchKernelGGL((route_split_kernel<T>), grid, dim3(256), lds, s, (const T *)a, (T *)d, (T *)e, (T *)f, R, N, H, W);
+    return check_launch();
+}
+
 }  // namespace xfm
 
 extern "C" {
+
+int xfm_ss2d_route_split(const void *xd, void *xr, void *Bs, void *Cs, int B, int R, int N, int H, int W, int dtype,
+                         void *stream) {
+    using namespace xfm;
+    if (!xd || !xr || !Bs || !Cs || B <= 0 || R <= 0 || N <= 0 || H <= 0 || W <= 0) return XFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case XFM_F32: return launch_route<float>(false, xd, nullptr, nullptr, xr, Bs, Cs, B, R, N, H, W, s);
+        case XFM_F16: return launch_route<f16_t>(false, xd, nullptr, nullptr, xr, Bs, Cs, B, R, N, H, W, s);
+        case XFM_BF16: return launch_route<bf16_t>(false, xd, nullptr, nullptr, xr, Bs, Cs, B, R, N, H, W, s);
+    }
+    return XFM_EDTYPE;
+}
+
+int xfm_ss2d_route_merge(const void *dxr, const float *dBs, const float *dCs, void *dxd, int B, int R, int N, int H,
+                         int W, int dtype, void *stream) {
+    using namespace xfm;
+    if (!dxr || !dBs || !dCs || !dxd || B <= 0 || R <= 0 || N <= 0 || H <= 0 || W <= 0) return XFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case XFM_F32: return launch_route<float>(true, dxr, dBs, dCs, dxd, nullptr, nullptr, B, R, N, H, W, s);
+        case XFM_F16: return launch_route<f16_t>(true, dxr, dBs, dCs, dxd, nullptr, nullptr, B, R, N, H, W, s);
+        case XFM_BF16: return launch_route<bf16_t>(true, dxr, dBs, dCs, dxd, nullptr, nullptr, B, R, N, H, W, s);
+    }
+    return XFM_EDTYPE;
+}
 
 int xfm_cross_scan(const void *x, void *y, int B, int C, int H, int W, int dtype, void *stream) {
     using namespace xfm;

@@ -23,6 +23,12 @@ struct RowScanArgs {
 
 template <int LT> constexpr int rs_pad() { return (LT + 3) & ~3; }
 
+// states processed together by the backward kernel, and the LDS floats its staging / transpose tiles need
+template <int NS> struct RowScanNI { static constexpr int value = 1; };   // 2 spills (343 live floats + temporaries > 512 VGPRs)
+template <int LT, int NS> constexpr int rs_bwd_tile() {
+    return (64 * LT > RowScanNI<NS>::value * LT * 65) ? 64 * LT : RowScanNI<NS>::value * LT * 65;
+}
+
 // stage one (64 x LT) operand tile: rows r0..r0+63 of tensor `src` -> flat LDS [row*LT + t]
 template <typename T, typename S, int LT>
 __device__ __forceinline__ void rs_stage(T *dst, const S *src, int64_t batch_off, int64_t row_stride, int r0, int lane) {
@@ -101,9 +107,10 @@ rowscan_bwd_kernel(const RowScanArgs a) {
     // LDS: one (64 x LT) fp32 tile used for staging / transposes / outputs, plus B and C of the group.
     // The row's own operands live in REGISTERS for the whole state loop (a wave is alone on its SIMD anyway:
     // the tile keeps occupancy LDS-bound, so the 512-register file is free to use).
-    float *sc = smem;                                   // [64][LT] or [LT][64]
-    float *Bt = sc + 64 * LT;                           // [NS][LP]
+    float *sc = smem;                                   // [64][LT] staging, or NI transposed tiles [LT][65]
+    float *Bt = sc + rs_bwd_tile<LT, NS>();             // [NS][LP]
     float *Ct = Bt + NS * LP;
+    Tin *ut = reinterpret_cast<Tin *>(Ct + NS * LP);    // [64][LT] u in its storage dtype: read per step, not held
     const Tin *Bg = (const Tin *)p.B + (int64_t)b * p.B_batch_stride + (int64_t)k * p.B_group_stride;
     const Tin *Cg = (const Tin *)p.C + (int64_t)b * p.C_batch_stride + (int64_t)k * p.C_group_stride;
     for (int e = lane; e < NS * LT; e += 64) {
@@ -111,8 +118,10 @@ rowscan_bwd_kernel(const RowScanArgs a) {
         Bt[n * LP + t] = ldf<Tin>(Bg + (int64_t)n * p.B_dstate_stride + t);
         Ct[n * LP + t] = ldf<Tin>(Cg + (int64_t)n * p.C_dstate_stride + t);
     }
+    rs_stage<Tin, Tin, LT>(ut, (const Tin *)p.u, (int64_t)b * p.u_batch_stride, p.u_d_stride, r0, lane);
+    const Tin *ur = ut + lane * LT;
     const float Dr = p.D ? p.D[r] : 0.f, bias = p.delta_bias ? p.delta_bias[r] : 0.f;
-    float dl[LT], du[LT], g[LT];                        // delta' , delta'*u , dout  of this lane's row
+    float dl[LT], g[LT];                                // delta' , dout  of this lane's row
     rs_stage<float, Tin, LT>(sc, (const Tin *)p.delta, (int64_t)b * p.delta_batch_stride, p.delta_d_stride, r0, lane);
     wave_sync();
 #pragma unroll
@@ -122,75 +131,110 @@ rowscan_bwd_kernel(const RowScanArgs a) {
         dl[t] = v;
     }
     wave_sync();
-    rs_stage<float, Tin, LT>(sc, (const Tin *)p.u, (int64_t)b * p.u_batch_stride, p.u_d_stride, r0, lane);
-    wave_sync();
-#pragma unroll
-    for (int t = 0; t < LT; ++t) du[t] = sc[lane * LT + t];          // u for now
-    wave_sync();
     rs_stage<float, Tout, LT>(sc, (const Tout *)p.dout, (int64_t)b * p.dout_batch_stride, p.dout_d_stride, r0, lane);
     wave_sync();
     float dD = 0.f;
 #pragma unroll
     for (int t = 0; t < LT; ++t) {
         g[t] = sc[lane * LT + t];
-        dD = fmaf(g[t], du[t], dD);
+        dD = fmaf(g[t], ldf<Tin>(ur + t), dD);
     }
     wave_sync();
-    float h[LT], s1[LT], s2[LT];
+    float s1[LT], s2[LT];
 #pragma unroll
     for (int t = 0; t < LT; ++t) s1[t] = s2[t] = 0.f;
     float *dBg = p.dB + ((int64_t)b * p.n_groups + k) * NS * L;
     float *dCg = p.dC + ((int64_t)b * p.n_groups + k) * NS * L;
-    // s1 accumulates sum_n dh*B, s2 sum_n dh*A*(a*h_prev); u is recovered as du/dl only where needed (final pass)
-#pragma unroll
-    for (int t = 0; t < LT; ++t) du[t] *= dl[t];
+    // s1 accumulates sum_n dh*B, s2 sum_n dh*A*(a*h_prev)
+    // NI states run interleaved: their recurrences are independent dependency chains, which is the only
+    // latency hiding a wave that is alone on its SIMD gets.  Tiles T[j] ([LT][TP], TP = 65: conflict-free both for
+    // the per-row writes and for the per-column sums) transpose the dB / dC contributions of the 64 rows.
+    constexpr int NI = RowScanNI<NS>::value;
+    constexpr int TP = 65;
 #pragma unroll 1
-    for (int n = 0; n < NS; ++n) {
-        const float An = p.A[(int64_t)r * p.A_d_stride + n];
-        const float A2 = An * kLog2e;
-        const float *Bn = Bt + n * LP, *Cn = Ct + n * LP;
-        float hp = 0.f;
+    for (int n = 0; n < NS; n += NI) {
+        float An[NI], A2[NI], hp[NI], E[NI], dA[NI];
+        float h[NI][LT];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            An[j] = p.A[(int64_t)r * p.A_d_stride + n + j];
+            A2[j] = An[j] * kLog2e;
+            hp[j] = E[j] = dA[j] = 0.f;
+        }
 #pragma unroll
         for (int t = 0; t < LT; ++t) {
-            hp = fmaf(exp2_fast(dl[t] * A2), hp, du[t] * Bn[t]);
-            h[t] = hp;
+            const float du = dl[t] * ldf<Tin>(ur + t);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                hp[j] = fmaf(exp2_fast(dl[t] * A2[j]), hp[j], du * Bt[(n + j) * LP + t]);
+                h[j][t] = hp[j];
+            }
+            if (t % 7 == 6) __builtin_amdgcn_sched_barrier(0);      // stop the scheduler from preloading all of B/C
         }
-        float E = 0.f, dA = 0.f;
 #pragma unroll
         for (int t = LT - 1; t >= 0; --t) {
-            const float av = exp2_fast(dl[t] * A2);
-            const float dh = fmaf(Cn[t], g[t], E);
-            E = av * dh;
-            const float ah = h[t] - du[t] * Bn[t];               // a_t * h_{t-1}
-            s1[t] = fmaf(dh, Bn[t], s1[t]);
-            s2[t] = fmaf(dh * An, ah, s2[t]);
-            dA = fmaf(dh * dl[t], ah, dA);
-            sc[t * 64 + lane] = dh * du[t];                      // dB contribution of this row, transposed
-            h[t] = g[t] * h[t];                                  // dC contribution (h_t is dead after this)
-        }
-        atomicAdd(p.dA + (int64_t)r * NS + n, dA);
-        wave_sync();
-        if (lane < LT) {                                         // lane t sums column t over the 64 rows
-            float acc = 0.f;
+            const float du = dl[t] * ldf<Tin>(ur + t);
 #pragma unroll
-            for (int q = 0; q < 64; q += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(sc + lane * 64 + q);
-                acc += (v.x + v.y) + (v.z + v.w);
+            for (int j = 0; j < NI; ++j) {
+                const float Bv = Bt[(n + j) * LP + t];
+                float ea = dl[t] * A2[j];
+                asm volatile("" : "+v"(ea));                       // recompute a_t: keeping 49*NI of them alive spills
+                const float av = exp2_fast(ea);
+                const float dh = fmaf(Ct[(n + j) * LP + t], g[t], E[j]);
+                E[j] = av * dh;
+                const float ah = h[j][t] - du * Bv;                 // a_t * h_{t-1}
+                s1[t] = fmaf(dh, Bv, s1[t]);
+                s2[t] = fmaf(dh * An[j], ah, s2[t]);
+                dA[j] = fmaf(dh * dl[t], ah, dA[j]);
+                sc[(j * LT + t) * TP + lane] = dh * du;              // dB contribution of this row, transposed
+                h[j][t] = g[t] * h[j][t];                            // dC contribution (h_t is dead after this)
             }
-            atomicAdd(dBg + n * L + lane, acc);
+            if (t % 7 == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) atomicAdd(p.dA + (int64_t)r * NS + n + j, dA[j]);   // summed over the batch
+        wave_sync();
+        if (lane < LT) {                                             // lane t sums column t over the 64 rows
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const float *col = sc + (j * LT + lane) * TP;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 1
+                for (int q0 = 0; q0 < 64; q0 += 16) {                // 16 reads in flight: keeps the register peak low
+#pragma unroll
+                    for (int q = q0; q < q0 + 16; q += 4) {
+                        a0 += col[q];
+                        a1 += col[q + 1];
+                        a2 += col[q + 2];
+                        a3 += col[q + 3];
+                    }
+                }
+                atomicAdd(dBg + (n + j) * L + lane, (a0 + a1) + (a2 + a3));
+            }
         }
         wave_sync();
 #pragma unroll
-        for (int t = 0; t < LT; ++t) sc[t * 64 + lane] = h[t];
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int t = 0; t < LT; ++t) sc[(j * LT + t) * TP + lane] = h[j][t];
         wave_sync();
         if (lane < LT) {
-            float acc = 0.f;
 #pragma unroll
-            for (int q = 0; q < 64; q += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(sc + lane * 64 + q);
-                acc += (v.x + v.y) + (v.z + v.w);
+            for (int j = 0; j < NI; ++j) {
+                const float *col = sc + (j * LT + lane) * TP;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 1
+                for (int q0 = 0; q0 < 64; q0 += 16) {                // 16 reads in flight: keeps the register peak low
+#pragma unroll
+                    for (int q = q0; q < q0 + 16; q += 4) {
+                        a0 += col[q];
+                        a1 += col[q + 1];
+                        a2 += col[q + 2];
+                        a3 += col[q + 3];
+                    }
+                }
+                atomicAdd(dCg + (n + j) * L + lane, (a0 + a1) + (a2 + a3));
             }
-            atomicAdd(dCg + n * L + lane, acc);
         }
         wave_sync();
     }
@@ -203,11 +247,9 @@ rowscan_bwd_kernel(const RowScanArgs a) {
     wave_sync();
     for (int e = lane; e < 64 * LT; e += 64) stf<Tin>(dub + e, sc[e]);
     wave_sync();
-    rs_stage<float, Tin, LT>(sc, (const Tin *)p.u, (int64_t)b * p.u_batch_stride, p.u_d_stride, r0, lane);   // u again (cheap)
-    wave_sync();
 #pragma unroll
     for (int t = 0; t < LT; ++t) {
-        float dd = fmaf(sc[lane * LT + t], s1[t], s2[t]);
+        float dd = fmaf(ldf<Tin>(ur + t), s1[t], s2[t]);
         if (p.delta_softplus && dl[t] <= 20.f) dd *= 1.f - __expf(-dl[t]);
         db += dd;
         sc[lane * LT + t] = dd;
@@ -226,7 +268,7 @@ static int rowscan_launch(const xfm_scan_params_t &p, bool bwd, hipStream_t s) {
     a.dim_per_group = p.dim / p.n_groups;
     const unsigned grid = (unsigned)((int64_t)p.batch * (p.dim / 64));
     if (bwd) {
-        const size_t lds = (size_t)(64 * LT + 2 * NS * LP) * sizeof(float);
+        const size_t lds = (size_t)(rs_bwd_tile<LT, NS>() + 2 * NS * LP) * sizeof(float) + (size_t)64 * LT * sizeof(Tin);
         hipLaunchKernelGGL((rowscan_bwd_kernel<Tin, Tout, LT, NS>), dim3(grid), dim3(64), lds, s, a);
     } else {
         const size_t lds = (size_t)(64 * LT + 2 * NS * LP) * sizeof(float) + (size_t)64 * LT * sizeof(Tin);

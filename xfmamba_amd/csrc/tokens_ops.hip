@@ -53,6 +53,20 @@ template <> struct Pack<bf16_t> {
 constexpr float kInvSqrt2 = 0.70710678118654752f;
 constexpr float kInvSqrt2Pi = 0.3989422804014327f;
 
+// erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. below fp32 resolution of the GELU it feeds) on the
+// hardware exp2 / rcp; also returns E = exp(-x^2), which is the Gaussian density the GELU derivative needs.
+__device__ __forceinline__ float erf_as(float x, float &E) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    E = __builtin_amdgcn_exp2f(-(x * x) * kLog2e);
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float r = fmaf(-(p * t), E, 1.0f);
+    return copysignf(r, x);
+}
+
 struct TokArgs {
     const void *z;        // (rows, C)
     const float *bias;    // (C) or null
@@ -86,7 +100,8 @@ template <typename T, int MODE> __global__ void tokens_kernel(TokArgs a) {
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 const float u = v[i] + b[i];
-                o[i] = 0.5f * u * (1.0f + erff(u * kInvSqrt2));
+                float E;
+                o[i] = 0.5f * u * (1.0f + erf_as(u * kInvSqrt2, E));
             }
             Pack<T>::st(out + off, o);
         } else if (MODE == 1) {
@@ -95,8 +110,9 @@ template <typename T, int MODE> __global__ void tokens_kernel(TokArgs a) {
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 const float u = v[i] + b[i];
-                const float cdf = 0.5f * (1.0f + erff(u * kInvSqrt2));
-                const float pdf = kInvSqrt2Pi * __expf(-0.5f * u * u);
+                float E;
+                const float cdf = 0.5f * (1.0f + erf_as(u * kInvSqrt2, E));
+                const float pdf = kInvSqrt2Pi * E;
                 o[i] = d[i] * fmaf(u, pdf, cdf);
                 acc[i] += o[i];
             }

@@ -38,7 +38,7 @@ from .layernorm2d import layernorm2d_fn
 from .mlp_tokens import linear_tokens_fn, mlp_tokens_fn
 from .proj import batched_proj
 from .rowln import add_layernorm_rows_fn, layernorm_rows_fn, rows_supported
-from .ss2d import ss2d_core_fn
+from .ss2d import ss2d_core_fn, ss2d_proj_core_fn, to_route_order
 
 SS2D_MODE = "fused"          # "fused" | "unfused"
 # Layout of the trunk's residual stream between VSS blocks.  "tokens": (B, H, W, C) fp32 -- LayerNorm (+ residual add
@@ -205,11 +205,12 @@ def _dwconv_act(conv: nn.Conv2d, act: nn.Module, x: torch.Tensor) -> torch.Tenso
     return act(conv(x))
 
 
-def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_override=None):
+def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_override=None, want_Cs=False):
     """x: (B, D, H, W) -> (y: (B, D, H*W) fp32, Cs in the layout of the active mode).
 
     ``Cs_override`` lets the view streams of Cross_SS2Dv5 read their state through the fused
-    stream's C (fusion_vmamba.py:537,568)."""
+    stream's C (fusion_vmamba.py:537,568); ``want_Cs`` makes the call return its own C for that purpose
+    (otherwise the second result is None on the fused path)."""
     B, D, H, W = x.shape
     L = H * W
     K, _, R = dt_projs_weight.shape
@@ -228,9 +229,10 @@ def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_
         # written once, contiguous per route, and never permuted.
         C2 = R + 2 * N
         x_dbl = batched_proj(x.reshape(B, D, L), x_proj_weight.reshape(K * C2, D))             # (B, K*C2, L)
-        x_dbl = x_dbl.view(B, 2, 2, C2, H, W)                                                  # k = 2*rev + col
-        x_dbl = torch.stack([x_dbl[:, :, 0].flatten(-2), x_dbl[:, :, 1].transpose(-1, -2).flatten(-2)], dim=2)
-        x_dbl = x_dbl.view(B, K, C2, L)
+        if Cs_override is None and not want_Cs:
+            # route split, dt_proj, scan and merge as one autograd node (the (B,4,.,L) B/C tensors stay inside)
+            return ss2d_proj_core_fn(x.reshape(B, D, L), x_dbl, dt_projs_weight, As, Dsf, bias, H, W), None
+        x_dbl = to_route_order(x_dbl.view(B, K, C2, L), H, W)
         dts = torch.matmul(dt_projs_weight.to(cd), x_dbl[:, :, :R])                            # (B, K, D, L)
         Bs = x_dbl[:, :, R:R + N].contiguous()
         Cs = x_dbl[:, :, R + N:].contiguous() if Cs_override is None else Cs_override
@@ -776,7 +778,7 @@ class Cross_SS2Dv5(nn.Module):
         def finish(y, like):
             return self.out_norm(y.transpose(1, 2).reshape(B, H, W, -1)).to(like.dtype)
 
-        y_fuse, Cs_fuse = _ss2d_core(x_fuse, *w)
+        y_fuse, Cs_fuse = _ss2d_core(x_fuse, *w, want_Cs=True)
         y, _ = _ss2d_core(x, *w, Cs_override=Cs_fuse)
         y_2, _ = _ss2d_core(x2, *w, Cs_override=Cs_fuse)
         return finish(y, x), finish(y_2, x2), finish(y_fuse, x_fuse)

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["ss2d_core_fn", "SS2DCoreHip", "to_route_order"]
+__all__ = ["ss2d_core_fn", "ss2d_proj_core_fn", "SS2DCoreHip", "SS2DProjCoreHip", "to_route_order"]
 
 
 def to_route_order(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
@@ -94,6 +94,99 @@ class SS2DCoreHip(torch.autograd.Function):
         with torch.cuda.device(dev), _lib.timed("ss2d_bwd", nbytes):
             _lib.check(_lib.lib().xfm_ss2d_bwd(ctypes.byref(p), _lib.stream_ptr()), "ss2d_bwd")
         return dx, ddts, dA, dBs.to(Bs.dtype), dCs.to(Cs.dtype), dD, dbias, None, None
+
+
+def _route_split(xd, R, N, H, W):
+    Bt, L = xd.shape[0], xd.shape[-1]
+    xr = torch.empty((Bt, 4, R, L), dtype=xd.dtype, device=xd.device)
+    Bs = torch.empty((Bt, 4, N, L), dtype=xd.dtype, device=xd.device)
+    Cs = torch.empty_like(Bs)
+    with torch.cuda.device(xd.device), _lib.timed("route_split", 2 * xd.numel() * xd.element_size()):
+        _lib.check(_lib.lib().xfm_ss2d_route_split(xd.data_ptr(), xr.data_ptr(), Bs.data_ptr(), Cs.data_ptr(), Bt, R, N,
+                                                   H, W, _lib.dtype_code(xd.dtype), _lib.stream_ptr()), "route_split")
+    return xr, Bs, Cs
+
+
+class SS2DProjCoreHip(torch.autograd.Function):
+    """x_proj output -> route split -> dt_proj -> fused 4-route scan/merge, as ONE autograd node.
+
+    Takes the natural-order x_proj result ``x_dbl`` (B, 4*(R+2N), L) and the dt_proj weights; everything between
+    them and the scan (route re-layout, the small contiguous B/C tensors, the dtype of their fp32 gradient
+    accumulators) stays inside, so the backward pass hands one gradient tensor back to x_proj without the
+    slice / stack / cast kernels an operator-by-operator formulation leaves to the framework."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, x_dbl, dt_w, A, D, bias, H, W):
+        _lib.require_cuda(x, x_dbl, dt_w, A, D, bias)
+        Bt, Dm, L = x.shape
+        K, _, R = dt_w.shape
+        N = A.shape[1]
+        C2 = R + 2 * N
+        if K != 4 or L != H * W or x_dbl.shape != (Bt, K * C2, L) or x_dbl.dtype != x.dtype:
+            raise RuntimeError("ss2d_proj_core: x (B,D,H*W), x_dbl (B,4*(R+2N),H*W) of one dtype, dt_w (4,D,R) expected")
+        x, x_dbl = x.contiguous(), x_dbl.contiguous()
+        A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
+        xr, Bs, Cs = _route_split(x_dbl, R, N, H, W)
+        w = dt_w.to(x.dtype)
+        dts = torch.matmul(w, xr)                                                    # (B, 4, D, L) in route order
+        plan = _plan(Bt, Dm, H, W, N, x.dtype)
+        chk = (torch.empty((Bt, 4, Dm, plan.n_chunks, N), dtype=torch.float32, device=x.device)
+               if plan.n_chunks > 1 else None)
+        y = torch.empty((Bt, Dm, L), dtype=torch.float32, device=x.device)
+        p = _lib.SS2DParams()
+        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk)
+        p.y = y.data_ptr()
+        isz = x.element_size()
+        nbytes = Bt * Dm * L * (5 * isz + 4) + 2 * Bt * 4 * N * L * isz
+        with torch.cuda.device(x.device), _lib.timed("ss2d_fwd", nbytes):
+            _lib.check(_lib.lib().xfm_ss2d_fwd(ctypes.byref(p), _lib.stream_ptr()), "ss2d_fwd")
+        ctx.hw = (H, W)
+        ctx.wdtype = dt_w.dtype
+        ctx.save_for_backward(x, xr, dts, w, A, Bs, Cs, D, bias, chk)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        from .proj import _bmm_f32
+        x, xr, dts, w, A, Bs, Cs, D, bias, chk = ctx.saved_tensors
+        H, W = ctx.hw
+        dev = x.device
+        Bt, Dm, L = x.shape
+        K, _, R = w.shape
+        N = A.shape[1]
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        ddts = torch.empty_like(dts)
+        nbc, na, nd = Bt * 4 * N * L, A.numel(), D.numel()
+        acc = torch.zeros(2 * nbc + na + 2 * nd, dtype=torch.float32, device=dev)     # ONE fill for all accumulators
+        dBs, dCs = acc[:nbc].view(Bs.shape), acc[nbc:2 * nbc].view(Cs.shape)
+        dA = acc[2 * nbc:2 * nbc + na].view(A.shape)
+        dD, dbias = acc[2 * nbc + na:2 * nbc + na + nd], acc[2 * nbc + na + nd:]
+        p = _lib.SS2DParams()
+        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk)
+        p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
+        p.dBs, p.dCs, p.dA, p.dD, p.ddelta_bias = (dBs.data_ptr(), dCs.data_ptr(), dA.data_ptr(), dD.data_ptr(),
+                                                   dbias.data_ptr())
+        isz = x.element_size()
+        nbytes = Bt * Dm * L * (10 * isz + 4) + 2 * Bt * 4 * N * L * (isz + 4)
+        with torch.cuda.device(dev), _lib.timed("ss2d_bwd", nbytes):
+            _lib.check(_lib.lib().xfm_ss2d_bwd(ctypes.byref(p), _lib.stream_ptr()), "ss2d_bwd")
+        dxr = torch.matmul(w.transpose(1, 2), ddts)                                   # (B, 4, R, L)
+        dw = _bmm_f32(ddts.view(Bt * K, Dm, L), xr.view(Bt * K, R, L).transpose(1, 2)).view(Bt, K, Dm, R).sum(0)
+        dxd = torch.empty((Bt, K * (R + 2 * N), L), dtype=x.dtype, device=dev)
+        with torch.cuda.device(dev), _lib.timed("route_merge", 2 * dxd.numel() * isz):
+            _lib.check(_lib.lib().xfm_ss2d_route_merge(dxr.data_ptr(), dBs.data_ptr(), dCs.data_ptr(), dxd.data_ptr(), Bt,
+                                                       R, N, H, W, _lib.dtype_code(x.dtype), _lib.stream_ptr()),
+                       "route_merge")
+        return dx, dxd, dw.to(ctx.wdtype), dA, dD, dbias, None, None
+
+
+def ss2d_proj_core_fn(x, x_dbl, dt_projs_weight, A, D, bias, H, W):
+    """x (B,D,L) natural; x_dbl (B,4*(R+2N),L) = x_proj of the four routes evaluated on the natural map;
+    dt_projs_weight (4,D,R); A (4D,N); D/bias (4D,) -> y (B,D,L) fp32."""
+    return SS2DProjCoreHip.apply(x, x_dbl, dt_projs_weight, A, D, bias, H, W)
 
 
 def ss2d_core_fn(x, dts, A, Bs, Cs, D, bias, H, W):
