@@ -95,6 +95,7 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from xfmamba_amd import _lib, fusion_vmamba
+    from xfmamba_amd.amp import WeightCache
     from xfmamba_amd.dp import GradBuckets, broadcast_parameters
     from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
     _lib.lib()                                                   # fail loudly if the HIP extension is missing
@@ -119,6 +120,7 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True,     # 1_train_model.py:141
                            capturable=use_graph)
     crit = torch.nn.CrossEntropyLoss()
+    wcache = WeightCache(model) if a.dtype == "bf16" else None     # bf16 shadows, one multi-tensor refresh per step
 
     torch.manual_seed(42 + rank)
     B = a.batch
@@ -135,6 +137,8 @@ def main():
         loss.backward()
         buckets.finish()
         opt.step()
+        if wcache is not None:
+            wcache.refresh()
         return loss
 
     def fence():

@@ -118,6 +118,13 @@ int xfm_ss2d_route_split(const void *xd, void *xr, void *Bs, void *Cs, int B, in
 int xfm_ss2d_route_merge(const void *dxr, const float *dBs, const float *dCs, void *dxd, int B, int R, int N, int H,
                          int W, int dtype, void *stream);
 
+/* dt_proj of the SS2D core: dts[b,k,d,l] = sum_r weight[k,d,r] * xr[b,k,r,l] (the grouped
+ * `einsum("b k r l, k d r -> b k d l")` of forward_corev2, models/fusion_vmamba.py:1154-1156).  xr (B,4,R,L) and
+ * dts (B,4,D,L) in `dtype` (XFM_F32 / XFM_BF16), weight (4,D,R) fp32; L % 4 == 0, R <= 64. */
+int xfm_ss2d_dt_proj_supported(int D, int R, int L);
+int xfm_ss2d_dt_proj_fwd(const void *xr, const float *weight, void *dts, int B, int D, int R, int L, int dtype,
+                         void *stream);
+
 /* Depthwise 3x3 convolution, padding 1, stride 1, optional bias, optionally fused with SiLU.
  * x, y, dy, dx: (B, D, H, W) contiguous in `dtype`; weight: (D, 1, 3, 3) fp32; bias: (D) fp32 or NULL.
  * Backward recomputes the pre-activation; dweight (D*9) and dbias (D) are fp32 and must be ZEROED. */

@@ -104,3 +104,25 @@ def test_drop_path_sample_scale_matches_forward_distribution():
     s = dp.sample_scale(4000, "cpu")
     assert all(min(abs(v), abs(v - 1 / 0.75)) < 1e-6 for v in s.unique().tolist()) and abs(float(s.mean()) - 1.0) < 0.05
     assert dp.eval().sample_scale(8, "cpu") is None and DropPath(0.0).train().sample_scale(8, "cpu") is None
+
+
+def test_weight_cache_serves_current_shadows_only():
+    """bf16 shadows are used while the parameter is unchanged since refresh(); any in-place update invalidates them."""
+    from xfmamba_amd.amp import WeightCache, cast_weight
+    lin = torch.nn.Linear(6, 4)
+    assert cast_weight(lin.weight, torch.bfloat16).data_ptr() != cast_weight(lin.weight, torch.bfloat16).data_ptr()
+    cache = WeightCache(lin)
+    a = cast_weight(lin.weight, torch.bfloat16)
+    assert a.data_ptr() == cast_weight(lin.weight, torch.bfloat16).data_ptr() and a.dtype == torch.bfloat16
+    assert torch.equal(a, lin.weight.detach().to(torch.bfloat16))
+    v = cast_weight(lin.weight.reshape(2, 12), torch.bfloat16)                   # reshaped view of the parameter
+    assert v.shape == (2, 12) and v.data_ptr() == a.data_ptr()
+    with torch.no_grad():
+        lin.weight.add_(1.0)                                                    # optimizer-style in-place update
+    stale = cast_weight(lin.weight, torch.bfloat16)
+    assert stale.data_ptr() != a.data_ptr() and torch.equal(stale, lin.weight.detach().to(torch.bfloat16))
+    cache.refresh()
+    assert torch.equal(cast_weight(lin.weight, torch.bfloat16), lin.weight.detach().to(torch.bfloat16))
+    assert cast_weight(lin.weight, torch.bfloat16).data_ptr() == a.data_ptr()
+    cache.close()
+    assert cast_weight(lin.weight, torch.bfloat16).data_ptr() != a.data_ptr()

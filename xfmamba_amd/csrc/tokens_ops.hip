@@ -13,43 +13,6 @@
 
 namespace xfm {
 
-template <typename T> struct Pack;           // 16-byte vector of T  <->  fp32 lanes
-template <> struct Pack<float> {
-    static constexpr int N = 4;
-    static __device__ __forceinline__ void ld(const float *p, float *v) {
-        const float4 r = *reinterpret_cast<const float4 *>(p);
-        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
-    }
-    static __device__ __forceinline__ void st(float *p, const float *v) {
-        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-};
-template <> struct Pack<bf16_t> {
-    static constexpr int N = 8;
-    static __device__ __forceinline__ void ld(const bf16_t *p, float *v) {
-        const uint4 r = *reinterpret_cast<const uint4 *>(p);
-        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __uint_as_float(w[i] << 16);
-            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-        }
-    }
-    static __device__ __forceinline__ uint32_t rne(float f) {
-        uint32_t u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    }
-    static __device__ __forceinline__ void st(bf16_t *p, const float *v) {
-        uint4 r;
-        r.x = rne(v[0]) | (rne(v[1]) << 16);
-        r.y = rne(v[2]) | (rne(v[3]) << 16);
-        r.z = rne(v[4]) | (rne(v[5]) << 16);
-        r.w = rne(v[6]) | (rne(v[7]) << 16);
-        *reinterpret_cast<uint4 *>(p) = r;
-    }
-};
-
 constexpr float kInvSqrt2 = 0.70710678118654752f;
 constexpr float kInvSqrt2Pi = 0.3989422804014327f;
 

@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from .amp import cast_weight
 from .proj import split_k_wgrad
 
 __all__ = ["bias_gelu_fn", "colsum_fn", "linear_tokens_fn", "mlp_tokens_fn"]
@@ -78,8 +79,8 @@ class LinearTokens(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         cd = x.dtype
-        w = weight.to(cd)
-        y = torch.nn.functional.linear(x, w, None if bias is None else bias.to(cd))
+        w = cast_weight(weight, cd)
+        y = torch.nn.functional.linear(x, w, None if bias is None else cast_weight(bias, cd))
         ctx.save_for_backward(x, w)
         ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
         return y

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import torch
 
+from .amp import cast_weight
+
 __all__ = ["batched_proj", "split_k_wgrad"]
 
 _F32_OUT = [None]      # does torch.bmm accept out_dtype on this build?  probed once
@@ -63,7 +65,7 @@ class BatchedProj(torch.autograd.Function):
         x = x.contiguous()
         B = x.shape[0]
         cd = x.dtype
-        w = weight.to(cd)
+        w = cast_weight(weight, cd)
         M, K = w.shape
         if out_tokens:
             xt = x if in_tokens else x.transpose(1, 2)                       # (B, L, K)

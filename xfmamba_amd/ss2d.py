@@ -15,6 +15,7 @@ import ctypes
 import torch
 
 from . import _lib
+from .amp import cast_weight
 
 __all__ = ["ss2d_core_fn", "ss2d_proj_core_fn", "SS2DCoreHip", "SS2DProjCoreHip", "to_route_order"]
 
@@ -128,8 +129,16 @@ class SS2DProjCoreHip(torch.autograd.Function):
         x, x_dbl = x.contiguous(), x_dbl.contiguous()
         A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
         xr, Bs, Cs = _route_split(x_dbl, R, N, H, W)
-        w = dt_w.to(x.dtype)
-        dts = torch.matmul(w, xr)                                                    # (B, 4, D, L) in route order
+        w = cast_weight(dt_w, x.dtype)
+        lib = _lib.lib()
+        if x.dtype in (torch.float32, torch.bfloat16) and lib.xfm_ss2d_dt_proj_supported(Dm, R, L):
+            wf = dt_w.detach().float().contiguous()
+            dts = torch.empty((Bt, 4, Dm, L), dtype=x.dtype, device=x.device)        # (B, 4, D, L) in route order
+            with torch.cuda.device(x.device), _lib.timed("dt_proj_fwd", dts.numel() * dts.element_size()):
+                _lib.check(lib.xfm_ss2d_dt_proj_fwd(xr.data_ptr(), wf.data_ptr(), dts.data_ptr(), Bt, Dm, R, L,
+                                                    _lib.dtype_code(x.dtype), _lib.stream_ptr()), "dt_proj_fwd")
+        else:
+            dts = torch.matmul(w, xr)
         plan = _plan(Bt, Dm, H, W, N, x.dtype)
         chk = (torch.empty((Bt, 4, Dm, plan.n_chunks, N), dtype=torch.float32, device=x.device)
                if plan.n_chunks > 1 else None)
