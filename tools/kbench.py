@@ -98,8 +98,9 @@ def main():
             t = time_raw(_lib.lib().xfm_selective_scan_bwd, p)
             print(f"{'scan_bwd ' + name:28s} {t:9.1f} {bb / t / 1e3:8.1f} {bb / t / 1e3 / 80:6.2f}")
     for name, Bt, D, H, N in shapes:
-        if a.only and a.only not in "ss2d" and a.only not in name:
+        if a.only and a.only not in ("ss2d", "dwconv") and a.only not in name:
             continue
+        do_ss2d = a.only != "dwconv"
         L = H * H
         x = torch.randn(Bt, D, L, device=dev).to(dt)
         dts = (0.5 * torch.rand(Bt, 4, D, L, device=dev)).to(dt)
@@ -126,20 +127,35 @@ def main():
         S2._fill(p, x, dts, A, Bs, Cs, Dp, bias, H, H, torch.float32, chk)
         p.y, p.dy, p.dx, p.ddts = y.data_ptr(), gy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
         p.dBs, p.dCs, p.dA, p.dD, p.ddelta_bias = dBs.data_ptr(), dCs.data_ptr(), dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
-        t = time_raw(_lib.lib().xfm_ss2d_fwd, p)
-        print(f"{'ss2d_fwd ' + name:28s} {t:9.1f} {fb / t / 1e3:8.1f} {fb / t / 1e3 / 80:6.2f}  {ptxt}")
-        t = time_raw(_lib.lib().xfm_ss2d_bwd, p)
-        print(f"{'ss2d_bwd ' + name:28s} {t:9.1f} {bb / t / 1e3:8.1f} {bb / t / 1e3 / 80:6.2f}")
-        if N == 1 and (not a.only or a.only in "dwconv"):
-            x4 = x.view(Bt, D, H, H)
+        if do_ss2d:
+            t = time_raw(_lib.lib().xfm_ss2d_fwd, p)
+            print(f"{'ss2d_fwd ' + name:28s} {t:9.1f} {fb / t / 1e3:8.1f} {fb / t / 1e3 / 80:6.2f}  {ptxt}")
+            t = time_raw(_lib.lib().xfm_ss2d_bwd, p)
+            print(f"{'ss2d_bwd ' + name:28s} {t:9.1f} {bb / t / 1e3:8.1f} {bb / t / 1e3 / 80:6.2f}")
+        if (N == 1 or a.only == "dwconv") and a.only != "ss2d":
+            lib = _lib.lib()
             w = torch.randn(D, 1, 3, 3, device=dev)
-            t = timeit(lambda: DWConv3x3SiLUHip.apply(x4, w, None, True))
+            y4, g4, dx4 = torch.empty_like(x), torch.randn_like(x), torch.empty_like(x)
+            dw, code = torch.zeros(D * 9, device=dev), _lib.dtype_code(dt)
+            st = _lib.stream_ptr()
+
+            def raw(fn, reps=30):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / reps
+
+            t = raw(lambda: lib.xfm_dwconv3x3_fwd(x.data_ptr(), w.data_ptr(), None, y4.data_ptr(), Bt, D, H, H, code, 1, st))
             nb = 2 * x.numel() * isz
             print(f"{'dwconv_fwd ' + name:28s} {t:9.1f} {nb / t / 1e3:8.1f} {nb / t / 1e3 / 80:6.2f}")
-            x4r = x4.clone().requires_grad_()
-            y4 = DWConv3x3SiLUHip.apply(x4r, w, None, True)
-            g4 = torch.randn_like(y4)
-            t = timeit(lambda: torch.autograd.grad(y4, x4r, g4, retain_graph=True))
+            t = raw(lambda: lib.xfm_dwconv3x3_bwd(x.data_ptr(), w.data_ptr(), None, g4.data_ptr(), dx4.data_ptr(),
+                                                  dw.data_ptr(), None, Bt, D, H, H, code, 1, st))
             nb = 3 * x.numel() * isz
             print(f"{'dwconv_bwd ' + name:28s} {t:9.1f} {nb / t / 1e3:8.1f} {nb / t / 1e3 / 80:6.2f}")
 

@@ -12,6 +12,8 @@
 // stay inside a wave.
 #include "xfm_common.hpp"
 
+#include <cstdlib>
+
 namespace xfm {
 
 __device__ __forceinline__ float sigmoidf_fast(float z) { return 1.f / (1.f + __expf(-z)); }
@@ -142,11 +144,255 @@ __global__ void __launch_bounds__(256) dwconv_bwd_kernel(const T *__restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path for maps whose rows are 7 vectors wide (W = 7 * VEC, VEC in {8,4,2,1}: the 56/28/14/7 maps of the trunk).
+// A workgroup owns PP channels (one LDS plane each, with a zero halo that is written once) and walks a slice of the
+// batch, so weights are loaded once and -- in the backward pass -- the 9 + 1 weight / bias gradient sums of a channel
+// stay in registers across the whole slice: one atomic per tap per workgroup instead of one per plane and wavefront.
+// TP = blockDim / PP threads share a plane; every thread moves whole 16-byte (VEC-element) vectors: one vector load,
+// 3 x (1 vector + 2 scalar) LDS reads for the 3x3 window of VEC outputs, one vector store.
+template <typename T> __device__ __forceinline__ float cvt16(uint16_t h);
+template <> __device__ __forceinline__ float cvt16<bf16_t>(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+template <> __device__ __forceinline__ float cvt16<f16_t>(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+template <typename T> __device__ __forceinline__ uint16_t pack16(float f);
+template <> __device__ __forceinline__ uint16_t pack16<bf16_t>(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+template <> __device__ __forceinline__ uint16_t pack16<f16_t>(float f) { return __half_as_ushort(__float2half(f)); }
+
+template <typename T, int VEC> __device__ __forceinline__ void ld_vec(const T *p, float *v) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = reinterpret_cast<const float *>(p)[i];   // merged into dwordx2/x4 loads
+    } else {
+        uint16_t h[VEC];
+        if constexpr (VEC == 8) *reinterpret_cast<uint4 *>(h) = *reinterpret_cast<const uint4 *>(p);
+        else if constexpr (VEC == 4) *reinterpret_cast<uint2 *>(h) = *reinterpret_cast<const uint2 *>(p);
+        else if constexpr (VEC == 2) *reinterpret_cast<uint32_t *>(h) = *reinterpret_cast<const uint32_t *>(p);
+        else h[0] = *reinterpret_cast<const uint16_t *>(p);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = cvt16<T>(h[i]);
+    }
+}
+template <typename T, int VEC> __device__ __forceinline__ void st_vec(T *p, const float *v) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) reinterpret_cast<float *>(p)[i] = v[i];
+    } else {
+        uint16_t h[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) h[i] = pack16<T>(v[i]);
+        if constexpr (VEC == 8) *reinterpret_cast<uint4 *>(p) = *reinterpret_cast<const uint4 *>(h);
+        else if constexpr (VEC == 4) *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(h);
+        else if constexpr (VEC == 2) *reinterpret_cast<uint32_t *>(p) = *reinterpret_cast<const uint32_t *>(h);
+        else *reinterpret_cast<uint16_t *>(p) = h[0];
+    }
+}
+
+struct Dw7Args {
+    const void *x, *dy;
+    const float *w, *bias;
+    void *out;                       // y (fwd) / dx (bwd)
+    float *dw, *dbias;
+    int B, D, H, PP, TP, bsplit, act;
+};
+
+constexpr int kDwLeft = 4;           // interior starts 4 floats into a padded row: vector LDS accesses stay aligned
+__host__ __device__ constexpr int dw7_pitch(int W) { return (W + kDwLeft + 1 + 3) & ~3; }
+
+// window of row `row` for outputs c0 .. c0+VEC-1: q[0] = left neighbour, q[1..VEC] = the vector, q[VEC+1] = right
+template <int VEC> __device__ __forceinline__ void ld_window(const float *row, int c0, float *q) {
+    const float *m = row + kDwLeft + c0;
+    q[0] = m[-1];
+    if constexpr (VEC >= 4) {
+#pragma unroll
+        for (int i = 0; i < VEC; i += 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(m + i);
+            q[1 + i] = t.x; q[2 + i] = t.y; q[3 + i] = t.z; q[4 + i] = t.w;
+        }
+    } else if constexpr (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(m);
+        q[1] = t.x; q[2] = t.y;
+    } else {
+        q[1] = m[0];
+    }
+    q[VEC + 1] = m[VEC];
+}
+
+template <int VEC> __device__ __forceinline__ void st_row(float *dst, const float *v) {
+    if constexpr (VEC >= 4) {
+#pragma unroll
+        for (int i = 0; i < VEC; i += 4) *reinterpret_cast<float4 *>(dst + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[1]);
+    } else {
+        dst[0] = v[0];
+    }
+}
+
+template <typename T, int VEC, bool BWD>
+__global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
+    constexpr int LPR = 7, W = LPR * VEC, PITCH = dw7_pitch(W);
+    extern __shared__ float smem[];
+    const int H = a.H, PH = H + 2, L = H * W, psz = PH * PITCH;
+    const int j = threadIdx.x / a.TP, tl = threadIdx.x - j * a.TP;
+    const int ngrp = a.D / a.PP;
+    const int grp = blockIdx.x % ngrp, sl = blockIdx.x / ngrp;
+    const int d = grp * a.PP + j;
+    const int b0 = (int)((int64_t)a.B * sl / a.bsplit), b1 = (int)((int64_t)a.B * (sl + 1) / a.bsplit);
+    float *xs = smem + j * psz;                                    // padded x plane of this thread's channel
+    float *zs = smem + (a.PP + j) * psz;                           // padded dz plane (backward only)
+    // zero halo: only the cells the 3x3 windows read outside the map (top / bottom rows, one column left / right)
+    for (int bufi = 0; bufi < (BWD ? 2 : 1); ++bufi) {
+        float *pl = smem + (bufi * a.PP + j) * psz;
+        for (int e = tl; e < 2 * PITCH; e += a.TP) pl[(e < PITCH ? 0 : (PH - 1) * PITCH) + (e < PITCH ? e : e - PITCH)] = 0.f;
+        for (int e = tl; e < 2 * PH; e += a.TP) pl[(e >> 1) * PITCH + ((e & 1) ? kDwLeft + W : kDwLeft - 1)] = 0.f;
+    }
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = a.w[d * 9 + i];
+    const float bv = a.bias ? a.bias[d] : 0.f;
+    float acc[9], accb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    const T *x = static_cast<const T *>(a.x), *dy = static_cast<const T *>(a.dy);
+    T *out = static_cast<T *>(a.out);
+    const int nvec = H * LPR;
+    for (int b = b0; b < b1; ++b) {
+        const int64_t po = ((int64_t)b * a.D + d) * L;
+        __syncthreads();                                           // previous plane fully consumed (and LDS zeroed)
+        for (int v = tl; v < nvec; v += a.TP) {
+            const int h = v / LPR, c0 = (v - h * LPR) * VEC;
+            float t[VEC];
+            ld_vec<T, VEC>(x + po + h * W + c0, t);
+            st_row<VEC>(xs + (h + 1) * PITCH + kDwLeft + c0, t);
+        }
+        __syncthreads();
+        for (int v = tl; v < nvec; v += a.TP) {
+            const int h = v / LPR, c0 = (v - h * LPR) * VEC;
+            float q[3][VEC + 2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) ld_window<VEC>(xs + (h + r) * PITCH, c0, q[r]);
+            float z[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float s = bv;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) s = fmaf(k[r * 3 + c], q[r][i + c], s);
+                z[i] = s;
+            }
+            if constexpr (!BWD) {
+                if (a.act) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) z[i] *= sigmoidf_fast(z[i]);
+                }
+                st_vec<T, VEC>(out + po + h * W + c0, z);
+            } else {
+                float g[VEC];
+                ld_vec<T, VEC>(dy + po + h * W + c0, g);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    if (a.act) {
+                        const float s = sigmoidf_fast(z[i]);
+                        g[i] *= s * fmaf(z[i], 1.f - s, 1.f);        // d silu(z)/dz = s * (1 + z * (1 - s))
+                    }
+                    accb += g[i];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) acc[r * 3 + c] = fmaf(g[i], q[r][i + c], acc[r * 3 + c]);
+                }
+                st_row<VEC>(zs + (h + 1) * PITCH + kDwLeft + c0, g);
+            }
+        }
+        if constexpr (BWD) {
+            __syncthreads();
+            for (int v = tl; v < nvec; v += a.TP) {
+                const int h = v / LPR, c0 = (v - h * LPR) * VEC;
+                float q[3][VEC + 2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) ld_window<VEC>(zs + (h + r) * PITCH, c0, q[r]);
+                float o[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) s = fmaf(k[8 - (r * 3 + c)], q[r][i + c], s);
+                    o[i] = s;
+                }
+                st_vec<T, VEC>(out + po + h * W + c0, o);
+            }
+        }
+    }
+    if constexpr (BWD) {
+        // fold the TP partial sums of each channel through LDS (the plane buffers are free now)
+        __syncthreads();
+        float *red = smem;                                          // [PP][10][TP]
+#pragma unroll
+        for (int i = 0; i < 9; ++i) red[(j * 10 + i) * a.TP + tl] = acc[i];
+        red[(j * 10 + 9) * a.TP + tl] = accb;
+        __syncthreads();
+        if (tl < 10) {
+            float s = 0.f;
+            for (int q = 0; q < a.TP; ++q) s += red[(j * 10 + tl) * a.TP + q];
+            if (tl < 9) atomicAdd(a.dw + d * 9 + tl, s);
+            else if (a.dbias) atomicAdd(a.dbias + d, s);
+        }
+    }
+}
+
+// plan of the fast path: PP channels per workgroup (TP = 256 / PP threads each), batch split into `bsplit` slices
+static bool dw7_plan(bool bwd, int B, int D, int H, int W, int &vec, int &PP, int &bsplit, size_t &lds) {
+    if (W % 7 != 0) return false;
+    vec = W / 7;
+    if (vec != 1 && vec != 2 && vec != 4 && vec != 8) return false;
+    if (!bwd && vec == 8) return false;          // measured: the one-plane-per-workgroup kernel is faster for the 56x56 forward
+    const size_t psz = (size_t)(H + 2) * dw7_pitch(W) * sizeof(float);
+    const int nvec = H * 7;
+    PP = 32;
+    while (PP > 1 && (256 / PP < 10 || nvec * PP > 1568 * 2 || (bwd ? 2 : 1) * PP * psz > 60 * 1024 || D % PP != 0)) PP >>= 1;
+    if (D % PP != 0 || (bwd ? 2 : 1) * PP * psz > 64 * 1024) return false;
+    lds = (bwd ? 2 : 1) * PP * psz;
+    if (bwd && lds < (size_t)PP * 10 * (256 / PP) * sizeof(float)) lds = (size_t)PP * 10 * (256 / PP) * sizeof(float);
+    const int ngrp = D / PP;
+    bsplit = 1;
+    while (ngrp * bsplit < 1024 && bsplit < B) bsplit *= 2;
+    if (bsplit > B) bsplit = B;
+    return true;
+}
+
+template <typename T, bool BWD> static int launch_dw7(int vec, const Dw7Args &a, int grid, size_t lds, hipStream_t s) {
+    switch (vec) {
+        case 8: hipLaunchKernelGGL((dwconv7_kernel<T, 8, BWD>), dim3(grid), dim3(256), lds, s, a); break;
+        case 4: hipLaunchKernelGGL((dwconv7_kernel<T, 4, BWD>), dim3(grid), dim3(256), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((dwconv7_kernel<T, 2, BWD>), dim3(grid), dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((dwconv7_kernel<T, 1, BWD>), dim3(grid), dim3(256), lds, s, a); break;
+    }
+    return check_launch();
+}
+
 static int pick_pp(int L) { return L >= 1024 ? 1 : (L >= 256 ? 2 : 4); }
 
 template <typename T>
 static int launch_dw(bool bwd, const void *x, const float *w, const float *bias, const void *dy, void *out, float *dw,
                      float *dbias, int B, int D, int H, int W, int act, hipStream_t s) {
+    {
+        int vec, PP, bsplit;
+        size_t lds7;
+        if (!getenv("XFM_DWCONV_GENERIC") && dw7_plan(bwd, B, D, H, W, vec, PP, bsplit, lds7)) {
+            Dw7Args a{};
+            a.x = x; a.dy = dy; a.w = w; a.bias = bias; a.out = out; a.dw = dw; a.dbias = dbias;
+            a.B = B; a.D = D; a.H = H; a.PP = PP; a.TP = 256 / PP; a.bsplit = bsplit; a.act = act;
+            const int grid = (D / PP) * bsplit;
+            return bwd ? launch_dw7<T, true>(vec, a, grid, lds7, s) : launch_dw7<T, false>(vec, a, grid, lds7, s);
+        }
+    }
     const int planes = B * D;
     const int pp = pick_pp(H * W);
     const size_t lds = (size_t)pp * (bwd ? 2 : 1) * (H + 2) * (W + 2) * sizeof(float);

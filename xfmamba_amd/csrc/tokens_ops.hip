@@ -55,34 +55,48 @@ template <typename T, int MODE> __global__ void tokens_kernel(TokArgs a) {
     const T *z = static_cast<const T *>(a.z);
     const T *dg = static_cast<const T *>(a.dg);
     T *out = static_cast<T *>(a.out);
-    for (long r = (long)blockIdx.x * a.R + rs; r < a.rows; r += (long)gridDim.x * a.R) {
-        const long off = r * a.C + c0;
-        float v[V], o[V];
-        Pack<T>::ld(z + off, v);
-        if (MODE == 0) {
+    // UN rows per trip, all loads issued before the maths: a thread keeps 2*UN 16-byte loads in flight
+    constexpr int UN = 4;
+    const long step = (long)gridDim.x * a.R;
+    for (long r = (long)blockIdx.x * a.R + rs; r < a.rows; r += UN * step) {
+        float v[UN][V], d[UN][V];
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                const float u = v[i] + b[i];
-                float E;
-                o[i] = 0.5f * u * (1.0f + erf_as(u * kInvSqrt2, E));
+        for (int u = 0; u < UN; ++u) {
+            const long ru = r + u * step;
+            if (ru < a.rows) {
+                Pack<T>::ld(z + ru * a.C + c0, v[u]);
+                if (MODE == 1) Pack<T>::ld(dg + ru * a.C + c0, d[u]);
             }
-            Pack<T>::st(out + off, o);
-        } else if (MODE == 1) {
-            float d[V];
-            Pack<T>::ld(dg + off, d);
+        }
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                const float u = v[i] + b[i];
-                float E;
-                const float cdf = 0.5f * (1.0f + erf_as(u * kInvSqrt2, E));
-                const float pdf = kInvSqrt2Pi * E;
-                o[i] = d[i] * fmaf(u, pdf, cdf);
-                acc[i] += o[i];
+        for (int u = 0; u < UN; ++u) {
+            const long ru = r + u * step;
+            if (ru >= a.rows) break;
+            const long off = ru * a.C + c0;
+            float o[V];
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float x = v[u][i] + b[i];
+                    float E;
+                    o[i] = 0.5f * x * (1.0f + erf_as(x * kInvSqrt2, E));
+                }
+                Pack<T>::st(out + off, o);
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float x = v[u][i] + b[i];
+                    float E;
+                    const float cdf = 0.5f * (1.0f + erf_as(x * kInvSqrt2, E));
+                    const float pdf = kInvSqrt2Pi * E;
+                    o[i] = d[u][i] * fmaf(x, pdf, cdf);
+                    acc[i] += o[i];
+                }
+                Pack<T>::st(out + off, o);
+            } else {
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[i] += v[u][i];
             }
-            Pack<T>::st(out + off, o);
-        } else {
-#pragma unroll
-            for (int i = 0; i < V; ++i) acc[i] += v[i];
         }
     }
     if (MODE != 0) {
@@ -136,7 +150,7 @@ static bool tok_shape(long rows, int C, int vec, bool reduce, TokShape &s) {
     s.threads = s.NT * s.R;
     if (reduce && (long)s.R * C * 4 > 64 * 1024) return false;
     long nb = (rows + s.R - 1) / s.R;
-    const long cap = reduce ? 512 : 16384;
+    const long cap = reduce ? 1024 : 4096;
     s.nblk = (int)(nb > cap ? cap : nb);
     return true;
 }
