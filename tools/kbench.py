@@ -66,6 +66,27 @@ def main():
     shapes = [("stage0", B, 96, 56, 1), ("stage1", B, 192, 28, 1), ("stage2", B, 384, 14, 1), ("stage3", B, 768, 7, 1),
               ("deep", B // 2, 1536, 7, 16)]
     print(f"{'kernel':28s} {'us':>9s} {'GB/s':>8s} {'%HBM':>6s}  plan")
+    if not a.only or a.only == "dtproj":
+        lib = _lib.lib()
+        for name, Bt, D, H in (("stage0", B, 96, 56), ("stage1", B, 192, 28), ("stage2", B, 384, 14)):
+            R, L = D // 16, H * H
+            xr = torch.randn(Bt, 4, R, L, device=dev).to(dt)
+            w = torch.randn(4, D, R, device=dev)
+            out = torch.empty(Bt, 4, D, L, device=dev, dtype=dt)
+            st, code = _lib.stream_ptr(), _lib.dtype_code(dt)
+            fn = lambda: lib.xfm_ss2d_dt_proj_fwd(xr.data_ptr(), w.data_ptr(), out.data_ptr(), Bt, D, R, L, code, st)
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(30):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e3 / 30
+            nb = out.numel() * out.element_size()
+            print(f"{'dt_proj_fwd ' + name:28s} {t:9.1f} {nb / t / 1e3:8.1f} {nb / t / 1e3 / 80:6.2f}")
     if not a.only or a.only in "rowscan":
         from xfmamba_amd import csms6s
         for name, Bt, KD, N in (("rowscan fusion", B // 2, 6144, 16), ("rowscan stage3", B, 3072, 1)):

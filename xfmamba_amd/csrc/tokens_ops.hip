@@ -150,7 +150,7 @@ static bool tok_shape(long rows, int C, int vec, bool reduce, TokShape &s) {
     s.threads = s.NT * s.R;
     if (reduce && (long)s.R * C * 4 > 64 * 1024) return false;
     long nb = (rows + s.R - 1) / s.R;
-    const long cap = reduce ? 1024 : 4096;
+    const long cap = reduce ? 512 : 4096;
     s.nblk = (int)(nb > cap ? cap : nb);
     return true;
 }
