@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--model", default="tiny", choices=["tiny", "small", "base"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--ss2d", default=None, choices=["fused", "unfused"])
+    ap.add_argument("--graph-scope", default=None, choices=["step", "fwdbwd"],
+                    help="what the hipGraph captures (default: whole step at N=1, forward+backward at N>1)")
     ap.add_argument("--stream", default=None, choices=["tokens", "planes"], help="residual-stream layout of the trunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -115,10 +117,15 @@ def main():
                 m.drop_prob = a.drop_path
     if world > 1:
         broadcast_parameters(model)
-    buckets = GradBuckets(model, bucket_mb=48.0)                 # also makes .grad views of flat buffers
-    use_graph = (not a.no_graph) and world == 1     # (captured RCCL collectives: not exercised yet -> eager for N > 1)
+    use_graph = not a.no_graph
+    # What the hipGraph holds: the whole step at N = 1 ("step"); with several ranks (or --graph-scope fwdbwd) the
+    # forward + backward + gradient packing, while the RCCL all-reduce of the flat buckets, Adam and the weight-shadow
+    # refresh -- a few dozen launches -- are issued eagerly after each replay, so no collective is captured.
+    scope = a.graph_scope or ("step" if world == 1 else "fwdbwd")
+    assert not (world > 1 and scope == "step"), "RCCL collectives are not captured: use --graph-scope fwdbwd with N > 1"
+    buckets = GradBuckets(model, bucket_mb=48.0, overlap=not use_graph)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True,     # 1_train_model.py:141
-                           capturable=use_graph)
+                           capturable=use_graph and scope == "step")
     crit = torch.nn.CrossEntropyLoss()
     wcache = WeightCache(model) if a.dtype == "bf16" else None     # bf16 shadows, one multi-tensor refresh per step
 
@@ -129,17 +136,39 @@ def main():
     lab = torch.randint(0, 2, (B,), device=dev)
     use_bf16 = a.dtype == "bf16"
 
-    def step():
+    def fwd_bwd():
         buckets.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
             out = model(xa, xb)
             loss = crit(out.float(), lab)
         loss.backward()
-        buckets.finish()
+        return loss
+
+    def update():
         opt.step()
         if wcache is not None:
             wcache.refresh()
+
+    def step():                                      # one eager training step
+        loss = fwd_bwd()
+        buckets.finish()
+        update()
         return loss
+
+    def captured_part():                             # what goes into the graph
+        loss = fwd_bwd()
+        if scope == "step":
+            buckets.finish()                         # world == 1: nothing to reduce
+            update()
+        elif world > 1:
+            buckets.pack_all()
+        return loss
+
+    def after_replay():                              # eager tail of a replayed step
+        if scope != "step":
+            if world > 1:
+                buckets.reduce_all()
+            update()
 
     def fence():
         if world > 1:
@@ -161,7 +190,7 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                loss_static = step()
+                loss_static = captured_part()
         except Exception as e:                       # noqa: BLE001  (report and fall back to eager launches)
             print(f"[bench] graph capture failed, running eager: {type(e).__name__}: {e}", file=sys.stderr)
             graph = None
@@ -170,6 +199,7 @@ def main():
     def run_step():
         if graph is not None:
             graph.replay()
+            after_replay()
             return loss_static
         return step()
 
@@ -241,7 +271,7 @@ def main():
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                             "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1),
                             "ms_per_step": round(v["total_ms"] / ksteps, 3)} for k, v in kernels.items()},
-            "launch_mode": "hipGraph" if graph is not None else "eager",
+            "launch_mode": (f"hipGraph({scope})" if graph is not None else "eager"),
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -28,7 +28,7 @@ def _worker(rank, world, port, overlap, q):
     torch.manual_seed(100 + rank)                 # different init per rank -> broadcast must fix it
     net = _Net()
     broadcast_parameters(net)
-    gb = GradBuckets(net, bucket_mb=0.0005, overlap=overlap)   # tiny buckets -> several collectives
+    gb = GradBuckets(net, bucket_mb=0.0005, overlap=overlap is True)   # tiny buckets -> several collectives
     assert len(gb.buckets) >= 2
     g = torch.Generator().manual_seed(7)
     x = torch.randn(8, 8, generator=g)
@@ -37,7 +37,11 @@ def _worker(rank, world, port, overlap, q):
         gb.zero_grad()
         sl = slice(rank * 4, rank * 4 + 4)
         torch.nn.functional.cross_entropy(net(x[sl]), y[sl]).backward()
-        gb.finish()
+        if overlap == "split":                     # the captured-graph flow of bench.py: pack, then reduce
+            gb.pack_all()
+            gb.reduce_all()
+        else:
+            gb.finish()
     grads = {k: p.grad.clone() for k, p in net.named_parameters()}
     ref = _Net()
     ref.load_state_dict(net.state_dict())
@@ -50,7 +54,7 @@ def _worker(rank, world, port, overlap, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, False, "split"])
 def test_grad_buckets_world2_gloo(overlap):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

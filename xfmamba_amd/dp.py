@@ -86,26 +86,47 @@ class GradBuckets:
         if self._pending[bi] == 0:
             self._launch(bi)
 
-    def _launch(self, bi):
-        if self._launched[bi]:
-            return
-        self._launched[bi] = True
-        flat, grp, views = self.buckets[bi], self._groups[bi], self._views[bi]
+    def _pack(self, bi):
+        """Copy the bucket's gradients into its flat buffer (one multi-tensor kernel) and re-point ``.grad``."""
+        grp, views = self._groups[bi], self._views[bi]
         have = [(v, p.grad) for v, p in zip(views, grp) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])      # one multi-tensor pack
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         for v, p in zip(views, grp):
             if p.grad is None:
                 v.zero_()                                   # never-used parameter: same on every rank
             p.grad = v
+
+    def _reduce(self, bi, async_op=True):
+        flat = self.buckets[bi]
+        flat.div_(self.world)
+        w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            self._work.append(w)
+
+    def _launch(self, bi):
+        if self._launched[bi]:
+            return
+        self._launched[bi] = True
+        self._pack(bi)
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
-                flat.div_(self.world)
-                self._work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._reduce(bi)
         else:
-            flat.div_(self.world)
-            self._work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._reduce(bi)
+
+    # ---- split form for a captured forward/backward: pack inside the graph, reduce outside -------------------
+    def pack_all(self):
+        """Pack every bucket (no communication).  Safe to capture in a hipGraph: after the capture ``.grad`` of
+        every parameter is a view of a flat buffer the replayed pack kernels refill."""
+        for bi in range(len(self.buckets)):
+            self._pack(bi)
+
+    def reduce_all(self):
+        """All-reduce (average) the packed buckets on the current stream."""
+        for bi in range(len(self.buckets)):
+            self._reduce(bi, async_op=False)
 
     # ---- call after loss.backward() ------------------------------------------------------------
     def finish(self):
