@@ -120,10 +120,12 @@ int xfm_ss2d_route_merge(const void *dxr, const float *dBs, const float *dCs, vo
 
 /* dt_proj of the SS2D core: dts[b,k,d,l] = sum_r weight[k,d,r] * xr[b,k,r,l] (the grouped
  * `einsum("b k r l, k d r -> b k d l")` of forward_corev2, models/fusion_vmamba.py:1154-1156).  xr (B,4,R,L) and
- * dts (B,4,D,L) in `dtype` (XFM_F32 / XFM_BF16), weight (4,D,R) fp32; L % 4 == 0, R <= 64. */
+ * dts (B,4,D,L) in `dtype` (XFM_F32 / XFM_BF16), weight (4,D,R) fp32; L % 4 == 0, R <= 64.
+ * softplus_bias (4*D fp32) != NULL: the epilogue stores softplus(dts + bias) (threshold 20) -- the activated step
+ * size, for xfm_ss2d_fwd/_bwd called with delta_softplus = 2. */
 int xfm_ss2d_dt_proj_supported(int D, int R, int L);
-int xfm_ss2d_dt_proj_fwd(const void *xr, const float *weight, void *dts, int B, int D, int R, int L, int dtype,
-                         void *stream);
+int xfm_ss2d_dt_proj_fwd(const void *xr, const float *weight, const float *softplus_bias, void *dts, int B, int D, int R,
+                         int L, int dtype, void *stream);
 
 /* Depthwise 3x3 convolution, padding 1, stride 1, optional bias, optionally fused with SiLU.
  * x, y, dy, dx: (B, D, H, W) contiguous in `dtype`; weight: (D, 1, 3, 3) fp32; bias: (D) fp32 or NULL.
@@ -193,7 +195,9 @@ int xfm_colsum(const void *x, float *out, float *workspace, long long rows, int 
  */
 typedef struct {
     int batch, d_inner, H, W, dstate;
-    int delta_softplus;
+    int delta_softplus;    /* 0: step = dts + bias; 1: step = softplus(dts + bias) (models/csms6s.py:49-50); 2: dts already
+                            * holds softplus(raw + bias) (xfm_ss2d_dt_proj_fwd epilogue): delta_bias is not read, and
+                            * ddts / ddelta_bias are still the gradients of the RAW pre-activation / of the bias */
     int in_dtype;          /* of x, dts, Bs, Cs, dx, ddts */
     int out_dtype;         /* of y / dy (fp32 = "oflex") */
     const void *x;         /* (batch, d_inner, H*W) */

@@ -74,7 +74,7 @@ def main():
             w = torch.randn(4, D, R, device=dev)
             out = torch.empty(Bt, 4, D, L, device=dev, dtype=dt)
             st, code = _lib.stream_ptr(), _lib.dtype_code(dt)
-            fn = lambda: lib.xfm_ss2d_dt_proj_fwd(xr.data_ptr(), w.data_ptr(), out.data_ptr(), Bt, D, R, L, code, st)
+            fn = lambda: lib.xfm_ss2d_dt_proj_fwd(xr.data_ptr(), w.data_ptr(), None, out.data_ptr(), Bt, D, R, L, code, st)
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()

@@ -106,7 +106,7 @@ def lib() -> C.CDLL:
         l.xfm_ss2d_route_split.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]
         l.xfm_ss2d_route_merge.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]
         l.xfm_ss2d_dt_proj_supported.argtypes = [C.c_int] * 3
-        l.xfm_ss2d_dt_proj_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]
+        l.xfm_ss2d_dt_proj_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
         l.xfm_colsum_blocks.argtypes = [C.c_longlong, C.c_int, C.c_int]
         l.xfm_bias_gelu_fwd.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]
         l.xfm_bias_gelu_bwd.argtypes = [C.c_void_p] * 6 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]

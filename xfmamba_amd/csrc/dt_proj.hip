@@ -12,6 +12,7 @@ namespace xfm {
 struct DtProjArgs {
     const void *xr;     // (B, 4, R, L)
     const float *w;     // (4, D, R) fp32
+    const float *bias;  // (4*D) or null: epilogue dts = softplus(acc + bias) (threshold 20, as F.softplus)
     void *out;          // (B, 4, D, L)
     int D, R, L, TL, ntile, dsplit;
 };
@@ -54,6 +55,11 @@ template <typename T, int VEC> __global__ __launch_bounds__(256) void dt_proj_fw
                 acc[i + 3] = fmaf(w, q.w, acc[i + 3]);
             }
         }
+        if (a.bias) {
+            const float bv = a.bias[k * a.D + d];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = softplus20(acc[i] + bv);
+        }
         T *o = out + (int64_t)d * a.L + c;
         if constexpr (VEC == Pack<T>::N) {
             Pack<T>::st(o, acc);
@@ -64,12 +70,14 @@ template <typename T, int VEC> __global__ __launch_bounds__(256) void dt_proj_fw
     }
 }
 
-template <typename T> static int dt_proj_launch(const void *xr, const float *w, void *out, int B, int D, int R, int L, hipStream_t s) {
+template <typename T>
+static int dt_proj_launch(const void *xr, const float *w, const float *bias, void *out, int B, int D, int R, int L,
+                          hipStream_t s) {
     constexpr int VN = Pack<T>::N;                      // 8 (16-bit) or 4 (fp32) elements per 16-byte vector
     const int vec = (L % VN == 0) ? VN : 4;
     if (L % 4 != 0) return XFM_ELIMIT;
     DtProjArgs a{};
-    a.xr = xr; a.w = w; a.out = out; a.D = D; a.R = R; a.L = L;
+    a.xr = xr; a.w = w; a.bias = bias; a.out = out; a.D = D; a.R = R; a.L = L;
     // L-tile: whole rows of vectors, R*TL floats <= 40 KB of LDS
     int ntile = 1;
     while ((int64_t)R * ((L / vec + ntile - 1) / ntile) * vec * 4 > 40 * 1024) ++ntile;
@@ -91,15 +99,15 @@ extern "C" {
 
 int xfm_ss2d_dt_proj_supported(int D, int R, int L) { return (L % 4 == 0 && R >= 1 && R <= 64 && D >= 1) ? 1 : 0; }
 
-int xfm_ss2d_dt_proj_fwd(const void *xr, const float *weight, void *dts, int B, int D, int R, int L, int dtype,
-                         void *stream) {
+int xfm_ss2d_dt_proj_fwd(const void *xr, const float *weight, const float *softplus_bias, void *dts, int B, int D, int R,
+                         int L, int dtype, void *stream) {
     using namespace xfm;
     if (!xr || !weight || !dts || B <= 0 || D <= 0 || R <= 0 || L <= 0) return XFM_EINVAL;
     if (!xfm_ss2d_dt_proj_supported(D, R, L)) return XFM_ELIMIT;
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
-        case XFM_F32: return dt_proj_launch<float>(xr, weight, dts, B, D, R, L, s);
-        case XFM_BF16: return dt_proj_launch<bf16_t>(xr, weight, dts, B, D, R, L, s);
+        case XFM_F32: return dt_proj_launch<float>(xr, weight, softplus_bias, dts, B, D, R, L, s);
+        case XFM_BF16: return dt_proj_launch<bf16_t>(xr, weight, softplus_bias, dts, B, D, R, L, s);
     }
     return XFM_EDTYPE;
 }

@@ -13,6 +13,7 @@
 #include "xfm_common.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace xfm {
 
@@ -182,8 +183,13 @@ template <typename T, int VEC> __device__ __forceinline__ void st_vec(T *p, cons
         for (int i = 0; i < VEC; ++i) reinterpret_cast<float *>(p)[i] = v[i];
     } else {
         uint16_t h[VEC];
+        if constexpr (std::is_same<T, bf16_t>::value && VEC >= 2) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) h[i] = pack16<T>(v[i]);
+            for (int i = 0; i < VEC; i += 2) *reinterpret_cast<uint32_t *>(h + i) = pack_bf16x2(v[i], v[i + 1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) h[i] = pack16<T>(v[i]);
+        }
         if constexpr (VEC == 8) *reinterpret_cast<uint4 *>(p) = *reinterpret_cast<const uint4 *>(h);
         else if constexpr (VEC == 4) *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(h);
         else if constexpr (VEC == 2) *reinterpret_cast<uint32_t *>(p) = *reinterpret_cast<const uint32_t *>(h);

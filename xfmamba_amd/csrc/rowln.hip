@@ -22,15 +22,10 @@ template <> struct Vec4IO<bf16_t> {
         return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
                            __uint_as_float(r.y & 0xffff0000u));
     }
-    static __device__ __forceinline__ uint32_t rne(float f) {     // fp32 -> bf16 bits, round to nearest even
-        uint32_t u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    }
     static __device__ __forceinline__ void st(bf16_t *p, float4 v) {
         uint2 r;
-        r.x = rne(v.x) | (rne(v.y) << 16);
-        r.y = rne(v.z) | (rne(v.w) << 16);
+        r.x = pack_bf16x2(v.x, v.y);
+        r.y = pack_bf16x2(v.z, v.w);
         *reinterpret_cast<uint2 *>(p) = r;
     }
 };

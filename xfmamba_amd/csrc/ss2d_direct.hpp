@@ -122,7 +122,7 @@ __device__ __forceinline__ void sweep_fwd_d(const SS2DArgs &a, const int k, cons
     const Tin *Bg = (const Tin *)p.Bs + bc_off, *Cg = (const Tin *)p.Cs + bc_off;
     const int64_t dts_room = (int64_t)p.batch * 4 * D * L - dts_off, bc_room = (int64_t)p.batch * 4 * N * L - bc_off;
     const float *Ar = p.A + (int64_t)row * N;
-    const float Dr = p.D[row], bias = p.delta_bias[row];
+    const float Dr = p.D[row], bias = p.delta_softplus == 2 ? 0.f : p.delta_bias[row];   // mode 2: dts = softplus(raw + bias) already
     const int ci = REV ? LPR - 1 - i : i;
     for (int n = i; n < N; n += LPR) carry[g * N + n] = 0.f;
     if (!N1 && bc) {
@@ -166,7 +166,7 @@ __device__ __forceinline__ void sweep_fwd_d(const SS2DArgs &a, const int k, cons
         for (int j = 0; j < C; ++j) {
             ok[j] = tp0 + (REV ? C - 1 - j : j) < L;
             float v = dl[j] + bias;
-            if (p.delta_softplus) v = softplus20(v);
+            if (p.delta_softplus == 1) v = softplus20(v);
             dl[j] = ok[j] ? v : 0.f;
             u[j] = ok[j] ? u[j] : 0.f;
             y[j] = 0.f;
@@ -252,7 +252,7 @@ __device__ __forceinline__ void sweep_bwd_d(const SS2DArgs &a, const int k, cons
     const Tin *Bg = (const Tin *)p.Bs + bc_off, *Cg = (const Tin *)p.Cs + bc_off;
     const int64_t dts_room = (int64_t)p.batch * 4 * D * L - dts_off, bc_room = (int64_t)p.batch * 4 * N * L - bc_off;
     const float *Ar = p.A + (int64_t)row * N;
-    const float Dr = p.D[row], bias = p.delta_bias[row];
+    const float Dr = p.D[row], bias = p.delta_softplus == 2 ? 0.f : p.delta_bias[row];   // mode 2: dts = softplus(raw + bias) already
     const int ci = REV ? LPR - 1 - i : i;
     for (int n = i; n < N; n += LPR) carryE[g * N + n] = 0.f;
     if (!N1 && bc) {
@@ -305,7 +305,7 @@ __device__ __forceinline__ void sweep_bwd_d(const SS2DArgs &a, const int k, cons
         for (int j = 0; j < C; ++j) {
             ok[j] = tp0 + (REV ? C - 1 - j : j) < L;
             float v = dl[j] + bias;
-            if (p.delta_softplus) v = softplus20(v);
+            if (p.delta_softplus == 1) v = softplus20(v);
             dl[j] = ok[j] ? v : 0.f;
             u[j] = ok[j] ? u[j] : 0.f;
             go[j] = ok[j] ? go[j] : 0.f;

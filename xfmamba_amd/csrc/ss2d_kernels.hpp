@@ -76,8 +76,7 @@ template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float *f) {
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const bf16_t lo = __float2bfloat16(f[2 * i]), hi = __float2bfloat16(f[2 * i + 1]);
-        w[i] = (uint32_t)(*reinterpret_cast<const uint16_t *>(&lo)) | ((uint32_t)(*reinterpret_cast<const uint16_t *>(&hi)) << 16);
+        w[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
@@ -238,7 +237,7 @@ __device__ __forceinline__ void sweep_fwd(const SS2DArgs &a, const int k, const 
     const Tin *Bg = (const Tin *)p.Bs + bc_off, *Cg = (const Tin *)p.Cs + bc_off;
     const int64_t dts_room = (int64_t)p.batch * 4 * D * L - dts_off, bc_room = (int64_t)p.batch * 4 * N * L - bc_off;
     const float *Ar = p.A + (int64_t)row * N;
-    const float Dr = p.D[row], bias = p.delta_bias[row];
+    const float Dr = p.D[row], bias = p.delta_softplus == 2 ? 0.f : p.delta_bias[row];   // mode 2: dts = softplus(raw + bias) already
     const int ci = REV ? LPR - 1 - i : i;          // physical chunk this lane owns
     const bool one_run = nseg == 1 || G == 1;      // the tile's dts rows form one contiguous HBM run
     const int pitch = nseg == 1 ? L : SL;
@@ -300,7 +299,7 @@ __device__ __forceinline__ void sweep_fwd(const SS2DArgs &a, const int k, const 
             const bool ok = off[j] >= 0;
             u[j] = ok ? xg[off[j]] : 0.f;
             float v = dl[j] + bias;
-            if (p.delta_softplus) v = softplus20(v);
+            if (p.delta_softplus == 1) v = softplus20(v);
             dl[j] = ok ? v : 0.f;
             y[j] = 0.f;
         }
@@ -376,7 +375,7 @@ __device__ __forceinline__ void sweep_bwd(const SS2DArgs &a, const int k, const 
     const int64_t dts_room = (int64_t)p.batch * 4 * D * L - dts_off, bc_room = (int64_t)p.batch * 4 * N * L - bc_off;
     float *dBg = p.dBs + bc_off, *dCg = p.dCs + bc_off;
     const float *Ar = p.A + (int64_t)row * N;
-    const float Dr = p.D[row], bias = p.delta_bias[row];
+    const float Dr = p.D[row], bias = p.delta_softplus == 2 ? 0.f : p.delta_bias[row];   // mode 2: dts = softplus(raw + bias) already
     const int ci = REV ? LPR - 1 - i : i;
     const bool one_run = nseg == 1 || G == 1;
     const int pitch = nseg == 1 ? L : SL;
@@ -440,7 +439,7 @@ __device__ __forceinline__ void sweep_bwd(const SS2DArgs &a, const int k, const 
             u[j] = ok ? xg[off[j]] : 0.f;
             go[j] = ok ? gg[off[j]] : 0.f;
             float v = dl[j] + bias;
-            if (p.delta_softplus) v = softplus20(v);
+            if (p.delta_softplus == 1) v = softplus20(v);
             dl[j] = ok ? v : 0.f;
             s1[j] = 0.f;
             s2[j] = 0.f;

@@ -179,7 +179,7 @@ __device__ __forceinline__ void lean_fwd_plane(const LeanArgs &a, const Tin *__r
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             float v = dl[j] + bias;
-            if (a.softplus) v = softplus20(v);
+            if (a.softplus == 1) v = softplus20(v);
             v = live ? v : 0.f;                       // dead lanes: identity map (a = 1, b = 0)
             av[j] = exp2_fast(v * A2);
             bb[j] = v * u[j] * Bv[j];
@@ -269,7 +269,8 @@ __device__ __forceinline__ void lean_bwd_plane(const LeanArgs &a, const Tin *__r
         for (int j = 0; j < C; ++j) {
             float v = dl[j] + bias;
             sg[j] = 1.f;
-            if (a.softplus) v = softplus20_sig(v, sg[j]);
+            if (a.softplus == 1) v = softplus20_sig(v, sg[j]);
+            else if (a.softplus == 2) sg[j] = v > 20.f ? 1.f : 1.f - exp2_fast(-v * kLog2e);   // dts holds softplus(raw)
             v = live ? v : 0.f;
             dl[j] = v;
             av[j] = exp2_fast(v * A2);
@@ -424,7 +425,7 @@ __global__ void __launch_bounds__(256) ss2d_fwd_lean_kernel(const LeanArgs a) {
             const int d = d0 + pl, row = k * D + d;
             const Tin *dts_row = (const Tin *)a.dts + (route * D + d) * L;
             float *chk_row = a.chk + (route * D + d) * a.nseg;
-            const float A2 = a.A[row] * kLog2e, Dr = a.D[row], bias = a.bias[row];
+            const float A2 = a.A[row] * kLog2e, Dr = a.D[row], bias = a.softplus == 2 ? 0.f : a.bias[row];
             const bool has_next = it * a.ppt + pl + 1 < n_planes;
             if (rev) lean_fwd_plane<Tin, C, true>(a, dts_row, Brow, Crow, chk_row, A2, Dr, bias, xq + pl * L, yq + pl * L, lane, pf, has_next);
             else lean_fwd_plane<Tin, C, false>(a, dts_row, Brow, Crow, chk_row, A2, Dr, bias, xq + pl * L, yq + pl * L, lane, pf, has_next);
@@ -496,7 +497,7 @@ __global__ void __launch_bounds__(256) ss2d_bwd_lean_kernel(const LeanArgs a) {
             const int d = d0 + pl, row = k * D + d;
             const int64_t ro = (route * D + d) * L;
             const float *chk_row = a.chk + (route * D + d) * nseg;
-            const float An = a.A[row], Dr = a.D[row], bias = a.bias[row];
+            const float An = a.A[row], Dr = a.D[row], bias = a.softplus == 2 ? 0.f : a.bias[row];
             float dA_acc = 0.f, dD_acc = 0.f, dbias_acc = 0.f;
             const bool has_next = it * a.ppt + pl + 1 < n_planes;
             if (rev)

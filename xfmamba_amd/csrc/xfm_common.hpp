@@ -29,6 +29,15 @@ template <> __device__ __forceinline__ void stf<float>(float *p, float v) { *p =
 template <> __device__ __forceinline__ void stf<f16_t>(f16_t *p, float v) { *p = __float2half(v); }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t *p, float v) { *p = __float2bfloat16(v); }  // RNE, NaN-safe cast
 
+// two fp32 -> packed bf16 pair (round to nearest even) in ONE instruction: gfx950 has v_cvt_pk_bf16_f32
+typedef __bf16 xfm_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float xfm_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const xfm_f32x2_t v = {lo, hi};
+    const xfm_bf16x2_t r = __builtin_convertvector(v, xfm_bf16x2_t);
+    return *reinterpret_cast<const uint32_t *>(&r);
+}
+
 // ---- 16-byte vector load / store with fp32 conversion -----------------------------------------
 template <typename T> struct Pack;           // 16-byte vector of T  <->  fp32 lanes
 template <> struct Pack<float> {
@@ -52,17 +61,12 @@ template <> struct Pack<bf16_t> {
             v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
-    static __device__ __forceinline__ uint32_t rne(float f) {
-        uint32_t u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    }
     static __device__ __forceinline__ void st(bf16_t *p, const float *v) {
         uint4 r;
-        r.x = rne(v[0]) | (rne(v[1]) << 16);
-        r.y = rne(v[2]) | (rne(v[3]) << 16);
-        r.z = rne(v[4]) | (rne(v[5]) << 16);
-        r.w = rne(v[6]) | (rne(v[7]) << 16);
+        r.x = pack_bf16x2(v[0], v[1]);
+        r.y = pack_bf16x2(v[2], v[3]);
+        r.z = pack_bf16x2(v[4], v[5]);
+        r.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4 *>(p) = r;
     }
 };

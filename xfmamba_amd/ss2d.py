@@ -34,10 +34,10 @@ def _plan(Bt, Dm, H, W, N, dtype):
     return plan
 
 
-def _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, out_dtype, chk):
+def _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, out_dtype, chk, softplus_mode=1):
     Bt, Dm, L = x.shape
     p.batch, p.d_inner, p.H, p.W, p.dstate = Bt, Dm, H, W, A.shape[1]
-    p.delta_softplus = 1
+    p.delta_softplus = softplus_mode
     p.in_dtype, p.out_dtype = _lib.dtype_code(x.dtype), _lib.dtype_code(out_dtype)
     p.x, p.dts, p.Bs, p.Cs = x.data_ptr(), dts.data_ptr(), Bs.data_ptr(), Cs.data_ptr()
     p.A, p.D, p.delta_bias = A.data_ptr(), D.data_ptr(), bias.data_ptr()
@@ -131,12 +131,16 @@ class SS2DProjCoreHip(torch.autograd.Function):
         xr, Bs, Cs = _route_split(x_dbl, R, N, H, W)
         w = cast_weight(dt_w, x.dtype)
         lib = _lib.lib()
+        mode = 1
         if x.dtype in (torch.float32, torch.bfloat16) and lib.xfm_ss2d_dt_proj_supported(Dm, R, L):
+            # dt_proj kernel with the bias + softplus epilogue: the scan kernels then read the activated step size
+            # (mode 2) instead of re-evaluating softplus per route element in the forward AND the backward pass
+            mode = 2
             wf = dt_w.detach().float().contiguous()
             dts = torch.empty((Bt, 4, Dm, L), dtype=x.dtype, device=x.device)        # (B, 4, D, L) in route order
             with torch.cuda.device(x.device), _lib.timed("dt_proj_fwd", dts.numel() * dts.element_size()):
-                _lib.check(lib.xfm_ss2d_dt_proj_fwd(xr.data_ptr(), wf.data_ptr(), dts.data_ptr(), Bt, Dm, R, L,
-                                                    _lib.dtype_code(x.dtype), _lib.stream_ptr()), "dt_proj_fwd")
+                _lib.check(lib.xfm_ss2d_dt_proj_fwd(xr.data_ptr(), wf.data_ptr(), bias.data_ptr(), dts.data_ptr(), Bt, Dm,
+                                                    R, L, _lib.dtype_code(x.dtype), _lib.stream_ptr()), "dt_proj_fwd")
         else:
             dts = torch.matmul(w, xr)
         plan = _plan(Bt, Dm, H, W, N, x.dtype)
@@ -144,13 +148,14 @@ class SS2DProjCoreHip(torch.autograd.Function):
                if plan.n_chunks > 1 else None)
         y = torch.empty((Bt, Dm, L), dtype=torch.float32, device=x.device)
         p = _lib.SS2DParams()
-        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk)
+        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, mode)
         p.y = y.data_ptr()
         isz = x.element_size()
         nbytes = Bt * Dm * L * (5 * isz + 4) + 2 * Bt * 4 * N * L * isz
         with torch.cuda.device(x.device), _lib.timed("ss2d_fwd", nbytes):
             _lib.check(_lib.lib().xfm_ss2d_fwd(ctypes.byref(p), _lib.stream_ptr()), "ss2d_fwd")
         ctx.hw = (H, W)
+        ctx.mode = mode
         ctx.wdtype = dt_w.dtype
         ctx.save_for_backward(x, xr, dts, w, A, Bs, Cs, D, bias, chk)
         return y
@@ -174,7 +179,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
         dA = acc[2 * nbc:2 * nbc + na].view(A.shape)
         dD, dbias = acc[2 * nbc + na:2 * nbc + na + nd], acc[2 * nbc + na + nd:]
         p = _lib.SS2DParams()
-        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk)
+        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, ctx.mode)
         p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
         p.dBs, p.dCs, p.dA, p.dD, p.ddelta_bias = (dBs.data_ptr(), dCs.data_ptr(), dA.data_ptr(), dD.data_ptr(),
                                                    dbias.data_ptr())
