@@ -699,25 +699,21 @@ class ShallowFuse_SS2Dv4(nn.Module):
                                Bs.contiguous(), Cs.contiguous(), self.Ds.float(),
                                self.dt_projs_bias.reshape(-1).float(), True, True, None).view(B, K, -1, L)
         y, y2 = SwappingMerge_multiview.apply(ys)
-        y = self.out_norm(y.transpose(1, 2).reshape(B, H, W, -1))
-        y2 = self.out_norm(y2.transpose(1, 2).reshape(B, H, W, -1))
-        return y.to(x.dtype), y2.to(x2.dtype)
+        yy = self.out_norm(torch.cat([y, y2], dim=0).transpose(1, 2).reshape(2 * B, H, W, -1)).to(x.dtype)
+        return yy[:B], yy[B:]
 
     def forward(self, x: torch.Tensor, x2: torch.Tensor):
-        xp = self.in_proj(x).permute(0, 3, 1, 2).contiguous()
-        x2p = self.in_proj(x2).permute(0, 3, 1, 2).contiguous()
-        if self.with_dconv:
-            xc, x2c = _dwconv_act(self.conv2d, self.act, xp), _dwconv_act(self.conv2d, self.act, x2p)
-        else:
-            xc, x2c = self.act(xp), self.act(x2p)
-        y1, y2 = self.forward_corev2(xc, x2c)
-        y1, y2 = self.out_act(y1), self.out_act(y2)
-        b, d = xp.shape[:2]
-        gate1 = self.fc1(self.avg_pool(xp).view(b, d)).view(b, 1, 1, d)
-        gate2 = self.fc1(self.avg_pool(x2p).view(b, d)).view(b, 1, 1, d)
-        y1 = y1 * gate2          # each view is gated by the OTHER view's squeeze (fusion_vmamba.py:870-871)
-        y2 = y2 * gate1
-        return self.dropout(self.out_proj(y1)), self.dropout(self.out_proj(y2))
+        # both views share every weight here: they run as one batch of 2B wherever the reference makes two calls
+        # (in_proj, conv, squeeze gate, out_norm, out_proj act per sample, so the values are the same)
+        B = x.shape[0]
+        xp = self.in_proj(torch.cat([x, x2], dim=0)).permute(0, 3, 1, 2).contiguous()        # (2B, D, H, W)
+        xc = _dwconv_act(self.conv2d, self.act, xp) if self.with_dconv else self.act(xp)
+        y1, y2 = self.forward_corev2(xc[:B], xc[B:])
+        y = self.out_act(torch.cat([y2, y1], dim=0))                                         # [view 2 | view 1]
+        d = xp.shape[1]
+        gate = self.fc1(self.avg_pool(xp).view(2 * B, d)).view(2 * B, 1, 1, d)               # [gate 1 | gate 2]
+        o = self.dropout(self.out_proj(y * gate))       # each view is gated by the OTHER view's squeeze (:870-871)
+        return o[B:], o[:B]
 
 
 class ShallowFusionBlock_v4(nn.Module):
@@ -783,16 +779,36 @@ class Cross_SS2Dv5(nn.Module):
         y_2, _ = _ss2d_core(x2, *w, Cs_override=Cs_fuse)
         return finish(y, x), finish(y_2, x2), finish(y_fuse, x_fuse)
 
+    def forward_core_batched(self, x3):
+        """The three streams [view 1 | view 2 | fused] as ONE batch of 3B through the operator chain (they share all
+        weights); the view streams read their state through the fused stream's C (:537,568), i.e. the C operand of
+        the whole batch is the fused third repeated.  Returns the out-normed (3B, H, W, D)."""
+        B3, D, H, W = x3.shape
+        B, L = B3 // 3, H * W
+        K, _, R = self.dt_projs_weight.shape
+        N = self.A_logs.shape[1]
+        cd = x3.dtype
+        xs = cross_scan_fn(x3, in_channel_first=True, out_channel_first=True, scans=0)           # (3B, 4, D, L)
+        x_dbl = torch.matmul(self.x_proj_weight.to(cd), xs)                                       # (3B, K, R+2N, L)
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.matmul(self.dt_projs_weight.to(cd), dts).view(B3, -1, L)
+        Cs = Cs[2 * B:].unsqueeze(0).expand(3, B, K, N, L).reshape(B3, K, N, L)
+        ys = selective_scan_fn(xs.view(B3, -1, L), dts, -self.A_logs.float().exp(), Bs.contiguous(), Cs,
+                               self.Ds.float(), self.dt_projs_bias.reshape(-1).float(), True, True, None)
+        y = cross_merge_fn(ys.view(B3, K, -1, H, W), in_channel_first=True, out_channel_first=True, scans=0)
+        return self.out_norm(y.view(B3, -1, L).transpose(1, 2).reshape(B3, H, W, -1)).to(cd)
+
     def forward(self, x, x2: torch.Tensor, **kwargs):
-        x_fuse = (x + x2) / 2
-        x, x2, x_fuse = self.in_proj_sec(x), self.in_proj_sec(x2), self.in_proj_sec(x_fuse)
-        z = self.act(x_fuse)
-
-        def prep(t):
-            t = t.permute(0, 3, 1, 2).contiguous()
-            return _dwconv_act(self.conv2d, self.act, t) if self.with_dconv else self.act(t)
-
-        y, y2, y_fuse = self.forward_corev2(prep(x), prep(x2), prep(x_fuse))
+        B, H, W = x.shape[0], x.shape[1], x.shape[2]
+        x3 = self.in_proj_sec(torch.cat([x, x2, (x + x2) / 2], dim=0))                 # one GEMM for the three streams
+        z = self.act(x3[2 * B:])
+        t = x3.permute(0, 3, 1, 2).contiguous()
+        t = _dwconv_act(self.conv2d, self.act, t) if self.with_dconv else self.act(t)
+        if SS2D_MODE == "fused" and H * W > 64:
+            y, y2, y_fuse = self.forward_corev2(t[:B], t[B:2 * B], t[2 * B:])
+        else:
+            y3 = self.forward_core_batched(t)
+            y, y2, y_fuse = y3[:B], y3[B:2 * B], y3[2 * B:]
         return self.dropout(self.out_proj(y * z + y2 * z + y_fuse * z))
 
 
