@@ -66,6 +66,39 @@ def main():
     shapes = [("stage0", B, 96, 56, 1), ("stage1", B, 192, 28, 1), ("stage2", B, 384, 14, 1), ("stage3", B, 768, 7, 1),
               ("deep", B // 2, 1536, 7, 16)]
     print(f"{'kernel':28s} {'us':>9s} {'GB/s':>8s} {'%HBM':>6s}  plan")
+    if not a.only or a.only == "ln2d":
+        lib = _lib.lib()
+        for name, Bt, C, H in (("stage0", B, 96, 56), ("stage1", B, 192, 28), ("stage2", B, 384, 14), ("stage3", B, 768, 7)):
+            L = H * H
+            x = torch.randn(Bt, C, L, device=dev)
+            y = torch.empty(Bt, C, L, device=dev, dtype=dt)
+            dy = torch.randn(Bt, C, L, device=dev).to(dt)
+            dx = torch.empty_like(x)
+            w, bb = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+            mean, rstd = torch.empty(Bt * L, device=dev), torch.empty(Bt * L, device=dev)
+            dw, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            st, cy = _lib.stream_ptr(), _lib.dtype_code(dt)
+
+            def raw(fn, reps=30):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / reps
+
+            t = raw(lambda: lib.xfm_layernorm2d_fwd(x.data_ptr(), w.data_ptr(), bb.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                    rstd.data_ptr(), Bt, C, L, 1e-5, 0, cy, st))
+            nb = x.numel() * (4 + y.element_size())
+            print(f"{'ln2d_fwd ' + name:28s} {t:9.1f} {nb / t / 1e3:8.1f} {nb / t / 1e3 / 80:6.2f}")
+            t = raw(lambda: lib.xfm_layernorm2d_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                    dx.data_ptr(), dw.data_ptr(), db.data_ptr(), Bt, C, L, 0, cy, st))
+            nb = x.numel() * (8 + y.element_size())
+            print(f"{'ln2d_bwd(dx+wb) ' + name:28s} {t:9.1f} {nb / t / 1e3:8.1f} {nb / t / 1e3 / 80:6.2f}")
     if not a.only or a.only == "dtproj":
         lib = _lib.lib()
         for name, Bt, D, H in (("stage0", B, 96, 56), ("stage1", B, 192, 28), ("stage2", B, 384, 14)):

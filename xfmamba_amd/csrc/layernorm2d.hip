@@ -95,8 +95,10 @@ __global__ void __launch_bounds__(1024) ln2d_fwd_cached_kernel(const Tx *__restr
                                                                int C, int L, int tiles_pb, float eps, int NW) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x / tiles_pb, p = (blockIdx.x - b * tiles_pb) * 64 + lane;
-    const bool ok = p < L;
+    // positions of all images form one index space (tiles_pb = B*L here): no ragged last tile per image
+    const int64_t P = (int64_t)blockIdx.x * 64 + lane;
+    const bool ok = P < tiles_pb;
+    const int b = ok ? (int)(P / L) : 0, p = ok ? (int)(P - (int64_t)b * L) : 0;
     const int64_t o = (int64_t)b * C * L + p;
     float v[CPT];
     float s = 0.f;
@@ -142,8 +144,10 @@ __global__ void __launch_bounds__(1024) ln2d_bwd_dx_cached_kernel(const Tx *__re
                                                                   int C, int L, int tiles_pb, int NW) {
     __shared__ float red[2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x / tiles_pb, p = (blockIdx.x - b * tiles_pb) * 64 + lane;
-    const bool ok = p < L;
+    // positions of all images form one index space (tiles_pb = B*L here): no ragged last tile per image
+    const int64_t P = (int64_t)blockIdx.x * 64 + lane;
+    const bool ok = P < tiles_pb;
+    const int b = ok ? (int)(P / L) : 0, p = ok ? (int)(P - (int64_t)b * L) : 0;
     const int64_t o = (int64_t)b * C * L + p;
     const float mu = ok ? mean[(int64_t)b * L + p] : 0.f, rs = ok ? rstd[(int64_t)b * L + p] : 0.f;
     float g[CPT], xh[CPT];
@@ -182,13 +186,23 @@ __global__ void __launch_bounds__(256) ln2d_bwd_wb_kernel(const Tx *__restrict__
     const int c = blockIdx.x / bsplit, sl = blockIdx.x - c * bsplit;
     const int b0 = (int)((int64_t)B * sl / bsplit), b1 = (int)((int64_t)B * (sl + 1) / bsplit);
     float a1 = 0.f, a2 = 0.f;
-    for (int b = b0; b < b1; ++b) {
-        const int64_t o = ((int64_t)b * C + c) * L;
-        const float *mb = mean + (int64_t)b * L, *rb = rstd + (int64_t)b * L;
-        for (int p = threadIdx.x; p < L; p += 256) {
-            const float g = ldf<Ty>(dy + o + p);
-            a1 = fmaf(g, (ldf<Tx>(x + o + p) - mb[p]) * rb[p], a1);
+    if (L < 256) {
+        for (int i = threadIdx.x; i < (b1 - b0) * L; i += 256) {    // short maps (7x7): (image, position) pairs
+            const int b = b0 + i / L, p = i - (i / L) * L;           // flattened, so the workgroup stays full
+            const int64_t o = ((int64_t)b * C + c) * L + p;
+            const float g = ldf<Ty>(dy + o);
+            a1 = fmaf(g, (ldf<Tx>(x + o) - mean[(int64_t)b * L + p]) * rstd[(int64_t)b * L + p], a1);
             a2 += g;
+        }
+    } else {
+        for (int b = b0; b < b1; ++b) {
+            const int64_t o = ((int64_t)b * C + c) * L;
+            const float *mb = mean + (int64_t)b * L, *rb = rstd + (int64_t)b * L;
+            for (int p = threadIdx.x; p < L; p += 256) {
+                const float g = ldf<Ty>(dy + o + p);
+                a1 = fmaf(g, (ldf<Tx>(x + o + p) - mb[p]) * rb[p], a1);
+                a2 += g;
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -212,12 +226,12 @@ static int ln_fwd(const void *x, const float *w, const float *b, void *y, float 
     const int tiles = (L + 63) / 64;
     if (C % 24 == 0 && C / 24 <= 16) {
         const int NW = C / 24;
-        hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 24>), dim3(B * tiles), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
-                           (Ty *)y, mean, rstd, C, L, tiles, eps, NW);
+        hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 24>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
+                           (Ty *)y, mean, rstd, C, L, B * L, eps, NW);
     } else if (C % 48 == 0 && C / 48 <= 16) {
         const int NW = C / 48;
-        hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 48>), dim3(B * tiles), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
-                           (Ty *)y, mean, rstd, C, L, tiles, eps, NW);
+        hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 48>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
+                           (Ty *)y, mean, rstd, C, L, B * L, eps, NW);
     } else {
         hipLaunchKernelGGL((ln2d_fwd_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, b, (Ty *)y, mean,
                            rstd, C, L, tiles, eps);
@@ -231,12 +245,12 @@ static int ln_bwd(const void *x, const float *w, const void *dy, const float *me
     const int tiles = (L + 63) / 64;
     if (C % 24 == 0 && C / 24 <= 16) {
         const int NW = C / 24;
-        hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 24>), dim3(B * tiles), dim3(64 * NW), 0, s, (const Tx *)x, w,
-                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, tiles, NW);
+        hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 24>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
     } else if (C % 48 == 0 && C / 48 <= 16) {
         const int NW = C / 48;
-        hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 48>), dim3(B * tiles), dim3(64 * NW), 0, s, (const Tx *)x, w,
-                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, tiles, NW);
+        hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 48>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
     } else {
         hipLaunchKernelGGL((ln2d_bwd_dx_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, (const Ty *)dy,
                            mean, rstd, (Tx *)dx, C, L, tiles);
