@@ -115,6 +115,40 @@ def test_vss_stage_tokens_stream_matches_planes_and_oracle(C, H, dt):
             assert_close(grads[k], gref, 5 * tol, 2 * tol * float(gref.abs().max()) + 1e-7, f"{layout} d{k}")
 
 
+def test_vss_stage_tokens_stream_drop_path_matches_planes():
+    """DropPath active (train mode): the token-major stream draws the same per-sample Bernoulli factors as the NCHW
+    modules (same generator state) and folds them into the fused add+LayerNorm kernel -- outputs and gradients of
+    the two layouts must agree, dropped samples included."""
+    from xfmamba_amd import fusion_vmamba as fv
+    torch.manual_seed(11)
+    C, H, B = 96, 28, 8
+    blocks = torch.nn.Sequential(*[
+        fv.VSSBlock(hidden_dim=C, drop_path=0.5, norm_layer=fv.LayerNorm2d, channel_first=True, ssm_d_state=1,
+                    ssm_ratio=1.0, ssm_dt_rank="auto", ssm_conv=3, ssm_conv_bias=False, ssm_init="v0",
+                    forward_type="v05_noz", mlp_ratio=4.0) for _ in range(3)]).to(DEV).train()
+    x = torch.randn(B, C, H, H, device=DEV)
+    gy = torch.randn(B, C, H, H, device=DEV)
+    res = {}
+    old = fv.STREAM_LAYOUT
+    try:
+        for layout in ("planes", "tokens"):
+            fv.STREAM_LAYOUT = layout
+            blocks.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_()
+            torch.manual_seed(123)                                    # same DropPath draws for both layouts
+            y = fv._run_blocks(blocks, xi)
+            y.backward(gy)
+            res[layout] = (y.detach().cpu(), xi.grad.cpu(), {k: p.grad.cpu().clone() for k, p in blocks.named_parameters()})
+    finally:
+        fv.STREAM_LAYOUT = old
+    (yp, dxp, gp), (yt, dxt, gt) = res["planes"], res["tokens"]
+    assert float((yp - x.cpu()).abs().amax(dim=(1, 2, 3)).min()) >= 0          # (some samples may be fully dropped)
+    assert_close(yt, yp, 1e-4, 1e-4 * float(yp.abs().max()), "y")
+    assert_close(dxt, dxp, 1e-3, 1e-4 * float(dxp.abs().max()), "dx")
+    for k in gp:
+        assert_close(gt[k], gp[k], 2e-3, 2e-4 * float(gp[k].abs().max()) + 1e-8, f"d{k}")
+
+
 def _tiny_with_synth_weights():
     from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
     shapes = load_json("g5_state_shapes.json")["tiny"]
