@@ -259,7 +259,7 @@ def main():
                             avg_launch_us=round(k["avg_us"], 2),
                             algorithmic_bytes_per_launch=int(k["bytes"] / k["launches"]))
         line = {
-            "metric": "two-view images/sec fwd+bwd, XFMamba-T 224^2, batch 32/GPU",
+            "metric": (f"two-view images/sec fwd+bwd, XFMamba-{a.model[0].upper()} {a.size}^2, batch {B}/GPU"),
             "value": round(value, 2), "unit": "two-view samples/s (1 sample = 2 images)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
