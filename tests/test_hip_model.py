@@ -216,17 +216,25 @@ def test_model_tiny_bf16_autocast_within_tolerance():
     assert rel < 2e-2, rel
 
 
-def test_captured_training_step_replays_like_eager():
+@pytest.mark.parametrize("B,find", [
+    (16, False), (32, True),
+    # seen on ROCm 7.2 / MI355X: with a merged batch of 8 the MIOpen weight-gradient solver picked for the 384->768
+    # stride-2 downsample convolution returns garbage from the SECOND replay on (library kernel, not this repo's;
+    # eager launches are fine).  bench.py's shapes (B = 32, find mode) and B = 16 replay correctly.
+    pytest.param(4, False, marks=pytest.mark.xfail(strict=False, reason="MIOpen wrw solver under hipGraph replay at tiny batch")),
+])
+def test_captured_training_step_replays_like_eager(B, find):
     """The bench path replays the whole step (fwd + bwd) from one hipGraph.  Every parameter gradient of replays 1..3
     must equal the eager gradient: guards the captured path against reductions that only work on their first run
     (seen with framework bias-gradient sums under replay -- the hot path keeps those inside its own kernels)."""
     from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
+    old_find = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = find             # bench.py runs MIOpen in find mode: other solvers, same contract
     torch.manual_seed(5)
     m = TwoViewXFMambaTop(in_channels=1, outputs=2, type="tiny").to(DEV).train()
     for mod in m.modules():
         if hasattr(mod, "drop_prob"):
             mod.drop_prob = 0.0                       # deterministic step
-    B = 16
     xa, xb = torch.randn(B, 1, 224, 224, device=DEV), torch.randn(B, 1, 224, 224, device=DEV)
     lab = torch.randint(0, 2, (B,), device=DEV)
 
@@ -260,3 +268,58 @@ def test_captured_training_step_replays_like_eager():
             # fp32 atomics feeding bf16 roundings make run-to-run differences of a few % of a (tiny) gradient's
             # scale legitimate; a reduction that breaks under replay is off by ~100 % (zeros / stale / NaN)
             assert float((p.grad - ref[k]).abs().max()) <= 1e-1 * scale + 1e-7, (i, k)
+    torch.backends.cudnn.benchmark = old_find
+
+
+def test_captured_forward_backward_with_packed_gradient_buckets(monkeypatch):
+    """The N > 1 flow of bench.py on one GPU: the hipGraph holds forward + backward + the multi-tensor packing of the
+    gradients into the flat buckets; the (here: stubbed) all-reduce and the optimizer run eagerly after each replay.
+    After a replay every ``.grad`` must be a view of its bucket holding eager_gradient / world."""
+    import torch.distributed as dist
+    from xfmamba_amd.dp import GradBuckets
+    from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
+    class _Done:
+        def wait(self):
+            return True
+
+    monkeypatch.setattr(dist, "all_reduce", lambda t, **kw: _Done() if kw.get("async_op") else None)
+    torch.manual_seed(9)
+    m = TwoViewXFMambaTop(in_channels=1, outputs=2, type="tiny").to(DEV).train()
+    for mod in m.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    B = 16
+    xa, xb = torch.randn(B, 1, 224, 224, device=DEV), torch.randn(B, 1, 224, 224, device=DEV)
+    lab = torch.randint(0, 2, (B,), device=DEV)
+    gb = GradBuckets(m, bucket_mb=16.0, overlap=False, world=2)
+    assert len(gb.buckets) >= 2
+
+    def fwd_bwd():
+        gb.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(m(xa, xb).float(), lab)
+        loss.backward()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fwd_bwd()
+            gb.finish()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}          # eager: packed, divided by world
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fwd_bwd()
+        gb.pack_all()
+    lo, hi = gb.buckets[0].data_ptr(), gb.buckets[0].data_ptr() + gb.buckets[0].numel() * 4
+    for i in range(2):
+        g.replay()
+        gb.reduce_all()
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), (i, k)
+            scale = float(ref[k].abs().max()) + 1e-12
+            assert float((p.grad - ref[k]).abs().max()) <= 1e-1 * scale + 1e-7, (i, k)
+        assert any(lo <= p.grad.data_ptr() < hi for p in m.parameters())

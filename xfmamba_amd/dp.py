@@ -36,9 +36,12 @@ def broadcast_buffers(module: torch.nn.Module, src: int = 0) -> None:
 class GradBuckets:
     """Gradient buckets with overlap-capable all-reduce (average)."""
 
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, process_group=None, overlap: bool = True):
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, process_group=None, overlap: bool = True,
+                 world: int = None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        if world is not None:                               # (tests: exercise the packing path without peers)
+            self.world = int(world)
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.buckets: List[torch.Tensor] = []
         self._groups: List[List[torch.nn.Parameter]] = []
