@@ -359,6 +359,27 @@ __device__ __forceinline__ void lean_planes_load(T *nat, T *tr, const S *src, in
                                                  uint32_t magicW) {
     using IO = VecIO<S, VS>;
     const int nvec = L / VS;                           // L % VS == 0 guaranteed by the plan
+    if (W % VS == 0) {
+        // Rows are whole vectors: consecutive lanes take the SAME column block of consecutive rows, so the scattered
+        // 2-byte writes of the transposed copy land on consecutive addresses (bank-conflict free; with the row-major
+        // lane order below they are W*VS*2 bytes apart = one bank for W = 56).  The price -- 16-byte global loads that
+        // are a row apart -- is paid in L2 hits, not HBM traffic.
+        const int vpr = W / VS;                         // vectors per row
+        for (int pl = 0; pl < nplanes; ++pl) {
+            const S *pg = src + (int64_t)pl * L;
+            for (int v = threadIdx.x; v < nvec; v += 256) {
+                const int wb = v / H, h = v - wb * H;   // h fastest
+                const int e0 = h * W + wb * VS;
+                float f[VS];
+                IO::unpack(*reinterpret_cast<const typename IO::V *>(pg + e0), f);
+                *reinterpret_cast<typename VecIO<T, VS>::V *>(nat + pl * L + e0) = VecIO<T, VS>::pack(f);
+#pragma unroll
+                for (int q = 0; q < VS; ++q) tr[pl * L + (wb * VS + q) * H + h] = from_float<T>(f[q]);
+            }
+        }
+        (void)vpr;
+        return;
+    }
     for (int pl = 0; pl < nplanes; ++pl) {
         const S *pg = src + (int64_t)pl * L;
         for (int v = threadIdx.x; v < nvec; v += 256) {
