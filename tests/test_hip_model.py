@@ -323,3 +323,23 @@ def test_captured_forward_backward_with_packed_gradient_buckets(monkeypatch):
             scale = float(ref[k].abs().max()) + 1e-12
             assert float((p.grad - ref[k]).abs().max()) <= 1e-1 * scale + 1e-7, (i, k)
         assert any(lo <= p.grad.data_ptr() < hi for p in m.parameters())
+
+
+def test_fp16_autocast_falls_back_to_planes():
+    """The row kernels of the token-major stream emit fp32 / bf16 only: under fp16 autocast the trunk must fall back to
+    the NCHW modules (no error, same result as STREAM_LAYOUT="planes")."""
+    from xfmamba_amd import fusion_vmamba as fv
+    m = _tiny_with_synth_weights().eval()
+    xa, xb, _ = (t.to(DEV) for t in g5_inputs())
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        y16 = m(xa, xb)
+        old = fv.STREAM_LAYOUT
+        fv.STREAM_LAYOUT = "planes"
+        try:
+            yp = m(xa, xb)
+        finally:
+            fv.STREAM_LAYOUT = old
+    assert_close(y16.float().cpu(), yp.float().cpu(), 5e-3, 5e-3 * float(yp.abs().max()), "fallback == planes")
+    z = load_npz("g5_model.npz")
+    ref = torch.from_numpy(z["logits_eval"])
+    assert_close(y16.float().cpu(), ref, 2e-2, 2e-2 * float(ref.abs().max()), "fp16 autocast logits")

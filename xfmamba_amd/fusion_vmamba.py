@@ -342,9 +342,16 @@ class SS2Dv2(nn.Module):
         return self.dropout(out.view(B, H, W, C))
 
 
+def _tokens_dtype(ref: torch.Tensor):
+    """Dtype the token-major path computes its GEMM operands in (autocast dtype, else the weights' dtype), or None
+    when the row kernels do not emit it (fp16): the caller then stays on the NCHW modules."""
+    d = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else ref.dtype
+    return d if d in (torch.float32, torch.bfloat16) else None
+
+
 def _norm_tokens(norm: nn.LayerNorm, x, pend):
     """LayerNorm of the token-major stream, folding in a pending ``x += scale * y``.  Returns (x, normalised)."""
-    out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+    out_dtype = _tokens_dtype(norm.weight)
     if pend is None:
         return x, layernorm_rows_fn(x, norm.weight, norm.bias, norm.eps, out_dtype)
     return add_layernorm_rows_fn(x, pend[0], pend[1], norm.weight, norm.bias, norm.eps, out_dtype)
@@ -428,7 +435,8 @@ def _blocks_tokens(blocks, t):
 
 def _run_blocks(blocks: nn.Sequential, x: torch.Tensor):
     """A stage's VSSBlocks on an NCHW map; internally on the token-major stream when ``STREAM_LAYOUT == "tokens"``."""
-    if STREAM_LAYOUT != "tokens" or not x.is_cuda or not _blocks_tokens_ok(blocks):
+    if (STREAM_LAYOUT != "tokens" or not x.is_cuda or not _blocks_tokens_ok(blocks)
+            or _tokens_dtype(next(blocks.parameters())) is None):
         return blocks(x)
     t = x.permute(0, 2, 3, 1).float().contiguous()
     return _blocks_tokens(blocks, t).permute(0, 3, 1, 2).contiguous()
@@ -440,6 +448,8 @@ def _conv_ln_tokens(conv: nn.Conv2d, norm: nn.Module, t: torch.Tensor, out_dtype
     them) WITHOUT its bias: the bias is added inside the LayerNorm kernel, whose backward pass also returns its
     gradient -- no per-channel reduction over the convolution output is left to the framework."""
     fused = isinstance(norm, LayerNorm2d)
+    if t.dtype != conv.weight.dtype and not torch.is_autocast_enabled():
+        t = t.to(conv.weight.dtype)                      # fp32 residual stream into a reduced-precision model
     y = F.conv2d(t.permute(0, 3, 1, 2), conv.weight, None if fused else conv.bias, conv.stride, conv.padding,
                  conv.dilation, conv.groups)
     y = y.permute(0, 2, 3, 1)
@@ -532,7 +542,7 @@ class VSSM(nn.Module):
 
     # ---- token-major trunk: patch embedding, stages and downsampling without ever leaving (B, H, W, C) ----------
     def tokens_trunk_ok(self, x: torch.Tensor) -> bool:
-        if STREAM_LAYOUT != "tokens" or not x.is_cuda:
+        if STREAM_LAYOUT != "tokens" or not x.is_cuda or _tokens_dtype(self.patch_embed[0].weight) is None:
             return False
         pe = self.patch_embed
         ok = (len(pe) == 8 and isinstance(pe[0], nn.Conv2d) and isinstance(pe[5], nn.Conv2d)
@@ -547,7 +557,7 @@ class VSSM(nn.Module):
     def stem_tokens(self, x: torch.Tensor) -> torch.Tensor:
         """patch_embed (conv s2 -> LN -> GELU -> conv s2 -> LN) -> fp32 tokens (B, H/4, W/4, C0)."""
         pe = self.patch_embed
-        act_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+        act_dtype = _tokens_dtype(pe[0].weight)
         t = x.permute(0, 2, 3, 1).contiguous()                  # (B, H, W, 3): a channels_last image
         t = pe[4](_conv_ln_tokens(pe[0], pe[2], t, act_dtype))  # norm output feeds GELU -> conv: the conv's dtype
         return _conv_ln_tokens(pe[5], pe[7], t, torch.float32)
