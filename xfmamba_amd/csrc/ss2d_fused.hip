@@ -219,6 +219,7 @@ int ss2d_launch_lean(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bw
     la.batch = p.batch; la.D_ = p.d_inner; la.H = p.H; la.W = p.W; la.L = p.H * p.W;
     la.nseg = pl.n_chunks; la.ppt = pl.ppt; la.pli = bwd ? pl.pli : pl.pli_fwd; la.softplus = p.delta_softplus;
     la.magicW = a.magicW;
+    la.magicL = (uint32_t)((0x100000000ull + la.L - 1) / la.L);
     la.dbg = a.dbg;
     const size_t lds = bwd ? pl.lds_bwd_block : pl.lds_fwd_block;
     const unsigned grid = (unsigned)((int64_t)p.batch * (p.d_inner / pl.ppt / la.pli));

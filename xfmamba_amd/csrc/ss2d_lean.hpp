@@ -31,6 +31,7 @@ struct LeanArgs {
     int softplus;
     int dbg;         // timing-only switches (XFM_SS2D_DBG): 1 skip sweeps, 2 skip plane loads, 4 skip merge/store, 8 skip dB/dC flush
     uint32_t magicW;
+    uint32_t magicL;   // ceil(2^32 / L): plane index of a tile element by multiply-high (tile elements < 2^16)
 };
 
 // ---- DPP helpers -------------------------------------------------------------------------------
@@ -401,6 +402,46 @@ __device__ __forceinline__ void lean_planes_load(T *nat, T *tr, const S *src, in
     }
 }
 
+// The same staging split in two, so that the HBM latency of the NEXT tile's planes hides under the sweeps of the
+// current one: `issue` starts the 16-byte loads into registers (NV vectors per thread cover a tile of at most
+// 256*NV*VS elements), `commit` converts and writes the natural + transposed LDS copies once the planes are free.
+template <typename S, int VS, int NV> struct PlaneRegs { typename VecIO<S, VS>::V v[NV]; };
+
+template <typename S, int VS, int NV>
+__device__ __forceinline__ void lean_planes_issue(PlaneRegs<S, VS, NV> &r, const S *src, int nelem) {
+    const int nvec = nelem / VS;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        const int v = threadIdx.x + m * 256;
+        if (v < nvec) r.v[m] = *reinterpret_cast<const typename VecIO<S, VS>::V *>(src + (int64_t)v * VS);
+    }
+}
+
+template <typename S, typename T, int VS, int NV>
+__device__ __forceinline__ void lean_planes_commit(const PlaneRegs<S, VS, NV> &r, T *nat, T *tr, int nelem, int L, int H,
+                                                   int W, uint32_t magicW, uint32_t magicL) {
+    const int nvec = nelem / VS;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        const int v = threadIdx.x + m * 256;
+        if (v >= nvec) continue;
+        const int e0 = v * VS;                          // element index inside the tile (planes are contiguous)
+        float f[VS];
+        VecIO<S, VS>::unpack(r.v[m], f);
+        *reinterpret_cast<typename VecIO<T, VS>::V *>(nat + e0) = VecIO<T, VS>::pack(f);
+        const int pl = (int)__umulhi((uint32_t)e0, magicL), ep = e0 - pl * L;        // plane, element in plane
+        int h = (int)__umulhi((uint32_t)ep, magicW), w = ep - h * W;
+#pragma unroll
+        for (int q = 0; q < VS; ++q) {
+            tr[pl * L + w * H + h] = from_float<T>(f[q]);
+            if (++w == W) {
+                w = 0;
+                ++h;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernels: wave w owns route {0,2,1,3}[w]; LDS (forward):  xN | xT (Tin, PPT planes) | 4 x y planes (fp32)
 //                                         LDS (backward): xN | xT | gN | gT (Tin) | dxN | dxT (fp32) | 4 x (accB|accC)
@@ -505,15 +546,36 @@ __global__ void __launch_bounds__(256) ss2d_bwd_lean_kernel(const LeanArgs a) {
         if (nseg > 1) pf.h = a.chk[r0 * nseg + nseg - 2];
     }
     const int n_planes = a.pli * a.ppt;
+    // plane staging is software-pipelined: the loads of tile it+1 are in flight while tile it is swept
+    constexpr int NVX = C == 8 ? 2 : 4;                // ppt*L <= 3200 elements (plan): 400 / 800 vectors over 256 threads
+    // (C == 8 variants only: they are LDS-limited to one or two workgroups per CU, so the extra registers are free and
+    //  nothing else hides the staging; the 14x14 variant runs 3 waves per SIMD and loses one to the registers)
+    constexpr bool kPipe = sizeof(Tin) == 2 && sizeof(Tout) == 4 && C == 8;
+    PlaneRegs<Tin, C, NVX> px;
+    PlaneRegs<Tout, 4, 4> pg;
+    if (kPipe && !(a.dbg & 2)) {
+        const int64_t po0 = ((int64_t)b * D + (int64_t)tg * a.pli * a.ppt) * L;
+        lean_planes_issue<Tin, C, NVX>(px, (const Tin *)a.x + po0, PL);
+        lean_planes_issue<Tout, 4, 4>(pg, (const Tout *)a.dy + po0, PL);
+    }
     for (int it = 0; it < a.pli; ++it) {
         const int d0 = (tg * a.pli + it) * a.ppt;
         const int64_t po = ((int64_t)b * D + d0) * L;
         __syncthreads();
         if (!(a.dbg & 2)) {
-            lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
-            lean_planes_load<Tout, Tin, 4>(gN, gT, (const Tout *)a.dy + po, a.ppt, L, H, W, a.magicW);
+            if (kPipe) {
+                lean_planes_commit<Tin, Tin, C, NVX>(px, xN, xT, PL, L, H, W, a.magicW, a.magicL);
+                lean_planes_commit<Tout, Tin, 4, 4>(pg, gN, gT, PL, L, H, W, a.magicW, a.magicL);
+            } else {
+                lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
+                lean_planes_load<Tout, Tin, 4>(gN, gT, (const Tout *)a.dy + po, a.ppt, L, H, W, a.magicW);
+            }
         }
         __syncthreads();
+        if (kPipe && !(a.dbg & 2) && it + 1 < a.pli) {
+            lean_planes_issue<Tin, C, NVX>(px, (const Tin *)a.x + po + PL, PL);
+            lean_planes_issue<Tout, 4, 4>(pg, (const Tout *)a.dy + po + PL, PL);
+        }
         for (int pl = 0; pl < ((a.dbg & 1) ? 0 : a.ppt); ++pl) {
             const int d = d0 + pl, row = k * D + d;
             const int64_t ro = (route * D + d) * L;
