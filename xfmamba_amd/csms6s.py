@@ -101,11 +101,14 @@ class SelectiveScanHip(torch.autograd.Function):
             dout = dout.to(ctx.out_dtype)
         dev = u.device
         du, ddelta = torch.empty(u.shape, dtype=u.dtype, device=dev), torch.empty(u.shape, dtype=u.dtype, device=dev)
-        dA = torch.zeros(A.shape, dtype=torch.float32, device=dev)
-        dB = torch.zeros(B.shape, dtype=torch.float32, device=dev)      # fp32 accumulate, cast on return
-        dC = torch.zeros(C.shape, dtype=torch.float32, device=dev)      # (selective_scan.cpp:332-333,360)
-        dD = torch.zeros_like(D) if D is not None else None
-        dbias = torch.zeros_like(delta_bias) if delta_bias is not None else None
+        # fp32 accumulators (selective_scan.cpp:332-333,360), carved out of ONE zero-filled buffer: one fill kernel
+        sizes = [A.numel(), B.numel(), C.numel(), D.numel() if D is not None else 0,
+                 delta_bias.numel() if delta_bias is not None else 0]
+        acc = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        parts = torch.split(acc, sizes)
+        dA, dB, dC = parts[0].view(A.shape), parts[1].view(B.shape), parts[2].view(C.shape)
+        dD = parts[3].view(D.shape) if D is not None else None
+        dbias = parts[4].view(delta_bias.shape) if delta_bias is not None else None
         p = _lib.ScanParams()
         _fill_common(p, u, delta, A, B, C, D, delta_bias, ctx.delta_softplus, ctx.out_dtype)
         p.x = _lib.ptr(x)

@@ -41,8 +41,9 @@ class DWConv3x3SiLUHip(torch.autograd.Function):
         B, D, H, W = x.shape
         dy = dy.contiguous().to(x.dtype)
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
-        db = torch.zeros_like(b) if b is not None else None
+        acc = torch.zeros(w.numel() + (b.numel() if b is not None else 0), dtype=torch.float32, device=w.device)
+        dw = acc[:w.numel()].view(w.shape)                              # one fill for both accumulators
+        db = acc[w.numel():] if b is not None else None
         nbytes = 3 * x.numel() * x.element_size()
         with torch.cuda.device(x.device), _lib.timed("dwconv3x3_bwd", nbytes):
             _lib.check(_lib.lib().xfm_dwconv3x3_bwd(x.data_ptr(), w.data_ptr(), _lib.ptr(b), dy.data_ptr(), dx.data_ptr(),

@@ -46,8 +46,9 @@ class LayerNorm2dHip(torch.autograd.Function):
         if dy.dtype != ctx.ydtype:
             dy = dy.to(ctx.ydtype)
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
-        db = torch.zeros_like(w) if ctx.has_bias else None
+        acc = torch.zeros(2 * w.numel() if ctx.has_bias else w.numel(), dtype=torch.float32, device=w.device)
+        dw = acc[:w.numel()]                                             # one fill for both accumulators
+        db = acc[w.numel():] if ctx.has_bias else None
         nbytes = x.numel() * (2 * x.element_size() + dy.element_size())
         with torch.cuda.device(x.device), _lib.timed("layernorm2d_bwd", nbytes):
             _lib.check(_lib.lib().xfm_layernorm2d_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),

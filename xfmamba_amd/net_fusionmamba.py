@@ -59,12 +59,13 @@ class TwoViewXFMambaTop(nn.Module):
         self.merge_views = True
 
     def forward(self, x_a, x_b):
-        x_a = x_a.expand(-1, 3, -1, -1)
-        x_b = x_b.expand(-1, 3, -1, -1)
         if self.merge_views:
-            z = self.mamba_feature_extrac(torch.cat([x_a, x_b], dim=0), only_last=True)[-1]
+            # (concatenate the 1-channel views first: the 3-channel broadcast stays a stride-0 view for the trunk)
+            z = self.mamba_feature_extrac(torch.cat([x_a, x_b], dim=0).expand(-1, 3, -1, -1), only_last=True)[-1]
             z_a, z_b = z[: x_a.shape[0]], z[x_a.shape[0]:]
         else:
+            x_a = x_a.expand(-1, 3, -1, -1)
+            x_b = x_b.expand(-1, 3, -1, -1)
             z_a = self.mamba_feature_extrac(x_a)[3]
             z_b = self.mamba_feature_extrac(x_b)[3]
         z_a, z_b = self.shallow_mamba_fusion(z_a, z_b)
