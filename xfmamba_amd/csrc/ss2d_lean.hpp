@@ -477,12 +477,21 @@ __global__ void __launch_bounds__(256) ss2d_fwd_lean_kernel(const LeanArgs a) {
         }
     }
     const int n_planes = a.pli * a.ppt;
+    constexpr int NVX = C == 8 ? 2 : 4;                // ppt*L <= 3200 elements (plan)
+    constexpr bool kPipe = sizeof(Tin) == 2 && C == 8;  // as in the backward: next tile's planes in flight during the sweeps
+    PlaneRegs<Tin, C, NVX> px;
+    if (kPipe && !(a.dbg & 2))
+        lean_planes_issue<Tin, C, NVX>(px, (const Tin *)a.x + ((int64_t)b * D + (int64_t)tg * a.pli * a.ppt) * L, PL);
     for (int it = 0; it < a.pli; ++it) {
         const int d0 = (tg * a.pli + it) * a.ppt;
         const int64_t po = ((int64_t)b * D + d0) * L;
         __syncthreads();
-        if (!(a.dbg & 2)) lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
+        if (!(a.dbg & 2)) {
+            if (kPipe) lean_planes_commit<Tin, Tin, C, NVX>(px, xN, xT, PL, L, H, W, a.magicW, a.magicL);
+            else lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
+        }
         __syncthreads();
+        if (kPipe && !(a.dbg & 2) && it + 1 < a.pli) lean_planes_issue<Tin, C, NVX>(px, (const Tin *)a.x + po + PL, PL);
         for (int pl = 0; pl < ((a.dbg & 1) ? 0 : a.ppt); ++pl) {
             const int d = d0 + pl, row = k * D + d;
             const Tin *dts_row = (const Tin *)a.dts + (route * D + d) * L;
