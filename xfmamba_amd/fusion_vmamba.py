@@ -53,31 +53,33 @@ def trunc_normal_(t, std=0.02):
 
 
 class DropPath(nn.Module):
-    """Per-sample stochastic depth (what the reference imports from timm 0.4.12)."""
+    """Per-sample stochastic depth (what the reference imports from timm 0.4.12: Bernoulli(keep) mask, divided by
+    keep).  The scaled mask comes out of ONE dropout kernel on a cached vector of ones (same distribution)."""
 
     def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
         super().__init__()
         self.drop_prob = float(drop_prob)
         self.scale_by_keep = scale_by_keep
-
-    def forward(self, x):
-        if self.drop_prob == 0.0 or not self.training:
-            return x
-        keep = 1.0 - self.drop_prob
-        mask = torch.empty((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device).bernoulli_(keep)
-        if keep > 0.0 and self.scale_by_keep:
-            mask = mask / keep
-        return x * mask
+        self._ones = {}
 
     def sample_scale(self, batch: int, device):
         """The per-sample factor ``forward`` multiplies by, as a (B,) fp32 vector (None when it is the identity)."""
         if self.drop_prob == 0.0 or not self.training:
             return None
         keep = 1.0 - self.drop_prob
-        mask = torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep)
+        key = (batch, str(device))
+        ones = self._ones.get(key)
+        if ones is None:
+            ones = self._ones[key] = torch.ones(batch, dtype=torch.float32, device=device)
         if keep > 0.0 and self.scale_by_keep:
-            mask = mask / keep
-        return mask
+            return F.dropout(ones, p=self.drop_prob, training=True)          # Bernoulli(keep) / keep
+        return torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep)
+
+    def forward(self, x):
+        mask = self.sample_scale(x.shape[0], x.device)
+        if mask is None:
+            return x
+        return x * mask.view((x.shape[0],) + (1,) * (x.ndim - 1)).to(x.dtype)
 
     def extra_repr(self):
         return f"drop_prob={self.drop_prob}"
