@@ -207,7 +207,7 @@ def _dwconv_act(conv: nn.Conv2d, act: nn.Module, x: torch.Tensor) -> torch.Tenso
     return act(conv(x))
 
 
-def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_override=None, want_Cs=False):
+def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_override=None, want_Cs=False, As=None):
     """x: (B, D, H, W) -> (y: (B, D, H*W) fp32, Cs in the layout of the active mode).
 
     ``Cs_override`` lets the view streams of Cross_SS2Dv5 read their state through the fused
@@ -217,7 +217,8 @@ def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_
     L = H * W
     K, _, R = dt_projs_weight.shape
     N = A_logs.shape[1]
-    As = -A_logs.float().exp()
+    if As is None:
+        As = -A_logs.float().exp()                   # (the trunk hands in a precomputed A: _NegExpAll)
     Dsf = Ds.float()
     bias = dt_projs_bias.reshape(-1).float()
     cd = x.dtype
@@ -282,6 +283,7 @@ class SS2Dv2(nn.Module):
             raise NotImplementedError(f"forward_type {forward_type!r}: xfmamba_amd builds the cross2d/oflex core only "
                                       f"({_HIP_FORWARD_TYPES}, optionally with _noz)")
         self.out_norm = (LayerNorm2d if channel_first else nn.LayerNorm)(self.d_inner)
+        self._As_pre = None          # A = -exp(A_logs) computed for all blocks of the trunk at once (transient)
 
         self.in_proj = Linear(self.d_model, self.d_inner if self.disable_z else self.d_inner * 2, bias=bias)
         self.act = act_layer()
@@ -302,7 +304,8 @@ class SS2Dv2(nn.Module):
 
     def forward_core(self, x: torch.Tensor):
         B, D, H, W = x.shape
-        y, _ = _ss2d_core(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs, self.Ds, self.dt_projs_bias)
+        y, _ = _ss2d_core(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs, self.Ds, self.dt_projs_bias,
+                          As=self._As_pre)
         y = y.view(B, -1, H, W)
         if self.channel_first:
             return self.out_norm(y, out_dtype=x.dtype)          # LayerNorm2d kernel emits x's dtype directly
@@ -421,6 +424,51 @@ class VSSBlock(nn.Module):
             x, h = _norm_tokens(self.norm2, x, pend)
             pend = (self.mlp.forward_tokens(h), self.drop_path.sample_scale(B, x.device))
         return x, pend
+
+
+class _NegExpAll(torch.autograd.Function):
+    """``A_i = -exp(A_log_i)`` for a list of tensors with two multi-tensor kernels (and one for the backward) instead
+    of an exp, a neg and their two backward kernels per SS2D block (models/fusion_vmamba.py:1161)."""
+
+    @staticmethod
+    def forward(ctx, *logs):
+        outs = torch._foreach_neg(torch._foreach_exp([t.float() for t in logs]))
+        ctx.save_for_backward(*outs)
+        ctx.dtypes = [t.dtype for t in logs]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        outs = ctx.saved_tensors
+        idx = [i for i, g in enumerate(grads) if g is not None]
+        res = [None] * len(grads)
+        if idx:
+            prod = torch._foreach_mul([grads[i] for i in idx], [outs[i] for i in idx])      # dA_log = dA * A
+            for i, p in zip(idx, prod):
+                res[i] = p.to(ctx.dtypes[i])
+        return tuple(res)
+
+
+class _PrecomputedA:
+    """Context: hand every SS2Dv2 of ``root`` its ``A = -exp(A_logs)`` from one batched evaluation."""
+
+    def __init__(self, root: nn.Module):
+        mods = root.__dict__.get("_ss2d_mods")           # (cached on the container: the module tree is static)
+        if mods is None:
+            mods = [m for m in root.modules() if isinstance(m, SS2Dv2)]
+            root.__dict__["_ss2d_mods"] = mods
+        self.mods = mods
+
+    def __enter__(self):
+        if self.mods and self.mods[0].A_logs.is_cuda:
+            for m, a in zip(self.mods, _NegExpAll.apply(*[m.A_logs for m in self.mods])):
+                m._As_pre = a
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.mods:
+            m._As_pre = None
+        return False
 
 
 def _blocks_tokens_ok(blocks) -> bool:
@@ -574,9 +622,10 @@ class VSSM(nn.Module):
 
     def forward(self, x: torch.Tensor):
         if self.tokens_trunk_ok(x):
-            t = self.stem_tokens(x)
-            for i in range(len(self.layers)):
-                o, t = self.stage_tokens(i, t)
+            with _PrecomputedA(self.layers):
+                t = self.stem_tokens(x)
+                for i in range(len(self.layers)):
+                    o, t = self.stage_tokens(i, t)
             x = o.permute(0, 3, 1, 2)
             return self.classifier(x)
         x = self.patch_embed(x)
@@ -643,12 +692,13 @@ class Backbone_VSSM(VSSM):
         (outnorm0-2, net_fusionmamba.py:200-201); values of the last output are unchanged."""
         last = len(self.layers) - 1
         if self.tokens_trunk_ok(x) and all(_norm_tokens_ok(getattr(self, f"outnorm{i}")) for i in self.out_indices):
-            t = self.stem_tokens(x)
             outs = []
-            for i in range(len(self.layers)):
-                o, t = self.stage_tokens(i, t)
-                if i in self.out_indices and (not only_last or i == last):
-                    outs.append(_ln_tokens(getattr(self, f"outnorm{i}"), o, torch.float32).permute(0, 3, 1, 2).contiguous())
+            with _PrecomputedA(self.layers):
+                t = self.stem_tokens(x)
+                for i in range(len(self.layers)):
+                    o, t = self.stage_tokens(i, t)
+                    if i in self.out_indices and (not only_last or i == last):
+                        outs.append(_ln_tokens(getattr(self, f"outnorm{i}"), o, torch.float32).permute(0, 3, 1, 2).contiguous())
             return outs if len(self.out_indices) else o.permute(0, 3, 1, 2).contiguous()
         x = self.patch_embed(x)
         outs = []
