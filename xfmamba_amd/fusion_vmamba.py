@@ -762,7 +762,8 @@ class ShallowFuse_SS2Dv4(nn.Module):
                                self.dt_projs_bias.reshape(-1).float(), True, True, None).view(B, K, -1, L)
         y, y2 = SwappingMerge_multiview.apply(ys)
         yy = self.out_norm(torch.cat([y, y2], dim=0).transpose(1, 2).reshape(2 * B, H, W, -1)).to(x.dtype)
-        return yy[:B], yy[B:]
+        y, y2 = yy.chunk(2, dim=0)                      # (chunk, not slices: its backward is one cat, not zeros + adds)
+        return y, y2
 
     def forward(self, x: torch.Tensor, x2: torch.Tensor):
         # both views share every weight here: they run as one batch of 2B wherever the reference makes two calls
@@ -770,12 +771,13 @@ class ShallowFuse_SS2Dv4(nn.Module):
         B = x.shape[0]
         xp = self.in_proj(torch.cat([x, x2], dim=0)).permute(0, 3, 1, 2).contiguous()        # (2B, D, H, W)
         xc = _dwconv_act(self.conv2d, self.act, xp) if self.with_dconv else self.act(xp)
-        y1, y2 = self.forward_corev2(xc[:B], xc[B:])
+        y1, y2 = self.forward_corev2(*xc.chunk(2, dim=0))
         y = self.out_act(torch.cat([y2, y1], dim=0))                                         # [view 2 | view 1]
         d = xp.shape[1]
         gate = self.fc1(self.avg_pool(xp).view(2 * B, d)).view(2 * B, 1, 1, d)               # [gate 1 | gate 2]
         o = self.dropout(self.out_proj(y * gate))       # each view is gated by the OTHER view's squeeze (:870-871)
-        return o[B:], o[:B]
+        o2, o1 = o.chunk(2, dim=0)
+        return o1, o2
 
 
 class ShallowFusionBlock_v4(nn.Module):
@@ -854,7 +856,7 @@ class Cross_SS2Dv5(nn.Module):
         x_dbl = torch.matmul(self.x_proj_weight.to(cd), xs)                                       # (3B, K, R+2N, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         dts = torch.matmul(self.dt_projs_weight.to(cd), dts).view(B3, -1, L)
-        Cs = Cs[2 * B:].unsqueeze(0).expand(3, B, K, N, L).reshape(B3, K, N, L)
+        Cs = torch.split(Cs, B, dim=0)[2].unsqueeze(0).expand(3, B, K, N, L).reshape(B3, K, N, L)
         ys = selective_scan_fn(xs.view(B3, -1, L), dts, -self.A_logs.float().exp(), Bs.contiguous(), Cs,
                                self.Ds.float(), self.dt_projs_bias.reshape(-1).float(), True, True, None)
         y = cross_merge_fn(ys.view(B3, K, -1, H, W), in_channel_first=True, out_channel_first=True, scans=0)
@@ -863,14 +865,14 @@ class Cross_SS2Dv5(nn.Module):
     def forward(self, x, x2: torch.Tensor, **kwargs):
         B, H, W = x.shape[0], x.shape[1], x.shape[2]
         x3 = self.in_proj_sec(torch.cat([x, x2, (x + x2) / 2], dim=0))                 # one GEMM for the three streams
-        z = self.act(x3[2 * B:])
+        z = self.act(torch.split(x3, B, dim=0)[2])
         t = x3.permute(0, 3, 1, 2).contiguous()
         t = _dwconv_act(self.conv2d, self.act, t) if self.with_dconv else self.act(t)
         if SS2D_MODE == "fused" and H * W > 64:
-            y, y2, y_fuse = self.forward_corev2(t[:B], t[B:2 * B], t[2 * B:])
+            y, y2, y_fuse = self.forward_corev2(*torch.split(t, B, dim=0))
         else:
             y3 = self.forward_core_batched(t)
-            y, y2, y_fuse = y3[:B], y3[B:2 * B], y3[2 * B:]
+            y, y2, y_fuse = torch.split(y3, B, dim=0)
         return self.dropout(self.out_proj(y * z + y2 * z + y_fuse * z))
 
 

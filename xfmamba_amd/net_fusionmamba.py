@@ -62,7 +62,7 @@ class TwoViewXFMambaTop(nn.Module):
         if self.merge_views:
             # (concatenate the 1-channel views first: the 3-channel broadcast stays a stride-0 view for the trunk)
             z = self.mamba_feature_extrac(torch.cat([x_a, x_b], dim=0).expand(-1, 3, -1, -1), only_last=True)[-1]
-            z_a, z_b = z[: x_a.shape[0]], z[x_a.shape[0]:]
+            z_a, z_b = z.chunk(2, dim=0)
         else:
             x_a = x_a.expand(-1, 3, -1, -1)
             x_b = x_b.expand(-1, 3, -1, -1)
