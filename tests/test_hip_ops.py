@@ -495,3 +495,37 @@ def test_ss2d_proj_core_matches_operator_chain(shape, dt):
     for name, a, b in zip(("y", "dx", "dx_dbl", "ddt_w", "dA", "dD", "dbias"), outs[1], outs[0]):
         assert a.dtype == b.dtype, name
         assert_close(a.float().cpu(), b.float().cpu(), tol, tol * float(b.float().abs().max()) + 1e-7, name)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 56, 56, 1), (2, 384, 14, 14, 1), (2, 64, 10, 6, 2)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_ss2d_xproj_core_matches_operator_chain(shape, dt):
+    """x_proj inside the node (its data gradient accumulated onto the scan's dx by the GEMM) vs x_proj as a framework
+    matmul in front of ss2d_proj_core_fn: output and every gradient, incl. x_proj_weight."""
+    from xfmamba_amd.ss2d import ss2d_proj_core_fn, ss2d_xproj_core_fn
+    B, D, H, W, N = shape
+    L, K = H * W, 4
+    R = max(1, D // 16)
+    C2 = R + 2 * N
+    g = torch.Generator().manual_seed(B * D + W)
+    x = torch.randn(B, D, L, generator=g).to(dt)
+    xw = torch.randn(K, C2, D, generator=g) * D ** -0.5
+    dtw = torch.randn(K, D, R, generator=g) * R ** -0.5
+    A = -torch.rand(K * D, N, generator=g) - 0.1
+    Dp = torch.randn(K * D, generator=g)
+    bias = 0.1 * torch.rand(K * D, generator=g)
+    gy = torch.randn(B, D, L, generator=g)
+    outs = []
+    for inside in (False, True):
+        t = [v.to(DEV).requires_grad_() for v in (x, xw, dtw, A, Dp, bias)]
+        if inside:
+            y = ss2d_xproj_core_fn(t[0], t[1], t[2], t[3], t[4], t[5], H, W)
+        else:
+            xd = torch.matmul(t[1].reshape(K * C2, D).to(dt), t[0])
+            y = ss2d_proj_core_fn(t[0], xd, t[2], t[3], t[4], t[5], H, W)
+        y.backward(gy.to(DEV))
+        outs.append([y.detach()] + [v.grad for v in t])
+    tol = 1e-4 if dt == torch.float32 else 1e-2
+    for name, a, b in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), outs[1], outs[0]):
+        assert a.dtype == b.dtype, name
+        assert_close(a.float().cpu(), b.float().cpu(), tol, tol * float(b.float().abs().max()) + 1e-7, name)

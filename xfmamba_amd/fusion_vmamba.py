@@ -38,7 +38,7 @@ from .layernorm2d import layernorm2d_fn
 from .mlp_tokens import linear_tokens_fn, mlp_tokens_fn
 from .proj import batched_proj
 from .rowln import add_layernorm_rows_fn, layernorm_rows_fn, rows_supported
-from .ss2d import ss2d_core_fn, ss2d_proj_core_fn, to_route_order
+from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
 
 SS2D_MODE = "fused"          # "fused" | "unfused"
 # Layout of the trunk's residual stream between VSS blocks.  "tokens": (B, H, W, C) fp32 -- LayerNorm (+ residual add
@@ -231,10 +231,10 @@ def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_
         # dts for those routes directly in the order the kernel walks them -- the big (B,4,D,L) tensor is
         # written once, contiguous per route, and never permuted.
         C2 = R + 2 * N
-        x_dbl = batched_proj(x.reshape(B, D, L), x_proj_weight.reshape(K * C2, D))             # (B, K*C2, L)
         if Cs_override is None and not want_Cs:
-            # route split, dt_proj, scan and merge as one autograd node (the (B,4,.,L) B/C tensors stay inside)
-            return ss2d_proj_core_fn(x.reshape(B, D, L), x_dbl, dt_projs_weight, As, Dsf, bias, H, W), None
+            # x_proj, route split, dt_proj, scan and merge as one autograd node (the (B,4,.,L) tensors stay inside)
+            return ss2d_xproj_core_fn(x.reshape(B, D, L), x_proj_weight, dt_projs_weight, As, Dsf, bias, H, W), None
+        x_dbl = batched_proj(x.reshape(B, D, L), x_proj_weight.reshape(K * C2, D))             # (B, K*C2, L)
         x_dbl = to_route_order(x_dbl.view(B, K, C2, L), H, W)
         dts = torch.matmul(dt_projs_weight.to(cd), x_dbl[:, :, :R])                            # (B, K, D, L)
         Bs = x_dbl[:, :, R:R + N].contiguous()

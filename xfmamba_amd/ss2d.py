@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from .amp import cast_weight
 
-__all__ = ["ss2d_core_fn", "ss2d_proj_core_fn", "SS2DCoreHip", "SS2DProjCoreHip", "to_route_order"]
+__all__ = ["ss2d_core_fn", "ss2d_proj_core_fn", "ss2d_xproj_core_fn", "SS2DCoreHip", "SS2DProjCoreHip", "to_route_order"]
 
 
 def to_route_order(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
@@ -118,12 +118,20 @@ class SS2DProjCoreHip(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, x_dbl, dt_w, A, D, bias, H, W):
-        _lib.require_cuda(x, x_dbl, dt_w, A, D, bias)
+    def forward(ctx, x, x_dbl, x_proj_w, dt_w, A, D, bias, H, W):
+        _lib.require_cuda(x, dt_w, A, D, bias)
         Bt, Dm, L = x.shape
         K, _, R = dt_w.shape
         N = A.shape[1]
         C2 = R + 2 * N
+        xw = None
+        if x_proj_w is not None:
+            # x_proj of the four routes inside the node: ONE dense GEMM on the natural map; in the backward pass its
+            # data gradient is accumulated onto the scan's dx by the GEMM itself (beta = 1), not by a separate add
+            x = x.contiguous()
+            xw = cast_weight(x_proj_w.reshape(K * C2, Dm), x.dtype)
+            x_dbl = torch.bmm(xw.unsqueeze(0).expand(Bt, K * C2, Dm), x)
+        _lib.require_cuda(x_dbl)
         if K != 4 or L != H * W or x_dbl.shape != (Bt, K * C2, L) or x_dbl.dtype != x.dtype:
             raise RuntimeError("ss2d_proj_core: x (B,D,H*W), x_dbl (B,4*(R+2N),H*W) of one dtype, dt_w (4,D,R) expected")
         x, x_dbl = x.contiguous(), x_dbl.contiguous()
@@ -157,14 +165,15 @@ class SS2DProjCoreHip(torch.autograd.Function):
         ctx.hw = (H, W)
         ctx.mode = mode
         ctx.wdtype = dt_w.dtype
-        ctx.save_for_backward(x, xr, dts, w, A, Bs, Cs, D, bias, chk)
+        ctx.xw_meta = None if x_proj_w is None else (x_proj_w.dtype, tuple(x_proj_w.shape))
+        ctx.save_for_backward(x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw)
         return y
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         from .proj import _bmm_f32
-        x, xr, dts, w, A, Bs, Cs, D, bias, chk = ctx.saved_tensors
+        x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw = ctx.saved_tensors
         H, W = ctx.hw
         dev = x.device
         Bt, Dm, L = x.shape
@@ -194,13 +203,23 @@ class SS2DProjCoreHip(torch.autograd.Function):
             _lib.check(_lib.lib().xfm_ss2d_route_merge(dxr.data_ptr(), dBs.data_ptr(), dCs.data_ptr(), dxd.data_ptr(), Bt,
                                                        R, N, H, W, _lib.dtype_code(x.dtype), _lib.stream_ptr()),
                        "route_merge")
-        return dx, dxd, dw.to(ctx.wdtype), dA, dD, dbias, None, None
+        if xw is None:
+            return dx, dxd, None, dw.to(ctx.wdtype), dA, dD, dbias, None, None
+        KC2 = xw.shape[0]
+        dx.baddbmm_(xw.t().unsqueeze(0).expand(Bt, Dm, KC2), dxd)                      # dx += Wx^T @ d x_dbl
+        dxw = _bmm_f32(dxd, x.transpose(1, 2)).sum(0).view(ctx.xw_meta[1]).to(ctx.xw_meta[0])
+        return dx, None, dxw, dw.to(ctx.wdtype), dA, dD, dbias, None, None
 
 
 def ss2d_proj_core_fn(x, x_dbl, dt_projs_weight, A, D, bias, H, W):
     """x (B,D,L) natural; x_dbl (B,4*(R+2N),L) = x_proj of the four routes evaluated on the natural map;
     dt_projs_weight (4,D,R); A (4D,N); D/bias (4D,) -> y (B,D,L) fp32."""
-    return SS2DProjCoreHip.apply(x, x_dbl, dt_projs_weight, A, D, bias, H, W)
+    return SS2DProjCoreHip.apply(x, x_dbl, None, dt_projs_weight, A, D, bias, H, W)
+
+
+def ss2d_xproj_core_fn(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W):
+    """Same with x_proj inside the node: x_proj_weight (4, R+2N, D)."""
+    return SS2DProjCoreHip.apply(x, None, x_proj_weight, dt_projs_weight, A, D, bias, H, W)
 
 
 def ss2d_core_fn(x, dts, A, Bs, Cs, D, bias, H, W):
