@@ -8,17 +8,19 @@ wired exactly like upstream.  Only what ``TwoViewXFMambaTop`` reaches is built
 (PatchMerging2D, gMlp, cascade scans, the Mamba-2 path ...) is out of scope.
 
 Inside the blocks, ``cross_scan_fn`` / ``selective_scan_fn`` / ``cross_merge_fn`` and the swap are
-served by the gfx950 kernels in ``libxfm_hip.so``; the dense contractions (1x1 / 3x3 convs,
-x_proj / dt_proj / in_proj / out_proj) go to rocBLAS / hipBLASLt / MIOpen through PyTorch, which
-is the MFMA path for plain library GEMMs.
+served by the gfx950 kernels in ``libxfm_hip.so``; the dense contractions go to hipBLASLt / MIOpen through
+PyTorch, which is the MFMA path for plain library GEMMs.
 
-Two equivalent evaluation orders of the SS2D core exist, selected by ``SS2D_MODE``:
-  * ``"fused"``   -- x_proj and dt_proj are evaluated once on the feature map in its NATURAL
-    row-major order (route k's projection of the permuted sequence equals the permuted
-    projection), and one kernel (``xfm_ss2d_fwd``) walks the four routes, scans and merges
-    without materialising the (B,4,D,L) tensors;
-  * ``"unfused"`` -- the reference's operator sequence cross_scan -> x_proj -> dt_proj ->
-    selective_scan -> cross_merge (fusion_vmamba.py:1145-1174), each on its own kernel.
+Two switches select equivalent evaluation orders (same parameters, same results; the tests run both):
+  * ``SS2D_MODE``: ``"fused"`` -- x_proj and dt_proj are evaluated once on the feature map in its NATURAL
+    row-major order (route k's projection of the permuted sequence equals the permuted projection), and one
+    kernel (``xfm_ss2d_fwd``) walks the four routes, scans and merges without materialising the (B,4,D,L)
+    tensors; ``"unfused"`` -- the reference's operator sequence cross_scan -> x_proj -> dt_proj ->
+    selective_scan -> cross_merge (fusion_vmamba.py:1145-1174), each on its own kernel (always used for 7x7 maps).
+  * ``STREAM_LAYOUT``: ``"tokens"`` -- the trunk's residual stream is token-major (B, H, W, C) fp32: residual add +
+    DropPath + LayerNorm are one row kernel, Mlp / 1x1 projections are plain GEMMs, 3x3 convolutions run
+    channels_last, and the (B, D, L) planes of the scan path come out of in_proj's batched GEMM; ``"planes"`` -- NCHW
+    modules exactly as the reference wires them.
 """
 from __future__ import annotations
 
