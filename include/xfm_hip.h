@@ -124,6 +124,12 @@ int xfm_ss2d_route_merge(const void *dxr, const float *dBs, const float *dCs, vo
  * softplus_bias (4*D fp32) != NULL: the epilogue stores softplus(dts + bias) (threshold 20) -- the activated step
  * size, for xfm_ss2d_fwd/_bwd called with delta_softplus = 2. */
 int xfm_ss2d_dt_proj_supported(int D, int R, int L);
+/* MFMA variant for bf16 I/O (D % 32 == 0, R <= 32; xfm_ss2d_dt_proj_mfma_rp() returns the padded contraction length
+ * 16 / 32, or 0 when the shape is not covered): weight_bf16 is the (4, D, R) weight in bf16 (what autocast feeds the
+ * reference's einsum); same result contract as xfm_ss2d_dt_proj_fwd. */
+int xfm_ss2d_dt_proj_mfma_rp(int D, int R, int L);
+int xfm_ss2d_dt_proj_fwd_mfma(const void *xr, const void *weight_bf16, const float *softplus_bias, void *dts, int B, int D,
+                              int R, int L, void *stream);
 int xfm_ss2d_dt_proj_fwd(const void *xr, const float *weight, const float *softplus_bias, void *dts, int B, int D, int R,
                          int L, int dtype, void *stream);
 

@@ -120,6 +120,26 @@ def main():
             t = e0.elapsed_time(e1) * 1e3 / 30
             nb = out.numel() * out.element_size()
             print(f"{'dt_proj_fwd ' + name:28s} {t:9.1f} {nb / t / 1e3:8.1f} {nb / t / 1e3 / 80:6.2f}")
+            rp = lib.xfm_ss2d_dt_proj_mfma_rp(D, R, L)
+            if rp and dt == torch.bfloat16:
+                bias = 0.1 * torch.rand(4 * D, device=dev)
+                wp = w.to(dt).contiguous()
+                out2 = torch.empty_like(out)
+                lib.xfm_ss2d_dt_proj_fwd(xr.data_ptr(), w.to(dt).float().data_ptr(), bias.data_ptr(), out.data_ptr(), Bt, D, R, L, code, st)
+                fn2 = lambda: lib.xfm_ss2d_dt_proj_fwd_mfma(xr.data_ptr(), wp.data_ptr(), bias.data_ptr(), out2.data_ptr(), Bt, D, R, L, st)
+                fn2()
+                torch.cuda.synchronize()
+                err = float((out2.float() - out.float()).abs().max() / out.float().abs().max())
+                for _ in range(3):
+                    fn2()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(30):
+                    fn2()
+                e1.record()
+                torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) * 1e3 / 30
+                print(f"{'dt_proj_mfma ' + name:28s} {t:9.1f} {nb / t / 1e3:8.1f} {nb / t / 1e3 / 80:6.2f}  max rel diff vs VALU kernel {err:.2e}")
     if not a.only or a.only in "rowscan":
         from xfmamba_amd import csms6s
         for name, Bt, KD, N in (("rowscan fusion", B // 2, 6144, 16), ("rowscan stage3", B, 3072, 1)):

@@ -93,9 +93,120 @@ static int dt_proj_launch(const void *xr, const float *w, const float *bias, voi
     return check_launch();
 }
 
+// MFMA variant (bf16, D % 32 == 0): per (b, k) the product is a (D x R) . (R x L) GEMM with a tiny contraction length; a
+// wavefront owns 32 positions, keeps the xr fragment(s) of `v_mfma_f32_32x32x16_bf16` in registers for the whole
+// channel loop and issues ONE MFMA (R <= 16) or two (R <= 32) per 32 x 32 output tile, so the VALU only runs the
+// bias + softplus epilogue.  Operand maps (cdna_hip_programming.md): lane l (r = l & 31, h = l >> 5) holds
+// A[row r][k = 8h + j], B[k = 8h + j][col r]; D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 h.
+typedef __bf16 xfm_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float xfm_f32x16_t __attribute__((ext_vector_type(16)));
+
+struct DtProjMfmaArgs {
+    const bf16_t *xr;     // (B, 4, R, L)
+    const bf16_t *w;      // (4, D, R) bf16 (padded to RP = 16 * KS with zeros while it is staged in LDS)
+    const float *bias;    // (4*D) or null
+    bf16_t *out;          // (B, 4, D, L)
+    int D, R, L, RP, ltiles, dsplit;
+};
+
+template <int KS> __global__ __launch_bounds__(256) void dt_proj_mfma_kernel(DtProjMfmaArgs a) {
+    constexpr int RP = 16 * KS, P = RP + 8;                       // LDS row pitch: 16-byte aligned, off the bank period
+    extern __shared__ uint16_t wl[];                               // [channels of this workgroup][P] zero-padded weights
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lt = (blockIdx.x % a.ltiles) * 4 + wave;
+    const int ds = (blockIdx.x / a.ltiles) % a.dsplit;
+    const int bk = blockIdx.x / (a.ltiles * a.dsplit);
+    const int k = bk & 3;
+    const int dper = (a.D / 32 + a.dsplit - 1) / a.dsplit;
+    const int t0 = ds * dper, t1 = min(a.D / 32, t0 + dper);
+    {
+        const uint16_t *wg = reinterpret_cast<const uint16_t *>(a.w) + ((int64_t)k * a.D + t0 * 32) * a.R;
+        const int nd = (t1 - t0) * 32;
+        for (int e = threadIdx.x; e < nd * RP; e += 256) {
+            const int dd = e / RP, r = e - dd * RP;
+            wl[dd * P + r] = r < a.R ? wg[dd * a.R + r] : (uint16_t)0;
+        }
+    }
+    __syncthreads();
+    const int c = lane & 31, h = lane >> 5;
+    const int pos = lt * 32 + c;
+    const bool valid = pos < a.L;
+    if (lt * 32 >= a.L) return;                                   // (whole wave; no barrier below)
+    const uint16_t *xr = reinterpret_cast<const uint16_t *>(a.xr) + (int64_t)bk * a.R * a.L;
+    xfm_bf16x8_t bf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        uint16_t t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 16 * s + 8 * h + j;
+            t[j] = (valid && r < a.R) ? xr[(int64_t)r * a.L + pos] : (uint16_t)0;
+        }
+        bf[s] = *reinterpret_cast<const xfm_bf16x8_t *>(t);
+    }
+    uint16_t *out = reinterpret_cast<uint16_t *>(a.out) + (int64_t)bk * a.D * a.L;
+    for (int dt = t0; dt < t1; ++dt) {
+        const int d0 = dt * 32;
+        xfm_f32x16_t acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const xfm_bf16x8_t af = *reinterpret_cast<const xfm_bf16x8_t *>(wl + ((dt - t0) * 32 + c) * P + 16 * s + 8 * h);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {
+            const int row0 = (v & 3) + 8 * (v >> 2) + 4 * h;        // rows of regs v and v + 1 are adjacent channels
+            float y0 = acc[v], y1 = acc[v + 1];
+            if (a.bias) {
+                y0 = softplus20(y0 + a.bias[k * a.D + d0 + row0]);
+                y1 = softplus20(y1 + a.bias[k * a.D + d0 + row0 + 1]);
+            }
+            if (valid) {
+                const uint32_t pk = pack_bf16x2(y0, y1);
+                out[(int64_t)(d0 + row0) * a.L + pos] = (uint16_t)(pk & 0xffffu);
+                out[(int64_t)(d0 + row0 + 1) * a.L + pos] = (uint16_t)(pk >> 16);
+            }
+        }
+    }
+}
+
+static int dt_proj_mfma(const void *xr, const bf16_t *w_padded, const float *bias, void *out, int B, int D, int R, int RP,
+                        int L, hipStream_t s) {
+    DtProjMfmaArgs a{};
+    a.xr = static_cast<const bf16_t *>(xr); a.w = w_padded; a.bias = bias; a.out = static_cast<bf16_t *>(out);
+    a.D = D; a.R = R; a.L = L; a.RP = RP;
+    a.ltiles = ((L + 31) / 32 + 3) / 4;                           // 4 waves = 4 position tiles per workgroup
+    int dsplit = 1;
+    while ((int64_t)B * 4 * a.ltiles * dsplit < 2048 && dsplit * 2 <= D / 32) dsplit *= 2;
+    a.dsplit = dsplit;
+    const dim3 grid((unsigned)((int64_t)B * 4 * a.ltiles * dsplit));
+    const int dper = (D / 32 + dsplit - 1) / dsplit;
+    const size_t lds = (size_t)dper * 32 * (RP + 8) * sizeof(uint16_t);
+    if (RP == 16) hipLaunchKernelGGL((dt_proj_mfma_kernel<1>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((dt_proj_mfma_kernel<2>), grid, dim3(256), lds, s, a);
+    return check_launch();
+}
+
 }  // namespace xfm
 
 extern "C" {
+
+/* bf16 MFMA path: weight_bf16 is the (4, D, R) weight in bf16; returns the padded contraction length (16 / 32) or 0. */
+int xfm_ss2d_dt_proj_mfma_rp(int D, int R, int L) {
+    if (D % 32 != 0 || R < 1 || R > 32 || L < 1) return 0;
+    return R <= 16 ? 16 : 32;
+}
+
+int xfm_ss2d_dt_proj_fwd_mfma(const void *xr, const void *weight_bf16, const float *softplus_bias, void *dts, int B, int D,
+                              int R, int L, void *stream) {
+    using namespace xfm;
+    if (!xr || !weight_bf16 || !dts || B <= 0) return XFM_EINVAL;
+    const int RP = xfm_ss2d_dt_proj_mfma_rp(D, R, L);
+    if (!RP) return XFM_ELIMIT;
+    return dt_proj_mfma(xr, static_cast<const bf16_t *>(weight_bf16), softplus_bias, dts, B, D, R, RP, L, (hipStream_t)stream);
+}
 
 int xfm_ss2d_dt_proj_supported(int D, int R, int L) { return (L % 4 == 0 && R >= 1 && R <= 64 && D >= 1) ? 1 : 0; }
 

@@ -144,11 +144,17 @@ class SS2DProjCoreHip(torch.autograd.Function):
             # dt_proj kernel with the bias + softplus epilogue: the scan kernels then read the activated step size
             # (mode 2) instead of re-evaluating softplus per route element in the forward AND the backward pass
             mode = 2
-            wf = dt_w.detach().float().contiguous()
             dts = torch.empty((Bt, 4, Dm, L), dtype=x.dtype, device=x.device)        # (B, 4, D, L) in route order
             with torch.cuda.device(x.device), _lib.timed("dt_proj_fwd", dts.numel() * dts.element_size()):
-                _lib.check(lib.xfm_ss2d_dt_proj_fwd(xr.data_ptr(), wf.data_ptr(), bias.data_ptr(), dts.data_ptr(), Bt, Dm,
-                                                    R, L, _lib.dtype_code(x.dtype), _lib.stream_ptr()), "dt_proj_fwd")
+                if x.dtype == torch.bfloat16 and lib.xfm_ss2d_dt_proj_mfma_rp(Dm, R, L):
+                    wb = w.contiguous()                                                # bf16 weights (shadow when cached)
+                    _lib.check(lib.xfm_ss2d_dt_proj_fwd_mfma(xr.data_ptr(), wb.data_ptr(), bias.data_ptr(), dts.data_ptr(),
+                                                             Bt, Dm, R, L, _lib.stream_ptr()), "dt_proj_fwd_mfma")
+                else:
+                    wf = dt_w.detach().float().contiguous()
+                    _lib.check(lib.xfm_ss2d_dt_proj_fwd(xr.data_ptr(), wf.data_ptr(), bias.data_ptr(), dts.data_ptr(), Bt,
+                                                        Dm, R, L, _lib.dtype_code(x.dtype), _lib.stream_ptr()),
+                               "dt_proj_fwd")
         else:
             dts = torch.matmul(w, xr)
         plan = _plan(Bt, Dm, H, W, N, x.dtype)
