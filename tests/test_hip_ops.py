@@ -529,3 +529,39 @@ def test_ss2d_xproj_core_matches_operator_chain(shape, dt):
     for name, a, b in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), outs[1], outs[0]):
         assert a.dtype == b.dtype, name
         assert_close(a.float().cpu(), b.float().cpu(), tol, tol * float(b.float().abs().max()) + 1e-7, name)
+
+
+@pytest.mark.parametrize("B,D,R,H", [(2, 96, 6, 56), (2, 192, 12, 28), (3, 384, 24, 14), (2, 64, 5, 10), (1, 32, 3, 6)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_dt_proj_kernels_match_torch_fp32(B, D, R, H, with_bias):
+    """dt_proj (`einsum("b k r l, k d r -> b k d l")`, fusion_vmamba.py:1154-1156) with the optional bias + softplus
+    epilogue (csms6s.py:49-50): the VALU kernel (fp32 and bf16 I/O) and the bf16 MFMA kernel vs plain PyTorch fp32."""
+    import ctypes
+    import torch.nn.functional as F
+    from xfmamba_amd import _lib
+    lib = _lib.lib()
+    L = H * H
+    g = torch.Generator().manual_seed(D + R)
+    xr = torch.randn(B, 4, R, L, generator=g)
+    w = torch.randn(4, D, R, generator=g) * R ** -0.5
+    bias = (torch.rand(4 * D, generator=g) * 4 - 3) if with_bias else None
+    st = _lib.stream_ptr()
+    for dt in (torch.float32, torch.bfloat16):
+        xd = xr.to(dt).to(DEV)
+        wq = w.to(dt).float()                                             # the weights the kernel is given
+        ref = torch.einsum("bkrl,kdr->bkdl", xd.float().cpu(), wq)
+        if with_bias:
+            ref = F.softplus(ref + bias.view(1, 4, D, 1))
+        out = torch.empty(B, 4, D, L, dtype=dt, device=DEV)
+        bd = None if bias is None else bias.to(DEV)
+        wd = wq.to(DEV).contiguous()
+        _lib.check(lib.xfm_ss2d_dt_proj_fwd(xd.data_ptr(), wd.data_ptr(), _lib.ptr(bd), out.data_ptr(), B, D, R, L,
+                                            _lib.dtype_code(dt), st), "dt_proj_fwd")
+        tol = 1e-4 if dt == torch.float32 else 1e-2
+        assert_close(out.float().cpu(), ref, tol, tol * float(ref.abs().max()), f"VALU {dt}")
+        if dt == torch.bfloat16 and lib.xfm_ss2d_dt_proj_mfma_rp(D, R, L):
+            out2 = torch.full_like(out, float("nan"))
+            wb = w.to(dt).to(DEV).contiguous()
+            _lib.check(lib.xfm_ss2d_dt_proj_fwd_mfma(xd.data_ptr(), wb.data_ptr(), _lib.ptr(bd), out2.data_ptr(), B, D, R,
+                                                     L, st), "dt_proj_fwd_mfma")
+            assert_close(out2.float().cpu(), ref, tol, tol * float(ref.abs().max()), "MFMA bf16")
