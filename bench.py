@@ -236,6 +236,12 @@ def main():
 
     if rank == 0:
         value = a.steps * B * world / dt
+        metric_name = f"two-view images/sec fwd+bwd, XFMamba-{a.model[0].upper()} {a.size}^2, batch {B}/GPU"
+        if (a.model, a.size, B) == ("tiny", 224, 32):            # the headline configuration: BASELINE.json's own wording
+            try:
+                metric_name = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+            except Exception:                                   # noqa: BLE001
+                pass
         roof = None
         kernels = {}
         if timer is not None:
@@ -259,7 +265,7 @@ def main():
                             avg_launch_us=round(k["avg_us"], 2),
                             algorithmic_bytes_per_launch=int(k["bytes"] / k["launches"]))
         line = {
-            "metric": (f"two-view images/sec fwd+bwd, XFMamba-{a.model[0].upper()} {a.size}^2, batch {B}/GPU"),
+            "metric": metric_name,
             "value": round(value, 2), "unit": "two-view samples/s (1 sample = 2 images)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
