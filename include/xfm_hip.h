@@ -128,6 +128,10 @@ int xfm_ss2d_dt_proj_supported(int D, int R, int L);
  * 16 / 32, or 0 when the shape is not covered): weight_bf16 is the (4, D, R) weight in bf16 (what autocast feeds the
  * reference's einsum); same result contract as xfm_ss2d_dt_proj_fwd. */
 int xfm_ss2d_dt_proj_mfma_rp(int D, int R, int L);
+/* Backward of dt_proj (bf16, same shape limits, L % 4 == 0): dxr[b,k,r,l] = sum_d weight[k,d,r] * ddts[b,k,d,l] and
+ * dweight[k,d,r] += sum_{b,l} ddts[b,k,d,l] * xr[b,k,r,l] (fp32, ZEROED by the caller; atomics); ddts is read once by each. */
+int xfm_ss2d_dt_proj_bwd_mfma(const void *ddts, const void *xr, const void *weight_bf16, void *dxr, float *dweight, int B,
+                              int D, int R, int L, void *stream);
 int xfm_ss2d_dt_proj_fwd_mfma(const void *xr, const void *weight_bf16, const float *softplus_bias, void *dts, int B, int D,
                               int R, int L, void *stream);
 int xfm_ss2d_dt_proj_fwd(const void *xr, const float *weight, const float *softplus_bias, void *dts, int B, int D, int R,

@@ -565,3 +565,24 @@ def test_dt_proj_kernels_match_torch_fp32(B, D, R, H, with_bias):
             _lib.check(lib.xfm_ss2d_dt_proj_fwd_mfma(xd.data_ptr(), wb.data_ptr(), _lib.ptr(bd), out2.data_ptr(), B, D, R,
                                                      L, st), "dt_proj_fwd_mfma")
             assert_close(out2.float().cpu(), ref, tol, tol * float(ref.abs().max()), "MFMA bf16")
+
+
+@pytest.mark.parametrize("B,D,R,H", [(2, 96, 6, 56), (2, 192, 12, 28), (3, 384, 24, 14), (2, 64, 5, 10)])
+def test_dt_proj_backward_mfma_matches_torch_fp32(B, D, R, H):
+    """Backward of dt_proj on MFMA (bf16): data gradient W^T.ddts and weight gradient sum_{b,l} ddts.xr^T vs fp32."""
+    from xfmamba_amd import _lib
+    lib = _lib.lib()
+    L = H * H
+    g = torch.Generator().manual_seed(D * R)
+    ddts = torch.randn(B, 4, D, L, generator=g).to(torch.bfloat16)
+    xr = torch.randn(B, 4, R, L, generator=g).to(torch.bfloat16)
+    w = (torch.randn(4, D, R, generator=g) * R ** -0.5).to(torch.bfloat16)
+    dxr_ref = torch.einsum("kdr,bkdl->bkrl", w.float(), ddts.float())
+    dw_ref = torch.einsum("bkdl,bkrl->kdr", ddts.float(), xr.float())
+    dd, xd, wd = ddts.to(DEV), xr.to(DEV), w.to(DEV)
+    dxr = torch.full((B, 4, R, L), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dw = torch.zeros(4, D, R, device=DEV)
+    _lib.check(lib.xfm_ss2d_dt_proj_bwd_mfma(dd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxr.data_ptr(), dw.data_ptr(), B, D,
+                                             R, L, _lib.stream_ptr()), "dt_proj_bwd_mfma")
+    assert_close(dxr.float().cpu(), dxr_ref, 1e-2, 1e-2 * float(dxr_ref.abs().max()), "dxr")
+    assert_close(dw.cpu(), dw_ref, 1e-3, 1e-3 * float(dw_ref.abs().max()), "dw")

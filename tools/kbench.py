@@ -140,6 +140,23 @@ def main():
                 torch.cuda.synchronize()
                 t = e0.elapsed_time(e1) * 1e3 / 30
                 print(f"{'dt_proj_mfma ' + name:28s} {t:9.1f} {nb / t / 1e3:8.1f} {nb / t / 1e3 / 80:6.2f}  max rel diff vs VALU kernel {err:.2e}")
+                ddts = torch.randn_like(out)
+                dxr = torch.empty_like(xr)
+                dwa = torch.zeros(4, D, R, device=dev)
+                fb = lambda: lib.xfm_ss2d_dt_proj_bwd_mfma(ddts.data_ptr(), xr.data_ptr(), wp.data_ptr(), dxr.data_ptr(), dwa.data_ptr(), Bt, D, R, L, st)
+                wT = wp.transpose(1, 2).contiguous()
+                ft = lambda: (torch.matmul(wT, ddts), torch.bmm(ddts.view(Bt * 4, D, L), xr.view(Bt * 4, R, L).transpose(1, 2)).view(Bt, 4, D, R).sum(0))
+                for nm, f in (("dt_proj_bwd_mfma", fb), ("dt_proj_bwd_torch", ft)):
+                    for _ in range(3):
+                        f()
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(30):
+                        f()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    t = e0.elapsed_time(e1) * 1e3 / 30
+                    print(f"{nm + ' ' + name:28s} {t:9.1f} {2 * nb / t / 1e3:8.1f}")
     if not a.only or a.only in "rowscan":
         from xfmamba_amd import csms6s
         for name, Bt, KD, N in (("rowscan fusion", B // 2, 6144, 16), ("rowscan stage3", B, 3072, 1)):

@@ -21,7 +21,7 @@ _DT = {torch.float32: XFM_F32, torch.float16: XFM_F16, torch.bfloat16: XFM_BF16}
 SYMBOLS = (
     "xfm_abi_version", "xfm_strerror", "xfm_last_hip_error", "xfm_scan_plan",
     "xfm_selective_scan_fwd", "xfm_selective_scan_bwd", "xfm_cross_scan", "xfm_cross_merge",
-    "xfm_swap_scan", "xfm_ss2d_route_split", "xfm_ss2d_route_merge", "xfm_ss2d_dt_proj_supported", "xfm_ss2d_dt_proj_mfma_rp", "xfm_ss2d_dt_proj_fwd_mfma", "xfm_ss2d_dt_proj_fwd",
+    "xfm_swap_scan", "xfm_ss2d_route_split", "xfm_ss2d_route_merge", "xfm_ss2d_dt_proj_supported", "xfm_ss2d_dt_proj_mfma_rp", "xfm_ss2d_dt_proj_fwd_mfma", "xfm_ss2d_dt_proj_bwd_mfma", "xfm_ss2d_dt_proj_fwd",
     "xfm_dwconv3x3_fwd", "xfm_dwconv3x3_bwd", "xfm_layernorm2d_fwd", "xfm_layernorm2d_bwd",
     "xfm_add_layernorm_rows_supported", "xfm_add_layernorm_rows_bwd_blocks", "xfm_add_layernorm_rows_fwd",
     "xfm_add_layernorm_rows_bwd", "xfm_colsum_blocks", "xfm_bias_gelu_fwd", "xfm_bias_gelu_bwd", "xfm_colsum",
@@ -108,6 +108,7 @@ def lib() -> C.CDLL:
         l.xfm_ss2d_dt_proj_supported.argtypes = [C.c_int] * 3
         l.xfm_ss2d_dt_proj_mfma_rp.argtypes = [C.c_int] * 3
         l.xfm_ss2d_dt_proj_fwd_mfma.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
+        l.xfm_ss2d_dt_proj_bwd_mfma.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]
         l.xfm_ss2d_dt_proj_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
         l.xfm_colsum_blocks.argtypes = [C.c_longlong, C.c_int, C.c_int]
         l.xfm_bias_gelu_fwd.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]

@@ -189,6 +189,102 @@ static int dt_proj_mfma(const void *xr, const bf16_t *w_padded, const float *bia
     return check_launch();
 }
 
+// ---- backward of dt_proj on MFMA (bf16) ----------------------------------------------------------------------------
+//   dxr[b,k,r,l] = sum_d W[k,d,r] * ddts[b,k,d,l]            (R x D) . (D x L): contraction over the channels
+//   dW[k,d,r]   += sum_{b,l} ddts[b,k,d,l] * xr[b,k,r,l]     (D x L) . (L x R): contraction over batch and positions
+// Both read the big ddts tensor exactly once.  dxr: a wavefront owns 32 positions and walks the channels 16 at a time
+// (W^T staged in LDS, zero-padded to 32 rows).  dW: a wavefront owns 32 channels of one (b, k), walks the positions 16
+// at a time and adds its 32 x R tile to the fp32 result with atomics (contiguous 4 R-byte runs per channel).
+struct DtProjBwdArgs {
+    const bf16_t *ddts;   // (B, 4, D, L)
+    const bf16_t *xr;     // (B, 4, R, L)
+    const bf16_t *w;      // (4, D, R)
+    bf16_t *dxr;          // (B, 4, R, L)
+    float *dw;            // (4, D, R) fp32, ZEROED by the caller
+    int D, R, L, ltiles;
+};
+
+__global__ __launch_bounds__(256) void dt_proj_bwd_dx_kernel(DtProjBwdArgs a) {
+    extern __shared__ uint16_t wt[];                               // W^T of this k: [32 rows r][D + 8]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bk = blockIdx.x / a.ltiles, k = bk & 3;
+    const int lt = (blockIdx.x % a.ltiles) * 4 + wave;
+    const int P = a.D + 8;
+    {
+        const uint16_t *wg = reinterpret_cast<const uint16_t *>(a.w) + (int64_t)k * a.D * a.R;
+        for (int e = threadIdx.x; e < 32 * a.D; e += 256) {
+            const int r = e / a.D, d = e - r * a.D;
+            wt[r * P + d] = r < a.R ? wg[d * a.R + r] : (uint16_t)0;
+        }
+    }
+    __syncthreads();
+    if (lt * 32 >= a.L) return;
+    const int c = lane & 31, h = lane >> 5;
+    const int pos = lt * 32 + c;
+    const bool valid = pos < a.L;
+    const uint16_t *g = reinterpret_cast<const uint16_t *>(a.ddts) + (int64_t)bk * a.D * a.L;
+    xfm_f32x16_t acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    // (channels 64 at a time: the 32 two-byte loads of four MFMA steps are in flight together; D % 32 == 0, so a
+    //  trailing half block is handled by the step guard)
+#pragma unroll 4
+    for (int d0 = 0; d0 < a.D; d0 += 16) {
+        uint16_t t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = valid ? g[(int64_t)(d0 + 8 * h + j) * a.L + pos] : (uint16_t)0;
+        const xfm_bf16x8_t bfr = *reinterpret_cast<const xfm_bf16x8_t *>(t);
+        const xfm_bf16x8_t afr = *reinterpret_cast<const xfm_bf16x8_t *>(wt + c * P + d0 + 8 * h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc, 0, 0, 0);
+    }
+    uint16_t *o = reinterpret_cast<uint16_t *>(a.dxr) + (int64_t)bk * a.R * a.L;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (valid && r < a.R) o[(int64_t)r * a.L + pos] = (uint16_t)(pack_bf16x2(acc[v], 0.f) & 0xffffu);
+    }
+}
+
+__global__ __launch_bounds__(256) void dt_proj_bwd_dw_kernel(DtProjBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dtiles = a.D / 32;
+    const int tile = blockIdx.x * 4 + wave;                        // (bk, d-tile)
+    if (tile >= a.ltiles) return;                                  // here ltiles = B * 4 * dtiles (total tiles)
+    const int bk = tile / dtiles, d0 = (tile - bk * dtiles) * 32, k = bk & 3;
+    const int c = lane & 31, h = lane >> 5;
+    const uint16_t *g = reinterpret_cast<const uint16_t *>(a.ddts) + ((int64_t)bk * a.D + d0 + c) * a.L;   // row of channel d0+c
+    const uint16_t *x = reinterpret_cast<const uint16_t *>(a.xr) + ((int64_t)bk * a.R + c) * a.L;          // row of rank c
+    const bool rv = c < a.R;
+    xfm_f32x16_t acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll 4
+    for (int l0 = 0; l0 < a.L; l0 += 16) {
+        uint16_t ta[8], tb[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 4) {                           // 8-byte loads: rows are 8-byte aligned (L % 4 == 0)
+            const int l = l0 + 8 * h + j;
+            uint2 va = make_uint2(0u, 0u), vb = make_uint2(0u, 0u);
+            if (l < a.L) {
+                va = *reinterpret_cast<const uint2 *>(g + l);
+                if (rv) vb = *reinterpret_cast<const uint2 *>(x + l);
+            }
+            *reinterpret_cast<uint2 *>(ta + j) = va;
+            *reinterpret_cast<uint2 *>(tb + j) = vb;
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const xfm_bf16x8_t *>(ta),
+                                                      *reinterpret_cast<const xfm_bf16x8_t *>(tb), acc, 0, 0, 0);
+    }
+    if (rv) {
+        float *dw = a.dw + ((int64_t)k * a.D + d0) * a.R + c;      // column r = c of this tile
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = (v & 3) + 8 * (v >> 2) + 4 * h;
+            atomicAdd(dw + (int64_t)row * a.R, acc[v]);
+        }
+    }
+}
+
 }  // namespace xfm
 
 extern "C" {
@@ -206,6 +302,28 @@ int xfm_ss2d_dt_proj_fwd_mfma(const void *xr, const void *weight_bf16, const flo
     const int RP = xfm_ss2d_dt_proj_mfma_rp(D, R, L);
     if (!RP) return XFM_ELIMIT;
     return dt_proj_mfma(xr, static_cast<const bf16_t *>(weight_bf16), softplus_bias, dts, B, D, R, RP, L, (hipStream_t)stream);
+}
+
+/* bf16 backward of dt_proj on MFMA: dxr (B,4,R,L) bf16 and dweight (4,D,R) fp32 (ZEROED by the caller, accumulated with
+ * atomics); D % 32 == 0, D <= 1024, R <= 32, L % 4 == 0. */
+int xfm_ss2d_dt_proj_bwd_mfma(const void *ddts, const void *xr, const void *weight_bf16, void *dxr, float *dweight, int B,
+                              int D, int R, int L, void *stream) {
+    using namespace xfm;
+    if (!ddts || !xr || !weight_bf16 || !dxr || !dweight || B <= 0) return XFM_EINVAL;
+    if (!xfm_ss2d_dt_proj_mfma_rp(D, R, L) || L % 4 != 0 || D > 1024) return XFM_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    DtProjBwdArgs a{};
+    a.ddts = static_cast<const bf16_t *>(ddts); a.xr = static_cast<const bf16_t *>(xr);
+    a.w = static_cast<const bf16_t *>(weight_bf16); a.dxr = static_cast<bf16_t *>(dxr); a.dw = dweight;
+    a.D = D; a.R = R; a.L = L;
+    a.ltiles = ((L + 31) / 32 + 3) / 4;
+    const size_t lds = (size_t)32 * (D + 8) * sizeof(uint16_t);
+    hipLaunchKernelGGL(dt_proj_bwd_dx_kernel, dim3((unsigned)((int64_t)B * 4 * a.ltiles)), dim3(256), lds, s, a);
+    int rc = check_launch();
+    if (rc != XFM_OK) return rc;
+    a.ltiles = B * 4 * (D / 32);                                  // dw kernel: total (b, k, channel-tile) count
+    hipLaunchKernelGGL(dt_proj_bwd_dw_kernel, dim3((unsigned)((a.ltiles + 3) / 4)), dim3(256), 0, s, a);
+    return check_launch();
 }
 
 int xfm_ss2d_dt_proj_supported(int D, int R, int L) { return (L % 4 == 0 && R >= 1 && R <= 64 && D >= 1) ? 1 : 0; }

@@ -189,10 +189,13 @@ class SS2DProjCoreHip(torch.autograd.Function):
         dx = torch.empty_like(x)
         ddts = torch.empty_like(dts)
         nbc, na, nd = Bt * 4 * N * L, A.numel(), D.numel()
-        acc = torch.zeros(2 * nbc + na + 2 * nd, dtype=torch.float32, device=dev)     # ONE fill for all accumulators
+        lib = _lib.lib()
+        mfma_bwd = (x.dtype == torch.bfloat16 and L % 4 == 0 and Dm <= 1024 and lib.xfm_ss2d_dt_proj_mfma_rp(Dm, R, L) > 0)
+        nw = w.numel() if mfma_bwd else 0
+        acc = torch.zeros(2 * nbc + na + 2 * nd + nw, dtype=torch.float32, device=dev)     # ONE fill for all accumulators
         dBs, dCs = acc[:nbc].view(Bs.shape), acc[nbc:2 * nbc].view(Cs.shape)
         dA = acc[2 * nbc:2 * nbc + na].view(A.shape)
-        dD, dbias = acc[2 * nbc + na:2 * nbc + na + nd], acc[2 * nbc + na + nd:]
+        dD, dbias = acc[2 * nbc + na:2 * nbc + na + nd], acc[2 * nbc + na + nd:2 * nbc + na + 2 * nd]
         p = _lib.SS2DParams()
         _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, ctx.mode)
         p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
@@ -202,8 +205,17 @@ class SS2DProjCoreHip(torch.autograd.Function):
         nbytes = Bt * Dm * L * (10 * isz + 4) + 2 * Bt * 4 * N * L * (isz + 4)
         with torch.cuda.device(dev), _lib.timed("ss2d_bwd", nbytes):
             _lib.check(_lib.lib().xfm_ss2d_bwd(ctypes.byref(p), _lib.stream_ptr()), "ss2d_bwd")
-        dxr = torch.matmul(w.transpose(1, 2), ddts)                                   # (B, 4, R, L)
-        dw = _bmm_f32(ddts.view(Bt * K, Dm, L), xr.view(Bt * K, R, L).transpose(1, 2)).view(Bt, K, Dm, R).sum(0)
+        if mfma_bwd:
+            # dt_proj backward on MFMA: ddts is read once for the data gradient and once for the weight gradient
+            dxr = torch.empty_like(xr)
+            dw = acc[2 * nbc + na + 2 * nd:].view(w.shape)
+            with torch.cuda.device(dev), _lib.timed("dt_proj_bwd", 2 * ddts.numel() * isz):
+                _lib.check(lib.xfm_ss2d_dt_proj_bwd_mfma(ddts.data_ptr(), xr.data_ptr(), w.contiguous().data_ptr(),
+                                                         dxr.data_ptr(), dw.data_ptr(), Bt, Dm, R, L, _lib.stream_ptr()),
+                           "dt_proj_bwd_mfma")
+        else:
+            dxr = torch.matmul(w.transpose(1, 2), ddts)                               # (B, 4, R, L)
+            dw = _bmm_f32(ddts.view(Bt * K, Dm, L), xr.view(Bt * K, R, L).transpose(1, 2)).view(Bt, K, Dm, R).sum(0)
         dxd = torch.empty((Bt, K * (R + 2 * N), L), dtype=x.dtype, device=dev)
         with torch.cuda.device(dev), _lib.timed("route_merge", 2 * dxd.numel() * isz):
             _lib.check(_lib.lib().xfm_ss2d_route_merge(dxr.data_ptr(), dBs.data_ptr(), dCs.data_ptr(), dxd.data_ptr(), Bt,
