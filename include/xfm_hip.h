@@ -165,9 +165,10 @@ int xfm_layernorm2d_bwd(const void *x, const float *weight, const void *dy, cons
  * bwd: dh = gradient of h, dres = gradient arriving on x_new from its other consumers (fp32, or NULL);
  * dx = gradient of x (== gradient of x_new), dy = scale[b]*dx in `dtype` (NULL when the forward had no y);
  * dweight / dbias (C) fp32 are OVERWRITTEN (dbias may be NULL); workspace: 3*C*xfm_add_layernorm_rows_bwd_blocks()
- * floats.  pre_bias (C, fp32, only with y == NULL): added to x before the norm -- the bias of the convolution that
- * produced x (patch-embed / downsample convs, models/fusion_vmamba.py:1504-1538), whose gradient dpre_bias (the column
- * sums of dx) then comes out of the same backward pass.  x_new: the forward's x_new (or its x when y was NULL). */
+ * floats.  pre_bias (C, fp32): with y == NULL it is added to x before the norm -- the bias of the convolution that
+ * produced x (patch-embed / downsample convs, models/fusion_vmamba.py:1504-1538); with y it is added to y inside the
+ * scaled sum, x_new = x + scale[b]*(y + pre_bias) -- the bias of the linear layer that produced y (Mlp.fc2).  Its
+ * gradient dpre_bias (the column sums of dx, resp. of dy) comes out of the same backward pass.  x_new: the forward's x_new (or its x when y was NULL). */
 int xfm_add_layernorm_rows_supported(int C);
 int xfm_add_layernorm_rows_bwd_blocks(int rows, int C);
 int xfm_add_layernorm_rows_fwd(const void *x, const void *y, const float *scale, const float *pre_bias,

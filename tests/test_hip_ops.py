@@ -586,3 +586,33 @@ def test_dt_proj_backward_mfma_matches_torch_fp32(B, D, R, H):
                                              R, L, _lib.stream_ptr()), "dt_proj_bwd_mfma")
     assert_close(dxr.float().cpu(), dxr_ref, 1e-2, 1e-2 * float(dxr_ref.abs().max()), "dxr")
     assert_close(dw.cpu(), dw_ref, 1e-3, 1e-3 * float(dw_ref.abs().max()), "dw")
+
+
+@pytest.mark.parametrize("C,dt", [(96, torch.float32), (384, torch.bfloat16), (768, torch.bfloat16)])
+def test_add_layernorm_rows_with_deferred_linear_bias(C, dt):
+    """x + drop_path(y + b2) followed by LayerNorm, with the bias of the linear layer that produced y (Mlp.fc2,
+    fusion_vmamba.py:135-153) added inside the kernel: outputs and all gradients incl. d b2 vs plain PyTorch fp32."""
+    from xfmamba_amd.rowln import add_layernorm_rows_fn
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C + 3)
+    B, H, W = 4, 6, 5
+    x = torch.randn(B, H, W, C, generator=g)
+    y = torch.randn(B, H, W, C, generator=g).to(dt)
+    yb = 0.3 * torch.randn(C, generator=g)
+    sc = torch.tensor([0.0, 1.25, 1.25, 1.25])
+    w = 1 + 0.2 * torch.randn(C, generator=g)
+    b = 0.1 * torch.randn(C, generator=g)
+    gh = torch.randn(B, H, W, C, generator=g).to(dt)
+    gres = torch.randn(B, H, W, C, generator=g)
+    ref = [t.clone().requires_grad_() for t in (x, y.float(), yb, w, b)]
+    sr = ref[0] + (ref[1] + ref[2]) * sc.view(B, 1, 1, 1)
+    hr = F.layer_norm(sr, (C,), ref[3], ref[4], 1e-5)
+    ((hr * gh.float()).sum() + (sr * gres).sum()).backward()
+    dev = [t.to(DEV).requires_grad_() for t in (x, y, yb, w, b)]
+    xn, h = add_layernorm_rows_fn(dev[0], dev[1], sc.to(DEV), dev[3], dev[4], 1e-5, dt, dev[2])
+    ((h.float() * gh.to(DEV).float()).sum() + (xn * gres.to(DEV)).sum()).backward()
+    tol = 1e-3 if dt == torch.float32 else 1e-2
+    assert_close(xn.detach().cpu(), sr.detach(), 1e-5, 1e-5, "x_new")
+    assert_close(h.float().detach().cpu(), hr.detach(), tol, tol * float(hr.abs().max()), "h")
+    for name, a, r in zip(("dx", "dy", "dy_bias", "dw", "db"), dev, ref):
+        assert_close(a.grad.float().cpu(), r.grad, tol, 2 * tol * float(r.grad.abs().max()), name)

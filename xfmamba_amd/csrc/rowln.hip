@@ -41,7 +41,8 @@ struct RowLnArgs {
     const void *y;          // (rows, C) branch output or null
     const float *scale;     // (B) per-sample DropPath factor or null
     const float *w, *b;     // (C); b may be null
-    const float *pre_bias;  // (C) or null: added to x before the norm (a convolution's bias), y must be null
+    const float *pre_bias;  // (C) or null: y == null: added to x before the norm (a convolution's bias);
+                            // y != null: added to y inside the scaled sum (the bias of the linear layer that made y)
     int nparts;             // 2 (dw, db) or 3 (+ d pre_bias) partial rows per workgroup
     float *x_new;           // (rows, C) residual stream out (null when y is null: x passes through)
     void *h;                // (rows, C) normalised output
@@ -84,17 +85,17 @@ template <typename Tx, typename Ty, int G, int NV> __global__ __launch_bounds__(
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             v[k] = Vec4IO<Tx>::ld(x + r * C + (k * G + sub) * 4);
-            v[k].x += pb[k].x; v[k].y += pb[k].y; v[k].z += pb[k].z; v[k].w += pb[k].w;
+            if (!y) { v[k].x += pb[k].x; v[k].y += pb[k].y; v[k].z += pb[k].z; v[k].w += pb[k].w; }
         }
         if (y) {
             const float s = a.scale ? a.scale[r / a.rows_per_sample] : 1.0f;
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const float4 t = Vec4IO<Ty>::ld(y + r * C + (k * G + sub) * 4);
-                v[k].x = fmaf(s, t.x, v[k].x);
-                v[k].y = fmaf(s, t.y, v[k].y);
-                v[k].z = fmaf(s, t.z, v[k].z);
-                v[k].w = fmaf(s, t.w, v[k].w);
+                v[k].x = fmaf(s, t.x + pb[k].x, v[k].x);
+                v[k].y = fmaf(s, t.y + pb[k].y, v[k].y);
+                v[k].z = fmaf(s, t.z + pb[k].z, v[k].z);
+                v[k].w = fmaf(s, t.w + pb[k].w, v[k].w);
                 if (live) Vec4IO<float>::st(a.x_new + r * C + (k * G + sub) * 4, v[k]);
             }
         }
@@ -139,7 +140,8 @@ template <typename Tx, typename Ty, int G, int NV> __global__ __launch_bounds__(
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         w[k] = Vec4IO<float>::ld(a.w + (k * G + sub) * 4);
-        pb[k] = a.pre_bias ? Vec4IO<float>::ld(a.pre_bias + (k * G + sub) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // (with a residual add the saved x_new already contains the bias of y: nothing to re-add)
+        pb[k] = (a.pre_bias && !a.dy) ? Vec4IO<float>::ld(a.pre_bias + (k * G + sub) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         aw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         ab[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         ap[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -187,7 +189,8 @@ template <typename Tx, typename Ty, int G, int NV> __global__ __launch_bounds__(
                 o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
             }
             if (live) {
-                ap[k].x += o.x; ap[k].y += o.y; ap[k].z += o.z; ap[k].w += o.w;
+                ap[k].x = fmaf(o.x, s, ap[k].x); ap[k].y = fmaf(o.y, s, ap[k].y);       // d pre_bias: sum of dx, or of
+                ap[k].z = fmaf(o.z, s, ap[k].z); ap[k].w = fmaf(o.w, s, ap[k].w);       // dy = s * dx with a residual add
                 Vec4IO<Tx>::st(dxo + off, o);
                 if (dy) Vec4IO<Ty>::st(dy + off, make_float4(o.x * s, o.y * s, o.z * s, o.w * s));
             }
@@ -323,7 +326,7 @@ int xfm_add_layernorm_rows_fwd(const void *x, const void *y, const float *scale,
                                float eps, int x_dtype, int dtype, void *stream) {
     using namespace xfm;
     if (!x || !weight || !h || !mean || !rstd || B <= 0 || rows_per_sample <= 0 || C <= 0) return XFM_EINVAL;
-    if (y && (!x_new || x_dtype != XFM_F32 || pre_bias)) return XFM_EINVAL;
+    if (y && (!x_new || x_dtype != XFM_F32)) return XFM_EINVAL;
     int G, NV;
     if (!pick_shape(C, G, NV)) return XFM_ELIMIT;
     RowLnArgs a{};

@@ -139,11 +139,19 @@ class Mlp(nn.Module):
 
     def forward_tokens(self, x):
         """Same Mlp on a token-major (B, H, W, C) tensor: two plain GEMMs (Linear2d weights are (out, in))."""
+        return self.forward_tokens_deferred(x, defer=False)[0]
+
+    def forward_tokens_deferred(self, x, defer=True):
+        """(y, deferred_bias): with ``defer`` (and no dropout after fc2) fc2's bias is handed back instead of added,
+        for the residual-add + LayerNorm kernel that consumes ``y``."""
         drop = self.drop if self.drop.p > 0.0 else None
+        defer = defer and drop is None and self.fc2.bias is not None
         if isinstance(self.act, nn.GELU) and self.act.approximate == "none":
-            return mlp_tokens_fn(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, drop)
-        x = self.drop(self.act(linear_tokens_fn(x, self.fc1.weight, self.fc1.bias)))
-        return self.drop(linear_tokens_fn(x, self.fc2.weight, self.fc2.bias))
+            y = mlp_tokens_fn(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, drop, defer_bias=defer)
+        else:
+            x = self.drop(self.act(linear_tokens_fn(x, self.fc1.weight, self.fc1.bias)))
+            y = self.drop(linear_tokens_fn(x, self.fc2.weight, None if defer else self.fc2.bias))
+        return y, (self.fc2.bias if defer else None)
 
 
 class mamba_init:
@@ -361,14 +369,16 @@ def _norm_tokens(norm: nn.LayerNorm, x, pend):
     out_dtype = _tokens_dtype(norm.weight)
     if pend is None:
         return x, layernorm_rows_fn(x, norm.weight, norm.bias, norm.eps, out_dtype)
-    return add_layernorm_rows_fn(x, pend[0], pend[1], norm.weight, norm.bias, norm.eps, out_dtype)
+    return add_layernorm_rows_fn(x, pend[0], pend[1], norm.weight, norm.bias, norm.eps, out_dtype, pend[2])
 
 
 def _settle(x, pend):
     """Apply a pending ``x += scale * y`` with nothing to fuse it into (end of a stage)."""
     if pend is None:
         return x
-    y, s = pend
+    y, s, yb = pend
+    if yb is not None:
+        y = y + yb.to(y.dtype)
     if s is not None:
         y = y * s.view(-1, *([1] * (y.ndim - 1))).to(y.dtype)
     return x + y
@@ -415,16 +425,19 @@ class VSSBlock(nn.Module):
                                            for m in norms)
                 and (not self.ssm_branch or self.op.channel_first))
 
-    def forward_tokens(self, x: torch.Tensor, pend=None):
-        """x: (B, H, W, C) fp32 residual stream; ``pend`` = (y, scale) is a branch output not yet added to it.
+    def forward_tokens(self, x: torch.Tensor, pend=None, defer_bias=True):
+        """x: (B, H, W, C) fp32 residual stream; ``pend`` = (y, scale, y_bias) is a branch output not yet added to it.
         Every ``x + drop_path(branch)`` is deferred into the LayerNorm kernel that reads the sum next."""
         B = x.shape[0]
         if self.ssm_branch:
             x, h = _norm_tokens(self.norm, x, pend)
-            pend = (self.op.forward_tokens(h), self.drop_path.sample_scale(B, x.device))
+            pend = (self.op.forward_tokens(h), self.drop_path.sample_scale(B, x.device), None)
         if self.mlp_branch:
             x, h = _norm_tokens(self.norm2, x, pend)
-            pend = (self.mlp.forward_tokens(h), self.drop_path.sample_scale(B, x.device))
+            # (defer fc2's bias into the next add + LayerNorm kernel -- unless nothing follows in this stage: the
+            #  plain settle would leave its gradient to a framework reduction)
+            y, yb = self.mlp.forward_tokens_deferred(h, defer=defer_bias)
+            pend = (y, self.drop_path.sample_scale(B, x.device), yb)
         return x, pend
 
 
@@ -480,8 +493,8 @@ def _blocks_tokens_ok(blocks) -> bool:
 def _blocks_tokens(blocks, t):
     """VSSBlocks of a stage on the token-major stream; the last residual add is settled here."""
     pend = None
-    for b in blocks:
-        t, pend = b.forward_tokens(t, pend)
+    for i, b in enumerate(blocks):
+        t, pend = b.forward_tokens(t, pend, defer_bias=i + 1 < len(blocks))
     return _settle(t, pend)
 
 

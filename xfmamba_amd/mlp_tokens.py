@@ -105,11 +105,13 @@ def linear_tokens_fn(x, weight, bias=None):
     return LinearTokens.apply(x, weight, bias)
 
 
-def mlp_tokens_fn(x, w1, b1, w2, b2, drop=None):
-    """fc2(drop(gelu(fc1(x)))) on token-major ``x`` (..., C); weights are the (out, in) Linear2d / nn.Linear weights."""
+def mlp_tokens_fn(x, w1, b1, w2, b2, drop=None, defer_bias=False):
+    """fc2(drop(gelu(fc1(x)))) on token-major ``x`` (..., C); weights are the (out, in) Linear2d / nn.Linear weights.
+    ``defer_bias``: leave fc2's bias out -- the caller adds it inside the residual-add + LayerNorm kernel, whose backward
+    pass then also yields its gradient (no column-sum pass over the fc2 output gradient)."""
     z = linear_tokens_fn(x, w1, None)
     g = bias_gelu_fn(z, b1)
     if drop is not None:
         g = drop(g)
-    y = linear_tokens_fn(g, w2, b2)
+    y = linear_tokens_fn(g, w2, None if defer_bias else b2)
     return y if drop is None else drop(y)

@@ -89,7 +89,7 @@ class LayerNormRowsHip(torch.autograd.Function):
 
 class AddLayerNormRowsHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, scale, weight, bias, eps, out_dtype):
+    def forward(ctx, x, y, scale, weight, bias, eps, out_dtype, y_bias):
         x, w, b, out_dtype = _prep(x, weight, bias, out_dtype, need_f32=True)
         _lib.require_cuda(y)
         ctx.ydtype = y.dtype
@@ -97,26 +97,29 @@ class AddLayerNormRowsHip(torch.autograd.Function):
         if y.shape != x.shape:
             raise RuntimeError(f"xfmamba_amd: residual {tuple(x.shape)} vs branch {tuple(y.shape)}")
         s = None if scale is None else scale.float().contiguous()
-        x_new, h, mean, rstd = _fwd(x, y, s, w, b, eps, out_dtype)
-        ctx.save_for_backward(x_new, w, mean, rstd, s)
-        ctx.meta = (bias is not None, weight.dtype, out_dtype)
+        yb = None if y_bias is None else y_bias.float().contiguous()
+        x_new, h, mean, rstd = _fwd(x, y, s, w, b, eps, out_dtype, yb)
+        ctx.save_for_backward(x_new, w, mean, rstd, s, yb)
+        ctx.meta = (bias is not None, weight.dtype, out_dtype, None if y_bias is None else y_bias.dtype)
         return x_new, h
 
     @staticmethod
     def backward(ctx, dres, dh):
-        x_new, w, mean, rstd, s = ctx.saved_tensors
-        has_bias, wdtype, dtype = ctx.meta
+        x_new, w, mean, rstd, s, yb = ctx.saved_tensors
+        has_bias, wdtype, dtype, ybdtype = ctx.meta
         if dh is None:                       # the norm output was not used: only the sum carries a gradient
             dx = dres
             dy = dres if s is None else dres * s.view(-1, *([1] * (dres.ndim - 1)))
-            return dx, dy.to(ctx.ydtype), None, None, None, None, None
+            dyb = None if yb is None else dy.reshape(-1, dy.shape[-1]).sum(0).to(ybdtype)
+            return dx, dy.to(ctx.ydtype), None, None, None, None, None, dyb
         dh = dh.contiguous() if dh.dtype == dtype else dh.to(dtype).contiguous()
         if dres is not None:
             dres = dres.float().contiguous()
-        dx, dy, dw, db, _ = _bwd(x_new, w, dh, dres, mean, rstd, s, True, has_bias, dtype)
+        dx, dy, dw, db, dyb = _bwd(x_new, w, dh, dres, mean, rstd, s, True, has_bias, dtype, yb)
         if dy.dtype != ctx.ydtype:
             dy = dy.to(ctx.ydtype)
-        return dx, dy, None, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None
+        return (dx, dy, None, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None,
+                (None if dyb is None else dyb.to(ybdtype)))
 
 
 def layernorm_rows_fn(x, weight, bias, eps=1e-5, out_dtype=None, pre_bias=None):
@@ -125,6 +128,7 @@ def layernorm_rows_fn(x, weight, bias, eps=1e-5, out_dtype=None, pre_bias=None):
     return LayerNormRowsHip.apply(x, weight, bias, eps, out_dtype, pre_bias)
 
 
-def add_layernorm_rows_fn(x, y, scale, weight, bias, eps=1e-5, out_dtype=None):
-    """``x_new = x + scale[b] * y`` (scale (B,) or None) and ``LayerNorm(x_new)``: returns ``(x_new, h)``."""
-    return AddLayerNormRowsHip.apply(x, y, scale, weight, bias, eps, out_dtype)
+def add_layernorm_rows_fn(x, y, scale, weight, bias, eps=1e-5, out_dtype=None, y_bias=None):
+    """``x_new = x + scale[b] * (y + y_bias)`` (scale (B,) or None; ``y_bias`` (C,) = the deferred bias of the linear
+    layer that produced ``y``, or None) and ``LayerNorm(x_new)``: returns ``(x_new, h)``."""
+    return AddLayerNormRowsHip.apply(x, y, scale, weight, bias, eps, out_dtype, y_bias)
