@@ -35,7 +35,8 @@ static int plan_ss2d(int batch, int D, int H, int W, int N, int in_dtype, Plan2 
         const bool has_reg = nseg <= 2;
         const int reg_nseg = (has_reg && !getenv("XFM_SS2D_LDSACC")) ? nseg : 0;
         const size_t bwd_blk = 8 * PL * sz + (reg_nseg ? 0 : (size_t)8 * L * sizeof(float));
-        if (fwd_blk <= kLdsPerCU && bwd_blk <= kLdsPerCU) {
+        // (PL <= 4096: the staging registers of the lean kernels cover a tile of 256 threads x 16 elements)
+        if (fwd_blk <= kLdsPerCU && bwd_blk <= kLdsPerCU && PL <= 4096) {
             out->lg = 6;
             out->items = c;
             out->n_chunks = nseg;

@@ -487,8 +487,10 @@ __global__ void __launch_bounds__(256) ss2d_fwd_lean_kernel(const LeanArgs a) {
         const int64_t po = ((int64_t)b * D + d0) * L;
         __syncthreads();
         if (!(a.dbg & 2)) {
-            if (kPipe) lean_planes_commit<Tin, Tin, C, NVX>(px, xN, xT, PL, L, H, W, a.magicW, a.magicL);
-            else lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
+            // (not pipelined: still ONE round trip for the whole tile -- the per-plane loop of lean_planes_load is a
+            //  chain of ppt dependent HBM latencies)
+            if (!kPipe) lean_planes_issue<Tin, C, NVX>(px, (const Tin *)a.x + po, PL);
+            lean_planes_commit<Tin, Tin, C, NVX>(px, xN, xT, PL, L, H, W, a.magicW, a.magicL);
         }
         __syncthreads();
         if (kPipe && !(a.dbg & 2) && it + 1 < a.pli) lean_planes_issue<Tin, C, NVX>(px, (const Tin *)a.x + po + PL, PL);
@@ -516,7 +518,8 @@ __global__ void __launch_bounds__(256) ss2d_fwd_lean_kernel(const LeanArgs a) {
 }
 
 template <typename Tin, typename Tout, int C, int NSEG>
-__global__ void __launch_bounds__(256) ss2d_bwd_lean_kernel(const LeanArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 4 ? 3 : 1)))   // 14x14: keep 3 waves/SIMD
+ss2d_bwd_lean_kernel(const LeanArgs a) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = a.L, H = a.H, W = a.W, D = a.D_, PL = a.ppt * L;
@@ -572,13 +575,12 @@ __global__ void __launch_bounds__(256) ss2d_bwd_lean_kernel(const LeanArgs a) {
         const int64_t po = ((int64_t)b * D + d0) * L;
         __syncthreads();
         if (!(a.dbg & 2)) {
-            if (kPipe) {
-                lean_planes_commit<Tin, Tin, C, NVX>(px, xN, xT, PL, L, H, W, a.magicW, a.magicL);
-                lean_planes_commit<Tout, Tin, 4, 4>(pg, gN, gT, PL, L, H, W, a.magicW, a.magicL);
-            } else {
-                lean_planes_load<Tin, Tin, C>(xN, xT, (const Tin *)a.x + po, a.ppt, L, H, W, a.magicW);
-                lean_planes_load<Tout, Tin, 4>(gN, gT, (const Tout *)a.dy + po, a.ppt, L, H, W, a.magicW);
+            if (!kPipe) {                               // one round trip for the tile (see the forward kernel)
+                lean_planes_issue<Tin, C, NVX>(px, (const Tin *)a.x + po, PL);
+                lean_planes_issue<Tout, 4, 4>(pg, (const Tout *)a.dy + po, PL);
             }
+            lean_planes_commit<Tin, Tin, C, NVX>(px, xN, xT, PL, L, H, W, a.magicW, a.magicL);
+            lean_planes_commit<Tout, Tin, 4, 4>(pg, gN, gT, PL, L, H, W, a.magicW, a.magicL);
         }
         __syncthreads();
         if (kPipe && !(a.dbg & 2) && it + 1 < a.pli) {
