@@ -231,6 +231,14 @@ def test_dwconv3x3_silu_matches_torch_fp32(shape, dtype, has_bias):
         assert_close(bd.grad.cpu(), br.grad, tol, tol * float(br.grad.abs().max()), "db")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(40, 96, 56, 56), (40, 192, 28, 28), (48, 384, 14, 14), (24, 768, 7, 7)])
+def test_dwconv3x3_silu_plane_pipeline(shape):
+    """Batches deep enough that one wave / workgroup walks several planes of its channel (the software-pipelined loop
+    of dwconv7_kernel, both the shared-plane and the wave-private variant), against plain PyTorch fp32."""
+    test_dwconv3x3_silu_matches_torch_fp32(shape, torch.bfloat16, True)
+
+
 SS2D_SHAPES = [
     # (B, D, H, W, N, dtype)
     (2, 96, 56, 56, 1, torch.float32),      # backbone stage 0 (multi-chunk rows)

@@ -5,14 +5,14 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/sq_r01
 rm -rf $O && mkdir -p $O
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/p -o sq -- python3 tools/kbench.py --only ss2d > $O/log.txt 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/p -o sq -- python3 tools/kbench.py --only ${KB:-ss2d} > $O/log.txt 2>&1
 tail -3 $O/log.txt
 python3 - <<'PY'
 import csv, glob, collections, re
 f = glob.glob('gpurun_out/sq_r01/p/**/*counter_collection.csv', recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.Counter()); n = collections.Counter()
 for r in csv.DictReader(open(f)):
-    m = re.search(r'xfm::(ss2d_\w+_lean_kernel<[^>]*>)', r['Kernel_Name'])
+    m = re.search(r'xfm::(\w+_kernel<[^>]*>)', r['Kernel_Name'])
     if not m: continue
     k = m.group(1) + ' grid=' + r.get('Grid_Size', r.get('Grid_Size_X', ''))
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])

@@ -238,23 +238,64 @@ template <int VEC> __device__ __forceinline__ void st_row(float *dst, const floa
     }
 }
 
-template <typename T, int VEC, bool BWD>
+// raw (unconverted) VEC-element global vectors held in registers between their load and their use
+template <typename T, int VEC> struct DwRaw { static constexpr int NW = ((int)sizeof(T) * VEC + 3) / 4; };
+template <typename T, int VEC> __device__ __forceinline__ void ld_raw(const T *p, uint32_t *w) {
+    constexpr int NB = (int)sizeof(T) * VEC;
+    if constexpr (NB == 32) {
+        const uint4 t0 = reinterpret_cast<const uint4 *>(p)[0], t1 = reinterpret_cast<const uint4 *>(p)[1];
+        w[0] = t0.x; w[1] = t0.y; w[2] = t0.z; w[3] = t0.w; w[4] = t1.x; w[5] = t1.y; w[6] = t1.z; w[7] = t1.w;
+    } else if constexpr (NB == 16) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(p);
+        w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+    } else if constexpr (NB == 8) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(p);
+        w[0] = t.x; w[1] = t.y;
+    } else if constexpr (NB == 4) {
+        w[0] = *reinterpret_cast<const uint32_t *>(p);
+    } else {
+        w[0] = *reinterpret_cast<const uint16_t *>(p);
+    }
+}
+template <typename T, int VEC> __device__ __forceinline__ void unpack_raw(const uint32_t *w, float *v) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        if constexpr (sizeof(T) == 4) v[i] = __uint_as_float(w[i]);
+        else v[i] = cvt16<T>((uint16_t)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu));
+    }
+}
+
+// vectors a thread moves per plane, at most: wave-private planes -> the 49*VEC vectors of a plane over 64 lanes;
+// planes shared by TP = 256 / PP threads -> dw7_plan checks the bound
+template <int VEC, bool WP> struct Dw7Iters { static constexpr int value = WP ? (49 * VEC + 63) / 64 : (VEC == 8 ? 4 : 7); };
+
+template <typename T, int VEC, bool BWD, bool WP>
 __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
     constexpr int LPR = 7, W = LPR * VEC, PITCH = dw7_pitch(W);
+    constexpr int NIT = Dw7Iters<VEC, WP>::value, NW = DwRaw<T, VEC>::NW;
     extern __shared__ float smem[];
     const int H = a.H, PH = H + 2, L = H * W, psz = PH * PITCH;
-    const int j = threadIdx.x / a.TP, tl = threadIdx.x - j * a.TP;
-    const int ngrp = a.D / a.PP;
+    // WP (maps up to 28x28): ONE WAVE OWNS ONE CHANNEL -- its LDS planes are private, the three hand-offs per plane
+    // (x staged -> dz written -> dx computed) are wave-level syncs and the four waves of a workgroup never wait for
+    // each other.  Otherwise (56x56: a wave-private plane pair would leave one wave per SIMD, measured 1.5x slower)
+    // TP = 256 / PP threads share a plane and the hand-offs are workgroup barriers.
+    const int TP = WP ? 64 : a.TP, PP = WP ? 4 : a.PP;
+    const int j = threadIdx.x / TP, tl = threadIdx.x - j * TP;
+    const int ngrp = a.D / PP;
     const int grp = blockIdx.x % ngrp, sl = blockIdx.x / ngrp;
-    const int d = grp * a.PP + j;
+    const int d = grp * PP + j;
+    auto sync = [&]() {
+        if constexpr (WP) wave_sync();
+        else __syncthreads();
+    };
     const int b0 = (int)((int64_t)a.B * sl / a.bsplit), b1 = (int)((int64_t)a.B * (sl + 1) / a.bsplit);
     float *xs = smem + j * psz;                                    // padded x plane of this thread's channel
-    float *zs = smem + (a.PP + j) * psz;                           // padded dz plane (backward only)
+    float *zs = smem + (PP + j) * psz;                           // padded dz plane (backward only)
     // zero halo: only the cells the 3x3 windows read outside the map (top / bottom rows, one column left / right)
     for (int bufi = 0; bufi < (BWD ? 2 : 1); ++bufi) {
-        float *pl = smem + (bufi * a.PP + j) * psz;
-        for (int e = tl; e < 2 * PITCH; e += a.TP) pl[(e < PITCH ? 0 : (PH - 1) * PITCH) + (e < PITCH ? e : e - PITCH)] = 0.f;
-        for (int e = tl; e < 2 * PH; e += a.TP) pl[(e >> 1) * PITCH + ((e & 1) ? kDwLeft + W : kDwLeft - 1)] = 0.f;
+        float *pl = smem + (bufi * PP + j) * psz;
+        for (int e = tl; e < 2 * PITCH; e += TP) pl[(e < PITCH ? 0 : (PH - 1) * PITCH) + (e < PITCH ? e : e - PITCH)] = 0.f;
+        for (int e = tl; e < 2 * PH; e += TP) pl[(e >> 1) * PITCH + ((e & 1) ? kDwLeft + W : kDwLeft - 1)] = 0.f;
     }
     float k[9];
 #pragma unroll
@@ -266,18 +307,44 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
     const T *x = static_cast<const T *>(a.x), *dy = static_cast<const T *>(a.dy);
     T *out = static_cast<T *>(a.out);
     const int nvec = H * LPR;
+    // Software pipeline over the planes of the batch slice: the x vectors of plane b+1 are requested as soon as plane
+    // b's have been written to LDS, the dy vectors as soon as plane b's have been consumed -- the loads fly under the
+    // stencil passes instead of each costing a round trip to HBM between two barriers.
+    uint32_t xr[NIT][NW], gr[BWD ? NIT : 1][NW];
+    int vh[NIT], vc[NIT];                                          // this thread's vectors: row, first column
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int v = tl + it * TP;
+        vh[it] = v / LPR;
+        vc[it] = (v - vh[it] * LPR) * VEC;
+        if (v >= nvec) vh[it] = -1;
+    }
+    auto issue = [&](const T *src, uint32_t (&r)[NIT][NW], int b) {
+        const int64_t po = ((int64_t)b * a.D + d) * L;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (vh[it] >= 0) ld_raw<T, VEC>(src + po + vh[it] * W + vc[it], r[it]);
+    };
+    if (b0 < b1) {
+        issue(x, xr, b0);
+        if constexpr (BWD) issue(dy, gr, b0);
+    }
     for (int b = b0; b < b1; ++b) {
         const int64_t po = ((int64_t)b * a.D + d) * L;
-        __syncthreads();                                           // previous plane fully consumed (and LDS zeroed)
-        for (int v = tl; v < nvec; v += a.TP) {
-            const int h = v / LPR, c0 = (v - h * LPR) * VEC;
-            float t[VEC];
-            ld_vec<T, VEC>(x + po + h * W + c0, t);
-            st_row<VEC>(xs + (h + 1) * PITCH + kDwLeft + c0, t);
-        }
-        __syncthreads();
-        for (int v = tl; v < nvec; v += a.TP) {
-            const int h = v / LPR, c0 = (v - h * LPR) * VEC;
+        sync();                                                    // previous plane fully consumed (and halo zeroed)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (vh[it] >= 0) {
+                float t[VEC];
+                unpack_raw<T, VEC>(xr[it], t);
+                st_row<VEC>(xs + (vh[it] + 1) * PITCH + kDwLeft + vc[it], t);
+            }
+        sync();
+        if (b + 1 < b1) issue(x, xr, b + 1);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (vh[it] < 0) continue;
+            const int h = vh[it], c0 = vc[it];
             float q[3][VEC + 2];
 #pragma unroll
             for (int r = 0; r < 3; ++r) ld_window<VEC>(xs + (h + r) * PITCH, c0, q[r]);
@@ -299,7 +366,7 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
                 st_vec<T, VEC>(out + po + h * W + c0, z);
             } else {
                 float g[VEC];
-                ld_vec<T, VEC>(dy + po + h * W + c0, g);
+                unpack_raw<T, VEC>(gr[it], g);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     if (a.act) {
@@ -316,9 +383,12 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
             }
         }
         if constexpr (BWD) {
-            __syncthreads();
-            for (int v = tl; v < nvec; v += a.TP) {
-                const int h = v / LPR, c0 = (v - h * LPR) * VEC;
+            if (b + 1 < b1) issue(dy, gr, b + 1);
+            sync();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (vh[it] < 0) continue;
+                const int h = vh[it], c0 = vc[it];
                 float q[3][VEC + 2];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) ld_window<VEC>(zs + (h + r) * PITCH, c0, q[r]);
@@ -336,17 +406,32 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
             }
         }
     }
-    if constexpr (BWD) {
+    if constexpr (BWD && WP) {
+        // fold the 64 partial sums of the channel: ten wave reductions, one atomic per tap per wave
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            float s = i < 9 ? acc[i] : accb;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (i < 9) acc[i] = s;
+            else accb = s;
+        }
+        if (tl == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) atomicAdd(a.dw + d * 9 + i, acc[i]);
+            if (a.dbias) atomicAdd(a.dbias + d, accb);
+        }
+    } else if constexpr (BWD) {
         // fold the TP partial sums of each channel through LDS (the plane buffers are free now)
         __syncthreads();
         float *red = smem;                                          // [PP][10][TP]
 #pragma unroll
-        for (int i = 0; i < 9; ++i) red[(j * 10 + i) * a.TP + tl] = acc[i];
-        red[(j * 10 + 9) * a.TP + tl] = accb;
+        for (int i = 0; i < 9; ++i) red[(j * 10 + i) * TP + tl] = acc[i];
+        red[(j * 10 + 9) * TP + tl] = accb;
         __syncthreads();
         if (tl < 10) {
             float s = 0.f;
-            for (int q = 0; q < a.TP; ++q) s += red[(j * 10 + tl) * a.TP + q];
+            for (int q = 0; q < TP; ++q) s += red[(j * 10 + tl) * TP + q];
             if (tl < 9) atomicAdd(a.dw + d * 9 + tl, s);
             else if (a.dbias) atomicAdd(a.dbias + d, s);
         }
@@ -354,7 +439,7 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
 }
 
 // plan of the fast path: PP channels per workgroup (TP = 256 / PP threads each), batch split into `bsplit` slices
-static bool dw7_plan(bool bwd, int B, int D, int H, int W, int &vec, int &PP, int &bsplit, size_t &lds) {
+static bool dw7_plan_shared(bool bwd, int B, int D, int H, int W, int &vec, int &PP, int &bsplit, size_t &lds) {
     if (W % 7 != 0) return false;
     vec = W / 7;
     if (vec != 1 && vec != 2 && vec != 4 && vec != 8) return false;
@@ -364,6 +449,7 @@ static bool dw7_plan(bool bwd, int B, int D, int H, int W, int &vec, int &PP, in
     PP = 32;
     while (PP > 1 && (256 / PP < 10 || nvec * PP > 1568 * 2 || (bwd ? 2 : 1) * PP * psz > 60 * 1024 || D % PP != 0)) PP >>= 1;
     if (D % PP != 0 || (bwd ? 2 : 1) * PP * psz > 64 * 1024) return false;
+    if ((nvec + 256 / PP - 1) / (256 / PP) > (vec == 8 ? 4 : 7)) return false;     // Dw7Iters: register-held vectors per thread
     lds = (bwd ? 2 : 1) * PP * psz;
     if (bwd && lds < (size_t)PP * 10 * (256 / PP) * sizeof(float)) lds = (size_t)PP * 10 * (256 / PP) * sizeof(float);
     const int ngrp = D / PP;
@@ -373,14 +459,53 @@ static bool dw7_plan(bool bwd, int B, int D, int H, int W, int &vec, int &PP, in
     return true;
 }
 
-template <typename T, bool BWD> static int launch_dw7(int vec, const Dw7Args &a, int grid, size_t lds, hipStream_t s) {
-    switch (vec) {
-        case 8: hipLaunchKernelGGL((dwconv7_kernel<T, 8, BWD>), dim3(grid), dim3(256), lds, s, a); break;
-        case 4: hipLaunchKernelGGL((dwconv7_kernel<T, 4, BWD>), dim3(grid), dim3(256), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((dwconv7_kernel<T, 2, BWD>), dim3(grid), dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL((dwconv7_kernel<T, 1, BWD>), dim3(grid), dim3(256), lds, s, a); break;
-    }
+// plan of the wave-private variant: four channels (waves) per workgroup, the batch split into `bsplit` slices so that the grid is
+// about one round of resident waves -- each wave then walks several planes and the plane pipeline has something to hide
+static bool dw7_plan_wave(bool bwd, int B, int D, int H, int W, int &vec, int &PP, int &bsplit, size_t &lds) {
+    if (W % 7 != 0 || H != W || D % 4 != 0) return false;
+    vec = W / 7;
+    if (vec != 1 && vec != 2 && vec != 4 && vec != 8) return false;
+    const size_t psz = (size_t)(H + 2) * dw7_pitch(W) * sizeof(float);
+    PP = 4;
+    lds = (bwd ? 2 : 1) * PP * psz;
+    if (lds > 160 * 1024) return false;
+    const size_t wg_per_cu = std::min<size_t>(8, (160 * 1024) / lds);
+    const int64_t slots = (int64_t)256 * wg_per_cu * 4;                // resident waves
+    bsplit = (int)((slots + D / 2) / D);
+    if (bsplit < 1) bsplit = 1;
+    if (bsplit > B) bsplit = B;
+    return true;
+}
+
+// wave-private planes up to 14x14 (forward) / 28x28 (backward), shared planes above (measured both ways per shape)
+static bool dw7_plan(bool bwd, int B, int D, int H, int W, int &vec, int &PP, int &bsplit, size_t &lds, bool &wp) {
+    wp = H == W && W % 7 == 0 && (W / 7 <= 2 || (bwd && W / 7 == 4)) && D % 4 == 0;
+    if (wp) return dw7_plan_wave(bwd, B, D, H, W, vec, PP, bsplit, lds);
+    return dw7_plan_shared(bwd, B, D, H, W, vec, PP, bsplit, lds);
+}
+
+template <typename T, int VEC, bool BWD, bool WP> static int launch_dw7v(const Dw7Args &a, int grid, size_t lds, hipStream_t s) {
+    auto fn = dwconv7_kernel<T, VEC, BWD, WP>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, a);
     return check_launch();
+}
+
+template <typename T, bool BWD> static int launch_dw7(int vec, bool wp, const Dw7Args &a, int grid, size_t lds, hipStream_t s) {
+    if (wp) {
+        switch (vec) {
+            case 4: return BWD ? launch_dw7v<T, 4, BWD, true>(a, grid, lds, s) : XFM_ELIMIT;
+            case 2: return launch_dw7v<T, 2, BWD, true>(a, grid, lds, s);
+            case 1: return launch_dw7v<T, 1, BWD, true>(a, grid, lds, s);
+        }
+        return XFM_ELIMIT;
+    }
+    switch (vec) {
+        case 8: return launch_dw7v<T, 8, BWD, false>(a, grid, lds, s);
+        case 4: return launch_dw7v<T, 4, BWD, false>(a, grid, lds, s);
+        case 2: return launch_dw7v<T, 2, BWD, false>(a, grid, lds, s);
+    }
+    return launch_dw7v<T, 1, BWD, false>(a, grid, lds, s);
 }
 
 static int pick_pp(int L) { return L >= 1024 ? 1 : (L >= 256 ? 2 : 4); }
@@ -391,12 +516,13 @@ static int launch_dw(bool bwd, const void *x, const float *w, const float *bias,
     {
         int vec, PP, bsplit;
         size_t lds7;
-        if (!getenv("XFM_DWCONV_GENERIC") && dw7_plan(bwd, B, D, H, W, vec, PP, bsplit, lds7)) {
+        bool wp;
+        if (!getenv("XFM_DWCONV_GENERIC") && dw7_plan(bwd, B, D, H, W, vec, PP, bsplit, lds7, wp)) {
             Dw7Args a{};
             a.x = x; a.dy = dy; a.w = w; a.bias = bias; a.out = out; a.dw = dw; a.dbias = dbias;
             a.B = B; a.D = D; a.H = H; a.PP = PP; a.TP = 256 / PP; a.bsplit = bsplit; a.act = act;
             const int grid = (D / PP) * bsplit;
-            return bwd ? launch_dw7<T, true>(vec, a, grid, lds7, s) : launch_dw7<T, false>(vec, a, grid, lds7, s);
+            return bwd ? launch_dw7<T, true>(vec, wp, a, grid, lds7, s) : launch_dw7<T, false>(vec, wp, a, grid, lds7, s);
         }
     }
     const int planes = B * D;
