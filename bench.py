@@ -89,11 +89,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # (development hook: XFM_BENCH_BACKEND=gloo runs the N > 1 flow -- captured forward/backward/packing, eager
+    #  all-reduce + Adam -- with every rank on GPU 0 of a one-GPU box; never used for a reported number)
+    backend = os.environ.get("XFM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from xfmamba_amd import _lib, fusion_vmamba
