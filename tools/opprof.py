@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--width", type=int, default=60)
     ap.add_argument("--stack", action="store_true")
     ap.add_argument("--find", action="store_true", help="MIOpen find mode (as bench.py)")
+    ap.add_argument("--ops-only", action="store_true", help="list framework ops only (no kernel rows)")
     a = ap.parse_args()
     from xfmamba_amd import _lib
     from xfmamba_amd.dp import GradBuckets
@@ -32,7 +33,9 @@ def main():
         torch.backends.cudnn.benchmark = True
     torch.manual_seed(42)
     model = TwoViewXFMambaTop(in_channels=1, outputs=2, type="tiny").to(dev).train()
+    from xfmamba_amd.amp import WeightCache
     buckets = GradBuckets(model, bucket_mb=48.0)
+    wcache = WeightCache(model)                                   # as bench.py: bf16 weight shadows, one refresh per step
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
     crit = torch.nn.CrossEntropyLoss()
     B = a.batch
@@ -48,6 +51,7 @@ def main():
         loss.backward()
         buckets.finish()
         opt.step()
+        wcache.refresh()
 
     for _ in range(4):
         step()
@@ -61,6 +65,8 @@ def main():
     rows = sorted(ka, key=lambda e: -e.self_device_time_total)
     tot = sum(e.self_device_time_total for e in rows)
     print(f"total self device time {tot / 1e3:.2f} ms")
+    if a.ops_only:
+        rows = [e for e in rows if e.key.startswith("aten::") or "Hip" in e.key or e.key.startswith("Optimizer")]
     for e in rows[:a.top]:
         shp = str(e.input_shapes)[:150] if a.shapes else ""
         print(f"{e.self_device_time_total / 1e3:8.3f} ms  n={e.count:4d}  {e.key[:a.width]:{a.width}s} {shp}")
