@@ -192,6 +192,18 @@ int xfm_bias_gelu_bwd(const void *z, const float *bias, const void *dg, void *dz
 int xfm_colsum(const void *x, float *out, float *workspace, long long rows, int C, int dtype, void *stream);
 
 /*
+ * Skinny token-major linear layer on MFMA (csrc/tokens_gemm.hip):  y[T, out] = x[T, con] . W^T (+ bias), bf16 in / out,
+ * fp32 accumulation -- `F.linear` of Mlp.fc1 / fc2 (reference models/fusion_vmamba.py:135-153) and its backward data
+ * product at the 56x56 stage, where the product is HBM-bound and the whole weight fits in LDS.
+ *   weight_bf16: (out, con) row-major when weight_transposed == 0 (forward: the Linear weight itself);
+ *                (con, out) row-major when weight_transposed != 0 (backward: dx = dy . W reads the same Linear weight).
+ *   bias: (out) fp32 or NULL.   xfm_tokens_gemm_supported(con, out) tells which (con, out) pairs are built.
+ */
+int xfm_tokens_gemm_supported(int con, int out);
+int xfm_tokens_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, long long T, int con, int out,
+                    int weight_transposed, void *stream);
+
+/*
  * Fused SS2D core: y[b,d,p] = sum_k scan_k(...)[b,d,.] gathered back to position p, i.e.
  * cross-scan + 4-route selective scan + cross-merge in ONE kernel; the (B,4,D,L) scan inputs /
  * fp32 scan outputs of the unfused chain never reach HBM.

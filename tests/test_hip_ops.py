@@ -655,3 +655,36 @@ def test_rowscan_strided_and_unaligned_operands(dtype, N):
         for i, (a, b) in enumerate(zip(got, ref)):
             r = 1e-5 if i < 3 else 1e-3                      # y, du, ddelta: same arithmetic; the rest go through atomics
             assert_close(a.float().cpu(), b.float().cpu(), r, r * (float(b.float().abs().max()) + 1e-6), f"{name}[{i}]")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,K,N", [(6272, 96, 384), (6272, 384, 96), (4099, 96, 384), (4133, 384, 96), (4096, 96, 96),
+                                   (5000, 96, 192)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_tokens_gemm_linear_matches_torch(T, K, N, bias):
+    """Skinny token-major linear layer on MFMA (xfm_tokens_gemm, Mlp.fc1 / fc2 at the 56x56 stage): value, data
+    gradient (same kernel, weight staged transposed) and weight / bias gradients against plain PyTorch fp32; row counts
+    that are not a multiple of the 32-row tile included."""
+    from xfmamba_amd import _lib
+    from xfmamba_amd.mlp_tokens import linear_tokens_fn, _skinny_ok
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g) if bias else None
+    gy = torch.randn(T, N, generator=g).to(torch.bfloat16)
+    xr, wr = x.float().requires_grad_(), w.to(torch.bfloat16).float().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(gy.float())
+    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    bd = b.to(DEV).requires_grad_() if bias else None
+    assert _skinny_ok(xd, wd.detach().to(torch.bfloat16))      # (the data gradient uses the kernel when (N, K) is built too)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = linear_tokens_fn(xd, wd, bd)
+    y.backward(gy.to(DEV))
+    assert y.dtype == torch.bfloat16
+    assert_close(y.float().cpu(), yr.detach(), 1e-2, 1e-2 * float(yr.abs().max()), "y")
+    assert_close(xd.grad.float().cpu(), xr.grad, 1e-2, 1e-2 * float(xr.grad.abs().max()), "dx")
+    assert_close(wd.grad.float().cpu(), wr.grad, 1e-2, 1e-2 * float(wr.grad.abs().max()), "dw")
+    if bias:
+        assert_close(bd.grad.float().cpu(), br.grad, 1e-2, 1e-2 * float(br.grad.abs().max()), "db")

@@ -1,0 +1,204 @@
+// tokens_gemm.hip -- Y[T, OUT] = X[T, CON] . Wl[OUT, CON]^T (+ bias) on the token-major stream, bf16 in / bf16 out,
+// fp32 accumulation on MFMA, for the SKINNY products of the 56x56 stage (CON, OUT in {96, 384}; T = B*H*W ~ 2e5).
+//
+// These products are HBM-bound (the weight is 72 KB; X is read once and Y written once), but a general GEMM library
+// tiles them for compute.  Here the whole weight lives in LDS for the lifetime of a persistent workgroup, a wavefront
+// owns 32 consecutive rows at a time, the A fragments of its next row tile are requested before the current tile's
+// MFMAs, and nothing but X and Y touches HBM.  The same kernel serves the backward data product (dX = dY . W) by staging
+// the weight transposed.
+//
+// v_mfma_f32_32x32x16_bf16 operand layout (lane l: r = l & 31, h = l >> 5): A[r][8h + j], B[8h + j][r];
+// D: column l & 31, row (reg & 3) + 8 (reg >> 2) + 4 h.  The product is formed TRANSPOSED, D[n][t] with A = weight rows
+// and B = token rows, so that a lane (token t = l & 31) ends up with runs of four consecutive output channels per
+// register group; after the bf16 pack two v_permlane32_swap per pair of groups hand each lane eight consecutive
+// channels, i.e. 16-byte stores (2-byte stores, one channel per lane, ran the wide-output shapes 1.6x SLOWER than the
+// library).
+#include "xfm_common.hpp"
+
+namespace xfm {
+
+typedef __bf16 tg_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float tg_f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t tg_u32x4_t __attribute__((ext_vector_type(4)));
+
+struct TokGemmArgs {
+    const uint16_t *x;      // (T, CON) bf16
+    const uint16_t *w;      // weight bf16: (OUT, CON) row-major, or (CON, OUT) when wt != 0
+    const float *bias;      // (OUT) or null
+    uint16_t *y;            // (T, OUT) bf16
+    int64_t T;
+    int wt;
+};
+
+template <int CON, int OUT, int OB>       // OB: output columns processed per pass (accumulators OB/32 x 16 registers)
+__global__ void __launch_bounds__(512) tokens_gemm_kernel(const TokGemmArgs a) {
+    constexpr int P = CON + 8;             // LDS row pitch (halfwords): 16-byte rows, conflict-free 16-byte column reads
+    constexpr int KS = CON / 16, NB = OB / 32, NPASS = OUT / OB;
+    static_assert(CON % 16 == 0 && OUT % OB == 0 && OB % 32 == 0, "shape");
+    extern __shared__ __align__(16) uint16_t wl[];              // [OUT][P] weight, then OUT floats of bias
+    float *bl = reinterpret_cast<float *>(wl + OUT * P);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n = threadIdx.x; n < OUT; n += 512) bl[n] = a.bias ? a.bias[n] : 0.f;
+    // ---- stage the weight once per workgroup
+    if (!a.wt) {
+        constexpr int VPR = CON / 8;                               // 16-byte vectors per row
+        for (int v = threadIdx.x; v < OUT * VPR; v += 512) {
+            const int n = v / VPR, q = v - n * VPR;
+            *reinterpret_cast<tg_u32x4_t *>(wl + n * P + 8 * q) = reinterpret_cast<const tg_u32x4_t *>(a.w)[v];
+        }
+    } else {                                                       // w is (CON, OUT): transpose while staging
+        for (int e = threadIdx.x; e < CON * OUT; e += 512) {
+            const int k = e / OUT, n = e - k * OUT;
+            wl[n * P + k] = a.w[e];
+        }
+    }
+    __syncthreads();
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t ntiles = (a.T + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+    // A fragments of the NEXT tile are requested one tile ahead while they fit the register budget of two waves per
+    // SIMD (CON <= 128); longer rows are loaded at the top of their tile and the other resident waves cover the latency
+    constexpr bool PREF = KS <= 8;
+    constexpr int NA = PREF ? KS : 1;
+    tg_u32x4_t an[NA];
+    auto src_of = [&](int64_t tl) {
+        int64_t row = tl * 32 + c;
+        if (row >= a.T) row = a.T - 1;
+        return reinterpret_cast<const tg_u32x4_t *>(a.x + row * CON + 8 * h);   // [2 s]: columns 16 s + 8 h .. + 7
+    };
+    if (PREF && tile < ntiles) {
+        const tg_u32x4_t *src = src_of(tile);
+#pragma unroll
+        for (int s = 0; s < NA; ++s) an[s] = src[2 * s];
+    }
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    auto store = [&](const tg_f32x16_t (&acc)[NB], int ps, int64_t t0) {
+        const int64_t row = t0 + c;
+        uint16_t *yr = a.y + row * OUT + ps * OB + 8 * h;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            uint32_t pk[4][2];                                     // group g: channels 32 b + 8 g + 4 h .. + 3
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bl + ps * OB + 32 * b + 8 * g + 4 * h);
+                pk[g][0] = pack_bf16x2(acc[b][4 * g] + bv.x, acc[b][4 * g + 1] + bv.y);
+                pk[g][1] = pack_bf16x2(acc[b][4 * g + 2] + bv.z, acc[b][4 * g + 3] + bv.w);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {                      // lower half gets channels +4..7 of group g, upper +0..3 of g+1
+                    const u32x2_t r = __builtin_amdgcn_permlane32_swap(pk[g][q], pk[g + 1][q], false, false);
+                    pk[g][q] = r[0];
+                    pk[g + 1][q] = r[1];
+                }
+            if (row < a.T) {
+                tg_u32x4_t v0, v1;
+                v0[0] = pk[0][0]; v0[1] = pk[0][1]; v0[2] = pk[1][0]; v0[3] = pk[1][1];      // channels 32 b + 8 h .. + 7
+                v1[0] = pk[2][0]; v1[1] = pk[2][1]; v1[2] = pk[3][0]; v1[3] = pk[3][1];      // channels 32 b + 16 + 8 h .. + 7
+                *reinterpret_cast<tg_u32x4_t *>(yr + 32 * b) = v0;
+                *reinterpret_cast<tg_u32x4_t *>(yr + 32 * b + 16) = v1;
+            }
+        }
+    };
+    for (; tile < ntiles; tile += stride) {
+        const int64_t t0 = tile * 32;
+        if constexpr (PREF) {
+            tg_u32x4_t af[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) af[s] = an[s];
+            if (tile + stride < ntiles) {
+                const tg_u32x4_t *src = src_of(tile + stride);
+#pragma unroll
+                for (int s = 0; s < NA; ++s) an[s] = src[2 * s];
+            }
+#pragma unroll 1
+            for (int ps = 0; ps < NPASS; ++ps) {
+                tg_f32x16_t acc[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const tg_bf16x8_t afr = __builtin_bit_cast(tg_bf16x8_t, af[s]);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const tg_bf16x8_t bfr =
+                            *reinterpret_cast<const tg_bf16x8_t *>(wl + (ps * OB + b * 32 + c) * P + 16 * s + 8 * h);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, afr, acc[b], 0, 0, 0);
+                    }
+                }
+                store(acc, ps, t0);
+            }
+        } else {
+            // long rows: the contraction runs in groups of KG k-steps, each group's A fragments loaded just before it
+            static_assert(PREF || NPASS == 1, "long contraction: one pass over the outputs");
+            constexpr int KG = 8;
+            static_assert(KS % KG == 0, "k-step groups");
+            const tg_u32x4_t *src = src_of(tile);
+            tg_f32x16_t acc[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+#pragma unroll 1
+            for (int s0 = 0; s0 < KS; s0 += KG) {
+                tg_u32x4_t af[KG];
+#pragma unroll
+                for (int s = 0; s < KG; ++s) af[s] = src[2 * (s0 + s)];
+#pragma unroll
+                for (int s = 0; s < KG; ++s) {
+                    const tg_bf16x8_t afr = __builtin_bit_cast(tg_bf16x8_t, af[s]);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const tg_bf16x8_t bfr =
+                            *reinterpret_cast<const tg_bf16x8_t *>(wl + (b * 32 + c) * P + 16 * (s0 + s) + 8 * h);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, afr, acc[b], 0, 0, 0);
+                    }
+                }
+            }
+            store(acc, 0, t0);
+        }
+    }
+}
+
+template <int CON, int OUT, int OB>
+static int tokens_gemm_launch(const TokGemmArgs &a, hipStream_t s) {
+    const size_t lds = (size_t)OUT * (CON + 8) * sizeof(uint16_t) + (size_t)OUT * sizeof(float);
+    auto fn = tokens_gemm_kernel<CON, OUT, OB>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t ntiles = (a.T + 31) / 32;
+    int grid = (int)std::min<int64_t>((ntiles + 7) / 8, 512);       // persistent: up to two workgroups per CU
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a);
+    return check_launch();
+}
+
+}  // namespace xfm
+
+extern "C" {
+
+int xfm_tokens_gemm_supported(int con, int out) {
+    return ((con == 96 && out == 384) || (con == 384 && out == 96) || (con == 96 && out == 96) || (con == 96 && out == 192)) ? 1 : 0;
+}
+
+int xfm_tokens_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, long long T, int con, int out,
+                    int weight_transposed, void *stream) {
+    using namespace xfm;
+    if (!x || !weight_bf16 || !y || T <= 0) return XFM_EINVAL;
+    TokGemmArgs a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(weight_bf16);
+    a.bias = bias;
+    a.y = static_cast<uint16_t *>(y);
+    a.T = T;
+    a.wt = weight_transposed;
+    hipStream_t s = (hipStream_t)stream;
+    if (con == 96 && out == 384) return tokens_gemm_launch<96, 384, 192>(a, s);
+    if (con == 384 && out == 96) return tokens_gemm_launch<384, 96, 96>(a, s);
+    if (con == 96 && out == 96) return tokens_gemm_launch<96, 96, 96>(a, s);
+    if (con == 96 && out == 192) return tokens_gemm_launch<96, 192, 96>(a, s);
+    return XFM_ELIMIT;
+}
+}

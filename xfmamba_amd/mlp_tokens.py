@@ -6,6 +6,8 @@ fc2's bias gradient is a column-sum kernel -- no framework reductions are left o
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -73,6 +75,30 @@ def bias_gelu_fn(z, bias=None):
     return BiasGeluHip.apply(z, bias)
 
 
+_SKINNY = os.environ.get("XFM_TOKENS_GEMM", "1") == "1"     # XFM_TOKENS_GEMM=0: library GEMMs everywhere
+
+
+def _skinny_ok(x, w, transposed=False):
+    """bf16 token-major product whose (contraction, output) widths the MFMA kernel of csrc/tokens_gemm.hip covers."""
+    if not _SKINNY or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or not x.is_cuda or not w.is_contiguous():
+        return False
+    con, out = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    return x.shape[-1] == con and x.numel() >= con * 4096 and bool(_lib.lib().xfm_tokens_gemm_supported(con, out))
+
+
+def _skinny(x, w, bias, out, transposed):
+    """``x @ w.T`` (w: (out, con)) or, transposed, ``x @ w`` (w: (con, out)) through ``xfm_tokens_gemm``."""
+    con = x.shape[-1]
+    T = x.numel() // con
+    y = torch.empty(*x.shape[:-1], out, dtype=x.dtype, device=x.device)
+    b = None if bias is None else bias.float().contiguous()
+    nbytes = T * (con + out) * 2
+    with torch.cuda.device(x.device), _lib.timed("tokens_gemm", nbytes):
+        _lib.check(_lib.lib().xfm_tokens_gemm(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), T, con, out,
+                                              1 if transposed else 0, _lib.stream_ptr()), "tokens_gemm")
+    return y
+
+
 class LinearTokens(torch.autograd.Function):
     """``F.linear`` on (..., K) tokens whose bias gradient comes from the column-sum kernel."""
 
@@ -80,7 +106,10 @@ class LinearTokens(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         cd = x.dtype
         w = cast_weight(weight, cd)
-        y = torch.nn.functional.linear(x, w, None if bias is None else cast_weight(bias, cd))
+        if _skinny_ok(x, w):
+            y = _skinny(x.contiguous(), w, bias, w.shape[0], False)
+        else:
+            y = torch.nn.functional.linear(x, w, None if bias is None else cast_weight(bias, cd))
         ctx.save_for_backward(x, w)
         ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
         return y
@@ -93,7 +122,10 @@ class LinearTokens(torch.autograd.Function):
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dy2, w).view(x.shape)
+            if _skinny_ok(dy2, w, transposed=True):
+                dx = _skinny(dy2, w, None, w.shape[1], True).view(x.shape)
+            else:
+                dx = torch.mm(dy2, w).view(x.shape)
         if ctx.needs_input_grad[1]:
             dw = split_k_wgrad(dy2, x2).to(wdtype)
         if bdtype is not None and ctx.needs_input_grad[2]:
