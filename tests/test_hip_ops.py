@@ -688,3 +688,36 @@ def test_tokens_gemm_linear_matches_torch(T, K, N, bias):
     assert_close(wd.grad.float().cpu(), wr.grad, 1e-2, 1e-2 * float(wr.grad.abs().max()), "dw")
     if bias:
         assert_close(bd.grad.float().cpu(), br.grad, 1e-2, 1e-2 * float(br.grad.abs().max()), "db")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_tokens,out_tokens", [(True, False), (False, True)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias):
+    """in_proj / out_proj of the 56x56 stage through xfm_proj_gemm (tokens -> planes, planes -> tokens; the backward data
+    product is the same kernel with the roles swapped and the weight staged transposed) against an fp32 einsum."""
+    from xfmamba_amd.proj import batched_proj, _mfma_proj
+    g = torch.Generator().manual_seed(8)
+    B, L, K, M = 5, 1024, 96, 96
+    xp = torch.randn(B, K, L, generator=g).to(torch.bfloat16)
+    w = torch.randn(M, K, generator=g) / K ** 0.5
+    bb = torch.randn(M, generator=g) if bias else None
+    gy = torch.randn(B, M, L, generator=g).to(torch.bfloat16)
+    xr, wr = xp.float().requires_grad_(), w.to(torch.bfloat16).float().requires_grad_()
+    br = bb.clone().requires_grad_() if bias else None
+    yr = torch.einsum("mk,bkl->bml", wr, xr) + (br[None, :, None] if bias else 0)
+    yr.backward(gy.float())
+    x = (xp.transpose(1, 2).contiguous() if in_tokens else xp.clone()).to(DEV).requires_grad_()
+    wd = w.to(DEV).requires_grad_()
+    bd = bb.to(DEV).requires_grad_() if bias else None
+    assert _mfma_proj(x.detach(), wd.detach().to(torch.bfloat16), None, in_tokens, out_tokens, False) is not None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = batched_proj(x, wd, bd, in_tokens=in_tokens, out_tokens=out_tokens)
+    y.backward((gy.transpose(1, 2).contiguous() if out_tokens else gy).to(DEV))
+    yc = (y.transpose(1, 2) if out_tokens else y).float().cpu()
+    assert_close(yc, yr.detach(), 1e-2, 1e-2 * float(yr.abs().max()), "y")
+    dx = (x.grad.transpose(1, 2) if in_tokens else x.grad).float().cpu()
+    assert_close(dx, xr.grad, 1e-2, 1e-2 * float(xr.grad.abs().max()), "dx")
+    assert_close(wd.grad.float().cpu(), wr.grad, 1e-2, 1e-2 * float(wr.grad.abs().max()), "dw")
+    if bias:
+        assert_close(bd.grad.float().cpu(), br.grad, 1e-2, 1e-2 * float(br.grad.abs().max()), "db")

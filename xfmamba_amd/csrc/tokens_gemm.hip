@@ -28,6 +28,7 @@ struct TokGemmArgs {
     uint16_t *y;            // (T, OUT) bf16
     int64_t T;
     int wt;
+    int L;                  // layout-changing variants: tokens per sample (planes are (B, C, L)), L % 32 == 0
 };
 
 template <int CON, int OUT, int OB>       // OB: output columns processed per pass (accumulators OB/32 x 16 registers)
@@ -164,6 +165,129 @@ __global__ void __launch_bounds__(512) tokens_gemm_kernel(const TokGemmArgs a) {
     }
 }
 
+// ---- layout-changing projections: token-major in -> plane-major out (IN_PL = false) or the reverse.  Same weight
+// residency and epilogue; a 32-token tile lies inside one sample (L % 32 == 0).
+//   tokens -> planes: D[t][n] (A = token rows, B = weight): a lane owns channel n and, after the swap, 8 consecutive tokens
+//   planes -> tokens: D[n][t] (A = weight, B[k][t] gathered from the planes with 2-byte loads, 64 bytes per wave and k)
+template <int CON, int OUT, bool IN_PL>
+__global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
+    constexpr int P = CON + 8;
+    constexpr int KS = CON / 16, NB = OUT / 32;
+    static_assert(CON % 16 == 0 && OUT % 32 == 0 && KS <= 12 && NB <= 6, "shape");
+    extern __shared__ __align__(16) uint16_t wl[];
+    float *bl = reinterpret_cast<float *>(wl + OUT * P);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n = threadIdx.x; n < OUT; n += 512) bl[n] = a.bias ? a.bias[n] : 0.f;
+    if (!a.wt) {
+        constexpr int VPR = CON / 8;
+        for (int v = threadIdx.x; v < OUT * VPR; v += 512) {
+            const int n = v / VPR, q = v - n * VPR;
+            *reinterpret_cast<tg_u32x4_t *>(wl + n * P + 8 * q) = reinterpret_cast<const tg_u32x4_t *>(a.w)[v];
+        }
+    } else {
+        for (int e = threadIdx.x; e < CON * OUT; e += 512) {
+            const int k = e / OUT, n = e - k * OUT;
+            wl[n * P + k] = a.w[e];
+        }
+    }
+    __syncthreads();
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t ntiles = a.T / 32;
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+    const int L = a.L;
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    tg_u32x4_t an[KS];                                             // the next tile's token / plane fragments
+    auto fetch = [&](int64_t tl) {
+        const int64_t t0 = tl * 32;
+        if constexpr (!IN_PL) {
+            const tg_u32x4_t *src = reinterpret_cast<const tg_u32x4_t *>(a.x + (t0 + c) * CON + 8 * h);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) an[s] = src[2 * s];
+        } else {
+            const int64_t bi = t0 / L;
+            const uint16_t *pp = a.x + bi * CON * L + (t0 - bi * L) + 8 * h * L + c;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                uint16_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = pp[(int64_t)j * L];
+                pp += 16 * (int64_t)L;
+                asm volatile("" : "+v"(pp));                                     // one running address, not 48 of them
+#pragma unroll
+                for (int q = 0; q < 4; ++q) an[s][q] = (uint32_t)v[2 * q] | ((uint32_t)v[2 * q + 1] << 16);
+            }
+        }
+    };
+    // (plane gathers are 48 two-byte loads per lane: they are issued at the top of their own tile -- holding a second
+    //  tile's worth in flight spills at two waves per SIMD; the other resident waves cover the latency)
+    if (!IN_PL && tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += stride) {
+        const int64_t t0 = tile * 32;
+        tg_u32x4_t af[KS];
+        if constexpr (IN_PL) fetch(tile);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) af[s] = an[s];
+        if (!IN_PL && tile + stride < ntiles) fetch(tile + stride);
+        tg_f32x16_t acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const tg_bf16x8_t xfr = __builtin_bit_cast(tg_bf16x8_t, af[s]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const tg_bf16x8_t wfr = *reinterpret_cast<const tg_bf16x8_t *>(wl + (b * 32 + c) * P + 16 * s + 8 * h);
+                if constexpr (IN_PL) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, xfr, acc[b], 0, 0, 0);   // D[n][t]
+                else acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xfr, wfr, acc[b], 0, 0, 0);                  // D[t][n]
+            }
+        }
+        const int64_t bi = t0 / L;
+        const int l0 = (int)(t0 - bi * L);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            uint32_t pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 bv;
+                if constexpr (IN_PL) bv = *reinterpret_cast<const float4 *>(bl + 32 * b + 8 * g + 4 * h);   // per channel
+                else bv.x = bv.y = bv.z = bv.w = bl[32 * b + c];                                            // lane's channel
+                pk[g][0] = pack_bf16x2(acc[b][4 * g] + bv.x, acc[b][4 * g + 1] + bv.y);
+                pk[g][1] = pack_bf16x2(acc[b][4 * g + 2] + bv.z, acc[b][4 * g + 3] + bv.w);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const u32x2_t r = __builtin_amdgcn_permlane32_swap(pk[g][q], pk[g + 1][q], false, false);
+                    pk[g][q] = r[0];
+                    pk[g + 1][q] = r[1];
+                }
+            tg_u32x4_t v0, v1;
+            v0[0] = pk[0][0]; v0[1] = pk[0][1]; v0[2] = pk[1][0]; v0[3] = pk[1][1];
+            v1[0] = pk[2][0]; v1[1] = pk[2][1]; v1[2] = pk[3][0]; v1[3] = pk[3][1];
+            uint16_t *dst;
+            if constexpr (IN_PL) dst = a.y + (t0 + c) * OUT + 32 * b + 8 * h;                     // token row, 8 channels
+            else dst = a.y + (bi * OUT + 32 * b + c) * L + l0 + 8 * h;                            // channel plane, 8 tokens
+            *reinterpret_cast<tg_u32x4_t *>(dst) = v0;
+            *reinterpret_cast<tg_u32x4_t *>(dst + 16) = v1;
+        }
+    }
+}
+
+template <int CON, int OUT, bool IN_PL>
+static int proj_gemm_launch(const TokGemmArgs &a, hipStream_t s) {
+    const size_t lds = (size_t)OUT * (CON + 8) * sizeof(uint16_t) + (size_t)OUT * sizeof(float);
+    auto fn = proj_gemm_kernel<CON, OUT, IN_PL>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t ntiles = a.T / 32;
+    int grid = (int)std::min<int64_t>((ntiles + 7) / 8, 512);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a);
+    return check_launch();
+}
+
 template <int CON, int OUT, int OB>
 static int tokens_gemm_launch(const TokGemmArgs &a, hipStream_t s) {
     const size_t lds = (size_t)OUT * (CON + 8) * sizeof(uint16_t) + (size_t)OUT * sizeof(float);
@@ -194,11 +318,31 @@ int xfm_tokens_gemm(const void *x, const void *weight_bf16, const float *bias, v
     a.y = static_cast<uint16_t *>(y);
     a.T = T;
     a.wt = weight_transposed;
+    a.L = 0;
     hipStream_t s = (hipStream_t)stream;
     if (con == 96 && out == 384) return tokens_gemm_launch<96, 384, 192>(a, s);
     if (con == 384 && out == 96) return tokens_gemm_launch<384, 96, 96>(a, s);
     if (con == 96 && out == 96) return tokens_gemm_launch<96, 96, 96>(a, s);
     if (con == 96 && out == 192) return tokens_gemm_launch<96, 192, 96>(a, s);
     return XFM_ELIMIT;
+}
+
+int xfm_proj_gemm_supported(int con, int out, int L) { return (con == 96 && out == 96 && L > 0 && L % 32 == 0) ? 1 : 0; }
+
+int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, int B, int L, int con, int out,
+                  int in_planes, int weight_transposed, void *stream) {
+    using namespace xfm;
+    if (!x || !weight_bf16 || !y || B <= 0) return XFM_EINVAL;
+    if (!xfm_proj_gemm_supported(con, out, L)) return XFM_ELIMIT;
+    TokGemmArgs a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(weight_bf16);
+    a.bias = bias;
+    a.y = static_cast<uint16_t *>(y);
+    a.T = (int64_t)B * L;
+    a.wt = weight_transposed;
+    a.L = L;
+    hipStream_t s = (hipStream_t)stream;
+    return in_planes ? proj_gemm_launch<96, 96, true>(a, s) : proj_gemm_launch<96, 96, false>(a, s);
 }
 }

@@ -10,6 +10,8 @@ Weight gradients are per-sample partial products (fp32) summed over the batch.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .amp import cast_weight
@@ -58,6 +60,31 @@ def split_k_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     return _bmm_f32(dy2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0)
 
 
+_MFMA = os.environ.get("XFM_TOKENS_GEMM", "1") == "1"     # XFM_TOKENS_GEMM=0: library GEMMs everywhere
+
+
+def _mfma_proj(x, w, bias, in_tokens, out_tokens, transposed):
+    """The layout-changing projection through ``xfm_proj_gemm`` (csrc/tokens_gemm.hip), or None when it does not cover
+    the call: bf16, exactly one plane-major side, widths built, L % 32 == 0.  ``transposed``: ``w`` is (con, out)."""
+    if not _MFMA or in_tokens == out_tokens or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or not x.is_cuda:
+        return None
+    from . import _lib
+    B = x.shape[0]
+    L, con = (x.shape[1], x.shape[2]) if in_tokens else (x.shape[2], x.shape[1])
+    out = w.shape[1] if transposed else w.shape[0]
+    if (w.shape[0] if transposed else w.shape[1]) != con or B * L < 4096 or not w.is_contiguous():
+        return None
+    lib = _lib.lib()
+    if not lib.xfm_proj_gemm_supported(con, out, L):
+        return None
+    y = torch.empty((B, L, out) if out_tokens else (B, out, L), dtype=x.dtype, device=x.device)
+    b = None if bias is None else bias.float().contiguous()
+    with torch.cuda.device(x.device), _lib.timed("proj_gemm", B * L * (con + out) * 2):
+        _lib.check(lib.xfm_proj_gemm(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), B, L, con, out,
+                                     0 if in_tokens else 1, 1 if transposed else 0, _lib.stream_ptr()), "proj_gemm")
+    return y
+
+
 class BatchedProj(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, in_tokens, out_tokens):
@@ -67,7 +94,10 @@ class BatchedProj(torch.autograd.Function):
         cd = x.dtype
         w = cast_weight(weight, cd)
         M, K = w.shape
-        if out_tokens:
+        y = _mfma_proj(x, w, bias, in_tokens, out_tokens, False)
+        if y is not None:
+            pass
+        elif out_tokens:
             xt = x if in_tokens else x.transpose(1, 2)                       # (B, L, K)
             y = torch.bmm(xt, w.t().unsqueeze(0).expand(B, K, M))            # (B, L, M)
             if bias is not None:
@@ -91,7 +121,10 @@ class BatchedProj(torch.autograd.Function):
         dyp = dy.transpose(1, 2) if out_tokens else dy                        # (B, M, L)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if in_tokens:
+            dx = _mfma_proj(dy, w, None, out_tokens, in_tokens, True)        # dy has the output's layout, dx the input's
+            if dx is not None:
+                pass
+            elif in_tokens:
                 dx = torch.bmm(dyp.transpose(1, 2), w.unsqueeze(0).expand(B, M, K))          # (B, L, K)
             else:
                 dx = torch.bmm(w.t().unsqueeze(0).expand(B, K, M), dyp)                      # (B, K, L)
