@@ -207,7 +207,8 @@ int xfm_tokens_gemm(const void *x, const void *weight_bf16, const float *bias, v
  * The same kernel family for the layout-changing 1x1 projections of an SS2D block (in_proj: tokens -> planes, out_proj:
  * planes -> tokens; reference Linear2d = F.conv2d with a 1x1 kernel, models/fusion_vmamba.py:42-45, :1190-1206) and their
  * backward data products:  in_planes == 0: x (B, L, con) tokens -> y (B, out, L) planes;  in_planes != 0: x (B, con, L)
- * planes -> y (B, L, out) tokens.  weight / weight_transposed / bias as in xfm_tokens_gemm.  L % 32 == 0.
+ * planes -> y (B, L, out) tokens.  weight / weight_transposed / bias as in xfm_tokens_gemm.  L % 8 == 0, (B * L) % 32 == 0;
+ * con = out = 96 or 192.
  */
 int xfm_proj_gemm_supported(int con, int out, int L);
 int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, int B, int L, int con, int out,

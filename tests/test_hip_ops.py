@@ -693,12 +693,13 @@ def test_tokens_gemm_linear_matches_torch(T, K, N, bias):
 @pytest.mark.gpu
 @pytest.mark.parametrize("in_tokens,out_tokens", [(True, False), (False, True)])
 @pytest.mark.parametrize("bias", [False, True])
-def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias):
+@pytest.mark.parametrize("B,L,C", [(5, 1024, 96), (8, 784, 192), (128, 40, 96)])     # (128, 40): samples end inside tiles
+def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias, B, L, C):
     """in_proj / out_proj of the 56x56 stage through xfm_proj_gemm (tokens -> planes, planes -> tokens; the backward data
     product is the same kernel with the roles swapped and the weight staged transposed) against an fp32 einsum."""
     from xfmamba_amd.proj import batched_proj, _mfma_proj
     g = torch.Generator().manual_seed(8)
-    B, L, K, M = 5, 1024, 96, 96
+    K = M = C
     xp = torch.randn(B, K, L, generator=g).to(torch.bfloat16)
     w = torch.randn(M, K, generator=g) / K ** 0.5
     bb = torch.randn(M, generator=g) if bias else None

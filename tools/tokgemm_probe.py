@@ -64,7 +64,7 @@ def main_proj():
     f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
     dev, bf = "cuda", torch.bfloat16
     st = _lib.stream_ptr()
-    for (B, L, K, M) in [(64, 3136, 96, 96), (3, 64, 96, 96)]:
+    for (B, L, K, M) in [(64, 3136, 96, 96), (64, 784, 192, 192), (12, 40, 96, 96), (12, 40, 192, 192)]:
         w = (torch.randn(M, K, device=dev) / K ** 0.5).to(bf)
         wt = w.t().contiguous()
         b = torch.randn(M, device=dev)
@@ -83,7 +83,7 @@ def main_proj():
                 tm = t(lambda: f(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), B, L, K, M, in_pl, flag, st))
                 gb = B * L * (K + M) * 2 / 1e3
                 print(f"B={B} L={L} {'planes->tokens' if in_pl else 'tokens->planes'} [{name:2s}] rc={rc} rel.err={err:.2e} {tm:7.1f} us {gb / tm:7.1f} GB/s")
-        if B == 64:
+        if B == 64:  # library reference
             print("   torch bmm tok->pl", t(lambda: torch.bmm(w.unsqueeze(0).expand(B, M, K), xt.transpose(1, 2))),
                   " pl->tok", t(lambda: torch.bmm(xp.transpose(1, 2), w.t().unsqueeze(0).expand(B, K, M))))
 

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(512) tokens_gemm_kernel(const TokGemmArgs a) {
 }
 
 // ---- layout-changing projections: token-major in -> plane-major out (IN_PL = false) or the reverse.  Same weight
-// residency and epilogue; a 32-token tile lies inside one sample (L % 32 == 0).
+// residency and epilogue; L % 8 == 0 and (B * L) % 32 == 0.
 //   tokens -> planes: D[t][n] (A = token rows, B = weight): a lane owns channel n and, after the swap, 8 consecutive tokens
 //   planes -> tokens: D[n][t] (A = weight, B[k][t] gathered from the planes with 2-byte loads, 64 bytes per wave and k)
 template <int CON, int OUT, bool IN_PL>
@@ -174,6 +174,8 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
     constexpr int P = CON + 8;
     constexpr int KS = CON / 16, NB = OUT / 32;
     static_assert(CON % 16 == 0 && OUT % 32 == 0 && KS <= 12 && NB <= 6, "shape");
+    constexpr int KH = KS > 6 ? KS / 2 : KS;                      // plane gathers: k-steps fetched together (48 loads)
+    static_assert(KS % KH == 0, "k halves");
     extern __shared__ __align__(16) uint16_t wl[];
     float *bl = reinterpret_cast<float *>(wl + OUT * P);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -197,55 +199,79 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
     int64_t tile = (int64_t)blockIdx.x * 8 + wave;
     const int L = a.L;
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-    tg_u32x4_t an[KS];                                             // the next tile's token / plane fragments
-    auto fetch = [&](int64_t tl) {
-        const int64_t t0 = tl * 32;
-        if constexpr (!IN_PL) {
-            const tg_u32x4_t *src = reinterpret_cast<const tg_u32x4_t *>(a.x + (t0 + c) * CON + 8 * h);
+    // Samples may end inside a 32-token tile (L % 8 == 0 only): a lane works out the sample of ITS token (gathers) or of
+    // its 8-token output run (plane stores) itself.
+    tg_u32x4_t an[IN_PL ? KH : KS];                                // token rows: the next tile's fragments; planes: one k half
+    auto fetch_tokens = [&](int64_t tl) {
+        const tg_u32x4_t *src = reinterpret_cast<const tg_u32x4_t *>(a.x + (tl * 32 + c) * CON + 8 * h);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) an[s] = src[2 * s];
-        } else {
-            const int64_t bi = t0 / L;
-            const uint16_t *pp = a.x + bi * CON * L + (t0 - bi * L) + 8 * h * L + c;
+        for (int s = 0; s < KS; ++s) an[s] = src[2 * s];
+    };
+    auto fetch_planes = [&](int64_t tl, int s0) {                  // k-steps s0 .. s0 + KH - 1 of tile tl
+        const int64_t t = tl * 32 + c, bi = t / L;
+        const uint16_t *pp = a.x + (bi * CON + 16 * s0 + 8 * h) * L + (t - bi * L);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                uint16_t v[8];
+        for (int s = 0; s < KH; ++s) {
+            uint16_t v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = pp[(int64_t)j * L];
-                pp += 16 * (int64_t)L;
-                asm volatile("" : "+v"(pp));                                     // one running address, not 48 of them
+            for (int j = 0; j < 8; ++j) v[j] = pp[(int64_t)j * L];
+            pp += 16 * (int64_t)L;
+            asm volatile("" : "+v"(pp));                                         // one running address, not 48 of them
 #pragma unroll
-                for (int q = 0; q < 4; ++q) an[s][q] = (uint32_t)v[2 * q] | ((uint32_t)v[2 * q + 1] << 16);
-            }
+            for (int q = 0; q < 4; ++q) an[s][q] = (uint32_t)v[2 * q] | ((uint32_t)v[2 * q + 1] << 16);
         }
     };
-    // (plane gathers are 48 two-byte loads per lane: they are issued at the top of their own tile -- holding a second
-    //  tile's worth in flight spills at two waves per SIMD; the other resident waves cover the latency)
-    if (!IN_PL && tile < ntiles) fetch(tile);
+    constexpr bool PREFT = KS <= 8;                                // token rows one tile ahead while the registers allow
+    if constexpr (!IN_PL && PREFT) {
+        if (tile < ntiles) fetch_tokens(tile);
+    }
     for (; tile < ntiles; tile += stride) {
         const int64_t t0 = tile * 32;
-        tg_u32x4_t af[KS];
-        if constexpr (IN_PL) fetch(tile);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) af[s] = an[s];
-        if (!IN_PL && tile + stride < ntiles) fetch(tile + stride);
         tg_f32x16_t acc[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+        if constexpr (!IN_PL) {
+            tg_u32x4_t af[PREFT ? KS : 1];
+            if constexpr (PREFT) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const tg_bf16x8_t xfr = __builtin_bit_cast(tg_bf16x8_t, af[s]);
+                for (int s = 0; s < KS; ++s) af[s] = an[s];
+                if (tile + stride < ntiles) fetch_tokens(tile + stride);
+            } else {
+                fetch_tokens(tile);
+            }
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const tg_bf16x8_t wfr = *reinterpret_cast<const tg_bf16x8_t *>(wl + (b * 32 + c) * P + 16 * s + 8 * h);
-                if constexpr (IN_PL) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, xfr, acc[b], 0, 0, 0);   // D[n][t]
-                else acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xfr, wfr, acc[b], 0, 0, 0);                  // D[t][n]
+            for (int s = 0; s < KS; ++s) {
+                const tg_bf16x8_t xfr = __builtin_bit_cast(tg_bf16x8_t, PREFT ? af[PREFT ? s : 0] : an[s]);
+                if (s % 4 == 3) __builtin_amdgcn_sched_barrier(0);     // keep the weight-fragment reads from piling up
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const tg_bf16x8_t wfr = *reinterpret_cast<const tg_bf16x8_t *>(wl + (b * 32 + c) * P + 16 * s + 8 * h);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xfr, wfr, acc[b], 0, 0, 0);                  // D[t][n]
+                }
+            }
+        } else {
+            // (plane gathers are 48 two-byte loads per lane and k half: issued at the top of their own half -- holding
+            //  more in flight spills at two waves per SIMD; the other resident waves cover the latency)
+#pragma unroll 1
+            for (int s0 = 0; s0 < KS; s0 += KH) {
+                fetch_planes(tile, s0);
+#pragma unroll
+                for (int s = 0; s < KH; ++s) {
+                    const tg_bf16x8_t xfr = __builtin_bit_cast(tg_bf16x8_t, an[s]);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const tg_bf16x8_t wfr =
+                            *reinterpret_cast<const tg_bf16x8_t *>(wl + (b * 32 + c) * P + 16 * (s0 + s) + 8 * h);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, xfr, acc[b], 0, 0, 0);              // D[n][t]
+                    }
+                }
             }
         }
-        const int64_t bi = t0 / L;
-        const int l0 = (int)(t0 - bi * L);
+        // plane stores: the lane's two 8-token runs start at tokens t0 + 8 h and t0 + 16 + 8 h
+        const int64_t ta = t0 + 8 * h, tb = ta + 16, ba = ta / L, bb2 = tb / L;
+        const int64_t oa = ba * OUT * L + (ta - ba * L), ob = bb2 * OUT * L + (tb - bb2 * L);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             uint32_t pk[4][2];
@@ -268,11 +294,14 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
             tg_u32x4_t v0, v1;
             v0[0] = pk[0][0]; v0[1] = pk[0][1]; v0[2] = pk[1][0]; v0[3] = pk[1][1];
             v1[0] = pk[2][0]; v1[1] = pk[2][1]; v1[2] = pk[3][0]; v1[3] = pk[3][1];
-            uint16_t *dst;
-            if constexpr (IN_PL) dst = a.y + (t0 + c) * OUT + 32 * b + 8 * h;                     // token row, 8 channels
-            else dst = a.y + (bi * OUT + 32 * b + c) * L + l0 + 8 * h;                            // channel plane, 8 tokens
-            *reinterpret_cast<tg_u32x4_t *>(dst) = v0;
-            *reinterpret_cast<tg_u32x4_t *>(dst + 16) = v1;
+            if constexpr (IN_PL) {                                                                // token row, 8 channels
+                uint16_t *dst = a.y + (t0 + c) * OUT + 32 * b + 8 * h;
+                *reinterpret_cast<tg_u32x4_t *>(dst) = v0;
+                *reinterpret_cast<tg_u32x4_t *>(dst + 16) = v1;
+            } else {                                                                              // channel plane, 8 tokens
+                *reinterpret_cast<tg_u32x4_t *>(a.y + oa + (int64_t)(32 * b + c) * L) = v0;
+                *reinterpret_cast<tg_u32x4_t *>(a.y + ob + (int64_t)(32 * b + c) * L) = v1;
+            }
         }
     }
 }
@@ -327,13 +356,15 @@ int xfm_tokens_gemm(const void *x, const void *weight_bf16, const float *bias, v
     return XFM_ELIMIT;
 }
 
-int xfm_proj_gemm_supported(int con, int out, int L) { return (con == 96 && out == 96 && L > 0 && L % 32 == 0) ? 1 : 0; }
+int xfm_proj_gemm_supported(int con, int out, int L) {
+    return (((con == 96 && out == 96) || (con == 192 && out == 192)) && L > 0 && L % 8 == 0) ? 1 : 0;
+}
 
 int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, int B, int L, int con, int out,
                   int in_planes, int weight_transposed, void *stream) {
     using namespace xfm;
     if (!x || !weight_bf16 || !y || B <= 0) return XFM_EINVAL;
-    if (!xfm_proj_gemm_supported(con, out, L)) return XFM_ELIMIT;
+    if (!xfm_proj_gemm_supported(con, out, L) || ((int64_t)B * L) % 32 != 0) return XFM_ELIMIT;
     TokGemmArgs a;
     a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(weight_bf16);
@@ -343,6 +374,7 @@ int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, voi
     a.wt = weight_transposed;
     a.L = L;
     hipStream_t s = (hipStream_t)stream;
-    return in_planes ? proj_gemm_launch<96, 96, true>(a, s) : proj_gemm_launch<96, 96, false>(a, s);
+    if (con == 96) return in_planes ? proj_gemm_launch<96, 96, true>(a, s) : proj_gemm_launch<96, 96, false>(a, s);
+    return in_planes ? proj_gemm_launch<192, 192, true>(a, s) : proj_gemm_launch<192, 192, false>(a, s);
 }
 }
