@@ -9,6 +9,8 @@
 // sums + one atomic per workgroup).  HBM-bound: algorithmic bytes = 1 read + 1 write (fwd),
 // 2 reads + 1 write (+ 2 re-reads for dw/db) (bwd).
 #include "xfm_common.hpp"
+#include <type_traits>
+#include <cstdlib>
 
 namespace xfm {
 
@@ -176,6 +178,179 @@ __global__ void __launch_bounds__(1024) ln2d_bwd_dx_cached_kernel(const Tx *__re
     }
 }
 
+// ---- vectorised forms of the two cached kernels for fp32 maps / bf16 outputs (the SS2D out_norm under autocast):
+// a lane owns VP consecutive positions (16- / 8-byte accesses instead of 4- / 2-byte ones), 16 waves split the channels.
+template <int VP> __device__ __forceinline__ void ldv_f32(const float *p, float (&v)[VP]) {
+    if constexpr (VP == 4) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; }
+}
+template <int VP> __device__ __forceinline__ void stv_f32(float *p, const float (&v)[VP]) {
+    if constexpr (VP == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+}
+template <int VP> __device__ __forceinline__ void ldv_bf16(const bf16_t *p, float (&v)[VP]) {
+    uint32_t w[VP / 2];
+    if constexpr (VP == 4) { const uint2 t = *reinterpret_cast<const uint2 *>(p); w[0] = t.x; w[1] = t.y; }
+    else w[0] = *reinterpret_cast<const uint32_t *>(p);
+#pragma unroll
+    for (int i = 0; i < VP / 2; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <int VP> __device__ __forceinline__ void stv_bf16(bf16_t *p, const float (&v)[VP]) {
+    if constexpr (VP == 4) *reinterpret_cast<uint2 *>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    else *reinterpret_cast<uint32_t *>(p) = pack_bf16x2(v[0], v[1]);
+}
+
+template <int CPT, int VP>
+__global__ void __launch_bounds__(1024) ln2d_fwd_vec_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, bf16_t *__restrict__ y,
+                                                            float *__restrict__ mean, float *__restrict__ rstd, int C, int L,
+                                                            int64_t NP, float eps) {
+    constexpr int NW = 16;
+    __shared__ float red[NW][64 * VP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t Pv = (int64_t)blockIdx.x * 64 + lane;
+    const bool ok = Pv < NP;
+    const int64_t P = ok ? Pv * VP : 0;
+    const int b = (int)(P / L), p = (int)(P - (int64_t)b * L);
+    const int64_t o = (int64_t)b * C * L + p;
+    float v[CPT][VP], s[VP];
+#pragma unroll
+    for (int i = 0; i < VP; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        ldv_f32<VP>(x + o + (int64_t)(wave + j * NW) * L, v[j]);
+#pragma unroll
+        for (int i = 0; i < VP; ++i) s[i] += v[j][i];
+    }
+    stv_f32<VP>(&red[wave][lane * VP], s);
+    __syncthreads();
+    float mu[VP];
+#pragma unroll
+    for (int i = 0; i < VP; ++i) mu[i] = 0.f;
+    for (int q = 0; q < NW; ++q) {
+        float t[VP];
+        ldv_f32<VP>(&red[q][lane * VP], t);
+#pragma unroll
+        for (int i = 0; i < VP; ++i) mu[i] += t[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+        mu[i] /= (float)C;
+        s[i] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            v[j][i] -= mu[i];
+            s[i] = fmaf(v[j][i], v[j][i], s[i]);
+        }
+    stv_f32<VP>(&red[wave][lane * VP], s);
+    __syncthreads();
+    float rs[VP];
+#pragma unroll
+    for (int i = 0; i < VP; ++i) rs[i] = 0.f;
+    for (int q = 0; q < NW; ++q) {
+        float t[VP];
+        ldv_f32<VP>(&red[q][lane * VP], t);
+#pragma unroll
+        for (int i = 0; i < VP; ++i) rs[i] += t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i) rs[i] = rsqrtf(rs[i] / (float)C + eps);
+    if (ok) {
+        if (wave == 0) {
+            stv_f32<VP>(mean + (int64_t)b * L + p, mu);
+            stv_f32<VP>(rstd + (int64_t)b * L + p, rs);
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = wave + j * NW;
+            const float wc = w[c], bc = bias ? bias[c] : 0.f;
+            float t[VP];
+#pragma unroll
+            for (int i = 0; i < VP; ++i) t[i] = fmaf(v[j][i] * rs[i], wc, bc);
+            stv_bf16<VP>(y + o + (int64_t)c * L, t);
+        }
+    }
+}
+
+template <int CPT, int VP>
+__global__ void __launch_bounds__(1024) ln2d_bwd_dx_vec_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                               const bf16_t *__restrict__ dy, const float *__restrict__ mean,
+                                                               const float *__restrict__ rstd, float *__restrict__ dx, int C,
+                                                               int L, int64_t NP) {
+    constexpr int NW = 16;
+    __shared__ float red[2][NW][64 * VP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t Pv = (int64_t)blockIdx.x * 64 + lane;
+    const bool ok = Pv < NP;
+    const int64_t P = ok ? Pv * VP : 0;
+    const int b = (int)(P / L), p = (int)(P - (int64_t)b * L);
+    const int64_t o = (int64_t)b * C * L + p;
+    float mu[VP], rs[VP];
+    ldv_f32<VP>(mean + (int64_t)b * L + p, mu);
+    ldv_f32<VP>(rstd + (int64_t)b * L + p, rs);
+    float g[CPT][VP], xh[CPT][VP], s1[VP], s2[VP];
+#pragma unroll
+    for (int i = 0; i < VP; ++i) s1[i] = s2[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = wave + j * NW;
+        const float wc = w[c];
+        ldv_bf16<VP>(dy + o + (int64_t)c * L, g[j]);
+        ldv_f32<VP>(x + o + (int64_t)c * L, xh[j]);
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            g[j][i] *= wc;
+            xh[j][i] = (xh[j][i] - mu[i]) * rs[i];
+            s1[i] += g[j][i];
+            s2[i] = fmaf(g[j][i], xh[j][i], s2[i]);
+        }
+    }
+    stv_f32<VP>(&red[0][wave][lane * VP], s1);
+    stv_f32<VP>(&red[1][wave][lane * VP], s2);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VP; ++i) s1[i] = s2[i] = 0.f;
+    for (int q = 0; q < NW; ++q) {
+        float t1[VP], t2[VP];
+        ldv_f32<VP>(&red[0][q][lane * VP], t1);
+        ldv_f32<VP>(&red[1][q][lane * VP], t2);
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            s1[i] += t1[i];
+            s2[i] += t2[i];
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            float t[VP];
+#pragma unroll
+            for (int i = 0; i < VP; ++i) t[i] = rs[i] * (g[j][i] - s1[i] / (float)C - xh[j][i] * (s2[i] / (float)C));
+            stv_f32<VP>(dx + o + (int64_t)(wave + j * NW) * L, t);
+        }
+    }
+}
+
+// (CPT, VP) of the vectorised kernels for C channels split over 16 waves, or false
+// (16 waves per workgroup cap a thread at 128 registers: 4 positions per lane up to 96 channels, 2 up to 192 / -- forward
+//  only -- 384; the 384-channel backward keeps the scalar kernel)
+static bool ln2d_vec_plan(int C, int L, bool bwd, int &cpt, int &vp) {
+    if (C % 16 != 0) return false;
+    cpt = C / 16;
+    if (cpt != 6 && cpt != 12 && cpt != 24) return false;
+    if (cpt == 24 && bwd) return false;
+    if (cpt != 24 && !bwd) return false;         // measured: the scalar forward is as fast or faster at 96 / 192 channels
+    vp = cpt == 6 ? 4 : 2;
+    return L % vp == 0;
+}
+
 // dw[c] = sum_{b,p} dy * xhat,  db[c] = sum_{b,p} dy;  one workgroup per (channel, batch slice)
 template <typename Tx, typename Ty>
 __global__ void __launch_bounds__(256) ln2d_bwd_wb_kernel(const Tx *__restrict__ x, const Ty *__restrict__ dy,
@@ -224,6 +399,19 @@ template <typename Tx, typename Ty>
 static int ln_fwd(const void *x, const float *w, const float *b, void *y, float *mean, float *rstd, int B, int C, int L,
                   float eps, hipStream_t s) {
     const int tiles = (L + 63) / 64;
+    if constexpr (std::is_same<Tx, float>::value && std::is_same<Ty, bf16_t>::value) {
+        int cpt, vp;
+        if (!getenv("XFM_LN2D_SCALAR") && ln2d_vec_plan(C, L, false, cpt, vp)) {
+            const int64_t NP = (int64_t)B * L / vp;
+            const dim3 grid((unsigned)((NP + 63) / 64)), block(1024);
+            const float *xf = (const float *)x;
+            bf16_t *yb = (bf16_t *)y;
+            if (cpt == 6) hipLaunchKernelGGL((ln2d_fwd_vec_kernel<6, 4>), grid, block, 0, s, xf, w, b, yb, mean, rstd, C, L, NP, eps);
+            else if (cpt == 12) hipLaunchKernelGGL((ln2d_fwd_vec_kernel<12, 2>), grid, block, 0, s, xf, w, b, yb, mean, rstd, C, L, NP, eps);
+            else hipLaunchKernelGGL((ln2d_fwd_vec_kernel<24, 2>), grid, block, 0, s, xf, w, b, yb, mean, rstd, C, L, NP, eps);
+            return check_launch();
+        }
+    }
     if (C % 24 == 0 && C / 24 <= 16) {
         const int NW = C / 24;
         hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 24>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
@@ -243,7 +431,22 @@ template <typename Tx, typename Ty>
 static int ln_bwd(const void *x, const float *w, const void *dy, const float *mean, const float *rstd, void *dx,
                   float *dw, float *db, int B, int C, int L, hipStream_t s) {
     const int tiles = (L + 63) / 64;
-    if (C % 24 == 0 && C / 24 <= 16) {
+    bool done = false;
+    if constexpr (std::is_same<Tx, float>::value && std::is_same<Ty, bf16_t>::value) {
+        int cpt, vp;
+        if (!getenv("XFM_LN2D_SCALAR") && ln2d_vec_plan(C, L, true, cpt, vp)) {
+            const int64_t NP = (int64_t)B * L / vp;
+            const dim3 grid((unsigned)((NP + 63) / 64)), block(1024);
+            const float *xf = (const float *)x;
+            const bf16_t *dyb = (const bf16_t *)dy;
+            float *dxf = (float *)dx;
+            if (cpt == 6) hipLaunchKernelGGL((ln2d_bwd_dx_vec_kernel<6, 4>), grid, block, 0, s, xf, w, dyb, mean, rstd, dxf, C, L, NP);
+            else hipLaunchKernelGGL((ln2d_bwd_dx_vec_kernel<12, 2>), grid, block, 0, s, xf, w, dyb, mean, rstd, dxf, C, L, NP);
+            done = true;
+        }
+    }
+    if (done) {
+    } else if (C % 24 == 0 && C / 24 <= 16) {
         const int NW = C / 24;
         hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 24>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
                            (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
