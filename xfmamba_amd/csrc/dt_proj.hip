@@ -106,7 +106,7 @@ struct DtProjMfmaArgs {
     const bf16_t *w;      // (4, D, R) bf16 (padded to RP = 16 * KS with zeros while it is staged in LDS)
     const float *bias;    // (4*D) or null
     bf16_t *out;          // (B, 4, D, L)
-    int D, R, L, RP, ltiles, dsplit;
+    int D, R, L, RP, ltiles, dsplit, wide;
 };
 
 template <int KS> __global__ __launch_bounds__(256) void dt_proj_mfma_kernel(DtProjMfmaArgs a) {
@@ -145,6 +145,51 @@ template <int KS> __global__ __launch_bounds__(256) void dt_proj_mfma_kernel(DtP
         bf[s] = *reinterpret_cast<const xfm_bf16x8_t *>(t);
     }
     uint16_t *out = reinterpret_cast<uint16_t *>(a.out) + (int64_t)bk * a.D * a.L;
+    if (a.wide) {
+        // Rows are whole 8-position runs: form the product TRANSPOSED (D[pos][d]: the lane owns channel d0 + c and four
+        // consecutive positions per register group), pack to bf16 and let two v_permlane32_swap per pair of groups give
+        // every lane 8 consecutive positions -- 16-byte stores instead of sixteen 2-byte ones per 32 x 32 block.
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const int pa = lt * 32 + 8 * h, pb = pa + 16;               // the lane's two runs
+        for (int dt = t0; dt < t1; ++dt) {
+            const int d0 = dt * 32;
+            xfm_f32x16_t acc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const xfm_bf16x8_t af = *reinterpret_cast<const xfm_bf16x8_t *>(wl + ((dt - t0) * 32 + c) * P + 16 * s + 8 * h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s], af, acc, 0, 0, 0);
+            }
+            const bool act = a.bias != nullptr;
+            const float bv = act ? a.bias[k * a.D + d0 + c] : 0.f;
+            uint32_t pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = act ? softplus20(acc[4 * g + i] + bv) : acc[4 * g + i];
+                pk[g][0] = pack_bf16x2(y[0], y[1]);
+                pk[g][1] = pack_bf16x2(y[2], y[3]);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const u32x2_t r = __builtin_amdgcn_permlane32_swap(pk[g][q], pk[g + 1][q], false, false);
+                    pk[g][q] = r[0];
+                    pk[g + 1][q] = r[1];
+                }
+            u32x4_t v0, v1;
+            v0[0] = pk[0][0]; v0[1] = pk[0][1]; v0[2] = pk[1][0]; v0[3] = pk[1][1];
+            v1[0] = pk[2][0]; v1[1] = pk[2][1]; v1[2] = pk[3][0]; v1[3] = pk[3][1];
+            uint16_t *row = out + (int64_t)(d0 + c) * a.L;
+            if (pa < a.L) *reinterpret_cast<u32x4_t *>(row + pa) = v0;
+            if (pb < a.L) *reinterpret_cast<u32x4_t *>(row + pb) = v1;
+        }
+        return;
+    }
     for (int dt = t0; dt < t1; ++dt) {
         const int d0 = dt * 32;
         xfm_f32x16_t acc;
@@ -177,6 +222,7 @@ static int dt_proj_mfma(const void *xr, const bf16_t *w_padded, const float *bia
     DtProjMfmaArgs a{};
     a.xr = static_cast<const bf16_t *>(xr); a.w = w_padded; a.bias = bias; a.out = static_cast<bf16_t *>(out);
     a.D = D; a.R = R; a.L = L; a.RP = RP;
+    a.wide = (L % 8 == 0 && !getenv("XFM_DTPROJ_NARROW")) ? 1 : 0;
     a.ltiles = ((L + 31) / 32 + 3) / 4;                           // 4 waves = 4 position tiles per workgroup
     int dsplit = 1;
     while ((int64_t)B * 4 * a.ltiles * dsplit < 2048 && dsplit * 2 <= D / 32) dsplit *= 2;
