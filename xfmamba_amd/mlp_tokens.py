@@ -83,6 +83,8 @@ def _skinny_ok(x, w, transposed=False):
     if not _SKINNY or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or not x.is_cuda or not w.is_contiguous():
         return False
     con, out = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    if x.data_ptr() % 16 or w.data_ptr() % 16 or not x.is_contiguous():     # 16-byte vector loads
+        return False
     return x.shape[-1] == con and x.numel() >= con * 4096 and bool(_lib.lib().xfm_tokens_gemm_supported(con, out))
 
 
@@ -107,7 +109,7 @@ class LinearTokens(torch.autograd.Function):
         cd = x.dtype
         w = cast_weight(weight, cd)
         if _skinny_ok(x, w):
-            y = _skinny(x.contiguous(), w, bias, w.shape[0], False)
+            y = _skinny(x, w, bias, w.shape[0], False)
         else:
             y = torch.nn.functional.linear(x, w, None if bias is None else cast_weight(bias, cd))
         ctx.save_for_backward(x, w)

@@ -72,7 +72,8 @@ def _mfma_proj(x, w, bias, in_tokens, out_tokens, transposed):
     B = x.shape[0]
     L, con = (x.shape[1], x.shape[2]) if in_tokens else (x.shape[2], x.shape[1])
     out = w.shape[1] if transposed else w.shape[0]
-    if (w.shape[0] if transposed else w.shape[1]) != con or B * L < 4096 or (B * L) % 32 or not w.is_contiguous():
+    if (w.shape[0] if transposed else w.shape[1]) != con or B * L < 4096 or (B * L) % 32 or not w.is_contiguous() \
+            or not x.is_contiguous() or x.data_ptr() % 16 or w.data_ptr() % 16:              # 16-byte vector accesses
         return None
     lib = _lib.lib()
     if not lib.xfm_proj_gemm_supported(con, out, L):
