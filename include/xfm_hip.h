@@ -215,6 +215,16 @@ int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, voi
                   int in_planes, int weight_transposed, void *stream);
 
 /*
+ * Plane-major on both sides: y (B, out, L) = W . x (B, con, L), or y += W . x when accumulate != 0 (the existing bf16
+ * values are widened, added in fp32 and rounded once).  (con, out) = (96, 32): the x_proj of the four routes evaluated
+ * on the natural map at the 56x56 stage (reference `einsum("b k d l, k c d -> b k c l", xs, x_proj_weight)`,
+ * models/fusion_vmamba.py:1150-1152); (32, 96) with weight_transposed and accumulate: its backward, dx += W^T . d x_dbl.
+ */
+int xfm_planes_gemm_supported(int con, int out, int L);
+int xfm_planes_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, int B, int L, int con, int out,
+                    int weight_transposed, int accumulate, void *stream);
+
+/*
  * Fused SS2D core: y[b,d,p] = sum_k scan_k(...)[b,d,.] gathered back to position p, i.e.
  * cross-scan + 4-route selective scan + cross-merge in ONE kernel; the (B,4,D,L) scan inputs /
  * fp32 scan outputs of the unfused chain never reach HBM.

@@ -722,3 +722,24 @@ def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias, B, L, C)
     assert_close(wd.grad.float().cpu(), wr.grad, 1e-2, 1e-2 * float(wr.grad.abs().max()), "dw")
     if bias:
         assert_close(bd.grad.float().cpu(), br.grad, 1e-2, 1e-2 * float(br.grad.abs().max()), "db")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L", [(4, 3136), (128, 40)])
+def test_planes_gemm_xproj_forward_and_accumulating_backward(B, L):
+    """x_proj on the natural map at the 56x56 stage (planes -> planes, 96 -> 32) and its backward data product
+    dx += W^T . d x_dbl (32 -> 96, accumulate) through xfm_planes_gemm, against fp32 matmuls."""
+    from xfmamba_amd.proj import mfma_planes
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, 96, L, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(32, 96, generator=g) / 96 ** 0.5).to(torch.bfloat16).to(DEV)
+    y = mfma_planes(x, w, 32)
+    assert y is not None and y.shape == (B, 32, L)
+    ref = torch.einsum("mk,bkl->bml", w.float(), x.float())
+    assert_close(y.float().cpu(), ref.cpu(), 1e-2, 1e-2 * float(ref.abs().max()), "x_dbl")
+    dxd = torch.randn(B, 32, L, generator=g).to(torch.bfloat16).to(DEV)
+    dx0 = torch.randn(B, 96, L, generator=g).to(torch.bfloat16).to(DEV)
+    dx = dx0.clone()
+    assert mfma_planes(dxd, w, 96, transposed=True, accumulate_into=dx) is dx
+    ref = dx0.float() + torch.einsum("mk,bml->bkl", w.float(), dxd.float())
+    assert_close(dx.float().cpu(), ref.cpu(), 1e-2, 1e-2 * float(ref.abs().max()), "dx")

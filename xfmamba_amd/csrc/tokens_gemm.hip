@@ -169,11 +169,15 @@ __global__ void __launch_bounds__(512) tokens_gemm_kernel(const TokGemmArgs a) {
 // residency and epilogue; L % 8 == 0 and (B * L) % 32 == 0.
 //   tokens -> planes: D[t][n] (A = token rows, B = weight): a lane owns channel n and, after the swap, 8 consecutive tokens
 //   planes -> tokens: D[n][t] (A = weight, B[k][t] gathered from the planes with 2-byte loads, 64 bytes per wave and k)
-template <int CON, int OUT, bool IN_PL>
+// OUT_PL: plane-major output (lane owns a channel, D[t][n]); otherwise token rows (D[n][t]).  ACC (plane output):
+// y += product, the existing bf16 values widened, added in fp32 and rounded once (x_proj backward adds into dx).
+template <int CON, int OUT, bool IN_PL, bool OUT_PL, bool ACC>
 __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
     constexpr int P = CON + 8;
     constexpr int KS = CON / 16, NB = OUT / 32;
     static_assert(CON % 16 == 0 && OUT % 32 == 0 && KS <= 12 && NB <= 6, "shape");
+    static_assert(IN_PL || OUT_PL, "token rows on both sides: tokens_gemm_kernel");
+    static_assert(!ACC || OUT_PL, "accumulation is implemented for plane-major outputs");
     constexpr int KH = KS > 6 ? KS / 2 : KS;                      // plane gathers: k-steps fetched together (48 loads)
     static_assert(KS % KH == 0, "k halves");
     extern __shared__ __align__(16) uint16_t wl[];
@@ -248,7 +252,7 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     const tg_bf16x8_t wfr = *reinterpret_cast<const tg_bf16x8_t *>(wl + (b * 32 + c) * P + 16 * s + 8 * h);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xfr, wfr, acc[b], 0, 0, 0);                  // D[t][n]
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xfr, wfr, acc[b], 0, 0, 0);                  // D[t][n] (tokens in: planes out)
                 }
             }
         } else {
@@ -264,7 +268,8 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
                     for (int b = 0; b < NB; ++b) {
                         const tg_bf16x8_t wfr =
                             *reinterpret_cast<const tg_bf16x8_t *>(wl + (b * 32 + c) * P + 16 * (s0 + s) + 8 * h);
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, xfr, acc[b], 0, 0, 0);              // D[n][t]
+                        if constexpr (OUT_PL) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xfr, wfr, acc[b], 0, 0, 0);      // D[t][n]
+                        else acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, xfr, acc[b], 0, 0, 0);                 // D[n][t]
                     }
                 }
             }
@@ -278,8 +283,16 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 bv;
-                if constexpr (IN_PL) bv = *reinterpret_cast<const float4 *>(bl + 32 * b + 8 * g + 4 * h);   // per channel
-                else bv.x = bv.y = bv.z = bv.w = bl[32 * b + c];                                            // lane's channel
+                if constexpr (!OUT_PL) bv = *reinterpret_cast<const float4 *>(bl + 32 * b + 8 * g + 4 * h);   // per channel
+                else bv.x = bv.y = bv.z = bv.w = bl[32 * b + c];                                              // lane's channel
+                if constexpr (ACC) {                   // the four tokens t0 + 8 g + 4 h .. + 3 of channel 32 b + c, before the swap
+                    const int64_t tg = t0 + 8 * g + 4 * h, bg = tg / L;
+                    const uint2 old = *reinterpret_cast<const uint2 *>(a.y + (bg * OUT + 32 * b + c) * L + (tg - bg * L));
+                    bv.x += __uint_as_float(old.x << 16);
+                    bv.y += __uint_as_float(old.x & 0xffff0000u);
+                    bv.z += __uint_as_float(old.y << 16);
+                    bv.w += __uint_as_float(old.y & 0xffff0000u);
+                }
                 pk[g][0] = pack_bf16x2(acc[b][4 * g] + bv.x, acc[b][4 * g + 1] + bv.y);
                 pk[g][1] = pack_bf16x2(acc[b][4 * g + 2] + bv.z, acc[b][4 * g + 3] + bv.w);
             }
@@ -294,7 +307,7 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
             tg_u32x4_t v0, v1;
             v0[0] = pk[0][0]; v0[1] = pk[0][1]; v0[2] = pk[1][0]; v0[3] = pk[1][1];
             v1[0] = pk[2][0]; v1[1] = pk[2][1]; v1[2] = pk[3][0]; v1[3] = pk[3][1];
-            if constexpr (IN_PL) {                                                                // token row, 8 channels
+            if constexpr (!OUT_PL) {                                                              // token row, 8 channels
                 uint16_t *dst = a.y + (t0 + c) * OUT + 32 * b + 8 * h;
                 *reinterpret_cast<tg_u32x4_t *>(dst) = v0;
                 *reinterpret_cast<tg_u32x4_t *>(dst + 16) = v1;
@@ -306,10 +319,10 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
     }
 }
 
-template <int CON, int OUT, bool IN_PL>
+template <int CON, int OUT, bool IN_PL, bool OUT_PL = !IN_PL, bool ACC = false>
 static int proj_gemm_launch(const TokGemmArgs &a, hipStream_t s) {
     const size_t lds = (size_t)OUT * (CON + 8) * sizeof(uint16_t) + (size_t)OUT * sizeof(float);
-    auto fn = proj_gemm_kernel<CON, OUT, IN_PL>;
+    auto fn = proj_gemm_kernel<CON, OUT, IN_PL, OUT_PL, ACC>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int64_t ntiles = a.T / 32;
     int grid = (int)std::min<int64_t>((ntiles + 7) / 8, 512);
@@ -376,5 +389,29 @@ int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, voi
     hipStream_t s = (hipStream_t)stream;
     if (con == 96) return in_planes ? proj_gemm_launch<96, 96, true>(a, s) : proj_gemm_launch<96, 96, false>(a, s);
     return in_planes ? proj_gemm_launch<192, 192, true>(a, s) : proj_gemm_launch<192, 192, false>(a, s);
+}
+
+/* planes -> planes: y (B, out, L) (+)= W . x (B, con, L); (con, out) = (96, 32): x_proj of the 56x56 stage on the natural
+ * map; (32, 96) with accumulate != 0: its backward, dx += W^T . d x_dbl. */
+int xfm_planes_gemm_supported(int con, int out, int L) {
+    return (((con == 96 && out == 32) || (con == 32 && out == 96)) && L > 0 && L % 8 == 0) ? 1 : 0;
+}
+
+int xfm_planes_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, int B, int L, int con, int out,
+                    int weight_transposed, int accumulate, void *stream) {
+    using namespace xfm;
+    if (!x || !weight_bf16 || !y || B <= 0) return XFM_EINVAL;
+    if (!xfm_planes_gemm_supported(con, out, L) || ((int64_t)B * L) % 32 != 0) return XFM_ELIMIT;
+    TokGemmArgs a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(weight_bf16);
+    a.bias = bias;
+    a.y = static_cast<uint16_t *>(y);
+    a.T = (int64_t)B * L;
+    a.wt = weight_transposed;
+    a.L = L;
+    hipStream_t s = (hipStream_t)stream;
+    if (con == 96) return accumulate ? proj_gemm_launch<96, 32, true, true, true>(a, s) : proj_gemm_launch<96, 32, true, true, false>(a, s);
+    return accumulate ? proj_gemm_launch<32, 96, true, true, true>(a, s) : proj_gemm_launch<32, 96, true, true, false>(a, s);
 }
 }

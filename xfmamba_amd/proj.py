@@ -16,7 +16,7 @@ import torch
 
 from .amp import cast_weight
 
-__all__ = ["batched_proj", "split_k_wgrad"]
+__all__ = ["batched_proj", "split_k_wgrad", "mfma_planes"]
 
 _F32_OUT = [None]      # does torch.bmm accept out_dtype on this build?  probed once
 
@@ -83,6 +83,30 @@ def _mfma_proj(x, w, bias, in_tokens, out_tokens, transposed):
     with torch.cuda.device(x.device), _lib.timed("proj_gemm", B * L * (con + out) * 2):
         _lib.check(lib.xfm_proj_gemm(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), B, L, con, out,
                                      0 if in_tokens else 1, 1 if transposed else 0, _lib.stream_ptr()), "proj_gemm")
+    return y
+
+
+def mfma_planes(x, w, out, transposed=False, accumulate_into=None):
+    """Plane-major product through ``xfm_planes_gemm``: ``W @ x[b]`` for x (B, con, L) -> (B, out, L); ``w`` is
+    (out, con), or (con, out) with ``transposed``; ``accumulate_into``: add into that (B, out, L) tensor instead.
+    Returns None when the kernel does not cover the call (the caller then uses the library)."""
+    if not _MFMA or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or not x.is_cuda:
+        return None
+    from . import _lib
+    B, con, L = x.shape
+    y = accumulate_into
+    if B * L < 4096 or (B * L) % 32 or not (x.is_contiguous() and w.is_contiguous()) or x.data_ptr() % 16 \
+            or w.data_ptr() % 16 or (y is not None and (not y.is_contiguous() or y.dtype != x.dtype or y.data_ptr() % 16)):
+        return None
+    lib = _lib.lib()
+    if not lib.xfm_planes_gemm_supported(con, out, L):
+        return None
+    if y is None:
+        y = torch.empty(B, out, L, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device), _lib.timed("planes_gemm", B * L * (con + out * (2 if accumulate_into is not None else 1)) * 2):
+        _lib.check(lib.xfm_planes_gemm(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, L, con, out,
+                                       1 if transposed else 0, 0 if accumulate_into is None else 1, _lib.stream_ptr()),
+                   "planes_gemm")
     return y
 
 

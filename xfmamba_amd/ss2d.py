@@ -16,6 +16,7 @@ import torch
 
 from . import _lib
 from .amp import cast_weight
+from .proj import mfma_planes
 
 __all__ = ["ss2d_core_fn", "ss2d_proj_core_fn", "ss2d_xproj_core_fn", "SS2DCoreHip", "SS2DProjCoreHip", "to_route_order"]
 
@@ -130,7 +131,9 @@ class SS2DProjCoreHip(torch.autograd.Function):
             # data gradient is accumulated onto the scan's dx by the GEMM itself (beta = 1), not by a separate add
             x = x.contiguous()
             xw = cast_weight(x_proj_w.reshape(K * C2, Dm), x.dtype)
-            x_dbl = torch.bmm(xw.unsqueeze(0).expand(Bt, K * C2, Dm), x)
+            x_dbl = mfma_planes(x.contiguous(), xw, K * C2)                     # x_proj on MFMA at the 56x56 stage
+            if x_dbl is None:
+                x_dbl = torch.bmm(xw.unsqueeze(0).expand(Bt, K * C2, Dm), x)
         _lib.require_cuda(x_dbl)
         if K != 4 or L != H * W or x_dbl.shape != (Bt, K * C2, L) or x_dbl.dtype != x.dtype:
             raise RuntimeError("ss2d_proj_core: x (B,D,H*W), x_dbl (B,4*(R+2N),H*W) of one dtype, dt_w (4,D,R) expected")
@@ -224,7 +227,8 @@ class SS2DProjCoreHip(torch.autograd.Function):
         if xw is None:
             return dx, dxd, None, dw.to(ctx.wdtype), dA, dD, dbias, None, None
         KC2 = xw.shape[0]
-        dx.baddbmm_(xw.t().unsqueeze(0).expand(Bt, Dm, KC2), dxd)                      # dx += Wx^T @ d x_dbl
+        if mfma_planes(dxd, xw, Dm, transposed=True, accumulate_into=dx) is None:
+            dx.baddbmm_(xw.t().unsqueeze(0).expand(Bt, Dm, KC2), dxd)                  # dx += Wx^T @ d x_dbl
         dxw = _bmm_f32(dxd, x.transpose(1, 2)).sum(0).view(ctx.xw_meta[1]).to(ctx.xw_meta[0])
         return dx, None, dxw, dw.to(ctx.wdtype), dA, dD, dbias, None, None
 
