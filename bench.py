@@ -250,6 +250,8 @@ def main():
                 metric_name = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
             except Exception:                                   # noqa: BLE001
                 pass
+        cfg_label = {("tiny", 224, 32, "bf16"): " (BASELINE configs[1])", ("small", 224, 32, "bf16"): " (BASELINE configs[2], one GPU of it)",
+                     ("base", 384, 16, "bf16"): " (BASELINE configs[3])"}.get((a.model, a.size, B, a.dtype), "")
         roof = None
         kernels = {}
         if timer is not None:
@@ -262,14 +264,21 @@ def main():
                 ach = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9
                 # HBM bytes per launch from the PMC counters of this very command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
                 # separate --pmc passes; MI355X_MICROARCH.md "HBM"): measured offline, committed under profiles/
-                traffic = None
+                traffic, traffic_source = None, None
                 try:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                    traffic = tj.get(name + "_lean_kernel", {}).get("hbm_bytes_per_launch")
+                    import glob
+                    tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+                    tj = json.load(open(tf))
+                    ent = tj.get(name + "_kernel") or tj.get(name + "_lean_kernel") or {}
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    if traffic is not None:
+                        traffic_source = (f"offline rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE), "
+                                          f"profiles/{os.path.basename(tf)}" + (f" @ {tj['commit']}" if "commit" in tj else ""))
                 except Exception:      # noqa: BLE001
                     pass
                 roof = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, launches=k["launches"],
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
+                            launches=k["launches"],
                             avg_launch_us=round(k["avg_us"], 2),
                             algorithmic_bytes_per_launch=int(k["bytes"] / k["launches"]))
         line = {
@@ -278,7 +287,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"XFMamba-{a.model[0].upper()} ({a.dtype}), 2x{a.size}x{a.size}, batch {B}/GPU, "
-                                   f"fwd+bwd+Adam, train mode (BASELINE configs[1])",
+                                   f"fwd+bwd+Adam, train mode" + cfg_label,
+                       "note": "outnorm0-2 of the trunk are skipped: the reference computes them and discards the "
+                               "results (net_fusionmamba.py:200-201); they carry no gradient",
                        "global_batch": B * world, "parallelism": f"dp{world}", "ss2d_mode": fusion_vmamba.SS2D_MODE,
                        "single_view_images_per_s": round(2 * value, 2)},
             "roofline": roof,

@@ -16,6 +16,9 @@ Groups:
   g5  TwoViewXFMambaTop(type='tiny') at 2x224^2, batch 2, synthetic weights from
       ``xfm_oracle.synth_state_dict``: logits, CE loss, per-parameter gradient statistics;
       plus the state_dict key->shape tables of the tiny/small/base models
+  g5s TwoViewXFMambaTop(type='small') at 2x224^2, batch 2 (BASELINE configs[2], net_fusionmamba.py:151-153)
+  g5b TwoViewXFMambaTop(type='base', hidden_dim=1024) at 2x384^2, batch 1 (BASELINE configs[3],
+      net_fusionmamba.py:154-156, 1_train_model.py:127): same record as g5
 """
 import argparse
 import json
@@ -209,9 +212,63 @@ def gen_g5(net, fv):
     print("g5 train logits", logits_tr, "loss", float(loss), "no-grad params", nograd)
 
 
+_G5X_GRADS = ("classifier.head.weight", "final_conv.bias",
+              "fusemamba.blocks.0.self_attention.dt_projs_bias",
+              "fusemamba.blocks.0.self_attention.x_proj_weight",
+              "shallow_mamba_fusion.shallowfuseSS2D.fc1.0.weight",
+              "mamba_feature_extrac.layers.0.blocks.0.op.x_proj_weight",
+              "mamba_feature_extrac.layers.0.blocks.0.op.dt_projs_weight",
+              "mamba_feature_extrac.layers.1.blocks.1.op.A_logs",
+              "mamba_feature_extrac.layers.2.blocks.7.op.dt_projs_bias",
+              "mamba_feature_extrac.layers.2.blocks.14.op.out_norm.weight",
+              "mamba_feature_extrac.layers.3.blocks.1.op.Ds",
+              "mamba_feature_extrac.patch_embed.0.weight")
+
+
+def gen_g5x(net, ty, kw, size, batch, tag):
+    """Same record as g5 for the other BASELINE model sizes (weights from synth_state_dict, DropPath off)."""
+    shapes = json.load(open(os.path.join(OUT, "g5_state_shapes.json")))[ty]
+    m = net.TwoViewXFMambaTop(in_channels=1, outputs=2, type=ty, **kw)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == shapes
+    m.load_state_dict(synth_state_dict(shapes, seed=0), strict=True)
+    xa, xb, lab = g5_inputs(batch, size)
+    m.eval()
+    with torch.no_grad():
+        logits_eval = m(xa, xb)
+    print(tag, "eval logits", logits_eval)
+    m.train()
+    for mod in m.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    m.zero_grad()
+    logits_tr = m(xa, xb)
+    loss = torch.nn.functional.cross_entropy(logits_tr, lab)
+    loss.backward()
+    store = dict(logits_eval=_np(logits_eval), logits_train=_np(logits_tr), loss=_np(loss))
+    names, stats, nograd = [], [], []
+    params = dict(m.named_parameters())
+    for k, p in params.items():
+        if p.grad is None:
+            nograd.append(k)
+            continue
+        gk = p.grad.double()
+        names.append(k)
+        stats.append([float(gk.sum()), float(gk.abs().sum()), float(gk.norm()), float(gk.reshape(-1)[0])])
+    store["grad_stats"] = np.asarray(stats, dtype=np.float64)
+    for k in _G5X_GRADS:
+        store["grad/" + k] = _np(params[k].grad)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            store["bn_after/" + k] = _np(v)
+    np.savez_compressed(os.path.join(OUT, f"{tag}_model.npz"), **store)
+    json.dump(dict(grad_names=names, no_grad=nograd, type=ty, kwargs=kw, size=size, batch=batch),
+              open(os.path.join(OUT, f"{tag}_grad_names.json"), "w"), indent=0)
+    print(tag, "train logits", logits_tr, "loss", float(loss), "no-grad params", nograd)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g1,g2,g3,g4,g5")
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g5s,g5b")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     cs, ct, fv, net = _refshim.load()
@@ -226,6 +283,10 @@ def main():
         gen_g4(fv)
     if "g5" in only:
         gen_g5(net, fv)
+    if "g5s" in only:
+        gen_g5x(net, "small", {}, 224, 2, "g5s")
+    if "g5b" in only:
+        gen_g5x(net, "base", dict(hidden_dim=1024), 384, 1, "g5b")
 
 
 if __name__ == "__main__":

@@ -149,12 +149,60 @@ def test_vss_stage_tokens_stream_drop_path_matches_planes():
         assert_close(gt[k], gp[k], 2e-3, 2e-4 * float(gp[k].abs().max()) + 1e-8, f"d{k}")
 
 
-def _tiny_with_synth_weights():
+# BASELINE.json model sizes: (golden tag, type, ctor kwargs, image size, batch) -- net_fusionmamba.py:150-159
+MODEL_CFGS = {
+    "tiny": ("g5", "tiny", {}, 224, 2),                                   # configs[0]/[1]
+    "small": ("g5s", "small", {}, 224, 2),                                # configs[2]
+    "base384": ("g5b", "base", dict(hidden_dim=1024), 384, 1),            # configs[3]
+}
+
+
+def _model_with_synth_weights(ty="tiny", kw=None):
     from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
-    shapes = load_json("g5_state_shapes.json")["tiny"]
-    m = TwoViewXFMambaTop(in_channels=1, outputs=2, type="tiny")
+    shapes = load_json("g5_state_shapes.json")[ty]
+    m = TwoViewXFMambaTop(in_channels=1, outputs=2, type=ty, **(kw or {}))
     m.load_state_dict(O.synth_state_dict(shapes, seed=0), strict=True)
     return m.to(DEV)
+
+
+def _tiny_with_synth_weights():
+    return _model_with_synth_weights("tiny")
+
+
+def _check_model_against_golden(m, tag, size, batch, tol_logits, tol_gnorm, tol_grad, autocast=False):
+    """eval logits, train logits, CE loss, which parameters get a gradient, every parameter-gradient norm, sampled
+    gradients and the BatchNorm buffers of a whole TwoViewXFMambaTop vs the record of the real reference."""
+    z = load_npz(f"{tag}_model.npz")
+    names = load_json(f"{tag}_grad_names.json")
+    xa, xb, lab = (t.to(DEV) for t in g5_inputs(batch, size))
+    ac = dict(device_type="cuda", dtype=torch.bfloat16, enabled=autocast)
+    m.eval()
+    with torch.no_grad(), torch.autocast(**ac):
+        logits = m(xa, xb)
+    ref = torch.from_numpy(z["logits_eval"])
+    assert_close(logits.float().cpu(), ref, tol_logits, tol_logits * float(ref.abs().max()), "eval logits")
+    m.train()
+    for mod in m.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    with torch.autocast(**ac):
+        out = m(xa, xb)
+    ref = torch.from_numpy(z["logits_train"])
+    assert_close(out.detach().float().cpu(), ref, tol_logits, tol_logits * float(ref.abs().max()), "train logits")
+    loss = torch.nn.functional.cross_entropy(out.float(), lab)
+    assert abs(float(loss.detach()) - float(z["loss"])) < 2 * tol_logits * max(1.0, float(ref.abs().max()))
+    loss.backward()
+    params = dict(m.named_parameters())
+    assert sorted(k for k, p in params.items() if p.grad is None) == sorted(names["no_grad"])
+    for k, row in zip(names["grad_names"], z["grad_stats"]):
+        gn = float(params[k].grad.double().norm())
+        assert abs(gn - row[2]) <= tol_gnorm * row[2] + 1e-6, (k, gn, row[2])
+    for k in z.files:
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(z[k])
+            assert_close(params[k[5:]].grad.float().cpu(), ref, tol_grad, 0.4 * tol_grad * float(ref.abs().max()) + 1e-8, k)
+        if k.startswith("bn_after/") and not autocast:
+            assert_close(m.state_dict()[k[9:]].cpu(), torch.from_numpy(z[k]), 1e-4, 1e-5, k)
 
 
 @pytest.mark.parametrize("mode,layout", [("unfused", "planes"), ("fused", "planes"), ("fused", "tokens")])
@@ -198,6 +246,32 @@ def test_model_tiny_fp32_matches_reference_golden(mode, layout, merge_views):
                 assert_close(m.state_dict()[k[9:]].cpu(), torch.from_numpy(z[k]), 1e-4, 1e-5, k)
     finally:
         fv.SS2D_MODE, fv.STREAM_LAYOUT = old, old_layout
+
+
+@pytest.mark.parametrize("cfg", ["small", "base384"])
+@pytest.mark.parametrize("layout", ["tokens", "planes"])
+def test_model_small_base_fp32_match_reference_golden(cfg, layout):
+    """BASELINE configs[2] (XFMamba-S, 2x224^2) and configs[3] (XFMamba-B hidden_dim=1024, 2x384^2: 96x96 ... 12x12
+    maps, d_inner 256 ... 2048) in fp32 against records of the real reference: other d_inner / dt_rank / map sizes
+    select other plans of the fused scan, other GEMM kernels and the L = 9216 chunked rows."""
+    from xfmamba_amd import fusion_vmamba as fv
+    tag, ty, kw, size, batch = MODEL_CFGS[cfg]
+    old = fv.STREAM_LAYOUT
+    fv.STREAM_LAYOUT = layout
+    try:
+        m = _model_with_synth_weights(ty, kw)
+        _check_model_against_golden(m, tag, size, batch, 1e-3, 5e-3, 5e-3)
+    finally:
+        fv.STREAM_LAYOUT = old
+
+
+@pytest.mark.parametrize("cfg", ["small", "base384"])
+def test_model_small_base_bf16_autocast(cfg):
+    """The bench configuration (bf16 autocast, bf16 scan I/O) of configs[2]/[3]: every kernel of the bf16 path at
+    these widths, whole-model logits within the end-to-end bf16 bound, gradients finite and of the right scale."""
+    tag, ty, kw, size, batch = MODEL_CFGS[cfg]
+    m = _model_with_synth_weights(ty, kw)
+    _check_model_against_golden(m, tag, size, batch, 3e-2, 0.35, 0.5, autocast=True)
 
 
 def test_model_tiny_bf16_autocast_within_tolerance():

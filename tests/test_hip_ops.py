@@ -575,7 +575,8 @@ def test_dt_proj_kernels_match_torch_fp32(B, D, R, H, with_bias):
             assert_close(out2.float().cpu(), ref, tol, tol * float(ref.abs().max()), "MFMA bf16")
 
 
-@pytest.mark.parametrize("B,D,R,H", [(2, 96, 6, 56), (2, 192, 12, 28), (3, 384, 24, 14), (2, 64, 5, 10)])
+@pytest.mark.parametrize("B,D,R,H", [(2, 96, 6, 56), (2, 192, 12, 28), (3, 384, 24, 14), (2, 64, 5, 10),
+                                     (1, 1024, 32, 24)])      # XFMamba-B stage 2: 66 KB of LDS (opt-in above 64 KB)
 def test_dt_proj_backward_mfma_matches_torch_fp32(B, D, R, H):
     """Backward of dt_proj on MFMA (bf16): data gradient W^T.ddts and weight gradient sum_{b,l} ddts.xr^T vs fp32."""
     from xfmamba_amd import _lib

@@ -126,3 +126,25 @@ def test_weight_cache_serves_current_shadows_only():
     assert cast_weight(lin.weight, torch.bfloat16).data_ptr() == a.data_ptr()
     cache.close()
     assert cast_weight(lin.weight, torch.bfloat16).data_ptr() != a.data_ptr()
+
+
+def test_weight_cache_serves_current_shadows_only():
+    """amp.WeightCache: a shadow is served while the parameter is unchanged, dropped after an in-place update of the
+    parameter, and -- the `.data` caveat -- must be invalidated explicitly after a write through ``p.data``."""
+    from xfmamba_amd.amp import WeightCache, cast_weight, invalidate_shadows
+    m = torch.nn.Linear(8, 4)
+    wc = WeightCache(m, torch.bfloat16)
+    s = cast_weight(m.weight, torch.bfloat16)
+    assert s.data_ptr() == wc.shadows[0].data_ptr()                       # served from the cache
+    assert cast_weight(m.weight.view(2, 16), torch.bfloat16).data_ptr() == s.data_ptr()     # reshaped view too
+    with torch.no_grad():
+        m.weight.fill_(3.0)                                               # version bump -> fresh cast
+    assert float(cast_weight(m.weight, torch.bfloat16).float().mean()) == 3.0
+    wc.refresh()
+    assert cast_weight(m.weight, torch.bfloat16).data_ptr() == wc.shadows[0].data_ptr()
+    m.weight.data.fill_(7.0)                                              # invisible to the version check ...
+    invalidate_shadows(m)                                                 # ... so writers through .data must invalidate
+    assert float(cast_weight(m.weight, torch.bfloat16).float().mean()) == 7.0
+    wc.refresh()
+    assert float(cast_weight(m.weight, torch.bfloat16).float().mean()) == 7.0
+    wc.close()

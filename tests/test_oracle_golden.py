@@ -167,3 +167,34 @@ def test_model_tiny_matches_reference_eval_and_train():
             assert_close(params[k[5:]].grad, ref, 2e-3, 2e-4 * float(ref.abs().max()) + 1e-8, k)
         if k.startswith("bn_after/"):
             assert_close(sd[k[9:]], torch.from_numpy(z[k]), 1e-4, 1e-6, k)
+
+
+@pytest.mark.parametrize("tag,ty", [("g5s", "small"), ("g5b", "base")])
+def test_model_small_base_match_reference(tag, ty):
+    """G5s / G5b: TwoViewXFMambaTop(type='small') at 2x224^2 batch 2 and (type='base', hidden_dim=1024) at 2x384^2
+    batch 1 (BASELINE configs[2], [3]; net_fusionmamba.py:150-156): the oracle vs the record of the real reference."""
+    shapes = load_json("g5_state_shapes.json")[ty]
+    z = load_npz(f"{tag}_model.npz")
+    names = load_json(f"{tag}_grad_names.json")
+    sd = O.synth_state_dict(shapes, seed=0)
+    xa, xb, lab = g5_inputs(names["batch"], names["size"])
+    with torch.no_grad():
+        logits = O.xfmamba_top_ref(dict(sd), xa, xb, False, c_scan.selective_scan_c)
+    ref = torch.from_numpy(z["logits_eval"])
+    assert_close(logits, ref, 1e-3, 1e-4 * float(ref.abs().max()), "eval logits")
+    params = {k: v.requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    sd.update(params)
+    out = O.xfmamba_top_ref(sd, xa, xb, True, c_scan.selective_scan_c)
+    ref = torch.from_numpy(z["logits_train"])
+    assert_close(out, ref, 1e-3, 1e-4 * float(ref.abs().max()), "train logits")
+    loss = torch.nn.functional.cross_entropy(out, lab)
+    assert abs(float(loss) - float(z["loss"])) < 1e-3
+    loss.backward()
+    assert sorted(k for k, v in params.items() if v.grad is None) == sorted(names["no_grad"])
+    for k, row in zip(names["grad_names"], z["grad_stats"]):
+        g = params[k].grad.double()
+        assert abs(float(g.norm()) - row[2]) <= 2e-3 * row[2] + 1e-7, (k, float(g.norm()), row[2])
+    for k in z.files:
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(z[k])
+            assert_close(params[k[5:]].grad, ref, 2e-3, 2e-4 * float(ref.abs().max()) + 1e-8, k)

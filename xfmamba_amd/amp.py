@@ -4,8 +4,14 @@ Under autocast every weight is cast fp32 -> bf16 by its own small kernel on ever
 XFMamba-T).  ``WeightCache`` keeps one bf16 copy per parameter and refreshes ALL of them with a single multi-tensor
 copy after the optimizer step; the hand-written projection / Mlp nodes (``proj.py``, ``mlp_tokens.py``) pick the copy
 up through ``cast_weight``.  A copy is only used while the parameter's version counter still equals the one recorded
-at refresh time, so a stale shadow can never be read: after any in-place update that was not followed by
-``refresh()`` the cast silently falls back to ``weight.to(dtype)``.
+at refresh time: after an in-place update OF THE PARAMETER that was not followed by ``refresh()`` the cast falls back to
+``weight.to(dtype)``.
+
+Caveat: writes through ``p.data`` (``p.data.copy_()``, ``dist.broadcast(p.data)``, EMA / clipping code that goes
+through ``.data``) do NOT bump the version counter of ``p``, so they are invisible to that check.  Code that writes
+weights that way must call ``WeightCache.refresh()`` or ``invalidate_shadows()`` afterwards; this package's own
+writers do (``dp.broadcast_parameters`` mutates the parameter itself under ``no_grad`` and invalidates;
+``load_state_dict`` copies into the parameter, which bumps the version).
 """
 from __future__ import annotations
 
@@ -13,7 +19,7 @@ import weakref
 
 import torch
 
-__all__ = ["WeightCache", "cast_weight"]
+__all__ = ["WeightCache", "cast_weight", "invalidate_shadows"]
 
 _SHADOWS = {}          # id(parameter) -> (weakref(parameter), shadow tensor, version at refresh)
 
@@ -32,6 +38,16 @@ def cast_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
             if w.is_contiguous() and w.numel() == src.numel() and src.is_contiguous():
                 return shadow.view(w.shape)
     return w.to(dtype)
+
+
+def invalidate_shadows(module: torch.nn.Module = None) -> None:
+    """Forget the registered shadows (of ``module``'s parameters, or all): the next ``cast_weight`` re-casts from the
+    fp32 master until ``WeightCache.refresh()`` registers fresh copies.  For code that wrote weights through ``.data``."""
+    if module is None:
+        _SHADOWS.clear()
+        return
+    for p in module.parameters():
+        _SHADOWS.pop(id(p), None)
 
 
 class WeightCache:

@@ -230,6 +230,7 @@ static int dt_proj_mfma(const void *xr, const bf16_t *w_padded, const float *bia
     const dim3 grid((unsigned)((int64_t)B * 4 * a.ltiles * dsplit));
     const int dper = (D / 32 + dsplit - 1) / dsplit;
     const size_t lds = (size_t)dper * 32 * (RP + 8) * sizeof(uint16_t);
+    if (lds > 64 * 1024) return XFM_ELIMIT;
     if (RP == 16) hipLaunchKernelGGL((dt_proj_mfma_kernel<1>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((dt_proj_mfma_kernel<2>), grid, dim3(256), lds, s, a);
     return check_launch();
@@ -364,6 +365,15 @@ int xfm_ss2d_dt_proj_bwd_mfma(const void *ddts, const void *xr, const void *weig
     a.D = D; a.R = R; a.L = L;
     a.ltiles = ((L + 31) / 32 + 3) / 4;
     const size_t lds = (size_t)32 * (D + 8) * sizeof(uint16_t);
+    if (lds > 64 * 1024) {                                        // D = 1024 (XFMamba-B stage 2): 66 048 B, opt in
+        static bool once = false;
+        if (!once) {
+            if (hipFuncSetAttribute((const void *)dt_proj_bwd_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess)
+                return XFM_ELAUNCH;
+            once = true;
+        }
+    }
     hipLaunchKernelGGL(dt_proj_bwd_dx_kernel, dim3((unsigned)((int64_t)B * 4 * a.ltiles)), dim3(256), lds, s, a);
     int rc = check_launch();
     if (rc != XFM_OK) return rc;

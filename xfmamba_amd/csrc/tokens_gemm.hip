@@ -28,7 +28,7 @@ struct TokGemmArgs {
     uint16_t *y;            // (T, OUT) bf16
     int64_t T;
     int wt;
-    int L;                  // layout-changing variants: tokens per sample (planes are (B, C, L)), L % 32 == 0
+    int L;                  // layout-changing variants: tokens per sample (planes are (B, C, L)); L % 8 == 0 && (B*L) % 32 == 0
 };
 
 template <int CON, int OUT, int OB>       // OB: output columns processed per pass (accumulators OB/32 x 16 registers)

@@ -24,8 +24,14 @@ __all__ = ["GradBuckets", "broadcast_parameters", "broadcast_buffers"]
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
-    for p in module.parameters():
-        dist.broadcast(p.data, src)
+    """Rank ``src``'s weights to every rank.  The parameter itself is the collective's output (under ``no_grad``), so
+    its version counter moves and low-precision weight shadows (``amp.WeightCache``) of the old values are not
+    served afterwards; they are dropped explicitly as well."""
+    from .amp import invalidate_shadows
+    with torch.no_grad():
+        for p in module.parameters():
+            dist.broadcast(p, src)
+    invalidate_shadows(module)
 
 
 def broadcast_buffers(module: torch.nn.Module, src: int = 0) -> None:

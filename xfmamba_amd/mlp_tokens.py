@@ -75,7 +75,8 @@ def bias_gelu_fn(z, bias=None):
     return BiasGeluHip.apply(z, bias)
 
 
-_SKINNY = os.environ.get("XFM_TOKENS_GEMM", "1") == "1"     # XFM_TOKENS_GEMM=0: library GEMMs everywhere
+# XFM_TOKENS_GEMM=0: library GEMMs everywhere.  Read ONCE at import: set it before importing xfmamba_amd.
+_SKINNY = os.environ.get("XFM_TOKENS_GEMM", "1") == "1"
 
 
 def _skinny_ok(x, w, transposed=False):

@@ -60,12 +60,14 @@ def split_k_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     return _bmm_f32(dy2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0)
 
 
-_MFMA = os.environ.get("XFM_TOKENS_GEMM", "1") == "1"     # XFM_TOKENS_GEMM=0: library GEMMs everywhere
+# XFM_TOKENS_GEMM=0: library GEMMs everywhere.  Read ONCE at import: set it before importing xfmamba_amd.
+_MFMA = os.environ.get("XFM_TOKENS_GEMM", "1") == "1"
 
 
 def _mfma_proj(x, w, bias, in_tokens, out_tokens, transposed):
     """The layout-changing projection through ``xfm_proj_gemm`` (csrc/tokens_gemm.hip), or None when it does not cover
-    the call: bf16, exactly one plane-major side, widths built, L % 32 == 0.  ``transposed``: ``w`` is (con, out)."""
+    the call: bf16, exactly one plane-major side, widths built, contiguous 16-byte aligned operands,
+    L % 8 == 0 and (B * L) % 32 == 0 (the kernel's own guard; samples may end inside 32-token tiles).  ``transposed``: ``w`` is (con, out)."""
     if not _MFMA or in_tokens == out_tokens or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or not x.is_cuda:
         return None
     from . import _lib
