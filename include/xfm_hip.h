@@ -266,6 +266,47 @@ int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, int in_dtype
 int xfm_ss2d_fwd(const xfm_ss2d_params_t *p, void *stream);
 int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream);
 
+/*
+ * "Channel-lane" fused SS2D core for short square maps (5x5 ... 14x14; csrc/ss2d_chan.hip): x_proj output ->
+ * dt_proj (MFMA, in-kernel) -> softplus -> n_routes-way selective scan -> cross-merge, forward and backward, so that the
+ * (B,4,D,L) step-size tensor of `forward_corev2` (reference models/fusion_vmamba.py:1150-1172; fusion blocks :490-540,
+ * :813-833) never exists.  One lane owns one channel and walks the sequence; the two halves of a wavefront are two samples.
+ *   x      (batch, d_inner, L) bf16 planes, natural order (the depthwise-conv + SiLU output).
+ *   xdbl   (batch, L, n_routes*C2p) bf16 TOKEN-MAJOR x_proj output evaluated on the natural map.  Route k owns columns
+ *          [k*C2p, (k+1)*C2p), C2p = Rp8 + (dstate == 1 ? 8 : 2*dstate), Rp8 = dt_rank rounded up to 8:
+ *          [0, dt_rank) dt_proj input, [Rp8, Rp8+dstate) B, then C at Rp8+1 (dstate 1) or Rp8+dstate; other columns 0.
+ *   wdt    (n_sets, d_inner, Kp) bf16 dt_proj weight (reference dt_projs_weight (K, D, R)) zero-padded to Kp = dt_rank
+ *          rounded up to 16.  n_sets = 4 with n_routes == 4 (route k uses set k); with n_routes == 1 (one forward
+ *          row-major route per sample: the two views of the shallow swap block as 2B samples) sample sb uses set sb / wdiv.
+ *   A (n_sets*d_inner, dstate), D / delta_bias (n_sets*d_inner) fp32.
+ *   c_mod > 0: sample sb reads its C columns from sample c_off + sb % c_mod (deep fusion block: the view streams read
+ *          their state through the fused stream's C, reference :536-538, :567-569) and its dC is added there.
+ *   y      (batch, d_inner, L) fp32 = sum over the routes, gathered back to natural order (n_routes == 1: that route).
+ *   chk    (batch, n_routes, xfm_ss2dc_nsteps(), dstate, d_inner) fp32 workspace written by fwd, read by bwd.
+ * backward: dy (batch, d_inner, L) fp32 -> dx (batch, d_inner, L) bf16; ddts (batch, n_routes, L, d_inner) bf16 = gradient
+ *   of the RAW step size (before bias + softplus), natural position order, channel fastest; dBC (batch, n_routes, 2,
+ *   dstate, L) fp32 ZEROED: gradients of the B (index 0) and C (index 1) columns, natural order; dA, dD, ddelta_bias fp32
+ *   ZEROED.  The dt_proj / x_proj weight gradients and d xdbl follow from ddts and dBC by dense products (host side).
+ * Supported: H == W in {7, 12, 14} with dstate 1 (n_routes 4); H == W in {5, 7, 12} with dstate 16 (n_routes 4 or 1);
+ * d_inner % 32 == 0; dt_rank <= 64.  xfm_ss2dc_supported() tells.
+ */
+typedef struct {
+    int batch, d_inner, H, W, dstate, dt_rank, n_routes;
+    int c_mod, c_off, wdiv;
+    const void *x, *xdbl, *wdt;
+    const void *zeros;     /* >= 256 bytes of zeros, 16-byte aligned (k-slots of the sibling route in the stacked product) */
+    const float *A, *D, *delta_bias;
+    void *y;
+    float *chk;
+    const void *dy;
+    void *dx, *ddts;
+    float *dBC, *dA, *dD, *ddelta_bias;
+} xfm_ss2dc_params_t;
+int xfm_ss2dc_supported(int H, int W, int dstate, int n_routes, int d_inner, int dt_rank);
+int xfm_ss2dc_nsteps(int H, int W);
+int xfm_ss2dc_fwd(const xfm_ss2dc_params_t *p, void *stream);
+int xfm_ss2dc_bwd(const xfm_ss2dc_params_t *p, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ SYMBOLS = (
     "xfm_add_layernorm_rows_supported", "xfm_add_layernorm_rows_bwd_blocks", "xfm_add_layernorm_rows_fwd",
     "xfm_add_layernorm_rows_bwd", "xfm_colsum_blocks", "xfm_bias_gelu_fwd", "xfm_bias_gelu_bwd", "xfm_colsum", "xfm_tokens_gemm_supported", "xfm_tokens_gemm", "xfm_proj_gemm_supported", "xfm_proj_gemm", "xfm_planes_gemm_supported", "xfm_planes_gemm",
     "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd",
+    "xfm_ss2dc_supported", "xfm_ss2dc_nsteps", "xfm_ss2dc_fwd", "xfm_ss2dc_bwd",
 )
 
 
@@ -64,6 +65,17 @@ class SS2DParams(C.Structure):
     ]
 
 
+class SS2DCParams(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int), ("d_inner", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dstate", C.c_int),
+        ("dt_rank", C.c_int), ("n_routes", C.c_int), ("c_mod", C.c_int), ("c_off", C.c_int), ("wdiv", C.c_int),
+        ("x", C.c_void_p), ("xdbl", C.c_void_p), ("wdt", C.c_void_p), ("zeros", C.c_void_p),
+        ("A", C.c_void_p), ("D", C.c_void_p), ("delta_bias", C.c_void_p),
+        ("y", C.c_void_p), ("chk", C.c_void_p), ("dy", C.c_void_p), ("dx", C.c_void_p), ("ddts", C.c_void_p),
+        ("dBC", C.c_void_p), ("dA", C.c_void_p), ("dD", C.c_void_p), ("ddelta_bias", C.c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -92,6 +104,11 @@ def lib() -> C.CDLL:
         for fn in (l.xfm_ss2d_fwd, l.xfm_ss2d_bwd):
             fn.argtypes = [C.POINTER(SS2DParams), C.c_void_p]
             fn.restype = C.c_int
+        for fn in (l.xfm_ss2dc_fwd, l.xfm_ss2dc_bwd):
+            fn.argtypes = [C.POINTER(SS2DCParams), C.c_void_p]
+            fn.restype = C.c_int
+        l.xfm_ss2dc_supported.argtypes = [C.c_int] * 6
+        l.xfm_ss2dc_nsteps.argtypes = [C.c_int] * 2
         l.xfm_cross_scan.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
         l.xfm_cross_merge.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         l.xfm_swap_scan.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]

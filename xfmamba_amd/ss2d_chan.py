@@ -1,0 +1,156 @@
+"""Channel-lane fused SS2D core for short maps (``xfm_ss2dc_fwd/_bwd``, ``csrc/ss2d_chan.hip``).
+
+One autograd node for ``x_proj -> split -> dt_proj -> softplus -> 4-route selective scan -> cross-merge`` of
+``SS2Dv2.forward_corev2`` (reference ``models/fusion_vmamba.py:1145-1174``) on maps of at most 14 x 14: the x_proj of all
+routes is one dense GEMM on the natural map whose result is kept TOKEN-MAJOR ``(B, L, 4*C2p)`` (padded so every operand
+block starts on a 16-byte boundary); dt_proj runs on MFMA inside the scan kernel, which therefore never reads or writes a
+``(B, 4, D, L)`` step-size tensor.  The backward kernel returns ``dx``, the gradient of the raw step size (bf16, token-major,
+consumed by two small dense products for ``d x_dbl`` and the dt_proj weight gradient) and the B / C column gradients.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from .amp import cast_weight
+
+__all__ = ["ss2d_chan_fn", "chan_supported", "SS2DChanHip"]
+
+ENABLED = os.environ.get("XFM_SS2D_CHAN", "1") == "1"       # read once at import (A/B switch of the benches)
+
+
+def chan_supported(x: torch.Tensor, H: int, W: int, N: int, n_routes: int, D: int, R: int) -> bool:
+    return bool(ENABLED and x.is_cuda and x.dtype == torch.bfloat16
+                and _lib.lib().xfm_ss2dc_supported(H, W, N, n_routes, D, R))
+
+
+def _col_layout(R: int, N: int):
+    """Columns of one route in the padded x_proj row -> (C2p, index of every original column)."""
+    Rp8 = (R + 7) // 8 * 8
+    NBo = 1 if N == 1 else N
+    C2p = Rp8 + (8 if N == 1 else 2 * N)
+    idx = list(range(R)) + [Rp8 + n for n in range(N)] + [Rp8 + NBo + n for n in range(N)]
+    return Rp8, NBo, C2p, idx
+
+
+_IDX_CACHE = {}
+
+
+def _row_index(K: int, R: int, N: int, device):
+    key = (K, R, N, str(device))
+    t = _IDX_CACHE.get(key)
+    if t is None:
+        _, _, C2p, idx = _col_layout(R, N)
+        t = torch.tensor([k * C2p + j for k in range(K) for j in idx], dtype=torch.long, device=device)
+        _IDX_CACHE[key] = t
+    return t
+
+
+_ZEROS = {}
+
+
+def _zeros(device):
+    z = _ZEROS.get(str(device))
+    if z is None:
+        z = _ZEROS[str(device)] = torch.zeros(1024, dtype=torch.uint8, device=device)
+    return z
+
+
+def _params(x, xdbl, wdt, A, D, bias, H, W, N, R, n_routes, c_mod, c_off, wdiv, chk):
+    p = _lib.SS2DCParams()
+    p.zeros = _zeros(x.device).data_ptr()
+    p.batch, p.d_inner, p.H, p.W, p.dstate, p.dt_rank, p.n_routes = x.shape[0], x.shape[1], H, W, N, R, n_routes
+    p.c_mod, p.c_off, p.wdiv = c_mod, c_off, wdiv
+    p.x, p.xdbl, p.wdt = x.data_ptr(), xdbl.data_ptr(), wdt.data_ptr()
+    p.A, p.D, p.delta_bias = A.data_ptr(), D.data_ptr(), bias.data_ptr()
+    p.chk = chk.data_ptr()
+    return p
+
+
+class SS2DChanHip(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, x_proj_w, dt_w, A, D, bias, H, W):
+        _lib.require_cuda(x, x_proj_w, dt_w, A, D, bias)
+        Bt, Dm, L = x.shape
+        K, C2, _ = x_proj_w.shape
+        R, N = dt_w.shape[2], A.shape[1]
+        if L != H * W or K != 4 or C2 != R + 2 * N or x.dtype != torch.bfloat16:
+            raise RuntimeError("ss2d_chan: x (B,D,H*W) bf16, x_proj_weight (4,R+2N,D), dt_projs_weight (4,D,R) expected")
+        x = x.contiguous()
+        Rp8, NBo, C2p, _ = _col_layout(R, N)
+        Kp = (R + 15) // 16 * 16
+        XC = K * C2p
+        rows = _row_index(K, R, N, x.device)
+        xw_pad = torch.zeros((XC, Dm), dtype=x.dtype, device=x.device)
+        xw_pad.index_copy_(0, rows, cast_weight(x_proj_w.reshape(K * C2, Dm), x.dtype))
+        wdt = torch.nn.functional.pad(cast_weight(dt_w, x.dtype), (0, Kp - R)).contiguous()      # (4, D, Kp)
+        xdbl = torch.bmm(x.transpose(1, 2), xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC))         # (B, L, XC) token-major
+        A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
+        lib = _lib.lib()
+        nst = lib.xfm_ss2dc_nsteps(H, W)
+        chk = torch.empty((Bt, K, nst, N, Dm), dtype=torch.float32, device=x.device)
+        y = torch.empty((Bt, Dm, L), dtype=torch.float32, device=x.device)
+        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, 0, 0, 1, chk)
+        p.y = y.data_ptr()
+        nbytes = Bt * Dm * L * (2 + 4) + xdbl.numel() * 2
+        with torch.cuda.device(x.device), _lib.timed("ss2dc_fwd", nbytes):
+            _lib.check(lib.xfm_ss2dc_fwd(ctypes.byref(p), _lib.stream_ptr()), "ss2dc_fwd")
+        ctx.hw = (H, W)
+        ctx.meta = (x_proj_w.dtype, tuple(x_proj_w.shape), dt_w.dtype)
+        ctx.save_for_backward(x, xdbl, xw_pad, wdt, A, D, bias, chk)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        from .proj import _bmm_f32
+        x, xdbl, xw_pad, wdt, A, D, bias, chk = ctx.saved_tensors
+        H, W = ctx.hw
+        xw_dtype, xw_shape, dtw_dtype = ctx.meta
+        dev = x.device
+        Bt, Dm, L = x.shape
+        K, C2 = xw_shape[0], xw_shape[1]
+        N = A.shape[1]
+        R = C2 - 2 * N
+        Rp8, NBo, C2p, _ = _col_layout(R, N)
+        XC = K * C2p
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        ddts = torch.empty((Bt, K, L, Dm), dtype=x.dtype, device=dev)
+        nbc, na, nd = Bt * K * 2 * N * L, A.numel(), D.numel()
+        acc = torch.zeros(nbc + na + 2 * nd, dtype=torch.float32, device=dev)            # ONE fill for all accumulators
+        dBC = acc[:nbc].view(Bt, K, 2, N, L)
+        dA = acc[nbc:nbc + na].view(A.shape)
+        dD, dbias = acc[nbc + na:nbc + na + nd], acc[nbc + na + nd:]
+        lib = _lib.lib()
+        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, 0, 0, 1, chk)
+        p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
+        p.dBC, p.dA, p.dD, p.ddelta_bias = dBC.data_ptr(), dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
+        nbytes = Bt * Dm * L * (2 + 4 + 2 + 2 * K) + xdbl.numel() * 2
+        with torch.cuda.device(dev), _lib.timed("ss2dc_bwd", nbytes):
+            _lib.check(lib.xfm_ss2dc_bwd(ctypes.byref(p), _lib.stream_ptr()), "ss2dc_bwd")
+        # ---- d x_dbl: dt_proj columns from ddts (contraction over the channels), B / C columns from the scan kernel
+        w2 = torch.zeros((K, Dm, C2p), dtype=x.dtype, device=dev)
+        w2[:, :, :R] = wdt[:, :, :R]
+        dxd = torch.matmul(ddts, w2).float()                                              # (B, K, L, C2p)
+        dxd[..., Rp8:Rp8 + N] += dBC[:, :, 0].transpose(-1, -2)
+        dxd[..., Rp8 + NBo:Rp8 + NBo + N] += dBC[:, :, 1].transpose(-1, -2)
+        dxdbl = dxd.permute(0, 2, 1, 3).reshape(Bt, L, XC).to(x.dtype)
+        # dt_proj weight gradient: contraction over batch and positions
+        xr = xdbl.view(Bt, L, K, C2p)[..., :R]
+        dwdt = torch.einsum("bkld,blkr->kdr", ddts.float(), xr.float())
+        # x_proj backward on the natural map
+        dx.baddbmm_(xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC), dxdbl.transpose(1, 2))   # dx += Wx^T . d x_dbl^T
+        dxw_pad = _bmm_f32(dxdbl.transpose(1, 2), x.transpose(1, 2)).sum(0)               # (XC, D)
+        rows = _row_index(K, R, N, dev)
+        dxw = dxw_pad.index_select(0, rows).view(xw_shape).to(xw_dtype)
+        return dx, dxw, dwdt.to(dtw_dtype), dA, dD, dbias, None, None
+
+
+def ss2d_chan_fn(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W):
+    """x (B,D,L) bf16 natural; x_proj_weight (4,R+2N,D); dt_projs_weight (4,D,R); A (4D,N); D/bias (4D,) -> y (B,D,L) fp32."""
+    return SS2DChanHip.apply(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W)
