@@ -223,6 +223,43 @@ template <> struct ChanTile<uint16_t> {
     }
 };
 
+// Merge one step's per-position values of both directions into the pass-private planes.  Every position is visited twice
+// in a pass, once by each direction.  Walking the steps in order (ASC: 0 .. NSTEP-1, else NSTEP-1 .. 0), both directions
+// are the FIRST visitor of their rows in the first half of the walk (plain store: the planes are never zero-filled) and
+// the second in the other half (read-modify-write); in the middle step of an odd map, where the two directions meet,
+// the visitor with the earlier sequence index (in walk order) stores first and the other adds after a wave-level sync.
+template <typename YT, int HW, bool COL, bool ASC, int NV>
+__device__ __forceinline__ void chan_merge(char *lds, const int yb, const int sgy, const int h, const int st,
+                                           const float (&v)[NV]) {
+    using G = ChanGeom<HW>;
+    using TL = ChanTile<YT>;
+    constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP;
+    if (G::MIDSTEP >= 0 && st == G::MIDSTEP) {
+        constexpr int SM = (L - 1) / 2 - (G::MIDSTEP < 0 ? 0 : G::MIDSTEP) * P;   // index of the centre inside the step
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bool first = ASC ? (h ? i < SM : i <= SM) : (h ? i > SM : i >= SM);
+            if (first) TL::st(lds + yb + sgy * G::template off<COL>(i), v[i]);
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bool first = ASC ? (h ? i < SM : i <= SM) : (h ? i > SM : i >= SM);
+            char *q = lds + yb + sgy * G::template off<COL>(i);
+            if (!first) TL::st(q, TL::ld(q) + v[i]);
+        }
+    } else if (ASC ? (2 * st + 1 < NSTEP) : (2 * st + 1 > NSTEP)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) TL::st(lds + yb + sgy * G::template off<COL>(i), v[i]);
+    } else {
+        float o[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) o[i] = TL::ld(lds + yb + sgy * G::template off<COL>(i));
+#pragma unroll
+        for (int i = 0; i < NV; ++i) TL::st(lds + yb + sgy * G::template off<COL>(i), o[i] + v[i]);
+    }
+}
+
 template <int HW, int N, int KS, bool COL, typename YT>
 __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, const int c0, const uint16_t *xs, YT *ys) {
     using G = ChanGeom<HW>;
@@ -316,36 +353,7 @@ __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, c
                     hst[n] = hh;
                 }
             }
-            // merge into the pass-private planes.  Every position is visited twice in a pass (once by each direction):
-            // in the first half of the steps both directions are the FIRST visitor of their rows (plain store, the
-            // planes are never zero-filled), in the second half the second (read-modify-write); the middle step of an
-            // odd map, where the two directions meet inside the step, goes one half after the other.
-            if (G::MIDSTEP >= 0 && st == G::MIDSTEP) {
-                // sequence index (inside this step) of the centre position, which both directions reach at once: the
-                // forward half is its first visitor.  Phase 1: first visits (plain stores), phase 2: second visits.
-                constexpr int SM = (L - 1) / 2 - (G::MIDSTEP < 0 ? 0 : G::MIDSTEP) * P;
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const bool first = h ? i < SM : i <= SM;
-                    if (first) TL::st(lds + yb + sgy * G::template off<COL>(i), yv[i]);
-                }
-                wave_sync();
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const bool first = h ? i < SM : i <= SM;
-                    char *q = lds + yb + sgy * G::template off<COL>(i);
-                    if (!first) TL::st(q, TL::ld(q) + yv[i]);
-                }
-            } else if (2 * st + 1 < NSTEP) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) TL::st(lds + yb + sgy * G::template off<COL>(i), yv[i]);
-            } else {
-                float yo[NV];
-#pragma unroll
-                for (int i = 0; i < NV; ++i) yo[i] = TL::ld(lds + yb + sgy * G::template off<COL>(i));
-#pragma unroll
-                for (int i = 0; i < NV; ++i) TL::st(lds + yb + sgy * G::template off<COL>(i), yo[i] + yv[i]);
-            }
+            chan_merge<YT, HW, COL, true, NV>(lds, yb, sgy, h, st, yv);
         };
         if (G::TAIL == P || st + 1 < NSTEP) body(std::integral_constant<int, P>{});
         else body(std::integral_constant<int, G::TAIL>{});
@@ -397,25 +405,30 @@ __global__ void __launch_bounds__(128) ss2dc_fwd_kernel(const ChanArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------------------
-// LDS of a wave:  dxs [32][Lq] fp32 | xs [32][Lp] bf16 | gs [32][Lp] bf16 | dsum [32] | bcacc [2 halves][2][N][L] fp32 |
-//                 red [2][2P][36] fp32 (aliased by the ddts staging rows [2][P][32] bf16)
-template <int HW, int N> struct ChanBwdLds {
+// LDS of a workgroup (wave 0: rows, wave 1: columns):
+//   dxs [2][32][pitch] YT (pass-private dx planes) | xs [32][Lp] bf16 | gs [32][Lp] bf16 | dsum [32] |
+//   per wave: bcacc [2 halves][2][N][L] fp32, red [2][2P][36] fp32 (aliased by the ddts staging rows [2][P][32] bf16)
+template <int HW, int N, typename YT> struct ChanBwdLds {
     using G = ChanGeom<HW>;
     static constexpr int P = G::P;
+    static constexpr int Lq = ChanTile<YT>::template pitch<HW>();
     static constexpr size_t dxs = 0;
-    static constexpr size_t xs = dxs + (size_t)32 * G::Lq * 4;
+    static constexpr size_t xs = (dxs + (size_t)2 * 32 * Lq * sizeof(YT) + 15) / 16 * 16;
     static constexpr size_t gs = xs + (size_t)32 * G::Lp * 2;
     static constexpr size_t dsum = gs + (size_t)32 * G::Lp * 2;
-    static constexpr size_t bcacc = dsum + 32 * 4;
-    static constexpr size_t red = (bcacc + (size_t)2 * 2 * N * G::L * 4 + 15) / 16 * 16;
-    static constexpr size_t total = red + (size_t)2 * 2 * P * 36 * 4;
+    static constexpr size_t wave0 = (dsum + 32 * 4 + 15) / 16 * 16;
+    static constexpr size_t bcacc_sz = (size_t)2 * 2 * N * G::L * 4;
+    static constexpr size_t red_off = (bcacc_sz + 15) / 16 * 16;                 // inside a wave's block
+    static constexpr size_t wave_sz = red_off + (size_t)2 * 2 * P * 36 * 4;
+    static constexpr size_t total = wave0 + 2 * wave_sz;
 };
 
-template <int HW, int N, int KS, bool COL>
+template <int HW, int N, int KS, bool COL, typename YT>
 __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, const int c0, const uint16_t *xs,
-                                              const uint16_t *gs, float *dxs, float *bcacc, float *red) {
+                                              const uint16_t *gs, YT *dxs, float *bcacc, float *red) {
     using G = ChanGeom<HW>;
-    constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP, Lp = G::Lp, Lq = G::Lq;
+    constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP, Lp = G::Lp, Lq = ChanTile<YT>::template pitch<HW>();
+    constexpr int YS = (int)sizeof(YT);
     constexpr int RV = 2 * P;                         // values reduced over the channel lanes per state: P dB + P dC
     const int lane = threadIdx.x & 63;
     const ChanLane<HW, N, KS, COL> ln(a, sb, c0, lane);
@@ -440,11 +453,12 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
 #pragma unroll
     for (int n = 0; n < N; ++n) E[n] = dAacc[n] = 0.f;
     float dbacc = 0.f;
-    char *lds = reinterpret_cast<char *>(dxs);                         // the wave's LDS region starts with dxs
+    char *lds = reinterpret_cast<char *>(dxs);                         // addressing relative to this pass's dx planes
     const int sg2 = h ? -2 : 2;
+    const int sgy = h ? -YS : YS;
     const int xbase = (int)((const char *)(xs + c * Lp) - (const char *)dxs) + (h ? 2 * (L - 1) : 0);
     const int gbase = (int)((const char *)(gs + c * Lp) - (const char *)dxs) + (h ? 2 * (L - 1) : 0);
-    const int dbase = c * Lq * 4 + (h ? 4 * (L - 1) : 0);
+    const int dbase = c * Lq * YS + (h ? YS * (L - 1) : 0);
     const int route = (COL ? 1 : 0) + 2 * h;
     const float *chk = a.chk + (((int64_t)sb * 4 + route) * NSTEP) * N * a.D + c0 + c;
     float *redw = red + h * RV * 36;                  // this half's [RV][36] scratch
@@ -474,7 +488,7 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
         auto body = [&](auto nv_tag) {
             constexpr int NV = decltype(nv_tag)::value;
             float dl[NV], sg[NV], u[NV], g[NV], sB[NV], sA[NV];
-            const int xb = xbase + sg2 * nb, gb = gbase + sg2 * nb, db = dbase + 2 * sg2 * nb;
+            const int xb = xbase + sg2 * nb, gb = gbase + sg2 * nb, db = dbase + sgy * nb;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 u[i] = bf16_bits_to_float(*reinterpret_cast<const uint16_t *>(lds + xb + sg2 * G::template off<COL>(i)));
@@ -555,23 +569,7 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
                 dbacc += ddl;
                 stg[(h * P + i) * 32 + c] = (uint16_t)(pack_bf16x2(ddl, 0.f) & 0xffffu);
             }
-            if (G::MIDSTEP >= 0 && st == G::MIDSTEP) {
-#pragma unroll 1
-                for (int hh2 = 0; hh2 < 2; ++hh2) {
-                    if (h == hh2) {
-#pragma unroll
-                        for (int i = 0; i < NV; ++i)
-                            *reinterpret_cast<float *>(lds + db + 2 * sg2 * G::template off<COL>(i)) += duv[i];
-                    }
-                    wave_sync();
-                }
-            } else {
-                float xo[NV];
-#pragma unroll
-                for (int i = 0; i < NV; ++i) xo[i] = *reinterpret_cast<const float *>(lds + db + 2 * sg2 * G::template off<COL>(i));
-#pragma unroll
-                for (int i = 0; i < NV; ++i) *reinterpret_cast<float *>(lds + db + 2 * sg2 * G::template off<COL>(i)) = xo[i] + duv[i];
-            }
+            chan_merge<YT, HW, COL, false, NV>(lds, db, sgy, h, st, duv);
             // ---- ddts rows of this step: [half][position][32 channels] bf16 -> 16-byte stores (4 lanes per position)
             wave_sync();
             {
@@ -596,62 +594,66 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
     atomicAdd(a.dbias + ln.wrow, dbacc);
 }
 
-template <int HW, int N, int KS>
-__global__ void __launch_bounds__(64) ss2dc_bwd_kernel(const ChanArgs a) {
+template <int HW, int N, int KS, typename YT>
+__global__ void __launch_bounds__(128) ss2dc_bwd_kernel(const ChanArgs a) {
     using G = ChanGeom<HW>;
-    using LD = ChanBwdLds<HW, N>;
-    constexpr int L = G::L, Lp = G::Lp, Lq = G::Lq;
+    using LD = ChanBwdLds<HW, N, YT>;
+    using TL = ChanTile<YT>;
+    constexpr int L = G::L, Lp = G::Lp, Lq = LD::Lq;
     extern __shared__ float smem[];
     char *sm = reinterpret_cast<char *>(smem);
-    float *dxs = reinterpret_cast<float *>(sm + LD::dxs);
+    YT *dxs = reinterpret_cast<YT *>(sm + LD::dxs);
     uint16_t *xs = reinterpret_cast<uint16_t *>(sm + LD::xs);
     uint16_t *gs = reinterpret_cast<uint16_t *>(sm + LD::gs);
     float *dsum = reinterpret_cast<float *>(sm + LD::dsum);
-    float *bcacc = reinterpret_cast<float *>(sm + LD::bcacc);
-    float *red = reinterpret_cast<float *>(sm + LD::red);
     const int tiles = a.D / 32;
     const int sb = blockIdx.x / tiles, c0 = 32 * (blockIdx.x - sb * tiles);
-    const int lane = threadIdx.x;
-    chan_load_planes<HW, 64>(xs, a.x + ((int64_t)sb * a.D + c0) * L, lane);
-    chan_load_planes_f32<HW, 64>(gs, a.dy + ((int64_t)sb * a.D + c0) * L, lane);
-    for (int e = lane; e < 32 * Lq; e += 64) dxs[e] = 0.f;
-    if (lane < 32) dsum[lane] = (a.Dp[c0 + lane] + a.Dp[a.D + c0 + lane]) + (a.Dp[2 * a.D + c0 + lane] + a.Dp[3 * a.D + c0 + lane]);
-    const int sbC = a.c_mod > 0 ? a.c_off + sb % a.c_mod : sb;      // dC of a borrowed C goes to its owner
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int e = lane; e < 2 * 2 * N * L; e += 64) bcacc[e] = 0.f;
-        wave_sync();
-        if (pass == 0) chan_bwd_pass<HW, N, KS, false>(a, sb, c0, xs, gs, dxs, bcacc, red);
-        else chan_bwd_pass<HW, N, KS, true>(a, sb, c0, xs, gs, dxs, bcacc, red);
-        wave_sync();
-        // dB / dC of the two routes of this pass: contiguous fp32 atomics (natural position order)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *bcacc = reinterpret_cast<float *>(sm + LD::wave0 + wave * LD::wave_sz);
+    float *red = reinterpret_cast<float *>(sm + LD::wave0 + wave * LD::wave_sz + LD::red_off);
+    chan_load_planes<HW, 128>(xs, a.x + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
+    chan_load_planes_f32<HW, 128>(gs, a.dy + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
+    for (int e = lane; e < 2 * 2 * N * L; e += 64) bcacc[e] = 0.f;
+    if (threadIdx.x < 32) {
+        const int t = threadIdx.x;
+        dsum[t] = (a.Dp[c0 + t] + a.Dp[a.D + c0 + t]) + (a.Dp[2 * a.D + c0 + t] + a.Dp[3 * a.D + c0 + t]);
+    }
+    __syncthreads();
+    if (wave == 0) chan_bwd_pass<HW, N, KS, false, YT>(a, sb, c0, xs, gs, dxs, bcacc, red);
+    else chan_bwd_pass<HW, N, KS, true, YT>(a, sb, c0, xs, gs, dxs + 32 * Lq, bcacc, red);
+    wave_sync();
+    {   // dB / dC of the two routes of this pass: contiguous fp32 atomics (natural position order)
+        const int sbC = a.c_mod > 0 ? a.c_off + sb % a.c_mod : sb;      // dC of a borrowed C goes to its owner
         for (int hs = 0; hs < 2; ++hs)
             for (int op = 0; op < 2; ++op) {
-                const int rt = pass + 2 * hs;
+                const int rt = wave + 2 * hs;
                 float *dst = a.dBC + ((((int64_t)(op ? sbC : sb) * 4 + rt) * 2 + op) * N) * L;
                 const float *src = bcacc + ((size_t)hs * 2 + op) * N * L;
                 for (int e = lane; e < N * L; e += 64) atomicAdd(dst + e, src[e]);
             }
-        wave_sync();
     }
-    // ---- dx = sum of the routes' du + (sum_k D_k) g ; dD_k[c] += sum_l g u (the same for every route k)
+    __syncthreads();
+    // ---- dx = rows + columns + (sum_k D_k) g ; dD_k[c] += sum_l g u (the same for every route k)
     uint16_t *dst = a.dx + ((int64_t)sb * a.D + c0) * L;
-    for (int v = lane; v < 32 * L / 2; v += 64) {
+    const char *d0 = reinterpret_cast<const char *>(dxs), *d1 = reinterpret_cast<const char *>(dxs + 32 * Lq);
+    for (int v = threadIdx.x; v < 32 * L / 2; v += 128) {
         float o[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = 2 * v + q;
             const int c = e / L, l = e - c * L;
-            o[q] = fmaf(dsum[c], bf16_bits_to_float(gs[c * Lp + l]), dxs[c * Lq + l]);
+            const int off = (c * Lq + l) * (int)sizeof(YT);
+            o[q] = fmaf(dsum[c], bf16_bits_to_float(gs[c * Lp + l]), TL::ld(d0 + off) + TL::ld(d1 + off));
         }
         *reinterpret_cast<uint32_t *>(dst + 2 * v) = pack_bf16x2(o[0], o[1]);
     }
     {
-        const int c = lane >> 1, part = lane & 1;                  // two lanes per channel split the plane
+        const int c = threadIdx.x >> 2, part = threadIdx.x & 3;       // four lanes per channel split the plane
         float s = 0.f;
-        for (int l = part; l < L; l += 2)
+        for (int l = part; l < L; l += 4)
             s = fmaf(bf16_bits_to_float(gs[c * Lp + l]), bf16_bits_to_float(xs[c * Lp + l]), s);
         s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
         if (part == 0)
             for (int k = 0; k < 4; ++k) atomicAdd(a.dD + k * a.D + c0 + c, s);
     }
@@ -665,8 +667,8 @@ template <int HW, int N, int KS> static int chan_launch(const ChanArgs &a, bool 
     // forward: fp32 pass-private planes while four workgroups (8 waves) fit a CU, bf16 planes beyond (14 x 14)
     using YT = typename std::conditional<(HW > 12), uint16_t, float>::type;
     const size_t lds_f = (size_t)2 * 32 * ChanTile<YT>::template pitch<HW>() * sizeof(YT) + (size_t)32 * G::Lp * 2 + 32 * 4;
-    const size_t lds = bwd ? ChanBwdLds<HW, N>::total : lds_f;
-    const void *fn = bwd ? (const void *)ss2dc_bwd_kernel<HW, N, KS> : (const void *)ss2dc_fwd_kernel<HW, N, KS, YT>;
+    const size_t lds = bwd ? ChanBwdLds<HW, N, YT>::total : lds_f;
+    const void *fn = bwd ? (const void *)ss2dc_bwd_kernel<HW, N, KS, YT> : (const void *)ss2dc_fwd_kernel<HW, N, KS, YT>;
     if (lds > 160 * 1024) return XFM_ELIMIT;
     static bool opted[2] = {false, false};                        // (per template instantiation: once per kernel)
     if (lds > 64 * 1024 && !opted[bwd]) {
@@ -676,7 +678,7 @@ template <int HW, int N, int KS> static int chan_launch(const ChanArgs &a, bool 
     const unsigned grid = (unsigned)(a.Bt * (a.D / 32));
     ChanArgs args = a;
     void *kargs[] = {&args};
-    const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(bwd ? 64 : 128), kargs, lds, s);
+    const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(128), kargs, lds, s);
     if (e != hipSuccess) {
         set_last_hip_error(e);
         return XFM_ELAUNCH;

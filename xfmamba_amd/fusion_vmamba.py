@@ -41,6 +41,7 @@ from .mlp_tokens import linear_tokens_fn, mlp_tokens_fn
 from .proj import batched_proj
 from .rowln import add_layernorm_rows_fn, layernorm_rows_fn, rows_supported
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
+from .ss2d_chan import chan_supported, ss2d_chan_fn
 
 SS2D_MODE = "fused"          # "fused" | "unfused"
 # Layout of the trunk's residual stream between VSS blocks.  "tokens": (B, H, W, C) fp32 -- LayerNorm (+ residual add
@@ -232,6 +233,10 @@ def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_
     Dsf = Ds.float()
     bias = dt_projs_bias.reshape(-1).float()
     cd = x.dtype
+    # short square maps (14 x 14 and below) in bf16: the channel-lane kernel -- dt_proj on MFMA inside the scan, one lane
+    # per channel; no (B,4,D,L) step-size tensor, no cross_scan / cross_merge copies (csrc/ss2d_chan.hip)
+    if SS2D_MODE == "fused" and Cs_override is None and not want_Cs and chan_supported(x, H, W, N, K, D, R):
+        return ss2d_chan_fn(x.reshape(B, D, L), x_proj_weight, dt_projs_weight, As, Dsf, bias, H, W), None
     # 7x7 maps (trunk stage 3, both fusion blocks): rows of 49 are too short for a parallel scan to pay; the
     # operator chain with the one-lane-per-row scan kernel is faster there and the (B,4,D,49) tensors are tiny.
     if SS2D_MODE == "fused" and L > 64:

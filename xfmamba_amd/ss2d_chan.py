@@ -133,16 +133,16 @@ class SS2DChanHip(torch.autograd.Function):
         nbytes = Bt * Dm * L * (2 + 4 + 2 + 2 * K) + xdbl.numel() * 2
         with torch.cuda.device(dev), _lib.timed("ss2dc_bwd", nbytes):
             _lib.check(lib.xfm_ss2dc_bwd(ctypes.byref(p), _lib.stream_ptr()), "ss2dc_bwd")
-        # ---- d x_dbl: dt_proj columns from ddts (contraction over the channels), B / C columns from the scan kernel
-        w2 = torch.zeros((K, Dm, C2p), dtype=x.dtype, device=dev)
-        w2[:, :, :R] = wdt[:, :, :R]
-        dxd = torch.matmul(ddts, w2).float()                                              # (B, K, L, C2p)
-        dxd[..., Rp8:Rp8 + N] += dBC[:, :, 0].transpose(-1, -2)
-        dxd[..., Rp8 + NBo:Rp8 + NBo + N] += dBC[:, :, 1].transpose(-1, -2)
-        dxdbl = dxd.permute(0, 2, 1, 3).reshape(Bt, L, XC).to(x.dtype)
-        # dt_proj weight gradient: contraction over batch and positions
-        xr = xdbl.view(Bt, L, K, C2p)[..., :R]
-        dwdt = torch.einsum("bkld,blkr->kdr", ddts.float(), xr.float())
+        # ---- d x_dbl (dt_proj columns from ddts, B / C columns from the scan kernel) and the dt_proj weight gradient:
+        # two MFMA kernels, each reading ddts once
+        KT = (Rp8 + 31) // 32
+        wdtT = torch.zeros((K, KT * 32, Dm), dtype=x.dtype, device=dev)
+        wdtT[:, :R] = wdt[:, :, :R].transpose(1, 2)
+        dxdbl = torch.empty((Bt, L, XC), dtype=x.dtype, device=dev)
+        dwdt = torch.zeros((K, Dm, R), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), _lib.timed("ss2dc_post", 2 * ddts.numel() * 2):
+            _lib.check(lib.xfm_ss2dc_post(ddts.data_ptr(), xdbl.data_ptr(), wdtT.data_ptr(), dBC.data_ptr(), dxdbl.data_ptr(),
+                                          dwdt.data_ptr(), Bt, Dm, L, R, N, _lib.stream_ptr()), "ss2dc_post")
         # x_proj backward on the natural map
         dx.baddbmm_(xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC), dxdbl.transpose(1, 2))   # dx += Wx^T . d x_dbl^T
         dxw_pad = _bmm_f32(dxdbl.transpose(1, 2), x.transpose(1, 2)).sum(0)               # (XC, D)
