@@ -35,7 +35,7 @@ def _inputs(B, D, HW, R, N, seed):
     return x, xw, dtw, A, Dp, bias, gy
 
 
-def _oracle(x, xw, dtw, A, Dp, bias, gy, HW, N):
+def _oracle(x, xw, dtw, A, Dp, bias, gy, HW, N, c_mod=0, c_off=0):
     B, D, L = x.shape
     K, R = 4, dtw.shape[2]
     t = [v.clone().requires_grad_() for v in (x, xw, dtw, A, Dp, bias)]
@@ -44,6 +44,8 @@ def _oracle(x, xw, dtw, A, Dp, bias, gy, HW, N):
     x_dbl = x_dbl + (_bf(x_dbl) - x_dbl).detach()                                    # the kernel's bf16 rounding point
     dts = torch.einsum("bkrl,kdr->bkdl", x_dbl[:, :, :R], t[2])
     Bs, Cs = x_dbl[:, :, R:R + N].contiguous(), x_dbl[:, :, R + N:].contiguous()
+    if c_mod > 0:                                   # deep fusion block: every stream reads through the fused stream's C
+        Cs = Cs[c_off + torch.arange(B) % c_mod].contiguous()
     ys = c_scan.selective_scan_c(xs.reshape(B, -1, L), dts.reshape(B, -1, L), t[3], Bs, Cs, t[4], t[5], True, True)
     y = O.cross_merge_ref(ys.view(B, K, D, HW, HW))
     y.backward(gy)
@@ -87,3 +89,30 @@ def test_ss2d_chan_equals_lean_fused_path_at_bench_shape():
         outs.append([y.detach()] + [v.grad for v in t])
     for name, a, b in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), outs[1], outs[0]):
         assert_close(a.float().cpu(), b.float().cpu(), 2e-2, 2e-2 * float(b.float().abs().max()) + 1e-7, name)
+
+
+CASES16 = [  # B (per stream), D, HW, R   -- d_state 16: the deep cross-fusion block (three streams, C of the fused one)
+    (2, 64, 5, 2), (2, 128, 7, 48), (1, 64, 12, 64), (3, 96, 7, 4),
+]
+
+
+@pytest.mark.parametrize("B,D,HW,R", CASES16)
+@pytest.mark.parametrize("streams", [1, 3])
+def test_ss2d_chan_dstate16_matches_oracle_chain(B, D, HW, R, streams):
+    """d_state 16 (models/fusion_vmamba.py:483-576): plain 4-route block (streams = 1) and the deep cross-fusion
+    exchange -- [view 1 | view 2 | fused] as one batch whose C operand is the fused third's (streams = 3)."""
+    from xfmamba_amd.ss2d_chan import chan_supported, ss2d_chan_fn
+    N = 16
+    Bt = B * streams
+    x, xw, dtw, A, Dp, bias, gy = _inputs(Bt, D, HW, R, N, B * D + HW + R + streams)
+    A = -(torch.arange(1, N + 1, dtype=torch.float32).repeat(4 * D, 1)) * (1 + 0.05 * torch.randn(4 * D, N))
+    c_mod, c_off = (B, 2 * B) if streams == 3 else (0, 0)
+    ref = _oracle(x, xw, dtw, A, Dp, bias, gy, HW, N, c_mod, c_off)
+    t = [v.to(DEV).requires_grad_() for v in (x.bfloat16(), xw, dtw, A, Dp, bias)]
+    assert chan_supported(t[0], HW, HW, N, 4, D, R)
+    y = ss2d_chan_fn(t[0], t[1], t[2], t[3], t[4], t[5], HW, HW, c_mod, c_off)
+    y.backward(gy.to(DEV))
+    got = [y.detach()] + [v.grad for v in t]
+    tols = (2e-3, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2)
+    for name, a, b, tol in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), got, ref, tols):
+        assert_close(a.float().cpu(), b.float(), tol, tol * float(b.abs().max()) + 1e-7, name)

@@ -72,6 +72,41 @@ def test_blocks_match_reference_golden(tag, training, mode):
         fv.SS2D_MODE = old
 
 
+def test_deep_fusion_block_golden_through_channel_lane_kernel():
+    """G4 `deep` (FusionBlock_v5, hidden 32 -> d_inner 64, d_state 16, 5x5 maps) under bf16 autocast: the three streams'
+    cross-fusion exchange runs as ONE launch of the channel-lane kernel (xfm_ss2dc_fwd/_bwd with the view streams reading
+    the fused stream's C rows); output and gradients against the record of the real reference at the bf16 bound."""
+    from xfmamba_amd import _lib
+    z = load_npz("g4_blocks.npz")
+    tag = "deep"
+    m = _build(tag)
+    pre = f"{tag}/sd/"
+    m.load_state_dict({k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}, strict=True)
+    m = m.to(DEV).train(True)
+    ins = [torch.from_numpy(z[f"{tag}/in{i}"]).to(DEV).requires_grad_() for i in range(2)]
+    timer = _lib.KernelTimer()
+    _lib.set_timer(timer)
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(*ins)
+        out.float().backward(torch.from_numpy(z[f"{tag}/gout0"]).to(DEV))
+    finally:
+        _lib.set_timer(None)
+    names = set(timer.summary())
+    assert {"ss2dc_fwd", "ss2dc_bwd"} <= names and not ({"cross_scan", "cross_merge", "selective_scan_fwd"} & names), names
+    ref = torch.from_numpy(z[f"{tag}/out0"])
+    assert_close(out.detach().float().cpu(), ref, 2e-2, 2e-2 * float(ref.abs().max()), "out")
+    for i, t in enumerate(ins):
+        ref = torch.from_numpy(z[f"{tag}/din{i}"])
+        assert_close(t.grad.float().cpu(), ref, 3e-2, 3e-2 * float(ref.abs().max()), f"din{i}")
+    pre = f"{tag}/grad/"
+    params = dict(m.named_parameters())
+    for k in z.files:
+        if k.startswith(pre):
+            ref = torch.from_numpy(z[k])
+            assert_close(params[k[len(pre):]].grad.float().cpu(), ref, 5e-2, 5e-2 * float(ref.abs().max()) + 1e-7, k)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,H", [(96, 56), (192, 28), (384, 14), (768, 7)])
 def test_vss_stage_tokens_stream_matches_planes_and_oracle(C, H, dt):

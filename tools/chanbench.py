@@ -32,15 +32,18 @@ def med(fn, reps=20, warm=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--only", default="")
     a = ap.parse_args()
     from xfmamba_amd import _lib
     from xfmamba_amd.ss2d import ss2d_xproj_core_fn
     from xfmamba_amd.ss2d_chan import ss2d_chan_fn
     dev = "cuda"
-    shapes = [("stage2 T", a.batch, 384, 14, 24), ("stage3 T", a.batch, 768, 7, 48), ("stage2 S", a.batch, 768, 14, 24),
-              ("stage3 B384", a.batch // 4, 2048, 12, 64)]
-    for name, B, D, HW, R in shapes:
-        L, K, N = HW * HW, 4, 1
+    shapes = [("stage2 T", a.batch, 384, 14, 24, 1), ("stage3 T", a.batch, 768, 7, 48, 1), ("stage2 S", a.batch, 768, 14, 24, 1),
+              ("stage3 B384", a.batch // 4, 2048, 12, 64, 1), ("deep T", a.batch // 2 * 3, 1536, 7, 48, 16)]
+    if a.only:
+        shapes = [s for s in shapes if a.only in s[0]]
+    for name, B, D, HW, R, N in shapes:
+        L, K = HW * HW, 4
         g = torch.Generator().manual_seed(0)
         x = torch.randn(B, D, L, generator=g).to(dev).bfloat16().requires_grad_()
         xw = (torch.randn(K, R + 2 * N, D, generator=g) * D ** -0.5).to(dev).requires_grad_()
@@ -49,7 +52,9 @@ def main():
         Dp = torch.randn(K * D, generator=g).to(dev).requires_grad_()
         bias = (0.1 * torch.rand(K * D, generator=g) - 4.0).to(dev).requires_grad_()
         gy = torch.randn(B, D, L, device=dev)
-        for label, fn in (("lean chain", ss2d_xproj_core_fn), ("chan", ss2d_chan_fn)):
+        cm = (B // 3, 2 * (B // 3)) if N > 1 else (0, 0)
+        chan = (lambda *t: ss2d_chan_fn(*t, c_mod=cm[0], c_off=cm[1]))
+        for label, fn in ((("lean chain", ss2d_xproj_core_fn),) if N == 1 else ()) + (("chan", chan),):
             timer = _lib.KernelTimer()
             _lib.set_timer(timer)
             ys = []

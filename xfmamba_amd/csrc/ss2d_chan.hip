@@ -21,6 +21,8 @@
 //   * B_t and C_t of a position are the same for every channel: an MFMA with an indicator matrix as its B operand
 //     broadcasts column R+n of the same x_proj rows to every channel lane (exact: 1.0 x bf16, fp32 accumulate).
 // Roofline: HBM (forward 2 + 4 B per (b,d,p) element plus the small x_proj rows; backward 2 + 4 + 2 + 8).
+#include <cstdlib>
+
 #include "xfm_common.hpp"
 
 namespace xfm {
@@ -46,6 +48,7 @@ struct ChanArgs {
     int Bt, D, R, C2p, XC, Kp, Rp8;
     int c_mod, c_off;        // c_mod > 0: the C operand of sample sb is read from sample c_off + sb % c_mod
     const uint16_t *zeros;   // >= 2 * Kp zero bf16 (16-byte aligned): k-slots of the other route of a pair
+    int ct;                  // consecutive 32-channel tiles walked by one workgroup (amortises the dB / dC flush)
 };
 
 template <int HW> struct ChanGeom {
@@ -209,6 +212,51 @@ __device__ __forceinline__ void chan_load_frags(const ChanArgs &a, const ChanLan
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
 // YT: element type of the pass-private output planes (float, or bf16 bits where LDS capacity decides: 14 x 14)
+// Sum per-lane values over the 32 channel lanes of each half WITHOUT an LDS round trip: the values (bf16) are the A
+// operand of an MFMA against a selector matrix, which hands lane `col` the 32 channels' copies of value `col` as its 16
+// accumulator registers (rows 8q + 4g + i on lane half g); an in-lane sum, one cross-half add, and lanes 0..15 hold the
+// totals: lanes 0..7 value j of half 0 (the forward route), lanes 8..15 value j of half 1 (the reverse route).
+__device__ __forceinline__ cbf16x8_t chan_selector(int lane) {
+    const int col = lane & 31, kb = lane >> 5;
+    return chan_indicator((col < 16 && (col >> 3) == kb) ? 0 : 1, (col < 16 && (col >> 3) == kb) ? (col & 7) : 0);
+}
+__device__ __forceinline__ float chan_colsum8(const float (&v)[8], const cbf16x8_t sel) {
+    cu32x4_t pk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pk[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+    const cf32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const cf32x16_t t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf16x8_t *>(&pk), sel, zero16, 0, 0, 0);
+    float s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    s += ((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]));
+    // add the other lane half's partial (channels 4..7, 12..15, ...): lane L <- s[L] + s[L + 32]
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const uint32_t sb = __float_as_uint(s);
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(sb, sb, false, false);
+    return s + __uint_as_float(r[1]);                  // r[1] lanes 0..31 = s of lanes 32..63
+}
+
+// dt_proj of one step on MFMA: rows = the step's positions (both directions), columns = this tile's channels.
+// d_state 1 keeps the weight fragments and the bias vector in registers for the whole pass and prefetches the next
+// step's x_proj rows; d_state > 1 (a step is 16x longer, registers are the scarce resource) loads them per step.
+template <int HW, int N, int KS, bool COL>
+__device__ __forceinline__ cf32x16_t chan_dt_step(const ChanArgs &a, const ChanLane<HW, N, KS, COL> &ln, const int c0,
+                                                  const int st, const float bv, cbf16x8_t &fB, cbf16x8_t &fC) {
+    ChanFrags<N, KS> fr;
+    chan_load_frags<HW, N, KS, COL>(a, ln, st, fr);
+    cf32x16_t acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bv;
+#pragma unroll
+    for (int m = 0; m < 2 * KS; ++m) {
+        const int rm = (COL ? 1 : 0) + 2 * (m / KS);
+        const cbf16x8_t w = chan_ld8(a.wdt + ((int64_t)rm * a.D + c0 + ln.c) * a.Kp + 16 * (m % KS) + 8 * ln.kb);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m < KS ? fr.f0[m] : fr.f1[m - KS], w, acc, 0, 0, 0);
+    }
+    fB = fr.fB;
+    fC = fr.fC;
+    return acc;
+}
+
 template <typename YT> struct ChanTile;
 template <> struct ChanTile<float> {
     template <int HW> static constexpr int pitch() { return ChanGeom<HW>::Lq; }
@@ -261,7 +309,8 @@ __device__ __forceinline__ void chan_merge(char *lds, const int yb, const int sg
 }
 
 template <int HW, int N, int KS, bool COL, typename YT>
-__device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, const int c0, const uint16_t *xs, YT *ys) {
+__device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, const int c0, const uint16_t *xs, YT *ys,
+                                              float *scr) {
     using G = ChanGeom<HW>;
     using TL = ChanTile<YT>;
     constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP, Lp = G::Lp, Lq = TL::template pitch<HW>();
@@ -269,22 +318,33 @@ __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, c
     const int lane = threadIdx.x & 63;
     const ChanLane<HW, N, KS, COL> ln(a, sb, c0, lane);
     const int c = ln.c, h = ln.h, kb = ln.kb;
-    cbf16x8_t wf[2 * KS];
+    cbf16x8_t wf[N == 1 ? 2 * KS : 1];
+    if constexpr (N == 1) {
 #pragma unroll
-    for (int m = 0; m < 2 * KS; ++m) {
-        const int rm = (COL ? 1 : 0) + 2 * (m / KS);
-        wf[m] = chan_ld8(a.wdt + ((int64_t)rm * a.D + c0 + c) * a.Kp + 16 * (m % KS) + 8 * kb);
+        for (int m = 0; m < 2 * KS; ++m) {
+            const int rm = (COL ? 1 : 0) + 2 * (m / KS);
+            wf[m] = chan_ld8(a.wdt + ((int64_t)rm * a.D + c0 + c) * a.Kp + 16 * (m % KS) + 8 * kb);
+        }
     }
     const float bv = a.bias[ln.wrow];
-    float A2[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) A2[n] = a.A[(int64_t)ln.wrow * N + n] * kLog2e;
+    // d_state 1: decay rate and state in registers; d_state > 1: in the wave's LDS scratch ([n][lane]), the loop over
+    // the states stays rolled (one state's B / C broadcast in registers at a time)
+    float A2[N == 1 ? 1 : 1], hst[N == 1 ? 1 : 1];
+    float *hs = scr + lane, *A2s = scr + N * 64 + lane;
+    if constexpr (N == 1) {
+        A2[0] = a.A[ln.wrow] * kLog2e;
+        hst[0] = 0.f;
+    } else {
+        for (int n = 0; n < N; ++n) {
+            hs[n * 64] = 0.f;
+            A2s[n * 64] = a.A[(int64_t)ln.wrow * N + n] * kLog2e;
+        }
+    }
     cf32x16_t biasv;
+    if constexpr (N == 1) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) biasv[j] = bv;
-    float hst[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) hst[n] = 0.f;
+        for (int j = 0; j < 16; ++j) biasv[j] = bv;
+    }
     // LDS byte addressing relative to the wave's region start (ys is its first array)
     char *lds = reinterpret_cast<char *>(ys);
     const int sg2 = h ? -2 : 2;                                         // bytes per bf16 position step, signed by direction
@@ -294,22 +354,26 @@ __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, c
     const int route = (COL ? 1 : 0) + 2 * h;
     float *chk = a.chk + (((int64_t)sb * 4 + route) * NSTEP) * N * a.D + c0 + c;
     ChanFrags<N, KS> fr;
-    chan_load_frags<HW, N, KS, COL>(a, ln, 0, fr);
+    if constexpr (N == 1) chan_load_frags<HW, N, KS, COL>(a, ln, 0, fr);
     const cf32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int st = 0; st < NSTEP; ++st) {
-        cf32x16_t acc = biasv;
-#pragma unroll
-        for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f0[m], wf[m], acc, 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f1[m], wf[KS + m], acc, 0, 0, 0);
-        const cbf16x8_t fBc = fr.fB, fCc = fr.fC;
-        cf32x16_t bB1, bC1;
+        cf32x16_t acc, bB1, bC1;
+        cbf16x8_t fBc, fCc;
         if constexpr (N == 1) {
+            acc = biasv;
+#pragma unroll
+            for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f0[m], wf[m], acc, 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f1[m], wf[KS + m], acc, 0, 0, 0);
+            fBc = fr.fB;
+            fCc = fr.fC;
             bB1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fBc, chan_indicator(kb, 0), zero16, 0, 0, 0);
             bC1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fCc, chan_indicator(kb, 1), zero16, 0, 0, 0);
+            if (st + 1 < NSTEP) chan_load_frags<HW, N, KS, COL>(a, ln, st + 1, fr);   // in flight under this step's work
+        } else {
+            acc = chan_dt_step<HW, N, KS, COL>(a, ln, c0, st, bv, fBc, fCc);
         }
-        if (st + 1 < NSTEP) chan_load_frags<HW, N, KS, COL>(a, ln, st + 1, fr);   // in flight under this step's work
         const int nb = G::template base<COL>(st);
         auto body = [&](auto nv_tag) {
             constexpr int NV = decltype(nv_tag)::value;
@@ -338,27 +402,34 @@ __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, c
                     du[i] = dl[i] * u[i];
                     yv[i] = 0.f;
                 }
-#pragma unroll
+                cbf16x8_t ind = chan_indicator(kb, 0);
+                cf32x16_t bBn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fBc, ind, zero16, 0, 0, 0);
+                cf32x16_t bCn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fCc, ind, zero16, 0, 0, 0);
+#pragma unroll 1
                 for (int n = 0; n < N; ++n) {
-                    const cbf16x8_t ind = chan_indicator(kb, n);
-                    const cf32x16_t bB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fBc, ind, zero16, 0, 0, 0);
-                    const cf32x16_t bC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fCc, ind, zero16, 0, 0, 0);
-                    float hh = hst[n];
+                    const cf32x16_t bB = bBn, bC = bCn;
+                    if (n + 1 < N) {                                 // next state's broadcast under this state's work
+                        ind = chan_indicator(kb, n + 1);
+                        bBn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fBc, ind, zero16, 0, 0, 0);
+                        bCn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fCc, ind, zero16, 0, 0, 0);
+                    }
+                    const float A2n = A2s[n * 64];
+                    float hh = hs[n * 64];
 #pragma unroll
                     for (int i = 0; i < NV; ++i) {
-                        const float av = exp2_fast(dl[i] * A2[n]);
+                        const float av = exp2_fast(dl[i] * A2n);
                         hh = fmaf(av, hh, du[i] * bB[i]);
                         yv[i] = fmaf(bC[i], hh, yv[i]);
                     }
-                    hst[n] = hh;
+                    hs[n * 64] = hh;
+                    chk[((int64_t)st * N + n) * a.D] = hh;
                 }
             }
             chan_merge<YT, HW, COL, true, NV>(lds, yb, sgy, h, st, yv);
         };
         if (G::TAIL == P || st + 1 < NSTEP) body(std::integral_constant<int, P>{});
         else body(std::integral_constant<int, G::TAIL>{});
-#pragma unroll
-        for (int n = 0; n < N; ++n) chk[((int64_t)st * N + n) * a.D] = hst[n];
+        if constexpr (N == 1) chk[(int64_t)st * a.D] = hst[0];
     }
 }
 
@@ -369,36 +440,42 @@ __global__ void __launch_bounds__(128) ss2dc_fwd_kernel(const ChanArgs a) {
     constexpr int L = G::L, Lp = G::Lp, Lq = TL::template pitch<HW>();
     extern __shared__ float smem[];
     // wave 0 walks the rows (routes 0, 2), wave 1 the columns (routes 1, 3): one private output plane set each,
-    // the x planes shared.  [2][32][Lq] YT | [32][Lp] bf16 | dsum [32]
+    // the x planes shared.  [2][32][Lq] YT | [32][Lp] bf16 | dsum [32] | d_state > 1: per wave [2][N][64] fp32 scratch
     YT *ys = reinterpret_cast<YT *>(smem);
     uint16_t *xs = reinterpret_cast<uint16_t *>(ys + 2 * 32 * Lq);
     float *dsum = reinterpret_cast<float *>(xs + 32 * Lp);
-    const int tiles = a.D / 32;
-    const int sb = blockIdx.x / tiles, c0 = 32 * (blockIdx.x - sb * tiles);
     const int wave = threadIdx.x >> 6;
-    chan_load_planes<HW, 128>(xs, a.x + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
-    if (threadIdx.x < 32) {
-        const int t = threadIdx.x;
-        dsum[t] = (a.Dp[c0 + t] + a.Dp[a.D + c0 + t]) + (a.Dp[2 * a.D + c0 + t] + a.Dp[3 * a.D + c0 + t]);
-    }
-    __syncthreads();
-    // (the pass-private planes are addressed relative to their own start, the x planes from there as well)
-    if (wave == 0) chan_fwd_pass<HW, N, KS, false, YT>(a, sb, c0, xs, ys);
-    else chan_fwd_pass<HW, N, KS, true, YT>(a, sb, c0, xs, ys + 32 * Lq);
-    __syncthreads();
-    // y = rows + columns + (sum_k D_k) * x: the contiguous run of 32*L floats of this (sample, channel tile)
-    float *dst = a.y + ((int64_t)sb * a.D + c0) * L;
-    const char *y0 = reinterpret_cast<const char *>(ys), *y1 = reinterpret_cast<const char *>(ys + 32 * Lq);
-    for (int v = threadIdx.x; v < 32 * L / 4; v += 128) {
-        float o[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = 4 * v + q;
-            const int c = e / L, l = e - c * L;
-            const int yo = (c * Lq + l) * (int)sizeof(YT);
-            o[q] = fmaf(dsum[c], bf16_bits_to_float(xs[c * Lp + l]), TL::ld(y0 + yo) + TL::ld(y1 + yo));
+    float *scr = dsum + 32 + wave * 2 * N * 64;
+    const int tiles = a.D / 32, groups = (tiles + a.ct - 1) / a.ct;
+    const int sb = blockIdx.x / groups, t0 = (blockIdx.x - sb * groups) * a.ct;
+#pragma unroll 1
+    for (int t = t0; t < min(tiles, t0 + a.ct); ++t) {
+        const int c0 = 32 * t;
+        chan_load_planes<HW, 128>(xs, a.x + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
+        if (threadIdx.x < 32) {
+            const int q = threadIdx.x;
+            dsum[q] = (a.Dp[c0 + q] + a.Dp[a.D + c0 + q]) + (a.Dp[2 * a.D + c0 + q] + a.Dp[3 * a.D + c0 + q]);
         }
-        *reinterpret_cast<float4 *>(dst + 4 * v) = make_float4(o[0], o[1], o[2], o[3]);
+        __syncthreads();
+        // (the pass-private planes are addressed relative to their own start, the x planes from there as well)
+        if (wave == 0) chan_fwd_pass<HW, N, KS, false, YT>(a, sb, c0, xs, ys, scr);
+        else chan_fwd_pass<HW, N, KS, true, YT>(a, sb, c0, xs, ys + 32 * Lq, scr);
+        __syncthreads();
+        // y = rows + columns + (sum_k D_k) * x: the contiguous run of 32*L floats of this (sample, channel tile)
+        float *dst = a.y + ((int64_t)sb * a.D + c0) * L;
+        const char *y0 = reinterpret_cast<const char *>(ys), *y1 = reinterpret_cast<const char *>(ys + 32 * Lq);
+        for (int v = threadIdx.x; v < 32 * L / 4; v += 128) {
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = 4 * v + q;
+                const int c = e / L, l = e - c * L;
+                const int yo = (c * Lq + l) * (int)sizeof(YT);
+                o[q] = fmaf(dsum[c], bf16_bits_to_float(xs[c * Lp + l]), TL::ld(y0 + yo) + TL::ld(y1 + yo));
+            }
+            *reinterpret_cast<float4 *>(dst + 4 * v) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();
     }
 }
 
@@ -407,7 +484,8 @@ __global__ void __launch_bounds__(128) ss2dc_fwd_kernel(const ChanArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS of a workgroup (wave 0: rows, wave 1: columns):
 //   dxs [2][32][pitch] YT (pass-private dx planes) | xs [32][Lp] bf16 | gs [32][Lp] bf16 | dsum [32] |
-//   per wave: bcacc [2 halves][2][N][L] fp32, red [2][2P][36] fp32 (aliased by the ddts staging rows [2][P][32] bf16)
+//   per wave: bcacc [2 halves][2][N][L] fp32, ddts staging rows [2][P][32] bf16,
+//             d_state > 1: E / dA accumulators [2][N][64] fp32
 template <int HW, int N, typename YT> struct ChanBwdLds {
     using G = ChanGeom<HW>;
     static constexpr int P = G::P;
@@ -419,39 +497,46 @@ template <int HW, int N, typename YT> struct ChanBwdLds {
     static constexpr size_t wave0 = (dsum + 32 * 4 + 15) / 16 * 16;
     static constexpr size_t bcacc_sz = (size_t)2 * 2 * N * G::L * 4;
     static constexpr size_t red_off = (bcacc_sz + 15) / 16 * 16;                 // inside a wave's block
-    static constexpr size_t wave_sz = red_off + (size_t)2 * 2 * P * 36 * 4;
+    static constexpr size_t scr_off = red_off + ((size_t)2 * P * 32 * 2 + 15) / 16 * 16;   // [2][N][64] fp32 (d_state > 1)
+    static constexpr size_t wave_sz = scr_off + (N == 1 ? 0 : (size_t)2 * N * 64 * 4);
     static constexpr size_t total = wave0 + 2 * wave_sz;
 };
 
 template <int HW, int N, int KS, bool COL, typename YT>
 __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, const int c0, const uint16_t *xs,
-                                              const uint16_t *gs, YT *dxs, float *bcacc, float *red) {
+                                              const uint16_t *gs, YT *dxs, float *bcacc, float *red, float *scr) {
     using G = ChanGeom<HW>;
     constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP, Lp = G::Lp, Lq = ChanTile<YT>::template pitch<HW>();
     constexpr int YS = (int)sizeof(YT);
-    constexpr int RV = 2 * P;                         // values reduced over the channel lanes per state: P dB + P dC
     const int lane = threadIdx.x & 63;
     const ChanLane<HW, N, KS, COL> ln(a, sb, c0, lane);
     const int c = ln.c, h = ln.h, kb = ln.kb;
-    cbf16x8_t wf[2 * KS];
+    cbf16x8_t wf[N == 1 ? 2 * KS : 1];
+    if constexpr (N == 1) {
 #pragma unroll
-    for (int m = 0; m < 2 * KS; ++m) {
-        const int rm = (COL ? 1 : 0) + 2 * (m / KS);
-        wf[m] = chan_ld8(a.wdt + ((int64_t)rm * a.D + c0 + c) * a.Kp + 16 * (m % KS) + 8 * kb);
+        for (int m = 0; m < 2 * KS; ++m) {
+            const int rm = (COL ? 1 : 0) + 2 * (m / KS);
+            wf[m] = chan_ld8(a.wdt + ((int64_t)rm * a.D + c0 + c) * a.Kp + 16 * (m % KS) + 8 * kb);
+        }
     }
     const float bv = a.bias[ln.wrow];
-    float An[N], A2[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        An[n] = a.A[(int64_t)ln.wrow * N + n];
-        A2[n] = An[n] * kLog2e;
+    // d_state 1: decay rate, adjoint carry E and dA sum in registers; d_state > 1: E / dA in the wave's LDS scratch
+    // ([n][lane]) and the decay rates re-read per state, the loop over the states stays rolled
+    float An[1], A2[1], E[1], dAacc[1];
+    float *Es = scr + lane, *dAs = scr + N * 64 + lane;
+    const float *Arow = a.A + (int64_t)ln.wrow * N;
+    if constexpr (N == 1) {
+        An[0] = Arow[0];
+        A2[0] = An[0] * kLog2e;
+        E[0] = dAacc[0] = 0.f;
+    } else {
+        for (int n = 0; n < N; ++n) Es[n * 64] = dAs[n * 64] = 0.f;
     }
     cf32x16_t biasv;
+    if constexpr (N == 1) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) biasv[j] = bv;
-    float E[N], dAacc[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) E[n] = dAacc[n] = 0.f;
+        for (int j = 0; j < 16; ++j) biasv[j] = bv;
+    }
     float dbacc = 0.f;
     char *lds = reinterpret_cast<char *>(dxs);                         // addressing relative to this pass's dx planes
     const int sg2 = h ? -2 : 2;
@@ -461,29 +546,31 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
     const int dbase = c * Lq * YS + (h ? YS * (L - 1) : 0);
     const int route = (COL ? 1 : 0) + 2 * h;
     const float *chk = a.chk + (((int64_t)sb * 4 + route) * NSTEP) * N * a.D + c0 + c;
-    float *redw = red + h * RV * 36;                  // this half's [RV][36] scratch
-    float *bch = bcacc + h * 2 * N * L;               // this half's (= route's) [2][N][L] accumulators
-    uint16_t *stg = reinterpret_cast<uint16_t *>(red);    // [2][P][32] bf16 rows of ddts (the scratch is free by then)
+    uint16_t *stg = reinterpret_cast<uint16_t *>(red);    // [2][P][32] bf16 rows of ddts
+    const cbf16x8_t sel = chan_selector(lane);
     ChanFrags<N, KS> fr;
-    chan_load_frags<HW, N, KS, COL>(a, ln, NSTEP - 1, fr);
+    if constexpr (N == 1) chan_load_frags<HW, N, KS, COL>(a, ln, NSTEP - 1, fr);
     const cf32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int st = NSTEP - 1; st >= 0; --st) {
-        cf32x16_t acc = biasv;
-#pragma unroll
-        for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f0[m], wf[m], acc, 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f1[m], wf[KS + m], acc, 0, 0, 0);
-        const cbf16x8_t fBc = fr.fB, fCc = fr.fC;
-        cf32x16_t bB1, bC1;
+        cf32x16_t acc, bB1, bC1;
+        cbf16x8_t fBc, fCc;
         if constexpr (N == 1) {
+            acc = biasv;
+#pragma unroll
+            for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f0[m], wf[m], acc, 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f1[m], wf[KS + m], acc, 0, 0, 0);
+            fBc = fr.fB;
+            fCc = fr.fC;
             bB1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fBc, chan_indicator(kb, 0), zero16, 0, 0, 0);
             bC1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fCc, chan_indicator(kb, 1), zero16, 0, 0, 0);
+            if (st > 0) chan_load_frags<HW, N, KS, COL>(a, ln, st - 1, fr);
+        } else {
+            acc = chan_dt_step<HW, N, KS, COL>(a, ln, c0, st, bv, fBc, fCc);
         }
-        if (st > 0) chan_load_frags<HW, N, KS, COL>(a, ln, st - 1, fr);
-        float hin[N];
-#pragma unroll
-        for (int n = 0; n < N; ++n) hin[n] = st > 0 ? chk[((int64_t)(st - 1) * N + n) * a.D] : 0.f;
+        float hin1 = 0.f;
+        if constexpr (N == 1) hin1 = st > 0 ? chk[(int64_t)(st - 1) * a.D] : 0.f;
         const int nb = G::template base<COL>(st);
         auto body = [&](auto nv_tag) {
             constexpr int NV = decltype(nv_tag)::value;
@@ -499,64 +586,75 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
                 dl[i] = chan_softplus_sig(acc[i], sg[i]);
                 sB[i] = sA[i] = 0.f;
             }
-#pragma unroll
-            for (int n = 0; n < N; ++n) {
-                cf32x16_t bB, bC;
-                if constexpr (N == 1) {
-                    bB = bB1;
-                    bC = bC1;
-                } else {
-                    const cbf16x8_t ind = chan_indicator(kb, n);
-                    bB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fBc, ind, zero16, 0, 0, 0);
-                    bC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fCc, ind, zero16, 0, 0, 0);
-                }
-                float av[NV], hv_[NV], bu[NV];
-                float hh = hin[n];
+            // one state: forward recompute from the state entering the step, reverse sweep; dB / dC of the state summed
+            // over the channel lanes by transposing MFMAs and added to the route's LDS accumulators (natural order)
+            auto one_state = [&](const cf32x16_t &bB, const cf32x16_t &bC, const float A2n, const float Ann, const float hin,
+                                 float &Ev, float &dAn, const int n) {
+                float av[NV], hv_[NV];
+                float hh = hin;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    av[i] = exp2_fast(dl[i] * A2[n]);
-                    bu[i] = dl[i] * u[i] * bB[i];
-                    hh = fmaf(av[i], hh, bu[i]);
+                    av[i] = exp2_fast(dl[i] * A2n);
+                    hh = fmaf(av[i], hh, dl[i] * u[i] * bB[i]);
                     hv_[i] = hh;
                 }
-                float dBv[NV], dCv[NV];
-                float Ev = E[n], dAn = dAacc[n];
+                float dBv[16], dCv[16];
+#pragma unroll
+                for (int i = NV; i < 16; ++i) dBv[i] = dCv[i] = 0.f;
 #pragma unroll
                 for (int i = NV - 1; i >= 0; --i) {
                     const float dh = fmaf(bC[i], g[i], Ev);
                     Ev = av[i] * dh;
-                    const float dha = dh * (hv_[i] - bu[i]);             // dh * a_t h_{t-1}
+                    const float dlu = dl[i] * u[i];
+                    const float dha = dh * (hv_[i] - dlu * bB[i]);           // dh * a_t h_{t-1}
                     sB[i] = fmaf(dh, bB[i], sB[i]);
-                    sA[i] = fmaf(dha, An[n], sA[i]);
+                    sA[i] = fmaf(dha, Ann, sA[i]);
                     dAn = fmaf(dha, dl[i], dAn);
-                    dBv[i] = dh * dl[i] * u[i];
-                    dCv[i] = g[i] * hv_[i];
+                    dBv[i] = dh * dlu;                                        // dB_t of this channel
+                    dCv[i] = g[i] * hv_[i];                                   // dC_t of this channel
                 }
-                E[n] = Ev;
-                dAacc[n] = dAn;
-                // ---- sum dBv / dCv over the 32 channel lanes of each half: LDS transpose, then lane j sums row j
-                wave_sync();
+                // lanes 0..15 receive the sums: lane (hh2, j) = value 8 m + j of half hh2
+                const int hh2 = (lane >> 3) & 1, jj = lane & 7;
 #pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    redw[i * 36 + c] = dBv[i];
-                    redw[(P + i) * 36 + c] = dCv[i];
-                }
-                wave_sync();
-                {
-                    const int j = c;                               // value index handled by this lane
-                    const int isC = j >= P, i = isC ? j - P : j;
-                    if (j < RV && i < NV) {
-                        const float *row = redw + j * 36;
-                        float s = 0.f;
+                for (int m = 0; m < (NV > 8 ? 2 : 1); ++m)
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const float4 v = *reinterpret_cast<const float4 *>(row + 4 * q);
-                            s += (v.x + v.y) + (v.z + v.w);
+                    for (int op = 0; op < 2; ++op) {
+                        float v8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v8[j] = op ? dCv[8 * m + j] : dBv[8 * m + j];
+                        const float tot = chan_colsum8(v8, sel);
+                        const int i = 8 * m + jj;
+                        if (lane < 16 && i < NV) {
+                            const int nf = nb + (COL ? (i % HW) * HW + i / HW : i);
+                            atomicAdd(bcacc + ((hh2 * 2 + op) * N + n) * L + (hh2 ? L - 1 - nf : nf), tot);
                         }
-                        const int nf = nb + (COL ? (i % HW) * HW + i / HW : i);
-                        float *dst = bch + (isC * N + n) * L + (h ? L - 1 - nf : nf);
-                        *dst += s;                                 // wave-private accumulator of this route
                     }
+            };
+            if constexpr (N == 1) {
+                one_state(bB1, bC1, A2[0], An[0], hin1, E[0], dAacc[0], 0);
+            } else {
+                cbf16x8_t ind = chan_indicator(kb, 0);
+                cf32x16_t bBn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fBc, ind, zero16, 0, 0, 0);
+                cf32x16_t bCn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fCc, ind, zero16, 0, 0, 0);
+                float hin_n = st > 0 ? chk[(int64_t)(st - 1) * N * a.D] : 0.f;
+                float An_n = Arow[0], E_n = Es[0], dA_n = dAs[0];
+#pragma unroll 1
+                for (int n = 0; n < N; ++n) {
+                    const cf32x16_t bB = bBn, bC = bCn;
+                    const float hin = hin_n, Ann = An_n;
+                    float Ev = E_n, dAn = dA_n;
+                    if (n + 1 < N) {                                 // next state's operands under this state's work
+                        ind = chan_indicator(kb, n + 1);
+                        bBn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fBc, ind, zero16, 0, 0, 0);
+                        bCn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fCc, ind, zero16, 0, 0, 0);
+                        hin_n = st > 0 ? chk[((int64_t)(st - 1) * N + n + 1) * a.D] : 0.f;
+                        An_n = Arow[n + 1];
+                        E_n = Es[(n + 1) * 64];
+                        dA_n = dAs[(n + 1) * 64];
+                    }
+                    one_state(bB, bC, Ann * kLog2e, Ann, hin, Ev, dAn, n);
+                    Es[n * 64] = Ev;
+                    dAs[n * 64] = dAn;
                 }
             }
             // ---- per-position results: du of this route into the wave's dx planes, d raw step size to the staging rows
@@ -589,8 +687,9 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
         if (G::TAIL == P || st + 1 < NSTEP) body(std::integral_constant<int, P>{});
         else body(std::integral_constant<int, G::TAIL>{});
     }
-#pragma unroll
-    for (int n = 0; n < N; ++n) atomicAdd(a.dA + (int64_t)ln.wrow * N + n, dAacc[n]);
+    if constexpr (N == 1) atomicAdd(a.dA + ln.wrow, dAacc[0]);
+    else
+        for (int n = 0; n < N; ++n) atomicAdd(a.dA + (int64_t)ln.wrow * N + n, dAs[n * 64]);
     atomicAdd(a.dbias + ln.wrow, dbacc);
 }
 
@@ -606,23 +705,53 @@ __global__ void __launch_bounds__(128) ss2dc_bwd_kernel(const ChanArgs a) {
     uint16_t *xs = reinterpret_cast<uint16_t *>(sm + LD::xs);
     uint16_t *gs = reinterpret_cast<uint16_t *>(sm + LD::gs);
     float *dsum = reinterpret_cast<float *>(sm + LD::dsum);
-    const int tiles = a.D / 32;
-    const int sb = blockIdx.x / tiles, c0 = 32 * (blockIdx.x - sb * tiles);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *bcacc = reinterpret_cast<float *>(sm + LD::wave0 + wave * LD::wave_sz);
     float *red = reinterpret_cast<float *>(sm + LD::wave0 + wave * LD::wave_sz + LD::red_off);
-    chan_load_planes<HW, 128>(xs, a.x + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
-    chan_load_planes_f32<HW, 128>(gs, a.dy + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
-    for (int e = lane; e < 2 * 2 * N * L; e += 64) bcacc[e] = 0.f;
-    if (threadIdx.x < 32) {
-        const int t = threadIdx.x;
-        dsum[t] = (a.Dp[c0 + t] + a.Dp[a.D + c0 + t]) + (a.Dp[2 * a.D + c0 + t] + a.Dp[3 * a.D + c0 + t]);
+    float *scr = reinterpret_cast<float *>(sm + LD::wave0 + wave * LD::wave_sz + LD::scr_off);
+    const int tiles = a.D / 32, groups = (tiles + a.ct - 1) / a.ct;
+    const int sb = blockIdx.x / groups, t0 = (blockIdx.x - sb * groups) * a.ct;
+    for (int e = lane; e < 2 * 2 * N * L; e += 64) bcacc[e] = 0.f;     // dB / dC of this wave's two routes, all tiles
+#pragma unroll 1
+    for (int t = t0; t < min(tiles, t0 + a.ct); ++t) {
+        const int c0 = 32 * t;
+        chan_load_planes<HW, 128>(xs, a.x + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
+        chan_load_planes_f32<HW, 128>(gs, a.dy + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
+        if (threadIdx.x < 32) {
+            const int q = threadIdx.x;
+            dsum[q] = (a.Dp[c0 + q] + a.Dp[a.D + c0 + q]) + (a.Dp[2 * a.D + c0 + q] + a.Dp[3 * a.D + c0 + q]);
+        }
+        __syncthreads();
+        if (wave == 0) chan_bwd_pass<HW, N, KS, false, YT>(a, sb, c0, xs, gs, dxs, bcacc, red, scr);
+        else chan_bwd_pass<HW, N, KS, true, YT>(a, sb, c0, xs, gs, dxs + 32 * Lq, bcacc, red, scr);
+        __syncthreads();
+        // ---- dx = rows + columns + (sum_k D_k) g ; dD_k[c] += sum_l g u (the same for every route k)
+        uint16_t *dst = a.dx + ((int64_t)sb * a.D + c0) * L;
+        const char *d0 = reinterpret_cast<const char *>(dxs), *d1 = reinterpret_cast<const char *>(dxs + 32 * Lq);
+        for (int v = threadIdx.x; v < 32 * L / 2; v += 128) {
+            float o[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = 2 * v + q;
+                const int c = e / L, l = e - c * L;
+                const int off = (c * Lq + l) * (int)sizeof(YT);
+                o[q] = fmaf(dsum[c], bf16_bits_to_float(gs[c * Lp + l]), TL::ld(d0 + off) + TL::ld(d1 + off));
+            }
+            *reinterpret_cast<uint32_t *>(dst + 2 * v) = pack_bf16x2(o[0], o[1]);
+        }
+        {
+            const int c = threadIdx.x >> 2, part = threadIdx.x & 3;   // four lanes per channel split the plane
+            float s = 0.f;
+            for (int l = part; l < L; l += 4)
+                s = fmaf(bf16_bits_to_float(gs[c * Lp + l]), bf16_bits_to_float(xs[c * Lp + l]), s);
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            if (part == 0)
+                for (int k = 0; k < 4; ++k) atomicAdd(a.dD + k * a.D + c0 + c, s);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (wave == 0) chan_bwd_pass<HW, N, KS, false, YT>(a, sb, c0, xs, gs, dxs, bcacc, red);
-    else chan_bwd_pass<HW, N, KS, true, YT>(a, sb, c0, xs, gs, dxs + 32 * Lq, bcacc, red);
-    wave_sync();
-    {   // dB / dC of the two routes of this pass: contiguous fp32 atomics (natural position order)
+    {   // dB / dC of this wave's two routes over all its tiles: contiguous fp32 atomics (natural position order)
         const int sbC = a.c_mod > 0 ? a.c_off + sb % a.c_mod : sb;      // dC of a borrowed C goes to its owner
         for (int hs = 0; hs < 2; ++hs)
             for (int op = 0; op < 2; ++op) {
@@ -631,31 +760,6 @@ __global__ void __launch_bounds__(128) ss2dc_bwd_kernel(const ChanArgs a) {
                 const float *src = bcacc + ((size_t)hs * 2 + op) * N * L;
                 for (int e = lane; e < N * L; e += 64) atomicAdd(dst + e, src[e]);
             }
-    }
-    __syncthreads();
-    // ---- dx = rows + columns + (sum_k D_k) g ; dD_k[c] += sum_l g u (the same for every route k)
-    uint16_t *dst = a.dx + ((int64_t)sb * a.D + c0) * L;
-    const char *d0 = reinterpret_cast<const char *>(dxs), *d1 = reinterpret_cast<const char *>(dxs + 32 * Lq);
-    for (int v = threadIdx.x; v < 32 * L / 2; v += 128) {
-        float o[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = 2 * v + q;
-            const int c = e / L, l = e - c * L;
-            const int off = (c * Lq + l) * (int)sizeof(YT);
-            o[q] = fmaf(dsum[c], bf16_bits_to_float(gs[c * Lp + l]), TL::ld(d0 + off) + TL::ld(d1 + off));
-        }
-        *reinterpret_cast<uint32_t *>(dst + 2 * v) = pack_bf16x2(o[0], o[1]);
-    }
-    {
-        const int c = threadIdx.x >> 2, part = threadIdx.x & 3;       // four lanes per channel split the plane
-        float s = 0.f;
-        for (int l = part; l < L; l += 4)
-            s = fmaf(bf16_bits_to_float(gs[c * Lp + l]), bf16_bits_to_float(xs[c * Lp + l]), s);
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        if (part == 0)
-            for (int k = 0; k < 4; ++k) atomicAdd(a.dD + k * a.D + c0 + c, s);
     }
 }
 
@@ -666,7 +770,8 @@ template <int HW, int N, int KS> static int chan_launch(const ChanArgs &a, bool 
     using G = ChanGeom<HW>;
     // forward: fp32 pass-private planes while four workgroups (8 waves) fit a CU, bf16 planes beyond (14 x 14)
     using YT = typename std::conditional<(HW > 12), uint16_t, float>::type;
-    const size_t lds_f = (size_t)2 * 32 * ChanTile<YT>::template pitch<HW>() * sizeof(YT) + (size_t)32 * G::Lp * 2 + 32 * 4;
+    const size_t lds_f = (size_t)2 * 32 * ChanTile<YT>::template pitch<HW>() * sizeof(YT) + (size_t)32 * G::Lp * 2 + 32 * 4 +
+                         (N == 1 ? 0 : (size_t)2 * 2 * N * 64 * 4);
     const size_t lds = bwd ? ChanBwdLds<HW, N, YT>::total : lds_f;
     const void *fn = bwd ? (const void *)ss2dc_bwd_kernel<HW, N, KS, YT> : (const void *)ss2dc_fwd_kernel<HW, N, KS, YT>;
     if (lds > 160 * 1024) return XFM_ELIMIT;
@@ -675,8 +780,12 @@ template <int HW, int N, int KS> static int chan_launch(const ChanArgs &a, bool 
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
         opted[bwd] = true;
     }
-    const unsigned grid = (unsigned)(a.Bt * (a.D / 32));
     ChanArgs args = a;
+    // one 32-channel tile per workgroup measured fastest also for d_state 16 (deep block, 96 x 48 tiles: 999 us against
+    // 1256 / 1648 / 2111 us with 2 / 4 / 8 tiles per workgroup: parallelism beats the smaller dB / dC flush)
+    args.ct = 1;
+    if (const char *e = getenv("XFM_CHAN_CT")) args.ct = atoi(e) > 0 ? atoi(e) : 1;   // tuning hook
+    const unsigned grid = (unsigned)(a.Bt * ((a.D / 32 + args.ct - 1) / args.ct));
     void *kargs[] = {&args};
     const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(128), kargs, lds, s);
     if (e != hipSuccess) {

@@ -872,6 +872,12 @@ class Cross_SS2Dv5(nn.Module):
         K, _, R = self.dt_projs_weight.shape
         N = self.A_logs.shape[1]
         cd = x3.dtype
+        if SS2D_MODE == "fused" and chan_supported(x3, H, W, N, K, D, R):
+            # ONE kernel for the cross-fusion exchange: the three streams' four routes, dt_proj on MFMA inside, the view
+            # streams reading their state through the fused stream's C rows (no cross_scan / expand / cross_merge copies)
+            y = ss2d_chan_fn(x3.reshape(B3, D, L), self.x_proj_weight, self.dt_projs_weight, -self.A_logs.float().exp(),
+                             self.Ds.float(), self.dt_projs_bias.reshape(-1).float(), H, W, c_mod=B, c_off=2 * B)
+            return self.out_norm(y.transpose(1, 2).reshape(B3, H, W, -1)).to(cd)
         xs = cross_scan_fn(x3, in_channel_first=True, out_channel_first=True, scans=0)           # (3B, 4, D, L)
         x_dbl = torch.matmul(self.x_proj_weight.to(cd), xs)                                       # (3B, K, R+2N, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)

@@ -73,7 +73,7 @@ def _params(x, xdbl, wdt, A, D, bias, H, W, N, R, n_routes, c_mod, c_off, wdiv, 
 class SS2DChanHip(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, x_proj_w, dt_w, A, D, bias, H, W):
+    def forward(ctx, x, x_proj_w, dt_w, A, D, bias, H, W, c_mod=0, c_off=0):
         _lib.require_cuda(x, x_proj_w, dt_w, A, D, bias)
         Bt, Dm, L = x.shape
         K, C2, _ = x_proj_w.shape
@@ -94,12 +94,13 @@ class SS2DChanHip(torch.autograd.Function):
         nst = lib.xfm_ss2dc_nsteps(H, W)
         chk = torch.empty((Bt, K, nst, N, Dm), dtype=torch.float32, device=x.device)
         y = torch.empty((Bt, Dm, L), dtype=torch.float32, device=x.device)
-        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, 0, 0, 1, chk)
+        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, c_mod, c_off, 1, chk)
         p.y = y.data_ptr()
         nbytes = Bt * Dm * L * (2 + 4) + xdbl.numel() * 2
         with torch.cuda.device(x.device), _lib.timed("ss2dc_fwd", nbytes):
             _lib.check(lib.xfm_ss2dc_fwd(ctypes.byref(p), _lib.stream_ptr()), "ss2dc_fwd")
         ctx.hw = (H, W)
+        ctx.cmod = (c_mod, c_off)
         ctx.meta = (x_proj_w.dtype, tuple(x_proj_w.shape), dt_w.dtype)
         ctx.save_for_backward(x, xdbl, xw_pad, wdt, A, D, bias, chk)
         return y
@@ -127,7 +128,7 @@ class SS2DChanHip(torch.autograd.Function):
         dA = acc[nbc:nbc + na].view(A.shape)
         dD, dbias = acc[nbc + na:nbc + na + nd], acc[nbc + na + nd:]
         lib = _lib.lib()
-        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, 0, 0, 1, chk)
+        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, ctx.cmod[0], ctx.cmod[1], 1, chk)
         p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
         p.dBC, p.dA, p.dD, p.ddelta_bias = dBC.data_ptr(), dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
         nbytes = Bt * Dm * L * (2 + 4 + 2 + 2 * K) + xdbl.numel() * 2
@@ -148,9 +149,12 @@ class SS2DChanHip(torch.autograd.Function):
         dxw_pad = _bmm_f32(dxdbl.transpose(1, 2), x.transpose(1, 2)).sum(0)               # (XC, D)
         rows = _row_index(K, R, N, dev)
         dxw = dxw_pad.index_select(0, rows).view(xw_shape).to(xw_dtype)
-        return dx, dxw, dwdt.to(dtw_dtype), dA, dD, dbias, None, None
+        return dx, dxw, dwdt.to(dtw_dtype), dA, dD, dbias, None, None, None, None
 
 
-def ss2d_chan_fn(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W):
-    """x (B,D,L) bf16 natural; x_proj_weight (4,R+2N,D); dt_projs_weight (4,D,R); A (4D,N); D/bias (4D,) -> y (B,D,L) fp32."""
-    return SS2DChanHip.apply(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W)
+def ss2d_chan_fn(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod=0, c_off=0):
+    """x (B,D,L) bf16 natural; x_proj_weight (4,R+2N,D); dt_projs_weight (4,D,R); A (4D,N); D/bias (4D,) -> y (B,D,L) fp32.
+    ``c_mod > 0``: sample sb reads its C operand from sample ``c_off + sb % c_mod`` (the deep fusion block's three streams
+    as one batch [view 1 | view 2 | fused]: the view streams read through the fused stream's C, reference
+    models/fusion_vmamba.py:536-538, 567-569)."""
+    return SS2DChanHip.apply(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod, c_off)
