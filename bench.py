@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--graph-scope", default=None, choices=["step", "fwdbwd"],
                     help="what the hipGraph captures (default: whole step at N=1, forward+backward at N>1)")
     ap.add_argument("--stream", default=None, choices=["tokens", "planes"], help="residual-stream layout of the trunk")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: fp8 (e4m3) weights for the SS2D x_proj / out_proj "
+                    "on the fp8 matrix cores, scan in bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--drop-path", type=float, default=None, help="override the reference's DropPath rates (e.g. 0)")
@@ -109,6 +111,10 @@ def main():
     from xfmamba_amd.dp import GradBuckets, broadcast_parameters
     from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
     _lib.lib()                                                   # fail loudly if the HIP extension is missing
+    if a.fp8:
+        from xfmamba_amd import fp8 as _fp8
+        assert a.dtype == "bf16", "--fp8 rides on the bf16 configuration"
+        _fp8.ENABLED = True
     if a.ss2d:
         fusion_vmamba.SS2D_MODE = a.ss2d
     if a.stream:
@@ -250,7 +256,7 @@ def main():
                 metric_name = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
             except Exception:                                   # noqa: BLE001
                 pass
-        cfg_label = {("tiny", 224, 32, "bf16"): " (BASELINE configs[1])", ("small", 224, 32, "bf16"): " (BASELINE configs[2], one GPU of it)",
+        cfg_label = {("tiny", 224, 32, "bf16"): " (BASELINE configs[4]: fp8 x_proj / out_proj weights)" if a.fp8 else " (BASELINE configs[1])", ("small", 224, 32, "bf16"): " (BASELINE configs[2], one GPU of it)",
                      ("base", 384, 16, "bf16"): " (BASELINE configs[3])"}.get((a.model, a.size, B, a.dtype), "")
         roof = None
         kernels = {}
@@ -290,7 +296,7 @@ def main():
                                    f"fwd+bwd+Adam, train mode" + cfg_label,
                        "note": "outnorm0-2 of the trunk are skipped: the reference computes them and discards the "
                                "results (net_fusionmamba.py:200-201); they carry no gradient",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "ss2d_mode": fusion_vmamba.SS2D_MODE,
+                       "global_batch": B * world, "parallelism": f"dp{world}", "ss2d_mode": fusion_vmamba.SS2D_MODE, "fp8_proj": bool(a.fp8),
                        "single_view_images_per_s": round(2 * value, 2)},
             "roofline": roof,
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),

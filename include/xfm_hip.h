@@ -282,7 +282,7 @@ int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream);
  *   c_mod > 0: sample sb reads its C columns from sample c_off + sb % c_mod (deep fusion block: the view streams read
  *          their state through the fused stream's C, reference :536-538, :567-569) and its dC is added there.
  *   y      (batch, d_inner, L) fp32 = sum over the routes, gathered back to natural order (n_routes == 1: that route).
- *   chk    (batch, n_routes, xfm_ss2dc_nsteps(), dstate, d_inner) fp32 workspace written by fwd, read by bwd.
+ *   chk    (batch, n_routes, xfm_ss2dc_nsteps(H, W, dstate), dstate, d_inner) fp32 workspace written by fwd, read by bwd.
  * backward: dy (batch, d_inner, L) fp32 -> dx (batch, d_inner, L) bf16; ddts (batch, n_routes, L, d_inner) bf16 = gradient
  *   of the RAW step size (before bias + softplus), natural position order, channel fastest; dBC (batch, n_routes, 2,
  *   dstate, L) fp32 ZEROED: gradients of the B (index 0) and C (index 1) columns, natural order; dA, dD, ddelta_bias fp32
@@ -303,7 +303,7 @@ typedef struct {
     float *dBC, *dA, *dD, *ddelta_bias;
 } xfm_ss2dc_params_t;
 int xfm_ss2dc_supported(int H, int W, int dstate, int n_routes, int d_inner, int dt_rank);
-int xfm_ss2dc_nsteps(int H, int W);
+int xfm_ss2dc_nsteps(int H, int W, int dstate);
 int xfm_ss2dc_fwd(const xfm_ss2dc_params_t *p, void *stream);
 int xfm_ss2dc_bwd(const xfm_ss2dc_params_t *p, void *stream);
 /* The two dense products behind xfm_ss2dc_bwd (n_routes == 4), both on MFMA, each reading ddts once (the backward of the
@@ -314,6 +314,17 @@ int xfm_ss2dc_bwd(const xfm_ss2dc_params_t *p, void *stream);
  *   dwdt  (4, d_inner, dt_rank) fp32 ZEROED += sum over batch and positions of ddts x (dt_proj input columns of xdbl). */
 int xfm_ss2dc_post(const void *ddts, const void *xdbl, const void *wdtT, const float *dBC, void *dxdbl, float *dwdt,
                    int batch, int d_inner, int L, int dt_rank, int dstate, void *stream);
+
+/*
+ * BASELINE.json configs[4]: x_proj / out_proj of an SS2D block with fp8 (OCP e4m3fn) weights on the CDNA4 fp8 matrix
+ * cores (reference call sites models/fusion_vmamba.py:1147-1150 and :1205, there plain F.conv1d / F.conv2d):
+ *   y[b, l, m] = scale * sum_k wq[m, k] * q(x[b, k, l])    x (B, K, L) bf16 planes -> y (B, L, M) bf16 tokens
+ * wq: (M, K) fp8 e4m3fn, quantised per tensor by the caller (scale = amax / 448, a DEVICE scalar); q(): clamp to +-448 and round to
+ * nearest even to e4m3fn inside the kernel (no activation scale).  K % 16 == 0, M % 4 == 0, M <= 1024.
+ */
+int xfm_fp8_planes_gemm_supported(int K, int M);
+int xfm_fp8_planes_gemm(const void *x_bf16, const void *wq_fp8, const float *scale, void *y_bf16, int B, int K, int L, int M,
+                        void *stream);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ def test_struct_layout_matches_header():
     hdr = open(os.path.join(ROOT, "include", "xfm_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     for struct, cls in (("xfm_scan_params_t", _lib.ScanParams), ("xfm_ss2d_params_t", _lib.SS2DParams),
-                        ("xfm_scan_plan_t", _lib.ScanPlan)):
+                        ("xfm_scan_plan_t", _lib.ScanPlan), ("xfm_ss2dc_params_t", _lib.SS2DCParams)):
         body = hdr[:hdr.index("} " + struct)].rsplit("typedef struct {", 1)[1]
         names = []
         for decl in body.split(";"):

@@ -51,11 +51,15 @@ struct ChanArgs {
     int ct;                  // consecutive 32-channel tiles walked by one workgroup (amortises the dB / dC flush)
 };
 
-template <int HW> struct ChanGeom {
+// N (d_state) only sets the step length: a step of d_state > 1 works 16x longer per position, and its per-position
+// operands (not its state) fill the registers, so it takes ONE row / column where d_state 1 takes two on 5x5 / 7x7 maps
+template <int HW, int N = 1> struct ChanGeom {
     static constexpr int L = HW * HW;
     static constexpr int Lp = L + 2 - (L & 1);               // bf16 plane pitch: Lp / 2 odd -> conflict-free channel lanes
     static constexpr int Lq = L | 1;                          // fp32 plane pitch (odd)
-    static constexpr int P = HW <= 8 ? 2 * HW : HW;          // positions per step (one or two rows / columns), <= 16
+    // positions per step (one or two rows / columns), <= 16.  (d_state 16 with ONE row per step and two waves per SIMD
+    // measured slower on the deep block -- backward 1159 vs 975 us, forward 264 vs 219 -- so N does not enter here.)
+    static constexpr int P = HW <= 8 ? 2 * HW : HW;
     static constexpr int Q = P / HW;
     static constexpr int NSTEP = (L + P - 1) / P;
     static constexpr int TAIL = L - (NSTEP - 1) * P;          // valid positions of the last step
@@ -147,7 +151,7 @@ template <int HW, int NT> __device__ __forceinline__ void chan_load_planes_f32(u
 
 // Per-lane roles shared by the forward and backward passes of one route pair (pass COL: routes COL and COL + 2)
 template <int HW, int N, int KS, bool COL> struct ChanLane {
-    using G = ChanGeom<HW>;
+    using G = ChanGeom<HW, N>;
     static constexpr int L = G::L, P = G::P;
     static constexpr int NB = N == 1 ? 1 : N;
     int c, h, kb, ha, offA;
@@ -276,10 +280,10 @@ template <> struct ChanTile<uint16_t> {
 // are the FIRST visitor of their rows in the first half of the walk (plain store: the planes are never zero-filled) and
 // the second in the other half (read-modify-write); in the middle step of an odd map, where the two directions meet,
 // the visitor with the earlier sequence index (in walk order) stores first and the other adds after a wave-level sync.
-template <typename YT, int HW, bool COL, bool ASC, int NV>
+template <typename YT, int HW, int N, bool COL, bool ASC, int NV>
 __device__ __forceinline__ void chan_merge(char *lds, const int yb, const int sgy, const int h, const int st,
                                            const float (&v)[NV]) {
-    using G = ChanGeom<HW>;
+    using G = ChanGeom<HW, N>;
     using TL = ChanTile<YT>;
     constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP;
     if (G::MIDSTEP >= 0 && st == G::MIDSTEP) {
@@ -311,7 +315,7 @@ __device__ __forceinline__ void chan_merge(char *lds, const int yb, const int sg
 template <int HW, int N, int KS, bool COL, typename YT>
 __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, const int c0, const uint16_t *xs, YT *ys,
                                               float *scr) {
-    using G = ChanGeom<HW>;
+    using G = ChanGeom<HW, N>;
     using TL = ChanTile<YT>;
     constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP, Lp = G::Lp, Lq = TL::template pitch<HW>();
     constexpr int YS = (int)sizeof(YT);                                 // bytes per output position
@@ -425,7 +429,7 @@ __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, c
                     chk[((int64_t)st * N + n) * a.D] = hh;
                 }
             }
-            chan_merge<YT, HW, COL, true, NV>(lds, yb, sgy, h, st, yv);
+            chan_merge<YT, HW, N, COL, true, NV>(lds, yb, sgy, h, st, yv);
         };
         if (G::TAIL == P || st + 1 < NSTEP) body(std::integral_constant<int, P>{});
         else body(std::integral_constant<int, G::TAIL>{});
@@ -435,7 +439,7 @@ __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, c
 
 template <int HW, int N, int KS, typename YT>
 __global__ void __launch_bounds__(128) ss2dc_fwd_kernel(const ChanArgs a) {
-    using G = ChanGeom<HW>;
+    using G = ChanGeom<HW, N>;
     using TL = ChanTile<YT>;
     constexpr int L = G::L, Lp = G::Lp, Lq = TL::template pitch<HW>();
     extern __shared__ float smem[];
@@ -487,7 +491,7 @@ __global__ void __launch_bounds__(128) ss2dc_fwd_kernel(const ChanArgs a) {
 //   per wave: bcacc [2 halves][2][N][L] fp32, ddts staging rows [2][P][32] bf16,
 //             d_state > 1: E / dA accumulators [2][N][64] fp32
 template <int HW, int N, typename YT> struct ChanBwdLds {
-    using G = ChanGeom<HW>;
+    using G = ChanGeom<HW, N>;
     static constexpr int P = G::P;
     static constexpr int Lq = ChanTile<YT>::template pitch<HW>();
     static constexpr size_t dxs = 0;
@@ -505,7 +509,7 @@ template <int HW, int N, typename YT> struct ChanBwdLds {
 template <int HW, int N, int KS, bool COL, typename YT>
 __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, const int c0, const uint16_t *xs,
                                               const uint16_t *gs, YT *dxs, float *bcacc, float *red, float *scr) {
-    using G = ChanGeom<HW>;
+    using G = ChanGeom<HW, N>;
     constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP, Lp = G::Lp, Lq = ChanTile<YT>::template pitch<HW>();
     constexpr int YS = (int)sizeof(YT);
     const int lane = threadIdx.x & 63;
@@ -667,7 +671,7 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
                 dbacc += ddl;
                 stg[(h * P + i) * 32 + c] = (uint16_t)(pack_bf16x2(ddl, 0.f) & 0xffffu);
             }
-            chan_merge<YT, HW, COL, false, NV>(lds, db, sgy, h, st, duv);
+            chan_merge<YT, HW, N, COL, false, NV>(lds, db, sgy, h, st, duv);
             // ---- ddts rows of this step: [half][position][32 channels] bf16 -> 16-byte stores (4 lanes per position)
             wave_sync();
             {
@@ -695,7 +699,7 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
 
 template <int HW, int N, int KS, typename YT>
 __global__ void __launch_bounds__(128) ss2dc_bwd_kernel(const ChanArgs a) {
-    using G = ChanGeom<HW>;
+    using G = ChanGeom<HW, N>;
     using LD = ChanBwdLds<HW, N, YT>;
     using TL = ChanTile<YT>;
     constexpr int L = G::L, Lp = G::Lp, Lq = LD::Lq;
@@ -767,7 +771,7 @@ __global__ void __launch_bounds__(128) ss2dc_bwd_kernel(const ChanArgs a) {
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 template <int HW, int N, int KS> static int chan_launch(const ChanArgs &a, bool bwd, hipStream_t s) {
-    using G = ChanGeom<HW>;
+    using G = ChanGeom<HW, N>;
     // forward: fp32 pass-private planes while four workgroups (8 waves) fit a CU, bf16 planes beyond (14 x 14)
     using YT = typename std::conditional<(HW > 12), uint16_t, float>::type;
     const size_t lds_f = (size_t)2 * 32 * ChanTile<YT>::template pitch<HW>() * sizeof(YT) + (size_t)32 * G::Lp * 2 + 32 * 4 +
@@ -855,7 +859,8 @@ extern "C" {
 int xfm_ss2dc_supported(int H, int W, int dstate, int n_routes, int d_inner, int dt_rank) {
     return xfm::chan_supported(H, W, dstate, n_routes, d_inner, dt_rank);
 }
-int xfm_ss2dc_nsteps(int H, int W) {
+int xfm_ss2dc_nsteps(int H, int W, int dstate) {
+    (void)dstate;
     const int P = H <= 8 ? 2 * H : H;
     return (H * W + P - 1) / P;
 }

@@ -42,6 +42,7 @@ from .proj import batched_proj
 from .rowln import add_layernorm_rows_fn, layernorm_rows_fn, rows_supported
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
 from .ss2d_chan import chan_supported, ss2d_chan_fn
+from . import fp8 as _fp8
 
 SS2D_MODE = "fused"          # "fused" | "unfused"
 # Layout of the trunk's residual stream between VSS blocks.  "tokens": (B, H, W, C) fp32 -- LayerNorm (+ residual add
@@ -358,7 +359,10 @@ class SS2Dv2(nn.Module):
         y = self.out_act(self.forward_core(x)).view(B, -1, L)
         if z is not None:
             y = y * z
-        out = batched_proj(y, self.out_proj.weight, self.out_proj.bias, in_tokens=False, out_tokens=True)
+        if self.out_proj.bias is None and _fp8.usable(y, y.shape[1], self.out_proj.weight.shape[0]):
+            out = _fp8.fp8_planes_linear(y, self.out_proj.weight)       # BASELINE configs[4]: fp8 weights, fp8 MFMA
+        else:
+            out = batched_proj(y, self.out_proj.weight, self.out_proj.bias, in_tokens=False, out_tokens=True)
         return self.dropout(out.view(B, H, W, C))
 
 

@@ -15,6 +15,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import fp8 as _fp8
 from .amp import cast_weight
 from .proj import mfma_planes
 
@@ -130,10 +131,19 @@ class SS2DProjCoreHip(torch.autograd.Function):
             # x_proj of the four routes inside the node: ONE dense GEMM on the natural map; in the backward pass its
             # data gradient is accumulated onto the scan's dx by the GEMM itself (beta = 1), not by a separate add
             x = x.contiguous()
-            xw = cast_weight(x_proj_w.reshape(K * C2, Dm), x.dtype)
-            x_dbl = mfma_planes(x.contiguous(), xw, K * C2)                     # x_proj on MFMA at the 56x56 stage
-            if x_dbl is None:
-                x_dbl = torch.bmm(xw.unsqueeze(0).expand(Bt, K * C2, Dm), x)
+            if _fp8.usable(x, Dm, K * C2):
+                # BASELINE configs[4]: fp8 weights on the fp8 matrix cores; the kernel emits tokens, this path wants planes
+                wq, scale, xw = _fp8.quantize_weight(x_proj_w.reshape(K * C2, Dm))
+                xt = torch.empty((Bt, L, K * C2), dtype=x.dtype, device=x.device)
+                with torch.cuda.device(x.device), _lib.timed("fp8_planes_gemm", Bt * L * (Dm + K * C2) * 2):
+                    _lib.check(_lib.lib().xfm_fp8_planes_gemm(x.data_ptr(), wq.data_ptr(), scale.data_ptr(), xt.data_ptr(), Bt,
+                                                              Dm, L, K * C2, _lib.stream_ptr()), "fp8_planes_gemm")
+                x_dbl = xt.transpose(1, 2).contiguous()
+            else:
+                xw = cast_weight(x_proj_w.reshape(K * C2, Dm), x.dtype)
+                x_dbl = mfma_planes(x.contiguous(), xw, K * C2)                 # x_proj on MFMA at the 56x56 stage
+                if x_dbl is None:
+                    x_dbl = torch.bmm(xw.unsqueeze(0).expand(Bt, K * C2, Dm), x)
         _lib.require_cuda(x_dbl)
         if K != 4 or L != H * W or x_dbl.shape != (Bt, K * C2, L) or x_dbl.dtype != x.dtype:
             raise RuntimeError("ss2d_proj_core: x (B,D,H*W), x_dbl (B,4*(R+2N),H*W) of one dtype, dt_w (4,D,R) expected")

@@ -15,6 +15,7 @@ import os
 import torch
 
 from . import _lib
+from . import fp8 as _fp8
 from .amp import cast_weight
 
 __all__ = ["ss2d_chan_fn", "chan_supported", "SS2DChanHip"]
@@ -85,13 +86,24 @@ class SS2DChanHip(torch.autograd.Function):
         Kp = (R + 15) // 16 * 16
         XC = K * C2p
         rows = _row_index(K, R, N, x.device)
-        xw_pad = torch.zeros((XC, Dm), dtype=x.dtype, device=x.device)
-        xw_pad.index_copy_(0, rows, cast_weight(x_proj_w.reshape(K * C2, Dm), x.dtype))
         wdt = torch.nn.functional.pad(cast_weight(dt_w, x.dtype), (0, Kp - R)).contiguous()      # (4, D, Kp)
-        xdbl = torch.bmm(x.transpose(1, 2), xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC))         # (B, L, XC) token-major
+        if _fp8.usable(x, Dm, XC):
+            # BASELINE configs[4]: x_proj with fp8 weights on the fp8 matrix cores (straight-through backward with the
+            # de-quantised weight)
+            xw_f = torch.zeros((XC, Dm), dtype=torch.float32, device=x.device)
+            xw_f.index_copy_(0, rows, x_proj_w.detach().reshape(K * C2, Dm).float())
+            wq, scale, xw_pad = _fp8.quantize_weight(xw_f)
+            xdbl = torch.empty((Bt, L, XC), dtype=x.dtype, device=x.device)
+            with torch.cuda.device(x.device), _lib.timed("fp8_planes_gemm", Bt * L * (Dm + XC) * 2):
+                _lib.check(_lib.lib().xfm_fp8_planes_gemm(x.data_ptr(), wq.data_ptr(), scale.data_ptr(), xdbl.data_ptr(), Bt, Dm,
+                                                          L, XC, _lib.stream_ptr()), "fp8_planes_gemm")
+        else:
+            xw_pad = torch.zeros((XC, Dm), dtype=x.dtype, device=x.device)
+            xw_pad.index_copy_(0, rows, cast_weight(x_proj_w.reshape(K * C2, Dm), x.dtype))
+            xdbl = torch.bmm(x.transpose(1, 2), xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC))     # (B, L, XC) token-major
         A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
         lib = _lib.lib()
-        nst = lib.xfm_ss2dc_nsteps(H, W)
+        nst = lib.xfm_ss2dc_nsteps(H, W, N)
         chk = torch.empty((Bt, K, nst, N, Dm), dtype=torch.float32, device=x.device)
         y = torch.empty((Bt, Dm, L), dtype=torch.float32, device=x.device)
         p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, c_mod, c_off, 1, chk)
