@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--stream", default=None, choices=["tokens", "planes"], help="residual-stream layout of the trunk")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: fp8 (e4m3) weights for the SS2D x_proj / out_proj "
                     "on the fp8 matrix cores, scan in bf16")
+    ap.add_argument("--torch-adam", action="store_true", help="library optimizer instead of the fused multi-tensor kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--drop-path", type=float, default=None, help="override the reference's DropPath rates (e.g. 0)")
@@ -108,6 +109,7 @@ def main():
 
     from xfmamba_amd import _lib, fusion_vmamba
     from xfmamba_amd.amp import WeightCache
+    from xfmamba_amd.optim import FusedAdam
     from xfmamba_amd.dp import GradBuckets, broadcast_parameters
     from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
     _lib.lib()                                                   # fail loudly if the HIP extension is missing
@@ -138,10 +140,15 @@ def main():
     scope = a.graph_scope or ("step" if world == 1 else "fwdbwd")
     assert not (world > 1 and scope == "step"), "RCCL collectives are not captured: use --graph-scope fwdbwd with N > 1"
     buckets = GradBuckets(model, bucket_mb=48.0, overlap=not use_graph)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True,     # 1_train_model.py:141
-                           capturable=use_graph and scope == "step")
     crit = torch.nn.CrossEntropyLoss()
-    wcache = WeightCache(model) if a.dtype == "bf16" else None     # bf16 shadows, one multi-tensor refresh per step
+    wcache = WeightCache(model) if a.dtype == "bf16" else None     # bf16 shadows of the GEMM weights
+    # Adam of the reference loop (1_train_model.py:141) for all parameters in ONE launch that also rewrites the shadows
+    # (csrc/adam.hip); --torch-adam: torch.optim.Adam(fused=True) + a multi-tensor shadow refresh, for A/B runs
+    if a.torch_adam:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True,
+                               capturable=use_graph and scope == "step")
+    else:
+        opt = FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-5, weight_cache=wcache)
 
     torch.manual_seed(42 + rank)
     B = a.batch
@@ -160,7 +167,7 @@ def main():
 
     def update():
         opt.step()
-        if wcache is not None:
+        if wcache is not None and a.torch_adam:
             wcache.refresh()
 
     def step():                                      # one eager training step

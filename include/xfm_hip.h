@@ -326,6 +326,18 @@ int xfm_fp8_planes_gemm_supported(int K, int M);
 int xfm_fp8_planes_gemm(const void *x_bf16, const void *wq_fp8, const float *scale, void *y_bf16, int B, int K, int L, int M,
                         void *stream);
 
+/*
+ * The optimizer step of the reference loop (torch.optim.Adam(lr, weight_decay), 1_train_model.py:141) for all parameters
+ * in ONE multi-tensor launch, fused with the refresh of the bf16 weight shadows of the mixed-precision forward:
+ *   g' = g + wd p;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * p/g/m/v/shadow_ptrs: device arrays of int64 device addresses (fp32 tensors; shadow = bf16 copy of p or 0); numel int64;
+ * chunks (int64): tensor index | (chunk index inside the tensor << 32) for each of the nchunks workgroups (chunk elements
+ * each, a multiple of 1024); step: device fp32 scalar t, read then incremented (graph-capturable).
+ */
+int xfm_adam_multi(const void *p_ptrs, const void *g_ptrs, const void *m_ptrs, const void *v_ptrs, const void *shadow_ptrs,
+                   const void *numel, const void *chunks, int nchunks, int chunk, float *step,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,7 +147,7 @@ def test_vss_stage_tokens_stream_matches_planes_and_oracle(C, H, dt):
         assert_close(y, yr.detach(), tol, tol * float(yr.abs().max()), f"{layout} y")
         assert_close(dx, xr.grad, tol, tol * float(xr.grad.abs().max()), f"{layout} dx")
         for k, gref in ((k, pr[f"b.{k}"].grad) for k in grads):
-            assert_close(grads[k], gref, 5 * tol, 2 * tol * float(gref.abs().max()) + 1e-7, f"{layout} d{k}")
+            assert_close(grads[k], gref, 3 * tol, (tol if dt == torch.float32 else 1.5 * tol) * float(gref.abs().max()) + 1e-7, f"{layout} d{k}")
 
 
 def test_vss_stage_tokens_stream_drop_path_matches_planes():
@@ -310,19 +310,27 @@ def test_model_small_base_bf16_autocast(cfg):
 
 
 def test_model_tiny_bf16_autocast_within_tolerance():
-    """bf16 compute (autocast GEMMs, bf16 scan I/O with fp32 state).  BASELINE's 1e-2 bound is an OPERATOR bound
-    and is enforced per kernel in test_hip_ops.py; through 24 residual blocks + 2 fusion blocks of bf16 GEMMs
-    the end-to-end logits of this synthetic-weight model (|logit| up to 11) sit at ~1.1-1.4e-2 of the logit
-    scale, of which the SS2D core contributes ~0.3e-2 (measured by running only it in fp32).  The end-to-end
-    bound asserted here is therefore 2e-2; the fp32 path matches the reference to 1e-6."""
+    """bf16 compute (autocast GEMMs, bf16 scan I/O with fp32 state).  BASELINE's 1e-2 bound is an OPERATOR bound and is
+    enforced per kernel in test_hip_ops.py / test_hip_chan.py.  End to end, through 24 residual blocks + 2 fusion blocks of
+    bf16 GEMMs, the policy is pinned RELATIVE to the oracle: the CPU oracle run under bf16 autocast (same GEMM precision,
+    fp32 scan) sits d_orc ~ 1.1e-2 of the logit scale from the fp32 reference record; the HIP path must be no farther
+    than 1.5 d_orc + 2e-3 (and never beyond 2e-2)."""
+    from oracle import c_scan
     z = load_npz("g5_model.npz")
     m = _tiny_with_synth_weights().eval()
-    xa, xb, _ = (t.to(DEV) for t in g5_inputs())
+    xa, xb, _ = g5_inputs()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        logits = m(xa, xb)
+        logits = m(xa.to(DEV), xb.to(DEV))
     ref = torch.from_numpy(z["logits_eval"])
-    rel = float((logits.float().cpu() - ref).abs().max() / ref.abs().max())
-    assert rel < 2e-2, rel
+    scale = float(ref.abs().max())
+    d_hip = float((logits.float().cpu() - ref).abs().max()) / scale
+    sd = O.synth_state_dict(load_json("g5_state_shapes.json")["tiny"], seed=0)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        lo = O.xfmamba_top_ref(sd, xa, xb, False, c_scan.selective_scan_c)
+    d_orc = float((lo.float() - ref).abs().max()) / scale
+    assert 2e-3 < d_orc < 3e-2, d_orc                  # (the yardstick itself is a bf16 run: ~1e-2)
+    assert d_hip <= 1.5 * d_orc + 2e-3, (d_hip, d_orc)
+    assert d_hip < 2e-2, d_hip
 
 
 @pytest.mark.parametrize("B,find", [
@@ -452,3 +460,58 @@ def test_fp16_autocast_falls_back_to_planes():
     z = load_npz("g5_model.npz")
     ref = torch.from_numpy(z["logits_eval"])
     assert_close(y16.float().cpu(), ref, 2e-2, 2e-2 * float(ref.abs().max()), "fp16 autocast logits")
+
+
+def test_fused_adam_matches_torch_adam_and_refreshes_shadows():
+    """xfm_adam_multi (one multi-tensor launch: Adam with L2 weight decay as torch.optim.Adam, reference
+    1_train_model.py:141, + bf16 shadow refresh) vs torch.optim.Adam over 3 steps on a mixed bag of tensor shapes."""
+    from xfmamba_amd.amp import WeightCache, cast_weight
+    from xfmamba_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    shapes = [(96, 96), (4, 8, 96), (384,), (5,), (33, 7), (768, 3072)]
+    net_a = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes])
+    net_b = torch.nn.ParameterList([torch.nn.Parameter(p.detach().clone()) for p in net_a])
+    wc = WeightCache(net_a)
+    opt_a = FusedAdam(net_a.parameters(), lr=1e-2, weight_decay=1e-2, weight_cache=wc)
+    opt_b = torch.optim.Adam(net_b.parameters(), lr=1e-2, weight_decay=1e-2)
+    for step in range(3):
+        for i, (pa, pb) in enumerate(zip(net_a, net_b)):
+            g = torch.randn_like(pa) * (step + 1)
+            pa.grad, pb.grad = (None, None) if i == 3 else (g.clone(), g.clone())   # one never-trained parameter
+        opt_a.step()
+        opt_b.step()
+        for pa, pb in zip(net_a, net_b):
+            assert_close(pa.detach().cpu(), pb.detach().cpu(), 1e-5, 1e-6, f"step {step}")
+    for pa in net_a:
+        sh = cast_weight(pa, torch.bfloat16)
+        assert torch.equal(sh, pa.detach().to(torch.bfloat16))
+    wc.close()
+
+
+def test_checkpoint_round_trip_and_reference_format_load():
+    """state_dict -> torch.save -> fresh model load_state_dict -> identical eval logits (what the reference's EarlyStopping
+    writes every epoch, early_stop.py:43-51, and 2_inference_*.py read back); a checkpoint whose Linear2d weights are
+    (out, in, 1, 1) convolution tensors (older VMamba files, models/fusion_vmamba.py:47-49) loads to the same logits."""
+    import io
+    from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
+    m = _tiny_with_synth_weights().eval()
+    xa, xb, _ = (t.to(DEV) for t in g5_inputs())
+    with torch.no_grad():
+        ref = m(xa, xb)
+    buf = io.BytesIO()
+    torch.save(m.state_dict(), buf)
+    buf.seek(0)
+    sd = torch.load(buf, map_location="cpu")
+    m2 = TwoViewXFMambaTop(in_channels=1, outputs=2, type="tiny")
+    assert not m2.load_state_dict(sd, strict=True).missing_keys
+    m2 = m2.to(DEV).eval()
+    with torch.no_grad():
+        assert_close(m2(xa, xb).cpu(), ref.cpu(), 1e-5, 1e-5, "reloaded logits")   # (library kernels are not bit-reproducible)
+    conv_style = {k: (v[:, :, None, None] if (v.ndim == 2 and (".in_proj.weight" in k or ".out_proj.weight" in k or ".mlp.fc" in k)
+                                         and k.startswith("mamba_feature_extrac.")) else v) for k, v in sd.items()}
+    assert any(v.ndim == 4 and v.shape[-1] == 1 for v in conv_style.values())
+    m3 = TwoViewXFMambaTop(in_channels=1, outputs=2, type="tiny")
+    m3.load_state_dict(conv_style, strict=True)
+    m3 = m3.to(DEV).eval()
+    with torch.no_grad():
+        assert_close(m3(xa, xb).cpu(), ref.cpu(), 1e-5, 1e-5, "conv-style checkpoint logits")

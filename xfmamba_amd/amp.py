@@ -64,6 +64,11 @@ class WeightCache:
         for p, s in zip(self.params, self.shadows):
             _SHADOWS[id(p)] = (weakref.ref(p), s, p._version)
 
+    def mark_current(self):
+        """Register the shadows as current WITHOUT copying (they were just written by ``optim.FusedAdam``'s kernel)."""
+        for p, s in zip(self.params, self.shadows):
+            _SHADOWS[id(p)] = (weakref.ref(p), s, p._version)
+
     def close(self):
         for p in self.params:
             ent = _SHADOWS.get(id(p))
