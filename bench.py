@@ -266,34 +266,54 @@ def main():
         cfg_label = {("tiny", 224, 32, "bf16"): " (BASELINE configs[4]: fp8 x_proj / out_proj weights)" if a.fp8 else " (BASELINE configs[1])", ("small", 224, 32, "bf16"): " (BASELINE configs[2], one GPU of it)",
                      ("base", 384, 16, "bf16"): " (BASELINE configs[3])"}.get((a.model, a.size, B, a.dtype), "")
         roof = None
+        roofs = {}
+        mfma = None
         kernels = {}
         if timer is not None:
             kernels = timer.summary()
             if kernels:
-                # the north-star kernel: the fused SS2D scan (forward or backward, whichever costs more per step)
-                scan = {k: v for k, v in kernels.items() if k.startswith("ss2d")} or kernels
-                name = max(scan, key=lambda k: scan[k]["total_ms"])
-                k = kernels[name]
-                ach = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9
-                # HBM bytes per launch from the PMC counters of this very command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-                # separate --pmc passes; MI355X_MICROARCH.md "HBM"): measured offline, committed under profiles/
-                traffic, traffic_source = None, None
+                import glob
+                tj, tf = {}, None
                 try:
-                    import glob
                     tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
                     tj = json.load(open(tf))
-                    ent = tj.get(name + "_kernel") or tj.get(name + "_lean_kernel") or {}
-                    traffic = ent.get("hbm_bytes_per_launch")
-                    if traffic is not None:
-                        traffic_source = (f"offline rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE), "
-                                          f"profiles/{os.path.basename(tf)}" + (f" @ {tj['commit']}" if "commit" in tj else ""))
                 except Exception:      # noqa: BLE001
                     pass
-                roof = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
-                            launches=k["launches"],
-                            avg_launch_us=round(k["avg_us"], 2),
-                            algorithmic_bytes_per_launch=int(k["bytes"] / k["launches"]))
+                # timer name -> kernel key of tools/pmc_traffic.py (HBM bytes per launch from the PMC counters of this very
+                # command: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc passes; MI355X_MICROARCH.md "HBM")
+                pmc_key = {"ss2d_bwd": "ss2d_bwd_lean_kernel", "ss2d_fwd": "ss2d_fwd_lean_kernel",
+                           "ss2dc_bwd": "ss2dc_bwd_kernel_n1", "ss2dc_fwd": "ss2dc_fwd_kernel_n1",
+                           "ss2dc16_bwd": "ss2dc_bwd_kernel_n16", "ss2dc16_fwd": "ss2dc_fwd_kernel_n16"}
+
+                def roof_of(name):
+                    k = kernels[name]
+                    ach = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9
+                    traffic = (tj.get(pmc_key.get(name, name + "_kernel")) or {}).get("hbm_bytes_per_launch")
+                    src = None
+                    if traffic is not None:
+                        src = (f"offline rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE), "
+                               f"profiles/{os.path.basename(tf)}")
+                    return dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=src,
+                                launches=k["launches"], avg_launch_us=round(k["avg_us"], 2),
+                                algorithmic_bytes_per_launch=int(k["bytes"] / k["launches"]),
+                                ms_per_step=round(k["total_ms"] / ksteps, 3))
+
+                # the north-star kernel family: the fused SS2D scans (lean chunk-scan kernels at 56x56 / 28x28, channel-lane
+                # kernels at 14x14 / 7x7, d_state 16 variant in the fusion block); `roofline` = the one costing most per step
+                scan = [k for k in kernels if k.startswith("ss2d")]
+                roofs = {k: roof_of(k) for k in scan}
+                if scan:
+                    roof = roofs[max(scan, key=lambda k: kernels[k]["total_ms"])]
+                try:                                   # matrix-core utilisation of the GEMM kernels, offline PMC pass
+                    mf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json")))[-1]
+                    mj = json.load(open(mf))
+                    top = sorted(mj.items(), key=lambda kv: -kv[1]["launches"] * kv[1]["avg_kernel_cycles"])[:12]
+                    mfma = dict(source=f"offline rocprofv3 PMC pass (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)), "
+                                       f"profiles/{os.path.basename(mf)}",
+                                kernels={k: v["mfma_util"] for k, v in top})
+                except Exception:      # noqa: BLE001
+                    pass
         line = {
             "metric": metric_name,
             "value": round(value, 2), "unit": "two-view samples/s (1 sample = 2 images)",
@@ -306,6 +326,8 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "ss2d_mode": fusion_vmamba.SS2D_MODE, "fp8_proj": bool(a.fp8),
                        "single_view_images_per_s": round(2 * value, 2)},
             "roofline": roof,
+            "roofline_scan_kernels": roofs,
+            "mfma_util": mfma,
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                             "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1),
                             "ms_per_step": round(v["total_ms"] / ksteps, 3)} for k, v in kernels.items()},

@@ -93,7 +93,7 @@ def test_deep_fusion_block_golden_through_channel_lane_kernel():
     finally:
         _lib.set_timer(None)
     names = set(timer.summary())
-    assert {"ss2dc_fwd", "ss2dc_bwd"} <= names and not ({"cross_scan", "cross_merge", "selective_scan_fwd"} & names), names
+    assert {"ss2dc16_fwd", "ss2dc16_bwd"} <= names and not ({"cross_scan", "cross_merge", "selective_scan_fwd"} & names), names
     ref = torch.from_numpy(z[f"{tag}/out0"])
     assert_close(out.detach().float().cpu(), ref, 2e-2, 2e-2 * float(ref.abs().max()), "out")
     for i, t in enumerate(ins):

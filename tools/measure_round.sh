@@ -1,9 +1,10 @@
 #!/bin/bash
 # End-of-round measurement on one MI355X (run through gpurun): default bench line, rocprofv3 kernel stats of the same
-# command, and the two PMC passes (FETCH_SIZE / WRITE_SIZE, own runs, kernel-trace only) for the roofline's `traffic`.
+# command, the two PMC passes (FETCH_SIZE / WRITE_SIZE, own runs, kernel-trace only) for the roofline's `traffic`, and one
+# PMC pass for the matrix-core utilisation of the GEMM kernels.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-R=${1:-r01}
+R=${1:-r02}
 O=gpurun_out/measure_$R
 rm -rf $O && mkdir -p $O
 python3 bench.py > $O/bench_line.json 2> $O/bench.err
@@ -14,6 +15,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-miopen-find --no-graph --no-kernel-timer > $O/pmc_$C.log 2>&1
   find $O/pmc_$C -name "*kernel_trace.csv" -delete
 done
-python3 tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv") 2 $O/traffic_pmc.csv $O/traffic.json | head -30
+python3 tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv") 2 $O/traffic_pmc.csv $O/traffic.json | head -5
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-miopen-find --no-graph --no-kernel-timer > $O/pmc_mfma.log 2>&1
+find $O/pmc_mfma -name "*kernel_trace.csv" -delete
+python3 tools/pmc_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv") $O/mfma_util.csv $O/mfma_util.json | head -30
 find $O -name "*counter_collection.csv" -size +20M -delete
 du -sh $O

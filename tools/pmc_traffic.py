@@ -18,11 +18,18 @@ def per_kernel(path, counter):
     for row in csv.DictReader(open(path)):
         if row.get("Counter_Name") != counter:
             continue
-        m = re.search(r"xfm::(\w+)", row["Kernel_Name"])
+        m = re.search(r"xfm::(\w+)(<[^>]*>)?", row["Kernel_Name"])
         if not m:
             continue
-        tot[m.group(1)] += float(row["Counter_Value"]) * 1024.0
-        n[m.group(1)] += 1
+        keys = [m.group(1)]
+        if m.group(2):
+            keys.append(m.group(1) + m.group(2))                 # per template instantiation as well
+            if m.group(1).startswith("ss2dc_"):                  # channel-lane kernels: d_state 1 / d_state 16 families
+                args = [t.strip() for t in m.group(2)[1:-1].split(",")]
+                keys.append(m.group(1) + ("_n1" if args[1] == "1" else "_n16"))
+        for k in keys:
+            tot[k] += float(row["Counter_Value"]) * 1024.0
+            n[k] += 1
     return tot, n
 
 

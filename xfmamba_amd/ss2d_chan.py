@@ -109,7 +109,7 @@ class SS2DChanHip(torch.autograd.Function):
         p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, c_mod, c_off, 1, chk)
         p.y = y.data_ptr()
         nbytes = Bt * Dm * L * (2 + 4) + xdbl.numel() * 2
-        with torch.cuda.device(x.device), _lib.timed("ss2dc_fwd", nbytes):
+        with torch.cuda.device(x.device), _lib.timed("ss2dc_fwd" if N == 1 else "ss2dc16_fwd", nbytes):
             _lib.check(lib.xfm_ss2dc_fwd(ctypes.byref(p), _lib.stream_ptr()), "ss2dc_fwd")
         ctx.hw = (H, W)
         ctx.cmod = (c_mod, c_off)
@@ -144,7 +144,7 @@ class SS2DChanHip(torch.autograd.Function):
         p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
         p.dBC, p.dA, p.dD, p.ddelta_bias = dBC.data_ptr(), dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
         nbytes = Bt * Dm * L * (2 + 4 + 2 + 2 * K) + xdbl.numel() * 2
-        with torch.cuda.device(dev), _lib.timed("ss2dc_bwd", nbytes):
+        with torch.cuda.device(dev), _lib.timed("ss2dc_bwd" if N == 1 else "ss2dc16_bwd", nbytes):
             _lib.check(lib.xfm_ss2dc_bwd(ctypes.byref(p), _lib.stream_ptr()), "ss2dc_bwd")
         # ---- d x_dbl (dt_proj columns from ddts, B / C columns from the scan kernel) and the dt_proj weight gradient:
         # two MFMA kernels, each reading ddts once
