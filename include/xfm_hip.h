@@ -308,11 +308,11 @@ int xfm_ss2dc_fwd(const xfm_ss2dc_params_t *p, void *stream);
 int xfm_ss2dc_bwd(const xfm_ss2dc_params_t *p, void *stream);
 /* The two dense products behind xfm_ss2dc_bwd (n_routes == 4), both on MFMA, each reading ddts once (the backward of the
  * dt_proj einsum, reference models/fusion_vmamba.py:1154-1156, in the token-major layout):
- *   dxdbl (batch, L, 4*C2p) bf16, every column written: [0, Rp8) = ddts . W_dt (contraction over the channels; wdtT is
- *         W_dt transposed, (4, KT*32, d_inner) bf16 with KT = ceil(Rp8 / 32) and zero rows beyond dt_rank), the B / C
- *         columns from dBC (batch, 4, 2, dstate, L) fp32, zeros elsewhere;
+ *   dxdbl (batch, L, 4*C2p) bf16, every column written: [0, Rp8) = ddts . W_dt (contraction over the channels; wdt is the
+ *         zero-padded (4, d_inner, Kp) bf16 weight xfm_ss2dc_fwd/_bwd take), the B / C columns from dBC
+ *         (batch, 4, 2, dstate, L) fp32, zeros elsewhere;
  *   dwdt  (4, d_inner, dt_rank) fp32 ZEROED += sum over batch and positions of ddts x (dt_proj input columns of xdbl). */
-int xfm_ss2dc_post(const void *ddts, const void *xdbl, const void *wdtT, const float *dBC, void *dxdbl, float *dwdt,
+int xfm_ss2dc_post(const void *ddts, const void *xdbl, const void *wdt, const float *dBC, void *dxdbl, float *dwdt,
                    int batch, int d_inner, int L, int dt_rank, int dstate, void *stream);
 
 /*

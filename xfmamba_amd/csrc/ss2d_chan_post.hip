@@ -16,7 +16,8 @@ typedef uint32_t pu32x2_t __attribute__((ext_vector_type(2)));
 struct ChanPostArgs {
     const uint16_t *ddts;    // (Bt, 4, L, D) bf16
     const uint16_t *xdbl;    // (Bt, L, XC) bf16
-    const uint16_t *wdtT;    // (4, KT*32, D) bf16: dt_proj weight transposed (r, d), zero rows beyond R
+    const uint16_t *wdt;     // (4, D, Kp) bf16: dt_proj weight, zero columns beyond R (the layout xfm_ss2dc_fwd/_bwd take)
+    int Kp;
     const float *dBC;        // (Bt, 4, 2, N, L) fp32
     uint16_t *dxdbl;         // (Bt, L, XC) bf16 (every column written)
     float *dwdt;             // (4, D, R) fp32 ZEROED (atomics)
@@ -43,17 +44,27 @@ template <int KT> __global__ void __launch_bounds__(256) chan_dxdbl_kernel(const
     const int p = pt * 32 + col;
     const bool pv = p < a.L;
     const uint16_t *brow = a.ddts + ((int64_t)bk * a.L + (pv ? p : 0)) * a.D + 8 * kb;
-    const uint16_t *arow = a.wdtT + ((int64_t)k * KT * 32 + col) * a.D + 8 * kb;
+    // A operand = W^T (rows r, k = channels): gathered from the (D, Kp) weight with 2-byte loads (32 lanes = 64
+    // contiguous bytes per channel; the weight is a few KB and stays in L1 / L2)
+    const uint16_t *arow = a.wdt + ((int64_t)k * a.D + 8 * kb) * a.Kp + col;
     pf32x16_t acc[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
     const int nks = a.D / 16;
+    auto load_a = [&](int s, pbf16x8_t(&af)[KT]) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            uint16_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (32 * t + col < a.Kp) ? arow[(int64_t)(16 * s + j) * a.Kp + 32 * t] : (uint16_t)0;
+            af[t] = *reinterpret_cast<const pbf16x8_t *>(v);
+        }
+    };
     pbf16x8_t bf = pv ? post_ld8(brow) : post_zero8();
     pbf16x8_t af[KT];
-#pragma unroll
-    for (int t = 0; t < KT; ++t) af[t] = post_ld8(arow + (int64_t)t * 32 * a.D);
+    load_a(0, af);
     for (int s = 0; s < nks; ++s) {
         const pbf16x8_t bc = bf;
         pbf16x8_t ac[KT];
@@ -61,8 +72,7 @@ template <int KT> __global__ void __launch_bounds__(256) chan_dxdbl_kernel(const
         for (int t = 0; t < KT; ++t) ac[t] = af[t];
         if (s + 1 < nks) {
             bf = pv ? post_ld8(brow + 16 * (s + 1)) : post_zero8();
-#pragma unroll
-            for (int t = 0; t < KT; ++t) af[t] = post_ld8(arow + (int64_t)t * 32 * a.D + 16 * (s + 1));
+            load_a(s + 1, af);
         }
 #pragma unroll
         for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[t], bc, acc[t], 0, 0, 0);
@@ -159,13 +169,13 @@ template <int KT> __global__ void __launch_bounds__(256) chan_dwdt_kernel(const 
 
 }  // namespace xfm
 
-extern "C" int xfm_ss2dc_post(const void *ddts, const void *xdbl, const void *wdtT, const float *dBC, void *dxdbl, float *dwdt,
+extern "C" int xfm_ss2dc_post(const void *ddts, const void *xdbl, const void *wdt, const float *dBC, void *dxdbl, float *dwdt,
                               int batch, int d_inner, int L, int dt_rank, int dstate, void *stream) {
     using namespace xfm;
-    if (!ddts || !xdbl || !wdtT || !dBC || !dxdbl || !dwdt || batch <= 0 || L <= 0) return XFM_EINVAL;
+    if (!ddts || !xdbl || !wdt || !dBC || !dxdbl || !dwdt || batch <= 0 || L <= 0) return XFM_EINVAL;
     if (d_inner % 32 || dt_rank < 1 || dt_rank > 64 || (dstate != 1 && dstate % 8)) return XFM_ELIMIT;
     ChanPostArgs a{};
-    a.ddts = (const uint16_t *)ddts; a.xdbl = (const uint16_t *)xdbl; a.wdtT = (const uint16_t *)wdtT; a.dBC = dBC;
+    a.ddts = (const uint16_t *)ddts; a.xdbl = (const uint16_t *)xdbl; a.wdt = (const uint16_t *)wdt; a.Kp = (dt_rank + 15) / 16 * 16; a.dBC = dBC;
     a.dxdbl = (uint16_t *)dxdbl; a.dwdt = dwdt;
     a.Bt = batch; a.D = d_inner; a.L = L; a.R = dt_rank; a.N = dstate;
     a.Rp8 = (dt_rank + 7) / 8 * 8;

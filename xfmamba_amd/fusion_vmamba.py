@@ -240,7 +240,9 @@ def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_
         return ss2d_chan_fn(x.reshape(B, D, L), x_proj_weight, dt_projs_weight, As, Dsf, bias, H, W), None
     # 7x7 maps (trunk stage 3, both fusion blocks): rows of 49 are too short for a parallel scan to pay; the
     # operator chain with the one-lane-per-row scan kernel is faster there and the (B,4,D,49) tensors are tiny.
-    if SS2D_MODE == "fused" and L > 64:
+    # (maps beyond the lean kernel's LDS plan -- 96 x 96 of XFMamba-B at 384^2 -- take the operator chain: the generic
+    #  fused tile kernel measured 32.5 ms per block forward + backward there, the chain 14.1 ms)
+    if SS2D_MODE == "fused" and 64 < L <= 4096:
         # x_proj of all K routes as ONE dense GEMM on the map in natural order (route k's projection of
         # the permuted sequence is the permuted projection).  Routes 1/3 walk columns, so their slice of
         # the small x_dbl tensor is transposed to column-major here; dt_proj (batched GEMM) then emits

@@ -86,20 +86,26 @@ class SS2DChanHip(torch.autograd.Function):
         Kp = (R + 15) // 16 * 16
         XC = K * C2p
         rows = _row_index(K, R, N, x.device)
-        wdt = torch.nn.functional.pad(cast_weight(dt_w, x.dtype), (0, Kp - R)).contiguous()      # (4, D, Kp)
+        wdt = cast_weight(dt_w, x.dtype)
+        wdt = (torch.nn.functional.pad(wdt, (0, Kp - R)) if Kp != R else wdt).contiguous()      # (4, D, Kp)
+        plain = Rp8 == R                         # the dt_proj block needs no inner padding: rows only grow at the END of a route
+
+        def padded(w3):                          # (K, C2, D) -> (K * C2p, D) in the column layout of the kernels
+            if plain:
+                return (torch.nn.functional.pad(w3, (0, 0, 0, C2p - C2)) if C2p != C2 else w3).reshape(XC, Dm)
+            out = torch.zeros((XC, Dm), dtype=w3.dtype, device=w3.device)
+            return out.index_copy_(0, rows, w3.reshape(K * C2, Dm))
+
         if _fp8.usable(x, Dm, XC):
             # BASELINE configs[4]: x_proj with fp8 weights on the fp8 matrix cores (straight-through backward with the
             # de-quantised weight)
-            xw_f = torch.zeros((XC, Dm), dtype=torch.float32, device=x.device)
-            xw_f.index_copy_(0, rows, x_proj_w.detach().reshape(K * C2, Dm).float())
-            wq, scale, xw_pad = _fp8.quantize_weight(xw_f)
+            wq, scale, xw_pad = _fp8.quantize_weight(padded(x_proj_w.detach().float()))
             xdbl = torch.empty((Bt, L, XC), dtype=x.dtype, device=x.device)
             with torch.cuda.device(x.device), _lib.timed("fp8_planes_gemm", Bt * L * (Dm + XC) * 2):
                 _lib.check(_lib.lib().xfm_fp8_planes_gemm(x.data_ptr(), wq.data_ptr(), scale.data_ptr(), xdbl.data_ptr(), Bt, Dm,
                                                           L, XC, _lib.stream_ptr()), "fp8_planes_gemm")
         else:
-            xw_pad = torch.zeros((XC, Dm), dtype=x.dtype, device=x.device)
-            xw_pad.index_copy_(0, rows, cast_weight(x_proj_w.reshape(K * C2, Dm), x.dtype))
+            xw_pad = padded(cast_weight(x_proj_w, x.dtype)).contiguous()
             xdbl = torch.bmm(x.transpose(1, 2), xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC))     # (B, L, XC) token-major
         A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
         lib = _lib.lib()
@@ -134,11 +140,12 @@ class SS2DChanHip(torch.autograd.Function):
         dy = dy.contiguous().float()
         dx = torch.empty_like(x)
         ddts = torch.empty((Bt, K, L, Dm), dtype=x.dtype, device=dev)
-        nbc, na, nd = Bt * K * 2 * N * L, A.numel(), D.numel()
-        acc = torch.zeros(nbc + na + 2 * nd, dtype=torch.float32, device=dev)            # ONE fill for all accumulators
+        nbc, na, nd, nw = Bt * K * 2 * N * L, A.numel(), D.numel(), K * Dm * R
+        acc = torch.zeros(nbc + na + 2 * nd + nw, dtype=torch.float32, device=dev)       # ONE fill for all accumulators
         dBC = acc[:nbc].view(Bt, K, 2, N, L)
         dA = acc[nbc:nbc + na].view(A.shape)
-        dD, dbias = acc[nbc + na:nbc + na + nd], acc[nbc + na + nd:]
+        dD, dbias = acc[nbc + na:nbc + na + nd], acc[nbc + na + nd:nbc + na + 2 * nd]
+        dwdt = acc[nbc + na + 2 * nd:].view(K, Dm, R)
         lib = _lib.lib()
         p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, ctx.cmod[0], ctx.cmod[1], 1, chk)
         p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
@@ -148,19 +155,17 @@ class SS2DChanHip(torch.autograd.Function):
             _lib.check(lib.xfm_ss2dc_bwd(ctypes.byref(p), _lib.stream_ptr()), "ss2dc_bwd")
         # ---- d x_dbl (dt_proj columns from ddts, B / C columns from the scan kernel) and the dt_proj weight gradient:
         # two MFMA kernels, each reading ddts once
-        KT = (Rp8 + 31) // 32
-        wdtT = torch.zeros((K, KT * 32, Dm), dtype=x.dtype, device=dev)
-        wdtT[:, :R] = wdt[:, :, :R].transpose(1, 2)
         dxdbl = torch.empty((Bt, L, XC), dtype=x.dtype, device=dev)
-        dwdt = torch.zeros((K, Dm, R), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev), _lib.timed("ss2dc_post", 2 * ddts.numel() * 2):
-            _lib.check(lib.xfm_ss2dc_post(ddts.data_ptr(), xdbl.data_ptr(), wdtT.data_ptr(), dBC.data_ptr(), dxdbl.data_ptr(),
+            _lib.check(lib.xfm_ss2dc_post(ddts.data_ptr(), xdbl.data_ptr(), wdt.data_ptr(), dBC.data_ptr(), dxdbl.data_ptr(),
                                           dwdt.data_ptr(), Bt, Dm, L, R, N, _lib.stream_ptr()), "ss2dc_post")
         # x_proj backward on the natural map
         dx.baddbmm_(xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC), dxdbl.transpose(1, 2))   # dx += Wx^T . d x_dbl^T
         dxw_pad = _bmm_f32(dxdbl.transpose(1, 2), x.transpose(1, 2)).sum(0)               # (XC, D)
-        rows = _row_index(K, R, N, dev)
-        dxw = dxw_pad.index_select(0, rows).view(xw_shape).to(xw_dtype)
+        if Rp8 == R:
+            dxw = dxw_pad.view(K, C2p, Dm)[:, :C2].to(xw_dtype)
+        else:
+            dxw = dxw_pad.index_select(0, _row_index(K, R, N, dev)).view(xw_shape).to(xw_dtype)
         return dx, dxw, dwdt.to(dtw_dtype), dA, dD, dbias, None, None, None, None
 
 
