@@ -248,6 +248,7 @@ SS2D_SHAPES = [
     (2, 32, 7, 7, 16, torch.float32),       # deep fusion block shape (N = 16)
     (1, 16, 12, 9, 4, torch.float32),       # non-square map, odd sizes
     (1, 8, 96, 96, 1, torch.float32),       # XFMamba-B @384 stage 0 plane
+    (2, 6, 96, 96, 1, torch.bfloat16),      # ... in bf16: the one-plane-per-tile lean variants (18 chunk rows, sums in registers)
     (1, 5, 3, 5, 2, torch.float32),         # tile of one plane (D not a multiple of 2)
 ]
 
@@ -505,7 +506,7 @@ def test_ss2d_proj_core_matches_operator_chain(shape, dt):
         assert_close(a.float().cpu(), b.float().cpu(), tol, tol * float(b.float().abs().max()) + 1e-7, name)
 
 
-@pytest.mark.parametrize("shape", [(2, 96, 56, 56, 1), (2, 384, 14, 14, 1), (2, 64, 10, 6, 2)])
+@pytest.mark.parametrize("shape", [(2, 96, 56, 56, 1), (2, 384, 14, 14, 1), (2, 64, 10, 6, 2), (1, 32, 96, 96, 1)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_ss2d_xproj_core_matches_operator_chain(shape, dt):
     """x_proj inside the node (its data gradient accumulated onto the scan's dx by the GEMM) vs x_proj as a framework

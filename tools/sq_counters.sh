@@ -8,6 +8,8 @@ O=gpurun_out/sq_r01
 rm -rf $O && mkdir -p $O
 if [ "${SQTOOL:-kbench}" = "chanbench" ]; then
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/p -o sq -- python3 tools/chanbench.py ${CHANARGS:-} > $O/log.txt 2>&1
+elif [ "${SQTOOL:-kbench}" = "leanbench" ]; then
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/p -o sq -- python3 tools/leanbench.py ${LEANARGS:-} > $O/log.txt 2>&1
 else
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/p -o sq -- python3 tools/kbench.py --only ${KB:-ss2d} > $O/log.txt 2>&1
 fi

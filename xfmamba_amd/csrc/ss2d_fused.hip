@@ -33,10 +33,13 @@ static int plan_ss2d(int batch, int D, int H, int W, int N, int in_dtype, Plan2 
         const size_t fwd_blk = 6 * PL * sz;
         // registers win for short rows; from ~4 chunks on the LDS accumulators are faster (measured, stage 0: 473 vs 563 us)
         const bool has_reg = nseg <= 2;
-        const int reg_nseg = (has_reg && !getenv("XFM_SS2D_LDSACC")) ? nseg : 0;
+        // one-plane tiles beyond the staging span of the regular variants (96 x 96, XFMamba-B at 384^2): the BIG
+        // variants -- 16-bit I/O only, accumulators of all 18 chunk rows in registers (ss2d_lean.hpp)
+        const bool big = PL > 4096 && ppt == 1 && c == 8 && nseg == 18 && L <= 9216 && f_lg <= 0;
+        const int reg_nseg = big ? 18 : ((has_reg && !getenv("XFM_SS2D_LDSACC")) ? nseg : 0);
         const size_t bwd_blk = 8 * PL * sz + (reg_nseg ? 0 : (size_t)8 * L * sizeof(float));
         // (PL <= 4096: the staging registers of the lean kernels cover a tile of 256 threads x 16 elements)
-        if (fwd_blk <= kLdsPerCU && bwd_blk <= kLdsPerCU && PL <= 4096) {
+        if (fwd_blk <= kLdsPerCU && bwd_blk <= kLdsPerCU && (PL <= 4096 || big)) {
             out->lg = 6;
             out->items = c;
             out->n_chunks = nseg;
@@ -221,6 +224,7 @@ int ss2d_launch_lean(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bw
     la.nseg = pl.n_chunks; la.ppt = pl.ppt; la.pli = bwd ? pl.pli : pl.pli_fwd; la.softplus = p.delta_softplus;
     la.magicW = a.magicW;
     la.magicL = (uint32_t)((0x100000000ull + la.L - 1) / la.L);
+    la.magicH = (uint32_t)((0x100000000ull + la.H - 1) / la.H);
     la.dbg = a.dbg;
     const size_t lds = bwd ? pl.lds_bwd_block : pl.lds_fwd_block;
     const unsigned grid = (unsigned)((int64_t)p.batch * (p.d_inner / pl.ppt / la.pli));

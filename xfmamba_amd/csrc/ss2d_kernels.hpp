@@ -766,8 +766,14 @@ static int ss2d_dispatch_impl(const SS2DArgs &a, const Plan2 &pl, bool bwd, hipS
     if (pl.kind == 3) {
         const void *fn;
         if (!bwd) {
+            if constexpr (sizeof(Tin) == 2) {
+                if (pl.reg_nseg == 18) return ss2d_launch_lean((const void *)ss2d_fwd_lean_kernel<Tin, Tout, 8, true>, a, pl, bwd, s);
+            }
             fn = pl.items == 8 ? (const void *)ss2d_fwd_lean_kernel<Tin, Tout, 8> : (const void *)ss2d_fwd_lean_kernel<Tin, Tout, 4>;
         } else if (pl.items == 8) {
+            if constexpr (sizeof(Tin) == 2) {
+                if (pl.reg_nseg == 18) return ss2d_launch_lean((const void *)ss2d_bwd_lean_kernel<Tin, Tout, 8, 18>, a, pl, bwd, s);
+            }
             switch (pl.reg_nseg) {                      // dB/dC sums in registers when the chunk count is a built variant
                 case 1: fn = (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 8, 1>; break;
                 case 2: fn = (const void *)ss2d_bwd_lean_kernel<Tin, Tout, 8, 2>; break;

@@ -240,9 +240,11 @@ def _ss2d_core(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_projs_bias, Cs_
         return ss2d_chan_fn(x.reshape(B, D, L), x_proj_weight, dt_projs_weight, As, Dsf, bias, H, W), None
     # 7x7 maps (trunk stage 3, both fusion blocks): rows of 49 are too short for a parallel scan to pay; the
     # operator chain with the one-lane-per-row scan kernel is faster there and the (B,4,D,49) tensors are tiny.
-    # (maps beyond the lean kernel's LDS plan -- 96 x 96 of XFMamba-B at 384^2 -- take the operator chain: the generic
-    #  fused tile kernel measured 32.5 ms per block forward + backward there, the chain 14.1 ms)
-    if SS2D_MODE == "fused" and 64 < L <= 4096:
+    # (96 x 96 of XFMamba-B at 384^2 in 16-bit I/O runs the one-plane-per-tile lean variants; other maps beyond the lean
+    #  kernel's LDS plan take the operator chain: the generic fused tile kernel measured 32.5 ms per block forward +
+    #  backward at 96 x 96, the chain 14.1 ms)
+    big_lean = N == 1 and cd in (torch.bfloat16, torch.float16) and 8704 < L <= 9216 and L % 8 == 0
+    if SS2D_MODE == "fused" and (64 < L <= 4096 or big_lean):
         # x_proj of all K routes as ONE dense GEMM on the map in natural order (route k's projection of
         # the permuted sequence is the permuted projection).  Routes 1/3 walk columns, so their slice of
         # the small x_dbl tensor is transposed to column-major here; dt_proj (batched GEMM) then emits
@@ -900,7 +902,8 @@ class Cross_SS2Dv5(nn.Module):
         z = self.act(torch.split(x3, B, dim=0)[2])
         t = x3.permute(0, 3, 1, 2).contiguous()
         t = _dwconv_act(self.conv2d, self.act, t) if self.with_dconv else self.act(t)
-        if SS2D_MODE == "fused" and H * W > 64:
+        K, _, R = self.dt_projs_weight.shape
+        if SS2D_MODE == "fused" and H * W > 64 and not chan_supported(t, H, W, self.A_logs.shape[1], K, t.shape[1], R):
             y, y2, y_fuse = self.forward_corev2(*torch.split(t, B, dim=0))
         else:
             y3 = self.forward_core_batched(t)
