@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--drop-path", type=float, default=None, help="override the reference's DropPath rates (e.g. 0)")
+    ap.add_argument("--comm-dtype", default=None, choices=["bf16", "fp32"],
+                    help="dtype of the gradient all-reduce at N > 1 (default: the step's --dtype)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave MIOpen's default solver heuristics (default: "
                     "torch.backends.cudnn.benchmark = True, i.e. MIOpen's own find pass during warm-up; +5 %% measured)")
@@ -139,7 +141,10 @@ def main():
     # refresh -- a few dozen launches -- are issued eagerly after each replay, so no collective is captured.
     scope = a.graph_scope or ("step" if world == 1 else "fwdbwd")
     assert not (world > 1 and scope == "step"), "RCCL collectives are not captured: use --graph-scope fwdbwd with N > 1"
-    buckets = GradBuckets(model, bucket_mb=48.0, overlap=not use_graph)
+    # gradients cross xGMI in the step's compute dtype: bf16 buckets for the bf16 step (half the bytes of the ring
+    # all-reduce; the optimizer still reads fp32), fp32 for --dtype fp32 or --comm-dtype fp32
+    comm = torch.bfloat16 if (a.comm_dtype or a.dtype) == "bf16" else None
+    buckets = GradBuckets(model, bucket_mb=48.0, overlap=not use_graph, comm_dtype=comm)
     crit = torch.nn.CrossEntropyLoss()
     wcache = WeightCache(model) if a.dtype == "bf16" else None     # bf16 shadows of the GEMM weights
     # Adam of the reference loop (1_train_model.py:141) for all parameters in ONE launch that also rewrites the shadows
@@ -323,7 +328,7 @@ def main():
                                    f"fwd+bwd+Adam, train mode" + cfg_label,
                        "note": "outnorm0-2 of the trunk are skipped: the reference computes them and discards the "
                                "results (net_fusionmamba.py:200-201); they carry no gradient",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "ss2d_mode": fusion_vmamba.SS2D_MODE, "fp8_proj": bool(a.fp8),
+                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_allreduce": ("bf16" if comm is not None else "fp32") if world > 1 else None, "ss2d_mode": fusion_vmamba.SS2D_MODE, "fp8_proj": bool(a.fp8),
                        "single_view_images_per_s": round(2 * value, 2)},
             "roofline": roof,
             "roofline_scan_kernels": roofs,

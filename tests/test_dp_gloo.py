@@ -21,14 +21,14 @@ class _Net(torch.nn.Module):
         return self.b(torch.tanh(self.a(x)))
 
 
-def _worker(rank, world, port, overlap, q):
+def _worker(rank, world, port, overlap, q, comm_dtype=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from xfmamba_amd.dp import GradBuckets, broadcast_parameters
     torch.manual_seed(100 + rank)                 # different init per rank -> broadcast must fix it
     net = _Net()
     broadcast_parameters(net)
-    gb = GradBuckets(net, bucket_mb=0.0005, overlap=overlap is True)   # tiny buckets -> several collectives
+    gb = GradBuckets(net, bucket_mb=0.0005, overlap=overlap is True, comm_dtype=comm_dtype)   # tiny buckets -> several collectives
     assert len(gb.buckets) >= 2
     g = torch.Generator().manual_seed(7)
     x = torch.randn(8, 8, generator=g)
@@ -49,20 +49,26 @@ def _worker(rank, world, port, overlap, q):
     ok = True
     for k, p in ref.named_parameters():
         want = p.grad if p.grad is not None else torch.zeros_like(p)
-        ok &= torch.allclose(grads[k], want, atol=1e-6)
+        # fp32 wire: exact up to summation order; bf16 wire: each rank's half rounded once to 8 bits, summed in bf16
+        ok &= grads[k].dtype == torch.float32
+        if comm_dtype is None:
+            ok &= torch.allclose(grads[k], want, atol=1e-6)
+        else:
+            ok &= torch.allclose(grads[k], want, rtol=2e-2, atol=2e-2 * float(want.abs().max()) + 1e-7)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("comm_dtype", [None, torch.bfloat16], ids=["fp32wire", "bf16wire"])
 @pytest.mark.parametrize("overlap", [True, False, "split"])
-def test_grad_buckets_world2_gloo(overlap):
+def test_grad_buckets_world2_gloo(overlap, comm_dtype):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q, comm_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -4,6 +4,9 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_step
 rm -rf $O && mkdir -p $O
+# (a first, unprofiled run fills MIOpen's per-user find cache: on a fresh box the convolution search otherwise lands in
+#  the profile -- seconds of naive_conv / ck search kernels)
+python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-timer "$@" > $O/warm.txt 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o s -- python3 bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-kernel-timer "$@" > $O/log.txt 2>&1
 find $O -name "*kernel_trace.csv" -delete
 tail -c 300 $O/log.txt

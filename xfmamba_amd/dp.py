@@ -43,8 +43,14 @@ class GradBuckets:
     """Gradient buckets with overlap-capable all-reduce (average)."""
 
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, process_group=None, overlap: bool = True,
-                 world: int = None):
+                 world: int = None, comm_dtype: torch.dtype = None):
+        """``comm_dtype=torch.bfloat16``: the collective moves bf16 (half the bytes on the xGMI links).  Each rank's
+        gradient is scaled by 1/world in fp32, rounded once to bf16 into a staging buffer, summed by the all-reduce
+        in bf16 and widened back into the fp32 flat buffer the optimizer reads; ``None`` / fp32 reduces the fp32
+        buffer in place."""
         self.group = process_group
+        self.comm_dtype = None if comm_dtype in (None, torch.float32) else comm_dtype
+        self._stage: List[torch.Tensor] = []
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         if world is not None:                               # (tests: exercise the packing path without peers)
             self.world = int(world)
@@ -79,6 +85,8 @@ class GradBuckets:
                 self._bucket_of[p] = bi
             self.buckets.append(flat)
             self._views.append(views)
+            if self.comm_dtype is not None:
+                self._stage.append(torch.zeros_like(flat, dtype=self.comm_dtype))
         self._sizes = [len(g) for g in self._groups]
         self._pending = list(self._sizes)
         self._launched = [False] * len(self._groups)
@@ -108,10 +116,26 @@ class GradBuckets:
 
     def _reduce(self, bi, async_op=True):
         flat = self.buckets[bi]
-        flat.div_(self.world)
-        w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if self.comm_dtype is None:
+            flat.div_(self.world)
+            w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                self._work.append(w)
+            return
+        stage = self._stage[bi]
+        torch.mul(flat, 1.0 / self.world, out=stage)        # scale in fp32, ONE rounding to the wire dtype
+        w = dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
-            self._work.append(w)
+            self._work.append((w, bi))
+        else:
+            flat.copy_(stage)
+
+    def _wait(self, w):
+        if isinstance(w, tuple):                            # reduced-precision wire: widen back once the sum is in
+            w[0].wait()
+            self.buckets[w[1]].copy_(self._stage[w[1]])
+        else:
+            w.wait()
 
     def _launch(self, bi):
         if self._launched[bi]:
@@ -144,10 +168,14 @@ class GradBuckets:
             return
         for bi in range(len(self.buckets)):
             self._launch(bi)
-        for w in self._work:
-            w.wait()
         if self._stream is not None:
+            with torch.cuda.stream(self._stream):           # (the widening copies queue behind their collectives)
+                for w in self._work:
+                    self._wait(w)
             torch.cuda.current_stream().wait_stream(self._stream)
+        else:
+            for w in self._work:
+                self._wait(w)
         self._work.clear()
         self._pending = list(self._sizes)
         self._launched = [False] * len(self.buckets)
