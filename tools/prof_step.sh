@@ -4,18 +4,31 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_step
 rm -rf $O && mkdir -p $O
-# (a first, unprofiled run fills MIOpen's per-user find cache: on a fresh box the convolution search otherwise lands in
-#  the profile -- seconds of naive_conv / ck search kernels)
-python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-timer "$@" > $O/warm.txt 2>&1
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o s -- python3 bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-kernel-timer "$@" > $O/log.txt 2>&1
-find $O -name "*kernel_trace.csv" -delete
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O -o s -- python3 bench.py --steps 6 --warmup 6 --no-cpu-baseline --no-kernel-timer "$@" > $O/log.txt 2>&1
 tail -c 300 $O/log.txt
 python3 - <<'PY'
-import csv, glob
-f = glob.glob('gpurun_out/prof_step/**/*kernel_stats.csv', recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
-tot = sum(float(r['TotalDurationNs']) for r in rows)
-print("total kernel ms:", tot/1e6)
-for r in rows[:45]:
-    print(f"{r['Name'][:95]:95s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:8.2f} ms {float(r['AverageNs'])/1e3:8.1f} us {float(r['Percentage']):5.1f}%")
+# Steady-state window only: MIOpen's convolution search (naive / ck / igemm candidates, seconds of kernels) runs inside
+# the first steps of every fresh process.  adam_multi_kernel runs once per step: keep what lies between the ends of the
+# 7th- and 1st-from-last optimizer launches = the last 6 steps.
+import csv, glob, collections
+f = glob.glob('gpurun_out/prof_step/**/*kernel_trace.csv', recursive=True)[0]
+rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f))]
+rows.sort()
+adam = [e for s, e, n in rows if 'adam_multi_kernel' in n or 'multi_tensor_apply_kernel' in n and 'Adam' in n]
+NS = 6
+lo, hi = adam[-NS - 1], adam[-1]
+tot = collections.Counter(); cnt = collections.Counter()
+for s, e, n in rows:
+    if s >= lo and e <= hi:
+        tot[n] += e - s; cnt[n] += 1
+with open('gpurun_out/prof_step/s_kernel_stats.csv', 'w') as out:
+    w = csv.writer(out)
+    w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage'])
+    T = sum(tot.values())
+    for n, t in tot.most_common():
+        w.writerow([n, cnt[n], t, t / cnt[n], 100.0 * t / T])
+print("steady-state window: %d steps, wall %.2f ms/step, kernel time %.2f ms/step" % (NS, (hi - lo) / 1e6 / NS, T / 1e6 / NS))
+for n, t in tot.most_common(45):
+    print(f"{n[:95]:95s} {cnt[n] / NS:6.1f} {t / 1e6 / NS:8.3f} ms/step {t / cnt[n] / 1e3:8.1f} us")
 PY
+find $O -name "*kernel_trace.csv" -delete

@@ -1,0 +1,278 @@
+// wgrad_gemm.hip -- token-contracting product on the matrix cores: the weight gradient of every channel projection,
+//
+//     dW[m][n] += sum over samples b, tokens l of  A[b, l, m] * B[b, l, n]          (fp32 accumulation, fp32 result)
+//
+// with each operand either TOKEN-major (batch, L, C) -- the residual stream, Mlp activations, x_dbl -- or PLANE-major
+// (batch, C, L) -- the scan path -- at a caller-given sample stride.  The framework formulation (per-sample or
+// per-slice GEMMs into fp32 partial products, then a sum over them: proj.py) writes and re-reads tens of MB of partials
+// per weight; here a workgroup owns a 128 x 128 tile of dW and a contiguous slice of the token axis, accumulates in
+// registers and adds its tile to dW once (contiguous 128-byte atomic runs; the slice count is chosen so that the adds
+// stay a small fraction of the operand bytes).
+//
+// The contraction index of v_mfma_f32_32x32x16_bf16 must be contiguous inside a lane's operand (8 values of k for one
+// row).  A plane-major tile [channel][token] has that natively (16-byte LDS reads).  A token-major tile [token][channel]
+// is stored as it comes from HBM (16-byte writes, no transposing scatter) and read with ds_read_b64_tr_b16: per group of
+// 16 lanes a 4-token x 16-channel block arrives transposed, two reads = the 8 tokens of a lane's operand
+// (cdna_hip_programming.md T10; rows of 256 bytes with the chunk XOR of its image (b), conflict-free for both the
+// 16-byte row writes and the transposed reads).
+#include "xfm_common.hpp"
+
+#include <algorithm>
+
+namespace xfm {
+
+typedef __bf16 wg_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float wg_f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t wg_u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t wg_u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kWgTile = 128;            // channels of each operand per workgroup
+constexpr int kWgK = 64;                // tokens per step
+constexpr int kWgPlanePitch = 144;      // bytes per channel row of a plane-major tile (128 + 16: conflict-free 16-byte reads)
+constexpr int kWgTokBytes = kWgK * 256; // token-major tile: 32 rows of 128 channels
+constexpr int kWgPlaneBytes = kWgTile * kWgPlanePitch;
+
+struct WgradArgs {
+    const uint16_t *a, *b;              // operands (bf16)
+    float *dw;                          // (M, N) fp32, accumulated into
+    int M, N;                           // channels of A / B
+    int batch, L;                       // samples, tokens per sample
+    int64_t a_bs, b_bs;                 // sample strides (elements)
+    int steps_per_sample;               // ceil(L / 64)
+    int total_steps, steps_per_slice;   // batch * steps_per_sample; steps a workgroup walks
+    int dbg;                            // timing switches (XFM_WGRAD_DBG): 1 no atomics, 2 no MFMA / fragment reads, 4 no global loads
+};
+
+// byte offset of 16-byte chunk ch (0..15) of token row `row` in a token-major tile (image (b) of the guide)
+__device__ __forceinline__ int wg_tok_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <bool PL>
+struct WgOperand {
+    // global -> registers: this thread's share of one 32-token x 128-channel tile
+    //   token-major: 4 vectors of 16 bytes (row = idx >> 4, chunk = idx & 15, idx = tid + 256 v)
+    //   plane-major: 8 vectors of 8 bytes (channel = idx >> 4, 4 tokens at 4 * (idx & 15), idx = tid + 256 v)
+    wg_u32x4_t tv[PL ? 1 : 4];
+    wg_u32x2_t pv[PL ? 8 : 1];
+
+    __device__ __forceinline__ void load(const uint16_t *base, const int64_t bs, const int C, const int L, const int c0,
+                                         const int sample, const int l0, const int tid) {
+        if constexpr (!PL) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int idx = tid + 256 * v, row = idx >> 4, ch = idx & 15;
+                const int l = l0 + row, c = c0 + 8 * ch;
+                tv[v] = wg_u32x4_t{0, 0, 0, 0};
+                if (l < L && c < C) tv[v] = *reinterpret_cast<const wg_u32x4_t *>(base + sample * bs + (int64_t)l * C + c);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int idx = tid + 256 * v, chn = idx >> 4, l = l0 + 4 * (idx & 15);
+                const int c = c0 + chn;
+                pv[v] = wg_u32x2_t{0, 0};
+                if (c < C && l < L) {                                   // (L % 4 == 0: a group of 4 tokens is in or out whole)
+                    pv[v] = *reinterpret_cast<const wg_u32x2_t *>(base + sample * bs + (int64_t)c * L + l);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(uint8_t *tile, const int tid) const {
+        if constexpr (!PL) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int idx = tid + 256 * v;
+                *reinterpret_cast<wg_u32x4_t *>(tile + wg_tok_off(idx >> 4, idx & 15)) = tv[v];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int idx = tid + 256 * v;
+                *reinterpret_cast<wg_u32x2_t *>(tile + (idx >> 4) * kWgPlanePitch + 8 * (idx & 15)) = pv[v];
+            }
+        }
+    }
+    // MFMA operand of k16-step s (tokens 16 s .. 16 s + 15 of the tile) for the 32 channels starting at ct:
+    // lane (r = lane & 31, kb = lane >> 5) gets channel ct + r, tokens 16 s + 8 kb .. + 7.  Token-major tiles: the two
+    // transposed reads are only ISSUED here (lo = tokens + 0..3, hi = + 4..7); wg_wait() below makes them usable.
+    static __device__ __forceinline__ void frag(const uint8_t *tile, const int ct, const int s, const int lane,
+                                                wg_bf16x4_t &lo, wg_bf16x4_t &hi) {
+        const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)tile;
+        if constexpr (PL) {
+            const uint32_t ad = base + (ct + (lane & 31)) * kWgPlanePitch + 32 * s + 16 * (lane >> 5);
+            asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(lo), "=&v"(hi) : "v"(ad) : "memory");
+        } else {
+            // 16-lane group g = lane >> 4: channels ct + 16 (g & 1) .. + 15, tokens 16 s + 8 (g >> 1) + 4 h .. + 3 (read h)
+            const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+            const int c0 = (ct + 16 * (g & 1)) >> 3;                        // first 16-byte chunk of the block
+            const int r0 = 16 * s + 8 * (g >> 1);
+            const uint32_t a0 = base + wg_tok_off(r0 + q, c0 + (p >> 1)) + 8 * (p & 1);
+            const uint32_t a1 = base + wg_tok_off(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1) : "memory");
+        }
+    }
+};
+
+// The fragment reads are inline asm (the compiler does not count them in lgkmcnt): explicit waits, tied to the eight
+// registers they make valid.  LDS reads complete in order; every k16-step issues exactly 8 of them (two per operand
+// tile), so "all but the 8 youngest" = the previous step's fragments while the next step's are in flight.
+template <int OUTSTANDING>
+__device__ __forceinline__ void wg_wait(wg_bf16x4_t (&lo)[4], wg_bf16x4_t (&hi)[4]) {
+    if constexpr (OUTSTANDING == 0)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+}
+
+template <bool APL, bool BPL>
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __align__(16) uint8_t wg_lds[];
+    constexpr int ABYTES = APL ? kWgPlaneBytes : kWgTokBytes, BBYTES = BPL ? kWgPlaneBytes : kWgTokBytes;
+    auto At = [&](const int buf) { return wg_lds + buf * ABYTES; };
+    auto Bt = [&](const int buf) { return wg_lds + 2 * ABYTES + buf * BBYTES; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbm = (a.M + kWgTile - 1) / kWgTile, nbn = (a.N + kWgTile - 1) / kWgTile;
+    const int tile_id = blockIdx.x % (nbm * nbn), slice = blockIdx.x / (nbm * nbn);
+    const int m0 = (tile_id / nbn) * kWgTile, n0 = (tile_id % nbn) * kWgTile;
+    const int st0 = slice * a.steps_per_slice;
+    const int st1 = min(st0 + a.steps_per_slice, a.total_steps);
+    if (st0 >= st1) return;                                // (uniform per workgroup)
+    const int wm = wave >> 1, wn = wave & 1;               // wave -> 64 x 64 of the tile
+    wg_f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    // Operand tiles travel HBM -> registers -> LDS TWO steps ahead of their MFMAs: with one workgroup per CU (the slice
+    // rule of the launcher) nothing else hides HBM latency, and one step of MFMAs (~0.3 us) does not cover it.  Register
+    // set P = parity of the step it holds; set (st & 1) is refilled with step st + 2 right after its old content (step st)
+    // went to LDS in the previous iteration.
+    WgOperand<APL> ra[2];
+    WgOperand<BPL> rb[2];
+    auto issue = [&](auto par, const int st) {
+        constexpr int P = decltype(par)::value;
+        const int sample = st / a.steps_per_sample, l0 = (st - sample * a.steps_per_sample) * kWgK;
+        if (a.dbg & 4) return;
+        ra[P].load(a.a, a.a_bs, a.M, a.L, m0, sample, l0, tid);
+        rb[P].load(a.b, a.b_bs, a.N, a.L, n0, sample, l0, tid);
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    issue(P0{}, st0);
+    if (st0 + 1 < st1) issue(P1{}, st0 + 1);
+    ra[0].store(At(0), tid);
+    rb[0].store(Bt(0), tid);
+    __syncthreads();
+    auto step = [&](auto par, const int st) {
+        constexpr int P = decltype(par)::value;               // parity of (st - st0): LDS buffer and register set of step st
+        const int buf = P;
+        if (st + 2 < st1) issue(par, st + 2);
+        wg_bf16x4_t lo[2][4], hi[2][4];                     // [ring][0,1: A channel tiles, 2,3: B channel tiles]
+        auto frags = [&](const int ring, const int s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                WgOperand<APL>::frag(At(buf), wm * 64 + i * 32, s, lane, lo[ring][i], hi[ring][i]);
+                WgOperand<BPL>::frag(Bt(buf), wn * 64 + i * 32, s, lane, lo[ring][2 + i], hi[ring][2 + i]);
+            }
+        };
+        if (!(a.dbg & 2)) {
+        frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < kWgK / 16; ++s) {
+            const int r = s & 1;
+            if (s + 1 < kWgK / 16) {
+                frags(r ^ 1, s + 1);
+                wg_wait<8>(lo[r], hi[r]);
+            } else {
+                wg_wait<0>(lo[r], hi[r]);
+            }
+            wg_bf16x8_t af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = __builtin_shufflevector(lo[r][i], hi[r][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[i] = __builtin_shufflevector(lo[r][2 + i], hi[r][2 + i], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        }
+        if (st + 1 < st1) {
+            ra[P ^ 1].store(At(buf ^ 1), tid);
+            rb[P ^ 1].store(Bt(buf ^ 1), tid);
+        }
+        __syncthreads();
+    };
+    for (int st = st0; st < st1; st += 2) {
+        step(P0{}, st);
+        if (st + 1 < st1) step(P1{}, st + 1);
+    }
+    // D[m][n]: column n = lane & 31, row m = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): 32 lanes = 128 contiguous bytes of a row
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + c;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m < a.M && n < a.N && !(a.dbg & 1)) atomicAdd(a.dw + (int64_t)m * a.N + n, acc[i][j][v]);
+            }
+        }
+}
+
+template <bool APL, bool BPL>
+static int wgrad_launch(const WgradArgs &a, int nslices, hipStream_t s) {
+    constexpr int ABYTES = APL ? kWgPlaneBytes : kWgTokBytes, BBYTES = BPL ? kWgPlaneBytes : kWgTokBytes;
+    const size_t lds = 2 * (ABYTES + BBYTES);
+    const int nbm = (a.M + kWgTile - 1) / kWgTile, nbn = (a.N + kWgTile - 1) / kWgTile;
+    hipLaunchKernelGGL((wgrad_kernel<APL, BPL>), dim3((unsigned)(nbm * nbn * nslices)), dim3(256), lds, s, a);
+    return check_launch();
+}
+
+}  // namespace xfm
+
+extern "C" {
+
+int xfm_wgrad_supported(int M, int N, int L, int a_planes, int b_planes) {
+    if (M <= 0 || N <= 0 || L <= 0) return 0;
+    if (a_planes ? (L % 4 != 0) : (M % 8 != 0)) return 0;
+    if (b_planes ? (L % 4 != 0) : (N % 8 != 0)) return 0;
+    return 1;
+}
+
+int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, int L, int64_t a_bs, int64_t b_bs,
+              int a_planes, int b_planes, void *stream) {
+    using namespace xfm;
+    if (!a || !b || !dw || batch <= 0) return XFM_EINVAL;
+    if (!xfm_wgrad_supported(M, N, L, a_planes, b_planes)) return XFM_ELIMIT;
+    if (((uintptr_t)a & 15) || ((uintptr_t)b & 15)) return XFM_EINVAL;
+    if ((!a_planes && (a_bs % 8)) || (!b_planes && (b_bs % 8)) || (a_planes && (a_bs % 4)) || (b_planes && (b_bs % 4))) return XFM_EINVAL;
+    WgradArgs w{};
+    w.a = (const uint16_t *)a; w.b = (const uint16_t *)b; w.dw = dw;
+    w.M = M; w.N = N; w.batch = batch; w.L = L; w.a_bs = a_bs; w.b_bs = b_bs;
+    w.steps_per_sample = (L + kWgK - 1) / kWgK;
+    if (const char *env = getenv("XFM_WGRAD_DBG")) w.dbg = atoi(env);
+    w.total_steps = batch * w.steps_per_sample;
+    // Slices of the token axis.  Every workgroup ends with 64 KB of fp32 atomic adds, and the chip retires those at
+    // ~1.3 TB/s against ~5+ TB/s of operand streaming: the adds of ALL workgroups (tiles * slices * 64 KB) are the floor of
+    // the launch.  So: no more workgroups than CUs (one round), and at least 16 steps (256 KB of operands) per workgroup.
+    const int tiles = ((M + kWgTile - 1) / kWgTile) * ((N + kWgTile - 1) / kWgTile);
+    int cap = 256;
+    if (const char *env = getenv("XFM_WGRAD_WGS")) cap = atoi(env);
+    int nsl = std::max(1, std::min(cap / tiles, w.total_steps / 16));
+    w.steps_per_slice = (w.total_steps + nsl - 1) / nsl;
+    nsl = (w.total_steps + w.steps_per_slice - 1) / w.steps_per_slice;
+    hipStream_t s = (hipStream_t)stream;
+    if (a_planes) return b_planes ? wgrad_launch<true, true>(w, nsl, s) : wgrad_launch<true, false>(w, nsl, s);
+    return b_planes ? wgrad_launch<false, true>(w, nsl, s) : wgrad_launch<false, false>(w, nsl, s);
+}
+
+}  // extern "C"

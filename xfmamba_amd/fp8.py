@@ -68,13 +68,16 @@ class Fp8PlanesLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from .proj import _bmm_f32
+        from .proj import _bmm_f32, wgrad_mfma
         x, wdq = ctx.saved_tensors
         B, K, L = x.shape
         M = wdq.shape[0]
         dy = dy.contiguous() if dy.dtype == wdq.dtype else dy.to(wdq.dtype).contiguous()
         dx = torch.bmm(wdq.t().unsqueeze(0).expand(B, K, M), dy.transpose(1, 2))                 # (B, K, L)
-        dw = _bmm_f32(dy.transpose(1, 2), x.transpose(1, 2)).sum(0).to(ctx.wdtype)                # (M, K)
+        dw = wgrad_mfma(dy, False, x, True)                                                       # dy tokens (B, L, M), x planes
+        if dw is None:
+            dw = _bmm_f32(dy.transpose(1, 2), x.transpose(1, 2)).sum(0)
+        dw = dw.to(ctx.wdtype)                                                                    # (M, K)
         return dx, dw
 
 

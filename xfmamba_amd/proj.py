@@ -16,7 +16,7 @@ import torch
 
 from .amp import cast_weight
 
-__all__ = ["batched_proj", "split_k_wgrad", "mfma_planes"]
+__all__ = ["batched_proj", "split_k_wgrad", "mfma_planes", "wgrad_mfma"]
 
 _F32_OUT = [None]      # does torch.bmm accept out_dtype on this build?  probed once
 
@@ -34,6 +34,43 @@ def _bmm_f32(a, b):
     if _F32_OUT[0]:
         return torch.bmm(a, b, out_dtype=torch.float32)
     return torch.bmm(a, b).float()
+
+
+# XFM_WGRAD=0: weight gradients through the library (per-sample / per-slice partial products + a sum).  Read once.
+_WGRAD = os.environ.get("XFM_WGRAD", "1") == "1"
+
+
+def wgrad_mfma(a: torch.Tensor, a_planes: bool, b: torch.Tensor, b_planes: bool, out: torch.Tensor = None):
+    """``dW[m, n] = sum_{b, l} A[b, l, m] B[b, l, n]`` -> (M, N) fp32 through ``xfm_wgrad`` (csrc/wgrad_gemm.hip), or None
+    when the kernel does not cover the call (the caller then uses the library).
+
+    ``a`` / ``b``: 3-D bf16 tensors, token-major (batch, L, C) or -- ``x_planes`` -- plane-major (batch, C, L); the last two
+    axes contiguous, any sample stride.  ``out``: an fp32 (M, N) tensor to ACCUMULATE into (e.g. a view of a buffer the
+    caller zero-fills together with other accumulators); by default a fresh zero-filled one."""
+    if not _WGRAD or a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or not a.is_cuda or a.dim() != 3 or b.dim() != 3:
+        return None
+    from . import _lib
+    Bt = a.shape[0]
+    L, M = (a.shape[2], a.shape[1]) if a_planes else (a.shape[1], a.shape[2])
+    Lb, N = (b.shape[2], b.shape[1]) if b_planes else (b.shape[1], b.shape[2])
+    if Lb != L or b.shape[0] != Bt:
+        return None
+
+    def dense(t):
+        return t.stride(2) == 1 and t.stride(1) == t.shape[2]
+
+    lib = _lib.lib()
+    if not (dense(a) and dense(b)) or a.data_ptr() % 16 or b.data_ptr() % 16 \
+            or not lib.xfm_wgrad_supported(M, N, L, int(a_planes), int(b_planes)):
+        return None
+    a_bs, b_bs = (a.stride(0) if Bt > 1 else a.shape[1] * a.shape[2]), (b.stride(0) if Bt > 1 else b.shape[1] * b.shape[2])
+    if (a_bs % (4 if a_planes else 8)) or (b_bs % (4 if b_planes else 8)):
+        return None
+    dw = torch.zeros((M, N), dtype=torch.float32, device=a.device) if out is None else out
+    with torch.cuda.device(a.device), _lib.timed("wgrad", (a.numel() + b.numel()) * 2):
+        _lib.check(lib.xfm_wgrad(a.data_ptr(), b.data_ptr(), dw.data_ptr(), M, N, Bt, L, a_bs, b_bs, int(a_planes),
+                                 int(b_planes), _lib.stream_ptr()), "wgrad")
+    return dw
 
 
 def _k_slices(rows: int, target: int = 2048, cap: int = 128) -> int:
@@ -54,6 +91,9 @@ def split_k_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     batched GEMM that fills the chip, with fp32 partial products summed afterwards."""
     dy2, x2 = dy2.contiguous(), x2.contiguous()
     rows = dy2.shape[0]
+    dw = wgrad_mfma(dy2.unsqueeze(0), False, x2.unsqueeze(0), False)       # one launch, no partial products
+    if dw is not None:
+        return dw
     S = _k_slices(rows)
     if S == 1:
         return _bmm_f32(dy2.t().unsqueeze(0), x2.unsqueeze(0))[0]
@@ -156,8 +196,11 @@ class BatchedProj(torch.autograd.Function):
             else:
                 dx = torch.bmm(w.t().unsqueeze(0).expand(B, K, M), dyp)                      # (B, K, L)
         if ctx.needs_input_grad[1]:
-            xt = x if in_tokens else x.transpose(1, 2)                                        # (B, L, K)
-            dw = _bmm_f32(dyp, xt).sum(0).to(wdtype)                                          # (M, K)
+            dw = wgrad_mfma(dy, not out_tokens, x, not in_tokens)                             # operands in the layouts they have
+            if dw is None:
+                xt = x if in_tokens else x.transpose(1, 2)                                    # (B, L, K)
+                dw = _bmm_f32(dyp, xt).sum(0)
+            dw = dw.to(wdtype)                                                                # (M, K)
         if bdtype is not False and ctx.needs_input_grad[2]:
             db = dy.sum((0, 1) if out_tokens else (0, 2), dtype=torch.promote_types(dy.dtype, torch.float32)).to(bdtype)
         return dx, dw, db, None, None

@@ -191,7 +191,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
-        from .proj import _bmm_f32
+        from .proj import _bmm_f32, wgrad_mfma
         x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw = ctx.saved_tensors
         H, W = ctx.hw
         dev = x.device
@@ -239,7 +239,10 @@ class SS2DProjCoreHip(torch.autograd.Function):
         KC2 = xw.shape[0]
         if mfma_planes(dxd, xw, Dm, transposed=True, accumulate_into=dx) is None:
             dx.baddbmm_(xw.t().unsqueeze(0).expand(Bt, Dm, KC2), dxd)                  # dx += Wx^T @ d x_dbl
-        dxw = _bmm_f32(dxd, x.transpose(1, 2)).sum(0).view(ctx.xw_meta[1]).to(ctx.xw_meta[0])
+        dxw = wgrad_mfma(dxd, True, x, True)                                           # (K*C2, D): both operands planes
+        if dxw is None:
+            dxw = _bmm_f32(dxd, x.transpose(1, 2)).sum(0)
+        dxw = dxw.view(ctx.xw_meta[1]).to(ctx.xw_meta[0])
         return dx, None, dxw, dw.to(ctx.wdtype), dA, dD, dbias, None, None
 
 

@@ -126,7 +126,7 @@ class SS2DChanHip(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
-        from .proj import _bmm_f32
+        from .proj import _bmm_f32, wgrad_mfma
         x, xdbl, xw_pad, wdt, A, D, bias, chk = ctx.saved_tensors
         H, W = ctx.hw
         xw_dtype, xw_shape, dtw_dtype = ctx.meta
@@ -161,7 +161,9 @@ class SS2DChanHip(torch.autograd.Function):
                                           dwdt.data_ptr(), Bt, Dm, L, R, N, _lib.stream_ptr()), "ss2dc_post")
         # x_proj backward on the natural map
         dx.baddbmm_(xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC), dxdbl.transpose(1, 2))   # dx += Wx^T . d x_dbl^T
-        dxw_pad = _bmm_f32(dxdbl.transpose(1, 2), x.transpose(1, 2)).sum(0)               # (XC, D)
+        dxw_pad = wgrad_mfma(dxdbl, False, x, True)                                       # (XC, D) fp32
+        if dxw_pad is None:
+            dxw_pad = _bmm_f32(dxdbl.transpose(1, 2), x.transpose(1, 2)).sum(0)
         if Rp8 == R:
             dxw = dxw_pad.view(K, C2p, Dm)[:, :C2].to(xw_dtype)
         else:
