@@ -20,4 +20,13 @@ timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACT
 find $O/pmc_mfma -name "*kernel_trace.csv" -delete
 python3 tools/pmc_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv") $O/mfma_util.csv $O/mfma_util.json | head -30
 find $O -name "*counter_collection.csv" -size +20M -delete
+# steady-state step profile (the last 6 of 12 eager steps: MIOpen's per-process convolution search excluded) + families
+bash tools/prof_step.sh --no-graph > $O/steady.txt 2>&1
+cp gpurun_out/prof_step/s_kernel_stats.csv $O/steady_kernel_stats.csv
+python3 tools/stepcat.py $O/steady_kernel_stats.csv > $O/steady_families.txt
+cat $O/steady_families.txt
+# SQ counters of the scan kernels at the bench shapes
+SQTOOL=leanbench bash tools/sq_counters.sh > $O/sq_lean.txt 2>&1; cp gpurun_out/sq_r01/summary.csv $O/sq_lean.csv
+SQTOOL=chanbench bash tools/sq_counters.sh > $O/sq_chan.txt 2>&1; cp gpurun_out/sq_r01/summary.csv $O/sq_chan.csv
+find $O -name "*counter_collection.csv" -size +5M -delete
 du -sh $O

@@ -11,13 +11,14 @@ for r in csv.DictReader(open(f)):
     if n.startswith('Cijk'):
         fam = 'hipBLASLt GEMM, fp32 out (wgrad)' if '_BSS_' in n or '_SB_' in n else 'hipBLASLt GEMM, bf16 out'
     elif 'xfm::ss2dc' in n or 'xfm::chan_' in n: fam = 'SS2D channel-lane scan (+post)'
-    elif 'lean' in n or 'dt_proj' in n or 'route_' in n or 'proj_gemm' in n: fam = 'SS2D lean scan + dt_proj + route split/merge'
+    elif 'lean' in n or 'dt_proj' in n or 'route_' in n: fam = 'SS2D lean scan + dt_proj + route split/merge'
     elif 'rowscan' in n or 'swap' in n or 'selective_scan' in n or 'xfm::scan_' in n: fam = 'shallow-fusion scan'
     elif 'at::native' in n: fam = 'framework reduce' if 'reduce_kernel' in n else 'framework elementwise / copy / fill'
     elif 'igemm' in n or 'miopen' in n.lower() or 'ck::' in n or '_ZN2ck' in n or 'batched_transpose' in n or 'SubTensor' in n or 'naive_conv' in n: fam = 'MIOpen convolution (+ its casts)'
     elif 'rowln' in n: fam = 'row LayerNorm (+residual)'
     elif 'ln2d' in n: fam = 'LayerNorm2d'
-    elif 'tokens_gemm' in n or 'tile_gemm' in n or 'planes_gemm' in n: fam = 'own MFMA GEMM'
+    elif 'wgrad_kernel' in n: fam = 'own MFMA weight-gradient GEMM'
+    elif 'tokens_gemm' in n or 'tile_gemm' in n or 'planes_gemm' in n or 'proj_gemm' in n: fam = 'own MFMA GEMM'
     elif 'tokens_kernel' in n or 'colsum' in n: fam = 'bias+GELU / column sums'
     elif 'dwconv' in n: fam = 'depthwise conv + SiLU'
     elif 'adam' in n: fam = 'fused Adam'

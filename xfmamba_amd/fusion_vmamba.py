@@ -914,8 +914,9 @@ class Cross_SS2Dv5(nn.Module):
             y, y2, y_fuse = self.forward_corev2(*torch.split(t, B, dim=0))
         else:
             y3 = self.forward_core_batched(t)
-            y, y2, y_fuse = torch.split(y3, B, dim=0)
-        return self.dropout(self.out_proj(y * z + y2 * z + y_fuse * z))
+            # y z + y2 z + y_fuse z (fusion_vmamba.py:604-608) with the gate factored out: one reduction over the three streams, one product
+            return self.dropout(self.out_proj(y3.view(3, B, *y3.shape[1:]).sum(0) * z))
+        return self.dropout(self.out_proj((y + y2 + y_fuse) * z))
 
 
 class FusionBlock_v5(nn.Module):
