@@ -299,6 +299,11 @@ __device__ __forceinline__ void lean_bwd_plane(const LeanArgs &a, const Tin *__r
     const int sstep = REV ? 64 * C : -64 * C;         // chunks are walked against the route
     const int tpf = (REV ? 0 : (nseg - 1) * 64 * C) + ci * C;
     int tp0 = tpf;
+    V xv_n = IO::zero(), gv_n = IO::zero();               // x / dy of the NEXT chunk row to process, from LDS
+    if (NSEG == 0 && tpf < L) {
+        xv_n = *reinterpret_cast<const V *>(xq + tpf);
+        gv_n = *reinterpret_cast<const V *>(gq + tpf);
+    }
     // One chunk row.  SLOT is static: the row's operands are consumed from stream slot SLOT and the request for the row
     // lean_pd(NSEG) ahead goes into the same registers -- rotating the slots with moves would make every move wait for the
     // load in flight to its source, i.e. collapse the stream to one row of look-ahead.
@@ -311,14 +316,39 @@ __device__ __forceinline__ void lean_bwd_plane(const LeanArgs &a, const Tin *__r
         IO::unpack(st.c[SLOT], ph); to_traversal<C, REV>(ph, Cv);
         const float hin0 = st.h[SLOT];
         lean_stream_issue<Tin, C, REV, SLOT, lean_pd(NSEG)>(st, Brow, Crow, L, nseg, ci);
-        V xv = IO::zero(), gv = IO::zero();
-        if (live) {
-            xv = *reinterpret_cast<const V *>(xq + tp0);
-            gv = *reinterpret_cast<const V *>(gq + tp0);
+        // LDS operands: x / dy of this chunk row were requested during the previous one (xv_n / gv_n); the running dB/dC
+        // sums of the LDS-accumulator variant are requested here, ~500 instructions before they are needed.  The
+        // backward kernels are LDS-capacity bound at one wave per SIMD: the registers this costs are free, and nothing
+        // else covers an LDS round trip.
+        V xv = xv_n, gv = gv_n;
+        if constexpr (NSEG != 0) {                       // (register-accumulator variants: no spare registers, plain reads)
+            xv = gv = IO::zero();
+            if (live) {
+                xv = *reinterpret_cast<const V *>(xq + tp0);
+                gv = *reinterpret_cast<const V *>(gq + tp0);
+            }
+        }
+        float4 aB[C / 4], aC[C / 4];
+        if constexpr (NSEG == 0) {
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < C / 4; ++q) {
+                    aB[q] = *reinterpret_cast<const float4 *>(accB + tp0 + 4 * q);
+                    aC[q] = *reinterpret_cast<const float4 *>(accC + tp0 + 4 * q);
+                }
+            }
+        }
+        const int tpn = tp0 + sstep;
+        if constexpr (NSEG == 0) {
+            if (s > 0 && tpn < L) {                      // (tpn >= 0 always: the walk ends at s == 0)
+                xv_n = *reinterpret_cast<const V *>(xq + tpn);
+                gv_n = *reinterpret_cast<const V *>(gq + tpn);
+            } else {
+                xv_n = gv_n = IO::zero();
+            }
         }
         IO::unpack(xv, ph); to_traversal<C, REV>(ph, u);
         IO::unpack(gv, ph); to_traversal<C, REV>(ph, go);
-        const int tpn = tp0 + sstep;
         // The element-wise maths runs on pairs (v_pk_mul/add/fma_f32: two elements per VALU instruction); only the four
         // recurrences (S/P, R, h, E) are scalar chains.  Lanes past the end of the row exist in the tail chunk row only.
         typedef float f2 __attribute__((ext_vector_type(2)));
@@ -463,14 +493,14 @@ __device__ __forceinline__ void lean_bwd_plane(const LeanArgs &a, const Tin *__r
                 to_traversal<C, REV>(dBv, t);
 #pragma unroll
                 for (int q = 0; q < C; q += 4) {
-                    float4 v = *reinterpret_cast<float4 *>(accB + tp0 + q);
+                    float4 v = aB[q / 4];
                     v.x += t[q]; v.y += t[q + 1]; v.z += t[q + 2]; v.w += t[q + 3];
                     *reinterpret_cast<float4 *>(accB + tp0 + q) = v;
                 }
                 to_traversal<C, REV>(dCv, t);
 #pragma unroll
                 for (int q = 0; q < C; q += 4) {
-                    float4 v = *reinterpret_cast<float4 *>(accC + tp0 + q);
+                    float4 v = aC[q / 4];
                     v.x += t[q]; v.y += t[q + 1]; v.z += t[q + 2]; v.w += t[q + 3];
                     *reinterpret_cast<float4 *>(accC + tp0 + q) = v;
                 }
