@@ -105,6 +105,8 @@ class GradBuckets:
 
     def _pack(self, bi):
         """Copy the bucket's gradients into its flat buffer (one multi-tensor kernel) and re-point ``.grad``."""
+        from .proj import join_wgrad_stream
+        join_wgrad_stream()                                 # (weight gradients launched on the side stream)
         grp, views = self._groups[bi], self._views[bi]
         have = [(v, p.grad) for v, p in zip(views, grp) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if have:

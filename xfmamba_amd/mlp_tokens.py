@@ -130,7 +130,7 @@ class LinearTokens(torch.autograd.Function):
             else:
                 dx = torch.mm(dy2, w).view(x.shape)
         if ctx.needs_input_grad[1]:
-            dw = split_k_wgrad(dy2, x2).to(wdtype)
+            dw = split_k_wgrad(dy2, x2, deferred=wdtype == torch.float32).to(wdtype)
         if bdtype is not None and ctx.needs_input_grad[2]:
             db = colsum_fn(dy2).to(bdtype)
         return dx, dw, db

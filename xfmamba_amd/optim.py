@@ -56,6 +56,8 @@ class FusedAdam:
 
     @torch.no_grad()
     def step(self):
+        from .proj import join_wgrad_stream
+        join_wgrad_stream()                          # weight gradients launched on the side stream (proj.wgrad_stream)
         # (gradients of the 3x3 convolutions may arrive channels_last: bring those few to the parameter's layout)
         active = [(p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), m, v)
                   for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq) if p.grad is not None]

@@ -16,7 +16,7 @@ import torch
 
 from .amp import cast_weight
 
-__all__ = ["batched_proj", "split_k_wgrad", "mfma_planes", "wgrad_mfma"]
+__all__ = ["batched_proj", "split_k_wgrad", "mfma_planes", "wgrad_mfma", "wgrad_stream", "join_wgrad_stream"]
 
 _F32_OUT = [None]      # does torch.bmm accept out_dtype on this build?  probed once
 
@@ -40,13 +40,37 @@ def _bmm_f32(a, b):
 _WGRAD = os.environ.get("XFM_WGRAD", "1") == "1"
 
 
-def wgrad_mfma(a: torch.Tensor, a_planes: bool, b: torch.Tensor, b_planes: bool, out: torch.Tensor = None):
+# ---- weight gradients on a side stream ------------------------------------------------------------------------------------
+# A weight gradient has no consumer before the optimizer, and the token-contracting kernel runs one workgroup per CU (its
+# atomic tail sets the slice count): next to it the CUs have room for the element-wise / LayerNorm / scan kernels of the
+# main backward chain.  With ``wgrad_stream(True)`` the launches whose result IS the returned gradient go to one side
+# stream (forked from the current stream, so they are captured into the step's hipGraph as a parallel branch) and the
+# caller joins it -- ``join_wgrad_stream()`` -- before anything reads ``.grad`` (FusedAdam.step and GradBuckets do).  Off by
+# default: code that reads gradients straight after ``backward()`` must not need to know about it -- and measured on the
+# XFMamba-T step it LOSES (1520 vs 1571 samples/s: the branch takes CUs from kernels that were already filling them).
+_SIDE = {"on": False, "stream": None, "pending": False}
+
+
+def wgrad_stream(enable: bool) -> None:
+    _SIDE["on"] = bool(enable)
+
+
+def join_wgrad_stream() -> None:
+    """Make the current stream wait for the weight-gradient launches issued so far (no-op when there are none)."""
+    if _SIDE["pending"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["pending"] = False
+
+
+def wgrad_mfma(a: torch.Tensor, a_planes: bool, b: torch.Tensor, b_planes: bool, out: torch.Tensor = None,
+               deferred: bool = False):
     """``dW[m, n] = sum_{b, l} A[b, l, m] B[b, l, n]`` -> (M, N) fp32 through ``xfm_wgrad`` (csrc/wgrad_gemm.hip), or None
     when the kernel does not cover the call (the caller then uses the library).
 
     ``a`` / ``b``: 3-D bf16 tensors, token-major (batch, L, C) or -- ``x_planes`` -- plane-major (batch, C, L); the last two
     axes contiguous, any sample stride.  ``out``: an fp32 (M, N) tensor to ACCUMULATE into (e.g. a view of a buffer the
-    caller zero-fills together with other accumulators); by default a fresh zero-filled one."""
+    caller zero-fills together with other accumulators); by default a fresh zero-filled one.  ``deferred``: the result
+    is only read after ``join_wgrad_stream()`` (see above) -- the launch may then go to the side stream."""
     if not _WGRAD or a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or not a.is_cuda or a.dim() != 3 or b.dim() != 3:
         return None
     from . import _lib
@@ -67,9 +91,24 @@ def wgrad_mfma(a: torch.Tensor, a_planes: bool, b: torch.Tensor, b_planes: bool,
     if (a_bs % (4 if a_planes else 8)) or (b_bs % (4 if b_planes else 8)):
         return None
     dw = torch.zeros((M, N), dtype=torch.float32, device=a.device) if out is None else out
-    with torch.cuda.device(a.device), _lib.timed("wgrad", (a.numel() + b.numel()) * 2):
-        _lib.check(lib.xfm_wgrad(a.data_ptr(), b.data_ptr(), dw.data_ptr(), M, N, Bt, L, a_bs, b_bs, int(a_planes),
-                                 int(b_planes), _lib.stream_ptr()), "wgrad")
+
+    def launch():
+        with torch.cuda.device(a.device), _lib.timed("wgrad", (a.numel() + b.numel()) * 2):
+            _lib.check(lib.xfm_wgrad(a.data_ptr(), b.data_ptr(), dw.data_ptr(), M, N, Bt, L, a_bs, b_bs, int(a_planes),
+                                     int(b_planes), _lib.stream_ptr()), "wgrad")
+
+    if deferred and _SIDE["on"]:
+        if _SIDE["stream"] is None:
+            _SIDE["stream"] = torch.cuda.Stream(device=a.device)
+        side = _SIDE["stream"]
+        side.wait_stream(torch.cuda.current_stream())      # operands (and the zero fill) are ready
+        with torch.cuda.stream(side):
+            launch()
+        for t in (a, b, dw):                                # allocated on the main stream, in use on the side stream
+            t.record_stream(side)
+        _SIDE["pending"] = True
+    else:
+        launch()
     return dw
 
 
@@ -83,7 +122,7 @@ def _k_slices(rows: int, target: int = 2048, cap: int = 128) -> int:
     return best
 
 
-def split_k_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+def split_k_wgrad(dy2: torch.Tensor, x2: torch.Tensor, deferred: bool = False) -> torch.Tensor:
     """``dy2^T @ x2`` for tall operands (rows, M), (rows, K) -> (M, K) fp32.
 
     A weight gradient contracts over every token (rows = B*H*W up to 2e5) into a small (M, K) result; handed to the
@@ -91,7 +130,7 @@ def split_k_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     batched GEMM that fills the chip, with fp32 partial products summed afterwards."""
     dy2, x2 = dy2.contiguous(), x2.contiguous()
     rows = dy2.shape[0]
-    dw = wgrad_mfma(dy2.unsqueeze(0), False, x2.unsqueeze(0), False)       # one launch, no partial products
+    dw = wgrad_mfma(dy2.unsqueeze(0), False, x2.unsqueeze(0), False, deferred=deferred)   # one launch, no partial products
     if dw is not None:
         return dw
     S = _k_slices(rows)
@@ -196,7 +235,8 @@ class BatchedProj(torch.autograd.Function):
             else:
                 dx = torch.bmm(w.t().unsqueeze(0).expand(B, K, M), dyp)                      # (B, K, L)
         if ctx.needs_input_grad[1]:
-            dw = wgrad_mfma(dy, not out_tokens, x, not in_tokens)                             # operands in the layouts they have
+            # (fp32 parameter: the kernel's output IS the gradient, nothing reads it before the optimizer)
+            dw = wgrad_mfma(dy, not out_tokens, x, not in_tokens, deferred=wdtype == torch.float32)
             if dw is None:
                 xt = x if in_tokens else x.transpose(1, 2)                                    # (B, L, K)
                 dw = _bmm_f32(dyp, xt).sum(0)
