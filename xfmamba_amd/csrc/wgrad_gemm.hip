@@ -28,9 +28,9 @@ typedef uint32_t wg_u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t wg_u32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kWgTile = 128;            // channels of each operand per workgroup
-constexpr int kWgK = 64;                // tokens per step
-constexpr int kWgPlanePitch = 144;      // bytes per channel row of a plane-major tile (128 + 16: conflict-free 16-byte reads)
-constexpr int kWgTokBytes = kWgK * 256; // token-major tile: 32 rows of 128 channels
+// tokens per step: BK = 64, or 128 for token-major x token-major products over long token runs (the Mlp weights): half the
+// barriers and LDS-fill phases per token, twice the loads in flight
+constexpr int kWgPlanePitch = 144;      // bytes per channel row of a plane-major tile (64 tokens: 128 + 16, conflict-free reads)
 constexpr int kWgPlaneBytes = kWgTile * kWgPlanePitch;
 
 struct WgradArgs {
@@ -47,19 +47,21 @@ struct WgradArgs {
 // byte offset of 16-byte chunk ch (0..15) of token row `row` in a token-major tile (image (b) of the guide)
 __device__ __forceinline__ int wg_tok_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-template <bool PL>
+template <bool PL, int BK>
 struct WgOperand {
+    static_assert(!PL || BK == 64, "plane-major tiles are 64 tokens");
+    static constexpr int NTV = BK / 16;   // 16-byte vectors per thread of a token-major tile (BK rows x 16 chunks / 256)
     // global -> registers: this thread's share of one 32-token x 128-channel tile
-    //   token-major: 4 vectors of 16 bytes (row = idx >> 4, chunk = idx & 15, idx = tid + 256 v)
+    //   token-major: BK / 16 vectors of 16 bytes (row = idx >> 4, chunk = idx & 15, idx = tid + 256 v)
     //   plane-major: 8 vectors of 8 bytes (channel = idx >> 4, 4 tokens at 4 * (idx & 15), idx = tid + 256 v)
-    wg_u32x4_t tv[PL ? 1 : 4];
+    wg_u32x4_t tv[PL ? 1 : NTV];
     wg_u32x2_t pv[PL ? 8 : 1];
 
     __device__ __forceinline__ void load(const uint16_t *base, const int64_t bs, const int C, const int L, const int c0,
                                          const int sample, const int l0, const int tid) {
         if constexpr (!PL) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < NTV; ++v) {
                 const int idx = tid + 256 * v, row = idx >> 4, ch = idx & 15;
                 const int l = l0 + row, c = c0 + 8 * ch;
                 tv[v] = wg_u32x4_t{0, 0, 0, 0};
@@ -80,7 +82,7 @@ struct WgOperand {
     __device__ __forceinline__ void store(uint8_t *tile, const int tid) const {
         if constexpr (!PL) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < NTV; ++v) {
                 const int idx = tid + 256 * v;
                 *reinterpret_cast<wg_u32x4_t *>(tile + wg_tok_off(idx >> 4, idx & 15)) = tv[v];
             }
@@ -127,9 +129,10 @@ __device__ __forceinline__ void wg_wait(wg_bf16x4_t (&lo)[4], wg_bf16x4_t (&hi)[
                      : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
 }
 
-template <bool APL, bool BPL>
-__global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
+template <bool APL, bool BPL, int BK>
+__global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const WgradArgs a) {
     extern __shared__ __align__(16) uint8_t wg_lds[];
+    constexpr int kWgTokBytes = BK * 256;
     constexpr int ABYTES = APL ? kWgPlaneBytes : kWgTokBytes, BBYTES = BPL ? kWgPlaneBytes : kWgTokBytes;
     auto At = [&](const int buf) { return wg_lds + buf * ABYTES; };
     auto Bt = [&](const int buf) { return wg_lds + 2 * ABYTES + buf * BBYTES; };
@@ -152,11 +155,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
     // rule of the launcher) nothing else hides HBM latency, and one step of MFMAs (~0.3 us) does not cover it.  Register
     // set P = parity of the step it holds; set (st & 1) is refilled with step st + 2 right after its old content (step st)
     // went to LDS in the previous iteration.
-    WgOperand<APL> ra[2];
-    WgOperand<BPL> rb[2];
+    WgOperand<APL, BK> ra[2];
+    WgOperand<BPL, BK> rb[2];
     auto issue = [&](auto par, const int st) {
         constexpr int P = decltype(par)::value;
-        const int sample = st / a.steps_per_sample, l0 = (st - sample * a.steps_per_sample) * kWgK;
+        const int sample = st / a.steps_per_sample, l0 = (st - sample * a.steps_per_sample) * BK;
         if (a.dbg & 4) return;
         ra[P].load(a.a, a.a_bs, a.M, a.L, m0, sample, l0, tid);
         rb[P].load(a.b, a.b_bs, a.N, a.L, n0, sample, l0, tid);
@@ -176,16 +179,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
         auto frags = [&](const int ring, const int s) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                WgOperand<APL>::frag(At(buf), wm * 64 + i * 32, s, lane, lo[ring][i], hi[ring][i]);
-                WgOperand<BPL>::frag(Bt(buf), wn * 64 + i * 32, s, lane, lo[ring][2 + i], hi[ring][2 + i]);
+                WgOperand<APL, BK>::frag(At(buf), wm * 64 + i * 32, s, lane, lo[ring][i], hi[ring][i]);
+                WgOperand<BPL, BK>::frag(Bt(buf), wn * 64 + i * 32, s, lane, lo[ring][2 + i], hi[ring][2 + i]);
             }
         };
         if (!(a.dbg & 2)) {
         frags(0, 0);
 #pragma unroll
-        for (int s = 0; s < kWgK / 16; ++s) {
+        for (int s = 0; s < BK / 16; ++s) {
             const int r = s & 1;
-            if (s + 1 < kWgK / 16) {
+            if (s + 1 < BK / 16) {
                 frags(r ^ 1, s + 1);
                 wg_wait<8>(lo[r], hi[r]);
             } else {
@@ -228,12 +231,20 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
         }
 }
 
-template <bool APL, bool BPL>
+template <bool APL, bool BPL, int BK>
 static int wgrad_launch(const WgradArgs &a, int nslices, hipStream_t s) {
+    constexpr int kWgTokBytes = BK * 256;
     constexpr int ABYTES = APL ? kWgPlaneBytes : kWgTokBytes, BBYTES = BPL ? kWgPlaneBytes : kWgTokBytes;
     const size_t lds = 2 * (ABYTES + BBYTES);
     const int nbm = (a.M + kWgTile - 1) / kWgTile, nbn = (a.N + kWgTile - 1) / kWgTile;
-    hipLaunchKernelGGL((wgrad_kernel<APL, BPL>), dim3((unsigned)(nbm * nbn * nslices)), dim3(256), lds, s, a);
+    if (lds > 64 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void *)wgrad_kernel<APL, BPL, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+    }
+    hipLaunchKernelGGL((wgrad_kernel<APL, BPL, BK>), dim3((unsigned)(nbm * nbn * nslices)), dim3(256), lds, s, a);
     return check_launch();
 }
 
@@ -258,21 +269,23 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     WgradArgs w{};
     w.a = (const uint16_t *)a; w.b = (const uint16_t *)b; w.dw = dw;
     w.M = M; w.N = N; w.batch = batch; w.L = L; w.a_bs = a_bs; w.b_bs = b_bs;
-    w.steps_per_sample = (L + kWgK - 1) / kWgK;
+    const int BK = (!a_planes && !b_planes && L >= 2048) ? 128 : 64;
+    w.steps_per_sample = (L + BK - 1) / BK;
     if (const char *env = getenv("XFM_WGRAD_DBG")) w.dbg = atoi(env);
     w.total_steps = batch * w.steps_per_sample;
     // Slices of the token axis.  Every workgroup ends with 64 KB of fp32 atomic adds, and the chip retires those at
     // ~1.3 TB/s against ~5+ TB/s of operand streaming: the adds of ALL workgroups (tiles * slices * 64 KB) are the floor of
-    // the launch.  So: no more workgroups than CUs (one round), and at least 16 steps (256 KB of operands) per workgroup.
+    // the launch.  So: no more workgroups than CUs (one round), and at least 1024 tokens (256 KB of operands) per workgroup.
     const int tiles = ((M + kWgTile - 1) / kWgTile) * ((N + kWgTile - 1) / kWgTile);
     int cap = 256;
     if (const char *env = getenv("XFM_WGRAD_WGS")) cap = atoi(env);
-    int nsl = std::max(1, std::min(cap / tiles, w.total_steps / 16));
+    int nsl = std::max(1, std::min(cap / tiles, w.total_steps / (1024 / BK)));
     w.steps_per_slice = (w.total_steps + nsl - 1) / nsl;
     nsl = (w.total_steps + w.steps_per_slice - 1) / w.steps_per_slice;
     hipStream_t s = (hipStream_t)stream;
-    if (a_planes) return b_planes ? wgrad_launch<true, true>(w, nsl, s) : wgrad_launch<true, false>(w, nsl, s);
-    return b_planes ? wgrad_launch<false, true>(w, nsl, s) : wgrad_launch<false, false>(w, nsl, s);
+    if (a_planes) return b_planes ? wgrad_launch<true, true, 64>(w, nsl, s) : wgrad_launch<true, false, 64>(w, nsl, s);
+    if (b_planes) return wgrad_launch<false, true, 64>(w, nsl, s);
+    return BK == 128 ? wgrad_launch<false, false, 128>(w, nsl, s) : wgrad_launch<false, false, 64>(w, nsl, s);
 }
 
 }  // extern "C"
