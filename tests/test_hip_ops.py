@@ -296,7 +296,8 @@ def test_fused_ss2d_matches_oracle_chain(shape):
         assert_close(got.float().cpu(), ref, tol, tol * (float(ref.abs().max()) + 1e-6), name)
 
 
-@pytest.mark.parametrize("shape", [(2, 96, 56, 56), (3, 192, 28, 28), (2, 384, 14, 14), (5, 768, 7, 7), (1, 33, 5, 9)])
+@pytest.mark.parametrize("shape", [(2, 96, 56, 56), (3, 192, 28, 28), (2, 384, 14, 14), (5, 768, 7, 7), (1, 33, 5, 9),
+                                   (2, 256, 24, 20), (1, 512, 12, 12), (2, 1024, 24, 24), (1, 2048, 12, 12)])   # XFMamba-B widths
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16)])
 def test_layernorm2d_matches_torch_fp32(shape, xdt, ydt):

@@ -420,6 +420,18 @@ static int ln_fwd(const void *x, const float *w, const float *b, void *y, float 
         const int NW = C / 48;
         hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 48>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
                            (Ty *)y, mean, rstd, C, L, B * L, eps, NW);
+    } else if (C % 16 == 0 && C / 16 <= 16) {            // power-of-two widths (XFMamba-B: 256 / 512 / 1024 channels)
+        const int NW = C / 16;
+        hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 16>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
+                           (Ty *)y, mean, rstd, C, L, B * L, eps, NW);
+    } else if (C % 32 == 0 && C / 32 <= 16) {
+        const int NW = C / 32;
+        hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 32>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
+                           (Ty *)y, mean, rstd, C, L, B * L, eps, NW);
+    } else if (C % 64 == 0 && C / 64 <= 16) {
+        const int NW = C / 64;
+        hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 64>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
+                           (Ty *)y, mean, rstd, C, L, B * L, eps, NW);
     } else {
         hipLaunchKernelGGL((ln2d_fwd_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, b, (Ty *)y, mean,
                            rstd, C, L, tiles, eps);
@@ -454,7 +466,17 @@ static int ln_bwd(const void *x, const float *w, const void *dy, const float *me
         const int NW = C / 48;
         hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 48>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
                            (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
+    } else if (C % 16 == 0 && C / 16 <= 16) {
+        const int NW = C / 16;
+        hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 16>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
+    } else if (C % 32 == 0 && C / 32 <= 16) {
+        const int NW = C / 32;
+        hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 32>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
     } else {
+        // (1024-channel rows, XFMamba-B stage 2: 2 x 64 values per thread do not fit the 128-register cap of a 16-wave
+        //  workgroup -- measured 519 us with the spills against 183 us for the two-pass kernel below)
         hipLaunchKernelGGL((ln2d_bwd_dx_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, (const Ty *)dy,
                            mean, rstd, (Tx *)dx, C, L, tiles);
     }
