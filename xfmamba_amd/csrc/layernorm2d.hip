@@ -14,39 +14,78 @@
 
 namespace xfm {
 
-template <typename Tx, typename Ty>
-__global__ void __launch_bounds__(256) ln2d_fwd_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
-                                                       const float *__restrict__ bias, Ty *__restrict__ y,
-                                                       float *__restrict__ mean, float *__restrict__ rstd, int C,
-                                                       int L, int tiles_pb, float eps) {
-    __shared__ float red[4][64];
+// NW waves per workgroup split the channels (4 for narrow rows; 16 for wide ones, where a sample's 64-position tile is
+// hundreds of KB and four waves with one load in flight each left the kernel latency-bound: 1024- to 2048-channel rows
+// of XFMamba-S / -B).  The channel loops run UNR loads ahead.
+template <typename Tx, typename Ty, int NW>
+__global__ void __launch_bounds__(64 * NW) ln2d_fwd_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, Ty *__restrict__ y,
+                                                          float *__restrict__ mean, float *__restrict__ rstd, int C,
+                                                          int L, int tiles_pb, float eps) {
+    constexpr int UNR = 4;
+    __shared__ float red[NW][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x / tiles_pb, p = (blockIdx.x - b * tiles_pb) * 64 + lane;
     const bool ok = p < L;
     const Tx *xb = x + (int64_t)b * C * L + p;
     float s = 0.f;
-    if (ok)
-        for (int c = wave; c < C; c += 4) s += ldf<Tx>(xb + (int64_t)c * L);
+    if (ok) {
+        int c = wave;
+        for (; c + (UNR - 1) * NW < C; c += UNR * NW) {
+            float t[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) t[q] = ldf<Tx>(xb + (int64_t)(c + q * NW) * L);
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) s += t[q];
+        }
+        for (; c < C; c += NW) s += ldf<Tx>(xb + (int64_t)c * L);
+    }
     red[wave][lane] = s;
     __syncthreads();
-    const float mu = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    float mu = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) mu += red[q][lane];
+    mu /= (float)C;
     __syncthreads();
     float v = 0.f;
-    if (ok)
-        for (int c = wave; c < C; c += 4) {
+    if (ok) {
+        int c = wave;
+        for (; c + (UNR - 1) * NW < C; c += UNR * NW) {
+            float t[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) t[q] = ldf<Tx>(xb + (int64_t)(c + q * NW) * L) - mu;
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) v = fmaf(t[q], t[q], v);
+        }
+        for (; c < C; c += NW) {
             const float d = ldf<Tx>(xb + (int64_t)c * L) - mu;
             v = fmaf(d, d, v);
         }
+    }
     red[wave][lane] = v;
     __syncthreads();
-    const float rs = rsqrtf((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C + eps);
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) var += red[q][lane];
+    const float rs = rsqrtf(var / (float)C + eps);
     if (ok) {
         if (wave == 0) {
             mean[(int64_t)b * L + p] = mu;
             rstd[(int64_t)b * L + p] = rs;
         }
         Ty *yb = y + (int64_t)b * C * L + p;
-        for (int c = wave; c < C; c += 4) {
+        int c = wave;
+        for (; c + (UNR - 1) * NW < C; c += UNR * NW) {
+            float t[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) t[q] = ldf<Tx>(xb + (int64_t)(c + q * NW) * L);
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const int cc = c + q * NW;
+                stf<Ty>(yb + (int64_t)cc * L, fmaf((t[q] - mu) * rs, w[cc], bias ? bias[cc] : 0.f));
+            }
+        }
+        for (; c < C; c += NW) {
             const float xh = (ldf<Tx>(xb + (int64_t)c * L) - mu) * rs;
             stf<Ty>(yb + (int64_t)c * L, fmaf(xh, w[c], bias ? bias[c] : 0.f));
         }
@@ -54,36 +93,75 @@ __global__ void __launch_bounds__(256) ln2d_fwd_kernel(const Tx *__restrict__ x,
 }
 
 // dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * w
-template <typename Tx, typename Ty>
-__global__ void __launch_bounds__(256) ln2d_bwd_dx_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
-                                                          const Ty *__restrict__ dy, const float *__restrict__ mean,
-                                                          const float *__restrict__ rstd, Tx *__restrict__ dx, int C,
-                                                          int L, int tiles_pb) {
-    __shared__ float red[2][4][64];
+template <typename Tx, typename Ty, int NW>
+__global__ void __launch_bounds__(64 * NW) ln2d_bwd_dx_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                             const Ty *__restrict__ dy, const float *__restrict__ mean,
+                                                             const float *__restrict__ rstd, Tx *__restrict__ dx, int C,
+                                                             int L, int tiles_pb) {
+    constexpr int UNR = 4;
+    __shared__ float red[2][NW][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x / tiles_pb, p = (blockIdx.x - b * tiles_pb) * 64 + lane;
     const bool ok = p < L;
     const int64_t o = (int64_t)b * C * L + p;
     const float mu = ok ? mean[(int64_t)b * L + p] : 0.f, rs = ok ? rstd[(int64_t)b * L + p] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    if (ok)
-        for (int c = wave; c < C; c += 4) {
+    if (ok) {
+        int c = wave;
+        for (; c + (UNR - 1) * NW < C; c += UNR * NW) {
+            float g[UNR], xv[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                g[q] = ldf<Ty>(dy + o + (int64_t)(c + q * NW) * L);
+                xv[q] = ldf<Tx>(x + o + (int64_t)(c + q * NW) * L);
+            }
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const float gg = g[q] * w[c + q * NW];
+                s1 += gg;
+                s2 = fmaf(gg, (xv[q] - mu) * rs, s2);
+            }
+        }
+        for (; c < C; c += NW) {
             const float g = ldf<Ty>(dy + o + (int64_t)c * L) * w[c];
             const float xh = (ldf<Tx>(x + o + (int64_t)c * L) - mu) * rs;
             s1 += g;
             s2 = fmaf(g, xh, s2);
         }
+    }
     red[0][wave][lane] = s1;
     red[1][wave][lane] = s2;
     __syncthreads();
-    const float m1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
-    const float m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
-    if (ok)
-        for (int c = wave; c < C; c += 4) {
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        m1 += red[0][q][lane];
+        m2 += red[1][q][lane];
+    }
+    m1 /= (float)C;
+    m2 /= (float)C;
+    if (ok) {
+        int c = wave;
+        for (; c + (UNR - 1) * NW < C; c += UNR * NW) {
+            float g[UNR], xv[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                g[q] = ldf<Ty>(dy + o + (int64_t)(c + q * NW) * L);
+                xv[q] = ldf<Tx>(x + o + (int64_t)(c + q * NW) * L);
+            }
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const int cc = c + q * NW;
+                const float xh = (xv[q] - mu) * rs;
+                stf<Tx>(dx + o + (int64_t)cc * L, rs * (g[q] * w[cc] - m1 - xh * m2));
+            }
+        }
+        for (; c < C; c += NW) {
             const float g = ldf<Ty>(dy + o + (int64_t)c * L) * w[c];
             const float xh = (ldf<Tx>(x + o + (int64_t)c * L) - mu) * rs;
             stf<Tx>(dx + o + (int64_t)c * L, rs * (g - m1 - xh * m2));
         }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,8 +511,12 @@ static int ln_fwd(const void *x, const float *w, const float *b, void *y, float 
         hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 64>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
                            (Ty *)y, mean, rstd, C, L, B * L, eps, NW);
     } else {
-        hipLaunchKernelGGL((ln2d_fwd_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, b, (Ty *)y, mean,
-                           rstd, C, L, tiles, eps);
+        if (C >= 512)
+            hipLaunchKernelGGL((ln2d_fwd_kernel<Tx, Ty, 16>), dim3(B * tiles), dim3(1024), 0, s, (const Tx *)x, w, b, (Ty *)y, mean,
+                               rstd, C, L, tiles, eps);
+        else
+            hipLaunchKernelGGL((ln2d_fwd_kernel<Tx, Ty, 4>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, b, (Ty *)y, mean,
+                               rstd, C, L, tiles, eps);
     }
     return check_launch();
 }
@@ -477,8 +559,12 @@ static int ln_bwd(const void *x, const float *w, const void *dy, const float *me
     } else {
         // (1024-channel rows, XFMamba-B stage 2: 2 x 64 values per thread do not fit the 128-register cap of a 16-wave
         //  workgroup -- measured 519 us with the spills against 183 us for the two-pass kernel below)
-        hipLaunchKernelGGL((ln2d_bwd_dx_kernel<Tx, Ty>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, (const Ty *)dy,
-                           mean, rstd, (Tx *)dx, C, L, tiles);
+        if (C >= 512)
+            hipLaunchKernelGGL((ln2d_bwd_dx_kernel<Tx, Ty, 16>), dim3(B * tiles), dim3(1024), 0, s, (const Tx *)x, w, (const Ty *)dy,
+                               mean, rstd, (Tx *)dx, C, L, tiles);
+        else
+            hipLaunchKernelGGL((ln2d_bwd_dx_kernel<Tx, Ty, 4>), dim3(B * tiles), dim3(256), 0, s, (const Tx *)x, w, (const Ty *)dy,
+                               mean, rstd, (Tx *)dx, C, L, tiles);
     }
     int rc = check_launch();
     if (rc) return rc;
