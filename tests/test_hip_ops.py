@@ -198,7 +198,7 @@ def test_swap_golden_and_passthrough_backward():
 
 
 @pytest.mark.parametrize("shape", [(2, 96, 56, 56), (2, 192, 28, 28), (3, 40, 14, 14), (5, 33, 7, 7), (1, 6, 96, 96),
-                                   (2, 5, 9, 13)])
+                                   (2, 5, 9, 13), (2, 64, 48, 48), (3, 128, 24, 24), (2, 36, 12, 12), (5, 256, 12, 12)])   # 6-vector rows (384^2 inputs)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("has_bias", [False, True])
 def test_dwconv3x3_silu_matches_torch_fp32(shape, dtype, has_bias):

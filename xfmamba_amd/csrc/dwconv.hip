@@ -267,12 +267,13 @@ template <typename T, int VEC> __device__ __forceinline__ void unpack_raw(const 
 
 // vectors a thread moves per plane, at most: wave-private planes -> the 49*VEC vectors of a plane over 64 lanes;
 // planes shared by TP = 256 / PP threads -> dw7_plan checks the bound
-template <int VEC, bool WP> struct Dw7Iters { static constexpr int value = WP ? (49 * VEC + 63) / 64 : (VEC == 8 ? 4 : 7); };
+template <int VEC, bool WP, int LPR> struct Dw7Iters { static constexpr int value = WP ? (LPR * LPR * VEC + 63) / 64 : (VEC == 8 ? 4 : 7); };
 
-template <typename T, int VEC, bool BWD, bool WP>
+// (LPR = vectors per row: 7 for the 224^2 maps, 6 for the 48 / 24 / 12 maps of 384^2 inputs)
+template <typename T, int VEC, bool BWD, bool WP, int LPR = 7>
 __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
-    constexpr int LPR = 7, W = LPR * VEC, PITCH = dw7_pitch(W);
-    constexpr int NIT = Dw7Iters<VEC, WP>::value, NW = DwRaw<T, VEC>::NW;
+    constexpr int W = LPR * VEC, PITCH = dw7_pitch(W);
+    constexpr int NIT = Dw7Iters<VEC, WP, LPR>::value, NW = DwRaw<T, VEC>::NW;
     extern __shared__ float smem[];
     const int H = a.H, PH = H + 2, L = H * W, psz = PH * PITCH;
     // WP (maps up to 28x28): ONE WAVE OWNS ONE CHANNEL -- its LDS planes are private, the three hand-offs per plane
@@ -439,13 +440,13 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
 }
 
 // plan of the fast path: PP channels per workgroup (TP = 256 / PP threads each), batch split into `bsplit` slices
-static bool dw7_plan_shared(bool bwd, int B, int D, int H, int W, int &vec, int &PP, int &bsplit, size_t &lds) {
-    if (W % 7 != 0) return false;
-    vec = W / 7;
+static bool dw7_plan_shared(bool bwd, int B, int D, int H, int W, int lpr, int &vec, int &PP, int &bsplit, size_t &lds) {
+    if (W % lpr != 0) return false;
+    vec = W / lpr;
     if (vec != 1 && vec != 2 && vec != 4 && vec != 8) return false;
     if (!bwd && vec == 8) return false;          // measured: the one-plane-per-workgroup kernel is faster for the 56x56 forward
     const size_t psz = (size_t)(H + 2) * dw7_pitch(W) * sizeof(float);
-    const int nvec = H * 7;
+    const int nvec = H * lpr;
     PP = 32;
     while (PP > 1 && (256 / PP < 10 || nvec * PP > 1568 * 2 || (bwd ? 2 : 1) * PP * psz > 60 * 1024 || D % PP != 0)) PP >>= 1;
     if (D % PP != 0 || (bwd ? 2 : 1) * PP * psz > 64 * 1024) return false;
@@ -461,9 +462,9 @@ static bool dw7_plan_shared(bool bwd, int B, int D, int H, int W, int &vec, int 
 
 // plan of the wave-private variant: four channels (waves) per workgroup, the batch split into `bsplit` slices so that the grid is
 // about one round of resident waves -- each wave then walks several planes and the plane pipeline has something to hide
-static bool dw7_plan_wave(bool bwd, int B, int D, int H, int W, int &vec, int &PP, int &bsplit, size_t &lds) {
-    if (W % 7 != 0 || H != W || D % 4 != 0) return false;
-    vec = W / 7;
+static bool dw7_plan_wave(bool bwd, int B, int D, int H, int W, int lpr, int &vec, int &PP, int &bsplit, size_t &lds) {
+    if (W % lpr != 0 || H != W || D % 4 != 0) return false;
+    vec = W / lpr;
     if (vec != 1 && vec != 2 && vec != 4 && vec != 8) return false;
     const size_t psz = (size_t)(H + 2) * dw7_pitch(W) * sizeof(float);
     PP = 4;
@@ -478,20 +479,33 @@ static bool dw7_plan_wave(bool bwd, int B, int D, int H, int W, int &vec, int &P
 }
 
 // wave-private planes up to 14x14 (forward) / 28x28 (backward), shared planes above (measured both ways per shape)
-static bool dw7_plan(bool bwd, int B, int D, int H, int W, int &vec, int &PP, int &bsplit, size_t &lds, bool &wp) {
-    wp = H == W && W % 7 == 0 && (W / 7 <= 2 || (bwd && W / 7 == 4)) && D % 4 == 0;
-    if (wp) return dw7_plan_wave(bwd, B, D, H, W, vec, PP, bsplit, lds);
-    return dw7_plan_shared(bwd, B, D, H, W, vec, PP, bsplit, lds);
+static bool dw7_plan(bool bwd, int B, int D, int H, int W, int &vec, int &PP, int &bsplit, size_t &lds, bool &wp, int &lpr) {
+    lpr = W % 7 == 0 ? 7 : 6;                             // rows of 7 vectors (224^2 inputs) or of 6 (384^2: 48 / 24 / 12)
+    if (W % lpr != 0 || (lpr == 6 && W / 6 != 8 && W / 6 != 4 && W / 6 != 2)) return false;
+    wp = H == W && (W / lpr <= 2 || (bwd && W / lpr == 4)) && D % 4 == 0;
+    if (wp) return dw7_plan_wave(bwd, B, D, H, W, lpr, vec, PP, bsplit, lds);
+    return dw7_plan_shared(bwd, B, D, H, W, lpr, vec, PP, bsplit, lds);
 }
 
-template <typename T, int VEC, bool BWD, bool WP> static int launch_dw7v(const Dw7Args &a, int grid, size_t lds, hipStream_t s) {
-    auto fn = dwconv7_kernel<T, VEC, BWD, WP>;
+template <typename T, int VEC, bool BWD, bool WP, int LPR = 7> static int launch_dw7v(const Dw7Args &a, int grid, size_t lds, hipStream_t s) {
+    auto fn = dwconv7_kernel<T, VEC, BWD, WP, LPR>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, a);
     return check_launch();
 }
 
-template <typename T, bool BWD> static int launch_dw7(int vec, bool wp, const Dw7Args &a, int grid, size_t lds, hipStream_t s) {
+template <typename T, bool BWD> static int launch_dw7(int vec, bool wp, int lpr, const Dw7Args &a, int grid, size_t lds, hipStream_t s) {
+    if (lpr == 6) {                                       // 48 x 48 (shared planes), 24 x 24 (wave-private in the backward), 12 x 12
+        if (wp) {
+            if (vec == 4) return BWD ? launch_dw7v<T, 4, BWD, true, 6>(a, grid, lds, s) : XFM_ELIMIT;
+            if (vec == 2) return launch_dw7v<T, 2, BWD, true, 6>(a, grid, lds, s);
+            return XFM_ELIMIT;
+        }
+        if (vec == 8) return launch_dw7v<T, 8, BWD, false, 6>(a, grid, lds, s);
+        if (vec == 4) return launch_dw7v<T, 4, BWD, false, 6>(a, grid, lds, s);
+        if (vec == 2) return launch_dw7v<T, 2, BWD, false, 6>(a, grid, lds, s);
+        return XFM_ELIMIT;
+    }
     if (wp) {
         switch (vec) {
             case 4: return BWD ? launch_dw7v<T, 4, BWD, true>(a, grid, lds, s) : XFM_ELIMIT;
@@ -517,12 +531,13 @@ static int launch_dw(bool bwd, const void *x, const float *w, const float *bias,
         int vec, PP, bsplit;
         size_t lds7;
         bool wp;
-        if (!getenv("XFM_DWCONV_GENERIC") && dw7_plan(bwd, B, D, H, W, vec, PP, bsplit, lds7, wp)) {
+        int lpr;
+        if (!getenv("XFM_DWCONV_GENERIC") && dw7_plan(bwd, B, D, H, W, vec, PP, bsplit, lds7, wp, lpr)) {
             Dw7Args a{};
             a.x = x; a.dy = dy; a.w = w; a.bias = bias; a.out = out; a.dw = dw; a.dbias = dbias;
             a.B = B; a.D = D; a.H = H; a.PP = PP; a.TP = 256 / PP; a.bsplit = bsplit; a.act = act;
             const int grid = (D / PP) * bsplit;
-            return bwd ? launch_dw7<T, true>(vec, wp, a, grid, lds7, s) : launch_dw7<T, false>(vec, wp, a, grid, lds7, s);
+            return bwd ? launch_dw7<T, true>(vec, wp, lpr, a, grid, lds7, s) : launch_dw7<T, false>(vec, wp, lpr, a, grid, lds7, s);
         }
     }
     const int planes = B * D;
