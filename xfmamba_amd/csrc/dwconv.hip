@@ -448,9 +448,12 @@ static bool dw7_plan_shared(bool bwd, int B, int D, int H, int W, int lpr, int &
     const size_t psz = (size_t)(H + 2) * dw7_pitch(W) * sizeof(float);
     const int nvec = H * lpr;
     PP = 32;
-    while (PP > 1 && (256 / PP < 10 || nvec * PP > 1568 * 2 || (bwd ? 2 : 1) * PP * psz > 60 * 1024 || D % PP != 0)) PP >>= 1;
+    const int nit_max = vec == 8 ? 4 : 7;               // Dw7Iters: register-held vectors per thread
+    while (PP > 1 && (256 / PP < 10 || nvec * PP > 1568 * 2 || (bwd ? 2 : 1) * PP * psz > 60 * 1024 || D % PP != 0 ||
+                      (nvec + 256 / PP - 1) / (256 / PP) > nit_max))
+        PP >>= 1;
     if (D % PP != 0 || (bwd ? 2 : 1) * PP * psz > 64 * 1024) return false;
-    if ((nvec + 256 / PP - 1) / (256 / PP) > (vec == 8 ? 4 : 7)) return false;     // Dw7Iters: register-held vectors per thread
+    if ((nvec + 256 / PP - 1) / (256 / PP) > nit_max) return false;
     lds = (bwd ? 2 : 1) * PP * psz;
     if (bwd && lds < (size_t)PP * 10 * (256 / PP) * sizeof(float)) lds = (size_t)PP * 10 * (256 / PP) * sizeof(float);
     const int ngrp = D / PP;
