@@ -402,7 +402,8 @@ def test_captured_training_step_replays_like_eager(B, find, wstream):
     torch.backends.cudnn.benchmark = old_find
 
 
-def test_captured_forward_backward_with_packed_gradient_buckets(monkeypatch):
+@pytest.mark.parametrize("wire", [None, torch.bfloat16], ids=["fp32wire", "bf16wire"])
+def test_captured_forward_backward_with_packed_gradient_buckets(monkeypatch, wire):
     """The N > 1 flow of bench.py on one GPU: the hipGraph holds forward + backward + the multi-tensor packing of the
     gradients into the flat buckets; the (here: stubbed) all-reduce and the optimizer run eagerly after each replay.
     After a replay every ``.grad`` must be a view of its bucket holding eager_gradient / world."""
@@ -422,7 +423,7 @@ def test_captured_forward_backward_with_packed_gradient_buckets(monkeypatch):
     B = 16
     xa, xb = torch.randn(B, 1, 224, 224, device=DEV), torch.randn(B, 1, 224, 224, device=DEV)
     lab = torch.randint(0, 2, (B,), device=DEV)
-    gb = GradBuckets(m, bucket_mb=16.0, overlap=False, world=2)
+    gb = GradBuckets(m, bucket_mb=16.0, overlap=False, world=2, comm_dtype=wire)     # bf16 wire: bench.py's default at N > 1
     assert len(gb.buckets) >= 2
 
     def fwd_bwd():
@@ -450,7 +451,7 @@ def test_captured_forward_backward_with_packed_gradient_buckets(monkeypatch):
         gb.reduce_all()
         torch.cuda.synchronize()
         for k, p in m.named_parameters():
-            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), (i, k)
+            assert p.grad is not None and p.grad.dtype == torch.float32 and bool(torch.isfinite(p.grad).all()), (i, k)
             scale = float(ref[k].abs().max()) + 1e-12
             assert float((p.grad - ref[k]).abs().max()) <= 1e-1 * scale + 1e-7, (i, k)
         assert any(lo <= p.grad.data_ptr() < hi for p in m.parameters())

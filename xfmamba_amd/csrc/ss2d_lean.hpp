@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(256) ss2d_fwd_lean_kernel(const LeanArgs a) {
 }
 
 template <typename Tin, typename Tout, int C, int NSEG>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 4 ? 2 : 1)))   // 4-element chunks (fp32 I/O, rows of 4k+4): two waves/SIMD
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((C == 4 && NSEG != 0) ? 2 : 1)))   // 4-element chunks (fp32 I/O, rows of 4k+4): two waves/SIMD
 ss2d_bwd_lean_kernel(const LeanArgs a) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
