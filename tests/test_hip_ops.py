@@ -830,7 +830,8 @@ def test_conv3x3s2_tokens_autograd_matches_conv2d(B, H, C, N):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("Bt,L,M,N", [(4, 196, 384, 1536), (3, 784, 192, 192), (2, 3136, 96, 384), (5, 49, 768, 128),
-                                      (2, 196, 128, 384), (1, 36, 24, 40)])
+                                      (2, 196, 128, 384), (1, 36, 24, 40),
+                                      (1, 4096, 384, 96), (1, 2112, 136, 72)])       # one long token run: the LDS-direct kernel
 @pytest.mark.parametrize("a_planes,b_planes", [(False, False), (False, True), (True, False), (True, True)])
 def test_wgrad_mfma_matches_torch_fp32(Bt, L, M, N, a_planes, b_planes):
     """dW = sum_{b,l} A[b,l,:]^T B[b,l,:] for every operand-layout pair against the fp32 einsum of the same bf16 operands;

@@ -231,6 +231,117 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
         }
 }
 
+// ---- token-major x token-major, operand tiles HBM -> LDS directly ------------------------------------------------------
+// The register-staged kernel above spends a third of a launch in its LDS-fill phases (timing switches: ~15 of 50 us on
+// the 12544 x 1536 x 384 product) and keeps one or two tiles in flight.  Here a tile never touches a VGPR:
+// global_load_lds_dwordx4 writes lane l's 16 bytes at LDS base + 16 l -- a lane-linear image -- so the chunk XOR of the
+// transposed-read layout is applied on the GLOBAL side (lane l of the instruction that fills rows 4 i .. 4 i + 3 reads
+// chunk (l & 15) ^ swz(row) of row 4 i + (l >> 4)); four 64-token stages of both operands (128 KB) ring through LDS, three
+// in flight while one feeds the MFMAs; one workgroup barrier per stage.  Needs whole stages (tokens % 64 == 0: the Mlp
+// products) and whole 128-channel tiles only in the sense that rows past M / N read clamped addresses: such rows and
+// columns of the tile are never written back.
+constexpr int kGlStages = 4, kGlBK = 64, kGlTile = kGlBK * 256;     // bytes of one operand stage
+
+__global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a) {
+    extern __shared__ __align__(16) uint8_t wg_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbm = (a.M + kWgTile - 1) / kWgTile, nbn = (a.N + kWgTile - 1) / kWgTile;
+    const int tile_id = blockIdx.x % (nbm * nbn), slice = blockIdx.x / (nbm * nbn);
+    const int m0 = (tile_id / nbn) * kWgTile, n0 = (tile_id % nbn) * kWgTile;
+    const int st0 = slice * a.steps_per_slice;
+    const int st1 = min(st0 + a.steps_per_slice, a.total_steps);
+    if (st0 >= st1) return;
+    const int wm = wave >> 1, wn = wave & 1;
+    wg_f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    auto At = [&](const int buf) { return wg_lds + buf * 2 * kGlTile; };
+    auto Bt = [&](const int buf) { return wg_lds + buf * 2 * kGlTile + kGlTile; };
+    // this lane's share of a stage: instruction i (0..3) of this wave fills rows 4 (4 wave + i) .. + 3 of the tile
+    int rowv[4];
+    int64_t offa[4], offb[4];                             // element offsets inside a 64-token stage of A / B
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * (4 * wave + i) + (lane >> 4);
+        const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        rowv[i] = row;
+        const int ca = min(m0 + 8 * ch, a.M - 8), cb = min(n0 + 8 * ch, a.N - 8);      // clamped: see above
+        offa[i] = (int64_t)row * a.M + ca;
+        offb[i] = (int64_t)row * a.N + cb;
+    }
+    auto issue = [&](const int st) {
+        const int buf = (st - st0) % kGlStages;
+        const int64_t t0 = (int64_t)st * kGlBK;           // (batch == 1: the token axis is one run)
+        const uint16_t *pa = a.a + t0 * a.M, *pb = a.b + t0 * a.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa + offa[i]),
+                                             (__attribute__((address_space(3))) void *)(At(buf) + (4 * wave + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb + offb[i]),
+                                             (__attribute__((address_space(3))) void *)(Bt(buf) + (4 * wave + i) * 1024), 16, 0, 0);
+        }
+    };
+    (void)rowv;
+#pragma unroll
+    for (int q = 0; q < kGlStages - 1; ++q)
+        if (st0 + q < st1) issue(st0 + q);
+    for (int st = st0; st < st1; ++st) {
+        const int buf = (st - st0) % kGlStages;
+        // stage st has landed when at most the 8 loads of each later stage in flight remain outstanding
+        const int later = min(st1 - 1 - st, kGlStages - 2);
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                  // everyone's share of stage st is in LDS; everyone is done with st - 1
+        if (st + kGlStages - 1 < st1) issue(st + kGlStages - 1);      // refills the buffer stage st - 1 used
+        wg_bf16x4_t lo[2][4], hi[2][4];
+        auto frags = [&](const int ring, const int s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                WgOperand<false, 64>::frag(At(buf), wm * 64 + i * 32, s, lane, lo[ring][i], hi[ring][i]);
+                WgOperand<false, 64>::frag(Bt(buf), wn * 64 + i * 32, s, lane, lo[ring][2 + i], hi[ring][2 + i]);
+            }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < kGlBK / 16; ++s) {
+            const int r = s & 1;
+            if (s + 1 < kGlBK / 16) {
+                frags(r ^ 1, s + 1);
+                wg_wait<8>(lo[r], hi[r]);
+            } else {
+                wg_wait<0>(lo[r], hi[r]);
+            }
+            wg_bf16x8_t af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = __builtin_shufflevector(lo[r][i], hi[r][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[i] = __builtin_shufflevector(lo[r][2 + i], hi[r][2 + i], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + c;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m < a.M && n < a.N) atomicAdd(a.dw + (int64_t)m * a.N + n, acc[i][j][v]);
+            }
+        }
+}
+
 template <bool APL, bool BPL, int BK>
 static int wgrad_launch(const WgradArgs &a, int nslices, hipStream_t s) {
     constexpr int kWgTokBytes = BK * 256;
@@ -269,7 +380,9 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     WgradArgs w{};
     w.a = (const uint16_t *)a; w.b = (const uint16_t *)b; w.dw = dw;
     w.M = M; w.N = N; w.batch = batch; w.L = L; w.a_bs = a_bs; w.b_bs = b_bs;
-    const int BK = (!a_planes && !b_planes && L >= 2048) ? 128 : 64;
+    const bool glds = !a_planes && !b_planes && batch == 1 && L % kGlBK == 0 && L >= 2048 && M >= 8 && N >= 8 &&
+                      !getenv("XFM_WGRAD_NO_GLDS");
+    const int BK = glds ? 64 : ((!a_planes && !b_planes && L >= 2048) ? 128 : 64);
     w.steps_per_sample = (L + BK - 1) / BK;
     if (const char *env = getenv("XFM_WGRAD_DBG")) w.dbg = atoi(env);
     w.total_steps = batch * w.steps_per_sample;
@@ -283,6 +396,16 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     w.steps_per_slice = (w.total_steps + nsl - 1) / nsl;
     nsl = (w.total_steps + w.steps_per_slice - 1) / w.steps_per_slice;
     hipStream_t s = (hipStream_t)stream;
+    if (glds) {
+        const size_t lds = (size_t)kGlStages * 2 * kGlTile;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void *)wgrad_tt_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL(wgrad_tt_glds_kernel, dim3((unsigned)(tiles * nsl)), dim3(256), lds, s, w);
+        return check_launch();
+    }
     if (a_planes) return b_planes ? wgrad_launch<true, true, 64>(w, nsl, s) : wgrad_launch<true, false, 64>(w, nsl, s);
     if (b_planes) return wgrad_launch<false, true, 64>(w, nsl, s);
     return BK == 128 ? wgrad_launch<false, false, 128>(w, nsl, s) : wgrad_launch<false, false, 64>(w, nsl, s);
