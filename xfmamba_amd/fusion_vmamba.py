@@ -878,7 +878,7 @@ class Cross_SS2Dv5(nn.Module):
         y_2, _ = _ss2d_core(x2, *w, Cs_override=Cs_fuse)
         return finish(y, x), finish(y_2, x2), finish(y_fuse, x_fuse)
 
-    def forward_core_batched(self, x3):
+    def forward_core_batched(self, x3, planes_out=False):
         """The three streams [view 1 | view 2 | fused] as ONE batch of 3B through the operator chain (they share all
         weights); the view streams read their state through the fused stream's C (:537,568), i.e. the C operand of
         the whole batch is the fused third repeated.  Returns the out-normed (3B, H, W, D)."""
@@ -892,6 +892,10 @@ class Cross_SS2Dv5(nn.Module):
             # streams reading their state through the fused stream's C rows (no cross_scan / expand / cross_merge copies)
             y = ss2d_chan_fn(x3.reshape(B3, D, L), self.x_proj_weight, self.dt_projs_weight, -self.A_logs.float().exp(),
                              self.Ds.float(), self.dt_projs_bias.reshape(-1).float(), H, W, c_mod=B, c_off=2 * B)
+            if planes_out:
+                # out_norm over the channel axis of the (3B, D, H, W) planes by the LayerNorm2d kernel (same maths as the
+                # channel-last nn.LayerNorm of the reference on the transposed tensor, no transposing copy)
+                return layernorm2d_fn(y.view(B3, D, H, W), self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, cd)
             return self.out_norm(y.transpose(1, 2).reshape(B3, H, W, -1)).to(cd)
         xs = cross_scan_fn(x3, in_channel_first=True, out_channel_first=True, scans=0)           # (3B, 4, D, L)
         x_dbl = torch.matmul(self.x_proj_weight.to(cd), xs)                                       # (3B, K, R+2N, L)
@@ -906,15 +910,25 @@ class Cross_SS2Dv5(nn.Module):
     def forward(self, x, x2: torch.Tensor, **kwargs):
         B, H, W = x.shape[0], x.shape[1], x.shape[2]
         x3 = self.in_proj_sec(torch.cat([x, x2, (x + x2) / 2], dim=0))                 # one GEMM for the three streams
-        z = self.act(torch.split(x3, B, dim=0)[2])
-        t = x3.permute(0, 3, 1, 2).contiguous()
-        t = _dwconv_act(self.conv2d, self.act, t) if self.with_dconv else self.act(t)
+        tp = x3.permute(0, 3, 1, 2).contiguous()                                       # (3B, D, H, W) planes, pre-activation
+        t = _dwconv_act(self.conv2d, self.act, tp) if self.with_dconv else self.act(tp)
         K, _, R = self.dt_projs_weight.shape
         if SS2D_MODE == "fused" and H * W > 64 and not chan_supported(t, H, W, self.A_logs.shape[1], K, t.shape[1], R):
             y, y2, y_fuse = self.forward_corev2(*torch.split(t, B, dim=0))
+            z = self.act(torch.split(x3, B, dim=0)[2])
         else:
+            if SS2D_MODE == "fused" and chan_supported(t, H, W, self.A_logs.shape[1], K, t.shape[1], R) \
+                    and self.out_proj.bias is None:
+                # planes all the way: scan -> LayerNorm2d kernel -> (y + y2 + y_fuse) * z on (B, D, L) -> out_proj as the
+                # planes-in / tokens-out projection (y z + y2 z + y_fuse z of fusion_vmamba.py:604-608 with the gate
+                # factored out: one reduction over the three streams, one product)
+                y3 = self.forward_core_batched(t, planes_out=True)                       # (3B, D, H, W)
+                zp = self.act(tp[2 * B:])                                               # the gate on planes
+                g = y3.view(3, B, t.shape[1], H * W).sum(0) * zp.reshape(B, t.shape[1], H * W)
+                return self.dropout(batched_proj(g, self.out_proj.weight, None, in_tokens=False, out_tokens=True)
+                                    .view(B, H, W, -1))
             y3 = self.forward_core_batched(t)
-            # y z + y2 z + y_fuse z (fusion_vmamba.py:604-608) with the gate factored out: one reduction over the three streams, one product
+            z = self.act(torch.split(x3, B, dim=0)[2])
             return self.dropout(self.out_proj(y3.view(3, B, *y3.shape[1:]).sum(0) * z))
         return self.dropout(self.out_proj((y + y2 + y_fuse) * z))
 
