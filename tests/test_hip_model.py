@@ -336,6 +336,7 @@ def test_model_tiny_bf16_autocast_within_tolerance():
 @pytest.mark.parametrize("B,find,wstream", [
     (16, False, False), (32, True, False),
     (32, True, True),       # bench.py --wgrad-stream: weight-gradient kernels on a side stream = a parallel branch of the graph
+    (32, True, "arena"),    # bench.py's default: weight gradients accumulate into one arena that is zeroed once per step
     # seen on ROCm 7.2 / MI355X: with a merged batch of 8 the MIOpen weight-gradient solver picked for the 384->768
     # stride-2 downsample convolution returns garbage from the SECOND replay on (library kernel, not this repo's;
     # eager launches are fine).  bench.py's shapes (B = 32, find mode) and B = 16 replay correctly.
@@ -356,11 +357,14 @@ def test_captured_training_step_replays_like_eager(B, find, wstream):
     xa, xb = torch.randn(B, 1, 224, 224, device=DEV), torch.randn(B, 1, 224, 224, device=DEV)
     lab = torch.randint(0, 2, (B,), device=DEV)
 
-    from xfmamba_amd.proj import join_wgrad_stream, wgrad_stream
+    from xfmamba_amd.proj import WgradArena, join_wgrad_stream, set_wgrad_arena, wgrad_stream
+    arena = [None]
 
     def step():
         for p in m.parameters():
             p.grad = None
+        if arena[0] is not None:
+            arena[0].zero()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             loss = torch.nn.functional.cross_entropy(m(xa, xb).float(), lab)
         loss.backward()
@@ -375,7 +379,11 @@ def test_captured_training_step_replays_like_eager(B, find, wstream):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     ref = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
-    wgrad_stream(wstream)
+    ref = {k: v.clone() for k, v in ref.items()}      # (the arena run below must not alias the reference)
+    if wstream == "arena":
+        arena[0] = WgradArena(m.parameters())
+        set_wgrad_arena(arena[0])
+    wgrad_stream(wstream is True)
     try:
         step()                                        # one eager step with the side stream: same gradients
         torch.cuda.synchronize()
@@ -388,6 +396,7 @@ def test_captured_training_step_replays_like_eager(B, find, wstream):
             step()
     finally:
         wgrad_stream(False)
+        set_wgrad_arena(None)
     for i in range(3):
         g.replay()
         torch.cuda.synchronize()

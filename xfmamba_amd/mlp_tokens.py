@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from .amp import cast_weight
-from .proj import split_k_wgrad
+from .proj import split_k_wgrad, wgrad_slot
 
 __all__ = ["bias_gelu_fn", "colsum_fn", "linear_tokens_fn", "mlp_tokens_fn"]
 
@@ -115,6 +115,7 @@ class LinearTokens(torch.autograd.Function):
             y = torch.nn.functional.linear(x, w, None if bias is None else cast_weight(bias, cd))
         ctx.save_for_backward(x, w)
         ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
+        ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None      # (identity only: the arena's slot key)
         return y
 
     @staticmethod
@@ -130,7 +131,8 @@ class LinearTokens(torch.autograd.Function):
             else:
                 dx = torch.mm(dy2, w).view(x.shape)
         if ctx.needs_input_grad[1]:
-            dw = split_k_wgrad(dy2, x2, deferred=wdtype == torch.float32).to(wdtype)
+            slot = wgrad_slot(ctx.wparam, w.shape[0], w.shape[1]) if wdtype == torch.float32 else None
+            dw = split_k_wgrad(dy2, x2, deferred=wdtype == torch.float32, out=slot).to(wdtype)
         if bdtype is not None and ctx.needs_input_grad[2]:
             db = colsum_fn(dy2).to(bdtype)
         return dx, dw, db

@@ -16,7 +16,8 @@ import torch
 
 from .amp import cast_weight
 
-__all__ = ["batched_proj", "split_k_wgrad", "mfma_planes", "wgrad_mfma", "wgrad_stream", "join_wgrad_stream"]
+__all__ = ["batched_proj", "split_k_wgrad", "mfma_planes", "wgrad_mfma", "wgrad_stream", "join_wgrad_stream", "WgradArena",
+           "set_wgrad_arena", "wgrad_slot"]
 
 _F32_OUT = [None]      # does torch.bmm accept out_dtype on this build?  probed once
 
@@ -60,6 +61,48 @@ def join_wgrad_stream() -> None:
     if _SIDE["pending"]:
         torch.cuda.current_stream().wait_stream(_SIDE["stream"])
         _SIDE["pending"] = False
+
+
+# ---- one zero fill per step for the weight-gradient accumulators -----------------------------------------------------------
+# xfm_wgrad ACCUMULATES into dw (fp32 atomics), so every launch needs a zeroed (M, N) tensor: ~60 fill kernels of a few us
+# each per step.  A ``WgradArena`` is one flat fp32 buffer with a slot per registered weight; the training loop zeroes it
+# once before ``backward()`` (``arena.zero()``: one fill) and the weight-gradient launches accumulate straight into their
+# slots, which autograd then adopts as ``.grad``.  Opt-in (``set_wgrad_arena``): the gradients alias a buffer the NEXT
+# ``arena.zero()`` wipes, which is only sound for loops that drop ``.grad`` before every backward pass (bench.py does).  A
+# weight that receives a second gradient in the same pass (shared weights, two sequential trunk calls) falls back to a fresh
+# tensor for it -- the slot must not be handed to autograd twice.
+class WgradArena:
+    def __init__(self, params):
+        ps = [p for p in params if p.requires_grad and p.dtype == torch.float32 and p.dim() >= 2 and p.is_cuda]
+        self.offsets, n = {}, 0
+        for p in ps:
+            self.offsets[id(p)] = (n, p.shape[0], p.numel() // p.shape[0])
+            n += (p.numel() + 63) // 64 * 64                    # 256-byte aligned slots
+        self.buf = torch.zeros(max(n, 1), dtype=torch.float32, device=ps[0].device if ps else "cpu")
+        self.used = set()
+
+    def zero(self):
+        self.buf.zero_()
+        self.used.clear()
+
+    def slot(self, weight, M, N):
+        """The (M, N) fp32 slot of ``weight``, or None (unregistered, other shape, or already used in this pass)."""
+        o = self.offsets.get(id(weight))
+        if o is None or (o[1], o[2]) != (M, N) or id(weight) in self.used:
+            return None
+        self.used.add(id(weight))
+        return self.buf[o[0]:o[0] + M * N].view(M, N)
+
+
+_ARENA = [None]
+
+
+def set_wgrad_arena(arena) -> None:
+    _ARENA[0] = arena
+
+
+def wgrad_slot(weight, M, N):
+    return None if _ARENA[0] is None or weight is None else _ARENA[0].slot(weight, M, N)
 
 
 def wgrad_mfma(a: torch.Tensor, a_planes: bool, b: torch.Tensor, b_planes: bool, out: torch.Tensor = None,
@@ -122,7 +165,7 @@ def _k_slices(rows: int, target: int = 2048, cap: int = 128) -> int:
     return best
 
 
-def split_k_wgrad(dy2: torch.Tensor, x2: torch.Tensor, deferred: bool = False) -> torch.Tensor:
+def split_k_wgrad(dy2: torch.Tensor, x2: torch.Tensor, deferred: bool = False, out: torch.Tensor = None) -> torch.Tensor:
     """``dy2^T @ x2`` for tall operands (rows, M), (rows, K) -> (M, K) fp32.
 
     A weight gradient contracts over every token (rows = B*H*W up to 2e5) into a small (M, K) result; handed to the
@@ -130,9 +173,11 @@ def split_k_wgrad(dy2: torch.Tensor, x2: torch.Tensor, deferred: bool = False) -
     batched GEMM that fills the chip, with fp32 partial products summed afterwards."""
     dy2, x2 = dy2.contiguous(), x2.contiguous()
     rows = dy2.shape[0]
-    dw = wgrad_mfma(dy2.unsqueeze(0), False, x2.unsqueeze(0), False, deferred=deferred)   # one launch, no partial products
+    dw = wgrad_mfma(dy2.unsqueeze(0), False, x2.unsqueeze(0), False, out=out, deferred=deferred)   # one launch, no partials
     if dw is not None:
         return dw
+    if out is not None:                               # (the library formulation below writes a fresh tensor)
+        return out.add_(split_k_wgrad(dy2, x2))
     S = _k_slices(rows)
     if S == 1:
         return _bmm_f32(dy2.t().unsqueeze(0), x2.unsqueeze(0))[0]
@@ -215,6 +260,7 @@ class BatchedProj(torch.autograd.Function):
                 y = y + bias.to(cd)[:, None]
         ctx.save_for_backward(x, w)
         ctx.meta = (in_tokens, out_tokens, weight.dtype, bias is not None and bias.dtype)
+        ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None      # (identity only: the arena's slot key)
         return y
 
     @staticmethod
@@ -236,7 +282,10 @@ class BatchedProj(torch.autograd.Function):
                 dx = torch.bmm(w.t().unsqueeze(0).expand(B, K, M), dyp)                      # (B, K, L)
         if ctx.needs_input_grad[1]:
             # (fp32 parameter: the kernel's output IS the gradient, nothing reads it before the optimizer)
-            dw = wgrad_mfma(dy, not out_tokens, x, not in_tokens, deferred=wdtype == torch.float32)
+            slot = wgrad_slot(ctx.wparam, M, K) if wdtype == torch.float32 else None
+            dw = wgrad_mfma(dy, not out_tokens, x, not in_tokens, out=slot, deferred=wdtype == torch.float32)
+            if dw is None and slot is not None:
+                ctx.wparam = None                                                       # (slot untouched: still all zeros)
             if dw is None:
                 xt = x if in_tokens else x.transpose(1, 2)                                    # (B, L, K)
                 dw = _bmm_f32(dyp, xt).sum(0)
