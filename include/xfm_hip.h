@@ -275,8 +275,8 @@ int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream);
  *   xdbl   (batch, L, n_routes*C2p) bf16 TOKEN-MAJOR x_proj output evaluated on the natural map.  Route k owns columns
  *          [k*C2p, (k+1)*C2p), C2p = Rp8 + (dstate == 1 ? 8 : 2*dstate), Rp8 = dt_rank rounded up to 8:
  *          [0, dt_rank) dt_proj input, [Rp8, Rp8+dstate) B, then C at Rp8+1 (dstate 1) or Rp8+dstate; other columns 0.
- *   wdt    (n_sets, d_inner, Kp) bf16 dt_proj weight (reference dt_projs_weight (K, D, R)) zero-padded to Kp = dt_rank
- *          rounded up to 16.  n_sets = 4 with n_routes == 4 (route k uses set k); with n_routes == 1 (one forward
+ *   wdt    (n_sets, d_inner, Rp8) bf16 dt_proj weight (reference dt_projs_weight (K, D, R)), zero columns beyond dt_rank
+ *          (none when dt_rank % 8 == 0: the cast weight itself).  n_sets = 4 with n_routes == 4 (route k uses set k); with n_routes == 1 (one forward
  *          row-major route per sample: the two views of the shallow swap block as 2B samples) sample sb uses set sb / wdiv.
  *   A (n_sets*d_inner, dstate), D / delta_bias (n_sets*d_inner) fp32.
  *   c_mod > 0: sample sb reads its C columns from sample c_off + sb % c_mod (deep fusion block: the view streams read
@@ -309,7 +309,7 @@ int xfm_ss2dc_bwd(const xfm_ss2dc_params_t *p, void *stream);
 /* The two dense products behind xfm_ss2dc_bwd (n_routes == 4), both on MFMA, each reading ddts once (the backward of the
  * dt_proj einsum, reference models/fusion_vmamba.py:1154-1156, in the token-major layout):
  *   dxdbl (batch, L, 4*C2p) bf16, every column written: [0, Rp8) = ddts . W_dt (contraction over the channels; wdt is the
- *         zero-padded (4, d_inner, Kp) bf16 weight xfm_ss2dc_fwd/_bwd take), the B / C columns from dBC
+ *         (4, d_inner, Rp8) bf16 weight xfm_ss2dc_fwd/_bwd take), the B / C columns from dBC
  *         (batch, 4, 2, dstate, L) fp32, zeros elsewhere;
  *   dwdt  (4, d_inner, dt_rank) fp32 ZEROED += sum over batch and positions of ddts x (dt_proj input columns of xdbl). */
 int xfm_ss2dc_post(const void *ddts, const void *xdbl, const void *wdt, const float *dBC, void *dxdbl, float *dwdt,

@@ -35,7 +35,7 @@ struct ChanArgs {
     const uint16_t *x;       // (Bt, D, L) bf16, natural row-major planes
     const uint16_t *xdbl;    // (Bt, L, XC) bf16 token-major x_proj rows; route k owns columns [k*C2p, (k+1)*C2p):
                              //   [0,R) dt_proj input | [Rp8, Rp8+N) B | [Rp8+NB, Rp8+NB+N) C   (NB = 1 if N == 1 else N)
-    const uint16_t *wdt;     // (4, D, Kp) bf16 dt_proj weight, zero-padded to Kp = 16*KS columns
+    const uint16_t *wdt;     // (4, D, Rp8) bf16 dt_proj weight (zero columns beyond R when R % 8 != 0)
     const float *A;          // (4*D, N)
     const float *Dp, *bias;  // (4*D)
     float *y;                // (Bt, D, L) fp32
@@ -107,6 +107,13 @@ __device__ __forceinline__ cbf16x8_t chan_ld8(const uint16_t *p) {
     const cu32x4_t v = *reinterpret_cast<const cu32x4_t *>(p);
     return *reinterpret_cast<const cbf16x8_t *>(&v);
 }
+// dt_proj weight fragment of route rm: 8 consecutive k of channel row `ch` from the (4, D, Rp8) weight; k-slots at or beyond
+// Rp8 (the contraction is walked in steps of 16) come from the block of zeros -- an address select, not a masked load
+template <typename Args>
+__device__ __forceinline__ const uint16_t *chan_w_ptr(const Args &a, const int rm, const int ch, const int k0) {
+    return k0 < a.Rp8 ? a.wdt + ((int64_t)rm * a.D + ch) * a.Rp8 + k0 : a.zeros;
+}
+
 __device__ __forceinline__ cbf16x8_t chan_zero8() {
     const cu32x4_t v = {0u, 0u, 0u, 0u};
     return *reinterpret_cast<const cbf16x8_t *>(&v);
@@ -253,7 +260,7 @@ __device__ __forceinline__ cf32x16_t chan_dt_step(const ChanArgs &a, const ChanL
 #pragma unroll
     for (int m = 0; m < 2 * KS; ++m) {
         const int rm = (COL ? 1 : 0) + 2 * (m / KS);
-        const cbf16x8_t w = chan_ld8(a.wdt + ((int64_t)rm * a.D + c0 + ln.c) * a.Kp + 16 * (m % KS) + 8 * ln.kb);
+        const cbf16x8_t w = chan_ld8(chan_w_ptr(a, rm, c0 + ln.c, 16 * (m % KS) + 8 * ln.kb));
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m < KS ? fr.f0[m] : fr.f1[m - KS], w, acc, 0, 0, 0);
     }
     fB = fr.fB;
@@ -327,7 +334,7 @@ __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, c
 #pragma unroll
         for (int m = 0; m < 2 * KS; ++m) {
             const int rm = (COL ? 1 : 0) + 2 * (m / KS);
-            wf[m] = chan_ld8(a.wdt + ((int64_t)rm * a.D + c0 + c) * a.Kp + 16 * (m % KS) + 8 * kb);
+            wf[m] = chan_ld8(chan_w_ptr(a, rm, c0 + c, 16 * (m % KS) + 8 * kb));
         }
     }
     const float bv = a.bias[ln.wrow];
@@ -520,7 +527,7 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
 #pragma unroll
         for (int m = 0; m < 2 * KS; ++m) {
             const int rm = (COL ? 1 : 0) + 2 * (m / KS);
-            wf[m] = chan_ld8(a.wdt + ((int64_t)rm * a.D + c0 + c) * a.Kp + 16 * (m % KS) + 8 * kb);
+            wf[m] = chan_ld8(chan_w_ptr(a, rm, c0 + c, 16 * (m % KS) + 8 * kb));
         }
     }
     const float bv = a.bias[ln.wrow];

@@ -16,8 +16,7 @@ typedef uint32_t pu32x2_t __attribute__((ext_vector_type(2)));
 struct ChanPostArgs {
     const uint16_t *ddts;    // (Bt, 4, L, D) bf16
     const uint16_t *xdbl;    // (Bt, L, XC) bf16
-    const uint16_t *wdt;     // (4, D, Kp) bf16: dt_proj weight, zero columns beyond R (the layout xfm_ss2dc_fwd/_bwd take)
-    int Kp;
+    const uint16_t *wdt;     // (4, D, Rp8) bf16: dt_proj weight, zero columns beyond R (the layout xfm_ss2dc_fwd/_bwd take)
     const float *dBC;        // (Bt, 4, 2, N, L) fp32
     uint16_t *dxdbl;         // (Bt, L, XC) bf16 (every column written)
     float *dwdt;             // (4, D, R) fp32 ZEROED (atomics)
@@ -44,9 +43,9 @@ template <int KT> __global__ void __launch_bounds__(256) chan_dxdbl_kernel(const
     const int p = pt * 32 + col;
     const bool pv = p < a.L;
     const uint16_t *brow = a.ddts + ((int64_t)bk * a.L + (pv ? p : 0)) * a.D + 8 * kb;
-    // A operand = W^T (rows r, k = channels): gathered from the (D, Kp) weight with 2-byte loads (32 lanes = 64
+    // A operand = W^T (rows r, k = channels): gathered from the (D, Rp8) weight with 2-byte loads (32 lanes = 64
     // contiguous bytes per channel; the weight is a few KB and stays in L1 / L2)
-    const uint16_t *arow = a.wdt + ((int64_t)k * a.D + 8 * kb) * a.Kp + col;
+    const uint16_t *arow = a.wdt + ((int64_t)k * a.D + 8 * kb) * a.Rp8 + col;
     pf32x16_t acc[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t)
@@ -58,7 +57,7 @@ template <int KT> __global__ void __launch_bounds__(256) chan_dxdbl_kernel(const
         for (int t = 0; t < KT; ++t) {
             uint16_t v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (32 * t + col < a.Kp) ? arow[(int64_t)(16 * s + j) * a.Kp + 32 * t] : (uint16_t)0;
+            for (int j = 0; j < 8; ++j) v[j] = (32 * t + col < a.Rp8) ? arow[(int64_t)(16 * s + j) * a.Rp8 + 32 * t] : (uint16_t)0;
             af[t] = *reinterpret_cast<const pbf16x8_t *>(v);
         }
     };
@@ -175,7 +174,7 @@ extern "C" int xfm_ss2dc_post(const void *ddts, const void *xdbl, const void *wd
     if (!ddts || !xdbl || !wdt || !dBC || !dxdbl || !dwdt || batch <= 0 || L <= 0) return XFM_EINVAL;
     if (d_inner % 32 || dt_rank < 1 || dt_rank > 64 || (dstate != 1 && dstate % 8)) return XFM_ELIMIT;
     ChanPostArgs a{};
-    a.ddts = (const uint16_t *)ddts; a.xdbl = (const uint16_t *)xdbl; a.wdt = (const uint16_t *)wdt; a.Kp = (dt_rank + 15) / 16 * 16; a.dBC = dBC;
+    a.ddts = (const uint16_t *)ddts; a.xdbl = (const uint16_t *)xdbl; a.wdt = (const uint16_t *)wdt; a.dBC = dBC;
     a.dxdbl = (uint16_t *)dxdbl; a.dwdt = dwdt;
     a.Bt = batch; a.D = d_inner; a.L = L; a.R = dt_rank; a.N = dstate;
     a.Rp8 = (dt_rank + 7) / 8 * 8;

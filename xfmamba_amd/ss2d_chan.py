@@ -83,11 +83,10 @@ class SS2DChanHip(torch.autograd.Function):
             raise RuntimeError("ss2d_chan: x (B,D,H*W) bf16, x_proj_weight (4,R+2N,D), dt_projs_weight (4,D,R) expected")
         x = x.contiguous()
         Rp8, NBo, C2p, _ = _col_layout(R, N)
-        Kp = (R + 15) // 16 * 16
         XC = K * C2p
         rows = _row_index(K, R, N, x.device)
         wdt = cast_weight(dt_w, x.dtype)
-        wdt = (torch.nn.functional.pad(wdt, (0, Kp - R)) if Kp != R else wdt).contiguous()      # (4, D, Kp)
+        wdt = (torch.nn.functional.pad(wdt, (0, Rp8 - R)) if Rp8 != R else wdt).contiguous()    # (4, D, Rp8): no copy when R % 8 == 0
         plain = Rp8 == R                         # the dt_proj block needs no inner padding: rows only grow at the END of a route
 
         def padded(w3):                          # (K, C2, D) -> (K * C2p, D) in the column layout of the kernels
