@@ -30,6 +30,8 @@ def main():
         Dp = torch.randn(K * D, generator=g).to(dev).requires_grad_()
         bias = (0.1 * torch.rand(K * D, generator=g) - 4.0).to(dev).requires_grad_()
         gy = torch.randn(B, D, L, device=dev)
+        for _ in range(2):                                  # warm-up (first launches pay module load / attribute calls)
+            ss2d_xproj_core_fn(x, xw, dtw, A, Dp, bias, HW, HW).backward(gy)
         timer = _lib.KernelTimer()
         _lib.set_timer(timer)
         for _ in range(5):

@@ -238,6 +238,8 @@ int ss2d_launch_lean(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bw
     return check_launch();
 }
 
+int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s);   // ss2d_l3.hip: wide maps, two waves per SIMD
+
 static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream) {
     if (!p || !p->x || !p->dts || !p->Bs || !p->Cs || !p->A || !p->D || !p->delta_bias) return XFM_EINVAL;
     if (!bwd && !p->y) return XFM_EINVAL;
@@ -245,6 +247,10 @@ static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream) {
         return XFM_EINVAL;
     if (p->in_dtype < 0 || p->in_dtype > 2) return XFM_EDTYPE;
     if (p->out_dtype != XFM_F32) return XFM_EDTYPE;          // the fused core always emits fp32 ("oflex")
+    if (!getenv("XFM_SS2D_FORCE")) {
+        const int rc3 = ss2d_l3_run(p, bwd, (hipStream_t)stream);
+        if (rc3 != XFM_ELIMIT) return rc3;
+    }
     Plan2 pl;
     int rc = plan_ss2d(p->batch, p->d_inner, p->H, p->W, p->dstate, p->in_dtype, &pl);
     if (rc) return rc;

@@ -1,0 +1,678 @@
+// ss2d_l3.hip -- fused SS2D scan kernels for the WIDE maps of the trunk (56 x 56, 28 x 28; d_state 1, bf16 I/O), built
+// for TWO waves per SIMD.  Same algorithm, layout contract and checkpoint format as ss2d_lean.hpp (reference
+// models/fusion_vmamba.py:1145-1174; adjoint per selective_scan_bwd_kernel.cuh:141-273), so either forward pairs with
+// either backward.  What changed against the lean kernels (one wave per SIMD: 100 KB of dB/dC sums in LDS, 388 VGPRs):
+//   * the map size is a template parameter: chunk-row count, tail lanes and every address stride are constants;
+//   * the dB / dC sums of a route over the planes a workgroup walks live in REGISTERS (one jump per chunk row into a
+//     block of static-register adds; the 8-lane tail row of a 56 x 56 map in a 512-byte LDS strip), which leaves
+//     50 KB of LDS per workgroup -> two workgroups per CU, and the kernel is held to 256 VGPRs;
+//   * both wave scans of a chunk row (states ascending, adjoints descending) are ONE block of DPP-fused VALU
+//     instructions (v_fmac_f32_dpp / v_mul_f32_dpp: a scan step is two instructions, not a move pair plus two), the
+//     two chains interleaved so that no DPP source is read within two instructions of its write; the descending
+//     cross-row steps run under EXEC row masks with the row totals in SGPRs (v_readlane);
+//   * the carries enter through one FMA and a one-lane wave shift instead of exclusive-prefix shifts of both halves
+//     of the map;
+//   * softplus handling is a template parameter (1: in-kernel with bias, 2: the step sizes arrive activated).
+// Roofline: HBM (24 B per (b,d,p) element backward, 14 B forward at this boundary: ss2d_kernels.hpp).
+#include <cstdlib>
+
+#include "ss2d_kernels.hpp"
+
+namespace xfm {
+
+#ifndef L3_NREG
+#define L3_NREG 6
+#endif
+#ifndef L3_WPE
+#define L3_WPE 2
+#endif
+typedef float l3f2 __attribute__((ext_vector_type(2)));
+
+template <int HW> struct L3Geom {
+    static constexpr int L = HW * HW;
+    static constexpr int ROW = 512;                             // positions per chunk row: 64 lanes x 8
+    static constexpr int NSEG = (L + ROW - 1) / ROW;
+    static constexpr int TAILV = (L - (NSEG - 1) * ROW) / 8;    // live lanes of the last chunk row
+    static constexpr bool HAS_TAIL = TAILV < 64;
+    // dB / dC sums of a route over the planes of a workgroup: the first NREG chunk rows in registers (16 per row), the
+    // rest in a wave-private LDS strip (56 x 56: row 5 and the 8-lane tail row -- 256 registers hold five rows next to
+    // the working set, and 4.6 KB per wave still leave two workgroups per CU)
+    static constexpr int NREG = NSEG < L3_NREG ? NSEG : L3_NREG;
+    static constexpr int NACC = NREG;
+    static constexpr int LSZ = NSEG > NREG ? L - NREG * ROW : 0;   // positions whose sums live in LDS
+};
+
+// Inclusive scan of the affine maps (P, S) over ascending lanes and of (Q, R) over descending lanes.
+// A step of the ascending scan is  S += S[lane - d] * P ; P *= P[lane - d]  (lanes without a source are disabled by the
+// DPP bound control: the identity), the descending one mirrors it with row_shl.  The two chains alternate, so every DPP
+// source was written at least three instructions earlier (the hardware needs two wait states).  EXEC must be all ones.
+__device__ __forceinline__ void l3_scan_pair(float &P, float &S, float &Q, float &R) {
+    uint32_t q1, r1, q2, r2, q3, r3;
+#define L3_STEP(N)                                                                   \
+    "v_fmac_f32_dpp %[S], %[S], %[P] row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"  \
+    "v_fmac_f32_dpp %[R], %[R], %[Q] row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t"  \
+    "v_mul_f32_dpp %[P], %[P], %[P] row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+    "v_mul_f32_dpp %[Q], %[Q], %[Q] row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile(
+        "s_nop 1\n\t"
+        L3_STEP(1) L3_STEP(2) L3_STEP(4) L3_STEP(8)
+        // ascending cross-row steps (lane 15 of a row -> the next row; lane 31 -> rows 2, 3), the row totals of the
+        // descending scan (first lane of rows 1..3) read in between
+        "v_fmac_f32_dpp %[S], %[S], %[P] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_readlane_b32 %[q1], %[Q], 16\n\t"
+        "v_readlane_b32 %[r1], %[R], 16\n\t"
+        "v_mul_f32_dpp %[P], %[P], %[P] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_readlane_b32 %[q3], %[Q], 48\n\t"
+        "v_readlane_b32 %[r3], %[R], 48\n\t"
+        "v_fmac_f32_dpp %[S], %[S], %[P] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_mul_f32_dpp %[P], %[P], %[P] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        // descending cross-row steps under EXEC row masks: rows 0 / 2 take the totals of rows 1 / 3, then rows 0, 1
+        // take the total of rows 2, 3
+        "s_mov_b32 exec_lo, 0xffff\n\t"
+        "s_mov_b32 exec_hi, 0\n\t"
+        "v_fmac_f32 %[R], %[r1], %[Q]\n\t"
+        "v_mul_f32 %[Q], %[q1], %[Q]\n\t"
+        "s_mov_b32 exec_lo, 0\n\t"
+        "s_mov_b32 exec_hi, 0xffff\n\t"
+        "v_fmac_f32 %[R], %[r3], %[Q]\n\t"
+        "v_mul_f32 %[Q], %[q3], %[Q]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_readlane_b32 %[q2], %[Q], 32\n\t"
+        "v_readlane_b32 %[r2], %[R], 32\n\t"
+        "s_mov_b32 exec_hi, 0\n\t"
+        "v_fmac_f32 %[R], %[r2], %[Q]\n\t"
+        "v_mul_f32 %[Q], %[q2], %[Q]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        : [P] "+v"(P), [S] "+v"(S), [Q] "+v"(Q), [R] "+v"(R), [q1] "=&s"(q1), [r1] "=&s"(r1), [q2] "=&s"(q2),
+          [r2] "=&s"(r2), [q3] "=&s"(q3), [r3] "=&s"(r3));
+#undef L3_STEP
+}
+
+// ascending scan only (forward kernel)
+__device__ __forceinline__ void l3_scan_up(float &P, float &S) {
+#define L3_STEP(N)                                                                   \
+    "v_fmac_f32_dpp %[S], %[S], %[P] row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"  \
+    "s_nop 0\n\t"                                                                    \
+    "v_mul_f32_dpp %[P], %[P], %[P] row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+    "s_nop 0\n\t"
+    asm volatile(
+        "s_nop 1\n\t"
+        L3_STEP(1) L3_STEP(2) L3_STEP(4) L3_STEP(8)
+        "v_fmac_f32_dpp %[S], %[S], %[P] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %[P], %[P], %[P] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %[S], %[S], %[P] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %[P], %[P], %[P] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        : [P] "+v"(P), [S] "+v"(S));
+#undef L3_STEP
+}
+
+// 8 bf16 of a 16-byte vector -> four pairs in TRAVERSAL order (a descending route walks the vector backwards)
+template <bool REV> __device__ __forceinline__ void l3_unpack(const uint4 &r, l3f2 (&o)[4]) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t x = w[REV ? 3 - q : q];
+        const float lo = __uint_as_float(x << 16), hi = __uint_as_float(x & 0xffff0000u);
+        o[q] = REV ? l3f2{hi, lo} : l3f2{lo, hi};
+    }
+}
+template <bool REV> __device__ __forceinline__ uint4 l3_pack(const l3f2 (&v)[4]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const l3f2 p = v[REV ? 3 - i : i];
+        w[i] = REV ? pack_bf16x2(p.y, p.x) : pack_bf16x2(p.x, p.y);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ l3f2 l3_exp2(const l3f2 t) { return l3f2{exp2_fast(t.x), exp2_fast(t.y)}; }
+
+// operands of one chunk row, requested one row ahead
+struct L3Ops { uint4 d, b, c; float h; };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, one route over one plane
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HW, bool REV, int MODE>
+__device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row, bf16_t *__restrict__ ddts_row,
+                                             const bf16_t *__restrict__ Brow, const bf16_t *__restrict__ Crow,
+                                             const float *__restrict__ chk_row, const bool more_planes, const float An,
+                                             const float Dr, const float bias, const bf16_t *xq, const bf16_t *gq,
+                                             bf16_t *dxq, float *ldsacc, l3f2 (&rB)[L3Geom<HW>::NACC][4],
+                                             l3f2 (&rC)[L3Geom<HW>::NACC][4], float &dA_acc, float &dD_acc,
+                                             float &dbias_acc, const int lane, L3Ops &op, const int dbg) {
+    using G = L3Geom<HW>;
+    constexpr int L = G::L, NSEG = G::NSEG;
+    const float A2 = An * kLog2e;
+    const int ci = REV ? 63 - lane : lane;
+    const bool tail_live = !G::HAS_TAIL || ci < G::TAILV;
+    float Ec = 0.f;                                   // adjoint flowing in from the chunk row processed before
+    l3f2 dA2 = {0.f, 0.f}, dD2 = dA2, db2 = dA2;
+#pragma unroll 1
+    for (int i = NSEG - 1; i >= 0; --i) {             // chunk rows against the route
+        const int sp = REV ? NSEG - 1 - i : i;        // physical chunk row
+        const int tp0 = sp * G::ROW + ci * 8;
+        const bool is_tail = G::HAS_TAIL && sp == NSEG - 1;
+        const uint4 dv = op.d, bv = op.b, cv = op.c;
+        const float hin = op.h;
+        // ---- request the next row to process (this plane's row i - 1, or the last row of the next plane)
+        {
+            const int in_ = i > 0 ? i - 1 : NSEG - 1;
+            const int spn = REV ? NSEG - 1 - in_ : in_;
+            const int tpn = spn * G::ROW + ci * 8;
+            const bf16_t *drow = i > 0 ? dts_row : dts_row + L;
+            const float *crow = i > 0 ? chk_row : chk_row + NSEG;
+            if ((i > 0 || more_planes) && !(dbg & 16)) {
+                const bool ok = !(G::HAS_TAIL && spn == NSEG - 1) || tail_live;
+                if (ok) {
+                    op.d = *reinterpret_cast<const uint4 *>(drow + tpn);
+                    op.b = *reinterpret_cast<const uint4 *>(Brow + tpn);
+                    op.c = *reinterpret_cast<const uint4 *>(Crow + tpn);
+                } else {
+                    op.d = op.b = op.c = make_uint4(0, 0, 0, 0);
+                }
+                op.h = in_ > 0 ? crow[in_ - 1] : 0.f;
+            }
+        }
+        uint4 xv, gv;
+        if (is_tail && !tail_live) {
+            xv = gv = make_uint4(0, 0, 0, 0);
+        } else {
+            xv = *reinterpret_cast<const uint4 *>(xq + tp0);
+            gv = *reinterpret_cast<const uint4 *>(gq + tp0);
+        }
+        l3f2 v[4], u[4], g[4], Bq[4], Cq[4], sg[4];
+        l3_unpack<REV>(dv, v);
+        l3_unpack<REV>(xv, u);
+        l3_unpack<REV>(gv, g);
+        l3_unpack<REV>(bv, Bq);
+        l3_unpack<REV>(cv, Cq);
+        if constexpr (MODE == 2) {                     // the step sizes arrive activated: sigmoid(raw) = 1 - exp(-softplus)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sg[q] = 1.f - l3_exp2(v[q] * (-kLog2e));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s0 = 1.f, s1 = 1.f;
+                float v0 = v[q].x + bias, v1 = v[q].y + bias;
+                if constexpr (MODE == 1) {
+                    v0 = softplus20_sig(v0, s0);
+                    v1 = softplus20_sig(v1, s1);
+                }
+                v[q] = l3f2{v0, v1};
+                sg[q] = l3f2{s0, s1};
+            }
+            if (is_tail) {                             // dead lanes of the tail row: identity elements
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = tail_live ? v[q] : l3f2{0.f, 0.f};
+                    sg[q] = tail_live ? sg[q] : l3f2{0.f, 0.f};
+                }
+            }
+        }
+        l3f2 a[4], vu[4], bb[4], cg[4], acg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = l3_exp2(v[q] * A2);
+            vu[q] = v[q] * u[q];
+            bb[q] = vu[q] * Bq[q];
+            cg[q] = Cq[q] * g[q];
+            acg[q] = a[q] * cg[q];
+        }
+        float P = 1.f, S = 0.f, R = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            S = fmaf(a[q].x, S, bb[q].x);
+            P *= a[q].x;
+            S = fmaf(a[q].y, S, bb[q].y);
+            P *= a[q].y;
+        }
+#pragma unroll
+        for (int q = 3; q >= 0; --q) {
+            R = fmaf(a[q].y, R, acg[q].y);
+            R = fmaf(a[q].x, R, acg[q].x);
+        }
+        float Q = P;
+        l3_scan_pair(P, S, Q, R);
+        // state entering this lane's chunk = the inclusive map of the lane below applied to the row's incoming state;
+        // adjoint entering it = the inclusive map of the lane above applied to the adjoint carried in
+        const float th = fmaf(P, hin, S);
+        float hh = dpp_mov<kWaveShr1>(hin, th);
+        const float tE = fmaf(Q, Ec, R);
+        float E = dpp_mov<kWaveShl1>(Ec, tE);
+        Ec = bcast_lane<0>(tE);
+        l3f2 h[4], dh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            hh = fmaf(a[q].x, hh, bb[q].x);
+            h[q].x = hh;
+            hh = fmaf(a[q].y, hh, bb[q].y);
+            h[q].y = hh;
+        }
+#pragma unroll
+        for (int q = 3; q >= 0; --q) {
+            dh[q].y = cg[q].y + E;
+            E = fmaf(a[q].y, E, acg[q].y);
+            dh[q].x = cg[q].x + E;
+            E = fmaf(a[q].x, E, acg[q].x);
+        }
+        l3f2 du[4], dd[4], dBq[4], dCq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const l3f2 ah = h[q] - bb[q];
+            const l3f2 s1 = dh[q] * Bq[q];
+            const l3f2 dhah = dh[q] * ah;
+            dA2 = __builtin_elementwise_fma(v[q], dhah, dA2);
+            dBq[q] = dh[q] * vu[q];
+            dCq[q] = g[q] * h[q];
+            du[q] = __builtin_elementwise_fma(v[q], s1, g[q] * Dr);
+            dd[q] = __builtin_elementwise_fma(u[q], s1, dhah * An) * sg[q];
+            dD2 = __builtin_elementwise_fma(g[q], u[q], dD2);
+            db2 += dd[q];
+        }
+        if ((!is_tail || tail_live) && !(dbg & 32)) {
+            *reinterpret_cast<uint4 *>(ddts_row + tp0) = l3_pack<REV>(dd);
+            *reinterpret_cast<uint4 *>(dxq + tp0) = l3_pack<REV>(du);      // this route's private dx plane
+        }
+        // ---- dB / dC sums over the planes of this workgroup: one jump per chunk row into static-register adds
+        // (values stay in traversal order and are un-permuted once, at the flush)
+        if (G::LSZ > 0 && sp >= G::NREG) {
+            if (!is_tail || tail_live) {
+                float *tb = ldsacc + (sp - G::NREG) * G::ROW + ci * 8, *tc = tb + G::LSZ;
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    float4 b4 = *reinterpret_cast<float4 *>(tb + 2 * q), c4 = *reinterpret_cast<float4 *>(tc + 2 * q);
+                    b4.x += dBq[q].x; b4.y += dBq[q].y; b4.z += dBq[q + 1].x; b4.w += dBq[q + 1].y;
+                    c4.x += dCq[q].x; c4.y += dCq[q].y; c4.z += dCq[q + 1].x; c4.w += dCq[q + 1].y;
+                    *reinterpret_cast<float4 *>(tb + 2 * q) = b4;
+                    *reinterpret_cast<float4 *>(tc + 2 * q) = c4;
+                }
+            }
+        }
+        {
+            // (always executed: inside an else the compiler merges two copies of every sum at the join)
+            // One statement per register row: a scalar compare-and-skip around eight packed adds INSIDE the statement,
+            // so that the compiler sees a plain read-modify-write of the row's sums (as a switch over the rows it
+            // double-buffers all of them and copies 96 registers on every path of every chunk row).
+#define L3_ACC_ROW(SS)                                                                                          \
+    if constexpr (SS < G::NREG)                                                                                 \
+        asm volatile("s_cmp_lg_u32 %[sp], " #SS "\n\t"                                                          \
+                     "s_cbranch_scc1 1f\n\t"                                                                    \
+                     "v_pk_add_f32 %[b0], %[b0], %[d0]\n\t"                                                     \
+                     "v_pk_add_f32 %[b1], %[b1], %[d1]\n\t"                                                     \
+                     "v_pk_add_f32 %[b2], %[b2], %[d2]\n\t"                                                     \
+                     "v_pk_add_f32 %[b3], %[b3], %[d3]\n\t"                                                     \
+                     "v_pk_add_f32 %[c0], %[c0], %[e0]\n\t"                                                     \
+                     "v_pk_add_f32 %[c1], %[c1], %[e1]\n\t"                                                     \
+                     "v_pk_add_f32 %[c2], %[c2], %[e2]\n\t"                                                     \
+                     "v_pk_add_f32 %[c3], %[c3], %[e3]\n\t"                                                     \
+                     "1:\n\t"                                                                                   \
+                     : [b0] "+v"(rB[SS < G::NREG ? SS : 0][0]), [b1] "+v"(rB[SS < G::NREG ? SS : 0][1]),        \
+                       [b2] "+v"(rB[SS < G::NREG ? SS : 0][2]), [b3] "+v"(rB[SS < G::NREG ? SS : 0][3]),        \
+                       [c0] "+v"(rC[SS < G::NREG ? SS : 0][0]), [c1] "+v"(rC[SS < G::NREG ? SS : 0][1]),        \
+                       [c2] "+v"(rC[SS < G::NREG ? SS : 0][2]), [c3] "+v"(rC[SS < G::NREG ? SS : 0][3])         \
+                     : [d0] "v"(dBq[0]), [d1] "v"(dBq[1]), [d2] "v"(dBq[2]), [d3] "v"(dBq[3]), [e0] "v"(dCq[0]), \
+                       [e1] "v"(dCq[1]), [e2] "v"(dCq[2]), [e3] "v"(dCq[3]), [sp] "s"(sp)                        \
+                     : "scc");
+            L3_ACC_ROW(0) L3_ACC_ROW(1) L3_ACC_ROW(2) L3_ACC_ROW(3) L3_ACC_ROW(4) L3_ACC_ROW(5) L3_ACC_ROW(6) L3_ACC_ROW(7)
+#undef L3_ACC_ROW
+        }
+
+    }
+    dA_acc = dA2.x + dA2.y;
+    dD_acc = dD2.x + dD2.y;
+    dbias_acc = db2.x + db2.y;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plane staging (natural + transposed bf16 copies in LDS) and the merge of the four private planes, for a compile-time
+// map size.  `tid` is the thread index plus an opaque zero taken inside the tile loop: the per-thread element positions
+// are a handful of constant divisions, and hoisted out of the tile loop they would sit in ~40 registers through the sweeps.
+// ---------------------------------------------------------------------------------------------------------------------
+// element position of vector v (VS elements) of a tile: when the rows are whole vectors consecutive lanes take the SAME
+// column block of consecutive rows, so that the 2-byte writes of the transposed copy (and the 2-byte reads of the merge)
+// of a wave instruction fall on consecutive addresses (ss2d_lean.hpp: lean_vec_pos)
+template <int HW, int VS> __device__ __forceinline__ void l3_vec_pos(const int v, int &e0, int &pl, int &h, int &w) {
+    constexpr int L = HW * HW;
+    const int idx = v * VS;
+    pl = idx / L;
+    const int ep = idx - pl * L;
+    if constexpr (HW % VS == 0) {
+        const int r = ep / VS;
+        const int wb = r / HW;
+        h = r - wb * HW;
+        w = wb * VS;
+    } else {
+        h = ep / HW;
+        w = ep - h * HW;
+    }
+    e0 = pl * L + h * HW + w;
+}
+
+template <int HW, int PPT, typename S, int VS, int NV>
+__device__ __forceinline__ void l3_planes_issue(PlaneRegs<S, VS, NV> &r, const S *src, const int tid) {
+    constexpr int nvec = PPT * HW * HW / VS;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        const int v = tid + m * 256;
+        if (v < nvec) {
+            int e0, pl, h, w;
+            l3_vec_pos<HW, VS>(v, e0, pl, h, w);
+            r.v[m] = *reinterpret_cast<const typename VecIO<S, VS>::V *>(src + e0);
+        }
+    }
+}
+
+template <int HW, int PPT, typename S, int VS, int NV>
+__device__ __forceinline__ void l3_planes_commit(const PlaneRegs<S, VS, NV> &r, bf16_t *nat, bf16_t *tr, const int tid) {
+    constexpr int L = HW * HW, nvec = PPT * L / VS;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        const int v = tid + m * 256;
+        if (v >= nvec) continue;
+        int e0, pl, h, w;
+        l3_vec_pos<HW, VS>(v, e0, pl, h, w);
+        float f[VS];
+        VecIO<S, VS>::unpack(r.v[m], f);
+        *reinterpret_cast<typename VecIO<bf16_t, VS>::V *>(nat + e0) = VecIO<bf16_t, VS>::pack(f);
+#pragma unroll
+        for (int q = 0; q < VS; ++q) {
+            tr[pl * L + w * HW + h] = from_float<bf16_t>(f[q]);
+            if constexpr (HW % VS != 0) {
+                if (++w == HW) {
+                    w = 0;
+                    ++h;
+                }
+            } else {
+                ++w;
+            }
+        }
+    }
+}
+
+// Maps whose rows are whole 8-element vectors (56 x 56): two passes.  Pass A loads the tile in MEMORY order (1 KB per wave
+// instruction; the lean kernels' one-pass form asks for 16-byte pieces a row apart and spends 77 us of a 300 us launch
+// there) and writes the natural images; pass B re-reads them with consecutive lanes on the same column block of
+// consecutive rows (16-byte reads 112 bytes apart: conflict-free per 16-lane group) and scatters the transposed images
+// with 2-byte writes that fall on consecutive addresses.
+template <int HW, int PPT>
+__device__ __forceinline__ void l3_transpose_pass(const bf16_t *nat, bf16_t *tr, const int tid) {
+    constexpr int L = HW * HW, nvec = PPT * L / 8;
+    for (int v = tid; v < nvec; v += 256) {
+        int e0, pl, h, w;
+        l3_vec_pos<HW, 8>(v, e0, pl, h, w);
+        const uint4 r = *reinterpret_cast<const uint4 *>(nat + e0);
+        const uint32_t wd[4] = {r.x, r.y, r.z, r.w};
+        uint16_t *t = reinterpret_cast<uint16_t *>(tr) + pl * L + w * HW + h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t[(2 * q) * HW] = (uint16_t)(wd[q] & 0xffffu);
+            t[(2 * q + 1) * HW] = (uint16_t)(wd[q] >> 16);
+        }
+    }
+}
+
+// dx = sum of the four private planes (routes 0 / 2 natural, 1 / 3 transposed), fixed order, 16-byte stores
+template <int HW, int PPT>
+__device__ __forceinline__ void l3_merge_store(bf16_t *out, const bf16_t *P0, const bf16_t *P1, const bf16_t *P2,
+                                               const bf16_t *P3, const int tid) {
+    constexpr int L = HW * HW, PL = PPT * L;
+    for (int v = tid; v < PL / 8; v += 256) {
+        int e0, pl, h, w;
+        l3_vec_pos<HW, 8>(v, e0, pl, h, w);
+        float n0[8], n1[8], o[8];
+        VecIO<bf16_t, 8>::unpack(*reinterpret_cast<const uint4 *>(P0 + e0), n0);
+        VecIO<bf16_t, 8>::unpack(*reinterpret_cast<const uint4 *>(P1 + e0), n1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int t0 = pl * L + w * HW + h;
+            o[q] = (n0[q] + n1[q]) + (ldf<bf16_t>(P2 + t0) + ldf<bf16_t>(P3 + t0));
+            if constexpr (HW % 8 != 0) {
+                if (++w == HW) {
+                    w = 0;
+                    ++h;
+                }
+            } else {
+                ++w;
+            }
+        }
+        *reinterpret_cast<uint4 *>(out + e0) = VecIO<bf16_t, 8>::pack(o);
+    }
+}
+
+// the whole walk of a workgroup for one direction (a template parameter from the top: the ascending and the descending
+// waves share no code path below this point, so the accumulators never meet at a join)
+template <int HW, int PPT, int MODE, bool REV>
+__device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, const int wave, const int lane) {
+    using G = L3Geom<HW>;
+    constexpr int L = G::L, PL = PPT * L, NSEG = G::NSEG;
+    const int D = a.D_;
+    const int tiles_pb = D / PPT;
+    const int groups_pb = tiles_pb / a.pli;
+    const int b = blockIdx.x / groups_pb, tg = blockIdx.x - b * groups_pb;
+    bf16_t *xN = reinterpret_cast<bf16_t *>(smem), *xT = xN + PL, *gN = xT + PL, *gT = gN + PL, *DX = gT + PL;
+    float *ldsacc = smem + (8 * (size_t)PL * 2) / 4 + wave * 2 * G::LSZ;
+    for (int e = lane; e < 2 * G::LSZ; e += 64) ldsacc[e] = 0.f;
+    l3f2 rB[G::NACC][4], rC[G::NACC][4];
+#pragma unroll
+    for (int s = 0; s < G::NACC; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rB[s][q] = rC[s][q] = l3f2{0.f, 0.f};
+    const bool col = wave >> 1;
+    const int k = (REV ? 2 : 0) + (wave >> 1);
+    const bf16_t *xq = col ? xT : xN, *gq = col ? gT : gN;
+    bf16_t *dxq = DX + (size_t)wave * PL;
+    const int64_t route = (int64_t)b * 4 + k;
+    const bf16_t *Brow = (const bf16_t *)a.Bs + route * L, *Crow = (const bf16_t *)a.Cs + route * L;
+    const int n_planes = a.pli * PPT;
+    const int ci = REV ? 63 - lane : lane;
+    // operands of the first chunk row to process (the last one, in route order, of the first plane)
+    L3Ops op;
+    {
+        const int64_t r0 = route * D + (int64_t)tg * a.pli * PPT;
+        const int sp = REV ? 0 : NSEG - 1;
+        const int tp = sp * G::ROW + ci * 8;
+        if (!(G::HAS_TAIL && sp == NSEG - 1) || ci < G::TAILV) {
+            op.d = *reinterpret_cast<const uint4 *>((const bf16_t *)a.dts + r0 * L + tp);
+            op.b = *reinterpret_cast<const uint4 *>(Brow + tp);
+            op.c = *reinterpret_cast<const uint4 *>(Crow + tp);
+        } else {
+            op.d = op.b = op.c = make_uint4(0, 0, 0, 0);
+        }
+        op.h = NSEG > 1 ? a.chk[r0 * NSEG + NSEG - 2] : 0.f;
+    }
+    constexpr int NVX = 2, NVG = 4;                    // PL <= 4096 elements: 512 / 1024 vectors over 256 threads
+    static_assert(PL <= 4096, "tile beyond the staging registers");
+#pragma unroll 1
+    for (int it = 0; it < a.pli; ++it) {
+        const int d0 = (tg * a.pli + it) * PPT;
+        const int64_t po = ((int64_t)b * D + d0) * L;
+        int tz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(tz));    // opaque zero: keeps the per-thread tile positions out of registers
+        const int tid = threadIdx.x + tz;
+        if constexpr (HW % 8 == 0) {
+            uint4 px[NVX];
+            float4 pg[NVG];
+            constexpr int nvx = PL / 8, nvg = PL / 4;
+            if (!(a.dbg & 2)) {
+#pragma unroll
+                for (int m = 0; m < NVX; ++m)
+                    if (tid + m * 256 < nvx) px[m] = *reinterpret_cast<const uint4 *>((const bf16_t *)a.x + po + (tid + m * 256) * 8);
+#pragma unroll
+                for (int m = 0; m < NVG; ++m)
+                    if (tid + m * 256 < nvg) pg[m] = *reinterpret_cast<const float4 *>((const float *)a.dy + po + (tid + m * 256) * 4);
+            }
+            __syncthreads();                           // (the previous tile's merge has read the planes)
+            if (!(a.dbg & 2)) {
+#pragma unroll
+                for (int m = 0; m < NVX; ++m)
+                    if (tid + m * 256 < nvx) *reinterpret_cast<uint4 *>(xN + (tid + m * 256) * 8) = px[m];
+#pragma unroll
+                for (int m = 0; m < NVG; ++m)
+                    if (tid + m * 256 < nvg)
+                        *reinterpret_cast<uint2 *>(gN + (tid + m * 256) * 4) =
+                            make_uint2(pack_bf16x2(pg[m].x, pg[m].y), pack_bf16x2(pg[m].z, pg[m].w));
+            }
+            __syncthreads();
+            if (!(a.dbg & 2)) {
+                l3_transpose_pass<HW, PPT>(xN, xT, tid);
+                l3_transpose_pass<HW, PPT>(gN, gT, tid);
+            }
+        } else {
+            PlaneRegs<bf16_t, 8, NVX> px;
+            PlaneRegs<float, 4, NVG> pg;
+            if (!(a.dbg & 2)) {
+                l3_planes_issue<HW, PPT, bf16_t, 8, NVX>(px, (const bf16_t *)a.x + po, tid);
+                l3_planes_issue<HW, PPT, float, 4, NVG>(pg, (const float *)a.dy + po, tid);
+            }
+            __syncthreads();                           // (the previous tile's merge has read the planes)
+            if (!(a.dbg & 2)) {
+                l3_planes_commit<HW, PPT, bf16_t, 8, NVX>(px, xN, xT, tid);
+                l3_planes_commit<HW, PPT, float, 4, NVG>(pg, gN, gT, tid);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int pl = 0; pl < ((a.dbg & 1) ? 0 : PPT); ++pl) {
+            const int d = d0 + pl, row = k * D + d;
+            const int64_t ro = (route * D + d) * L;
+            const float *chk_row = a.chk + (route * D + d) * NSEG;
+            const float An = a.A[row], Dr = a.D[row], bias = MODE == 2 ? 0.f : a.bias[row];
+            const bool more = it * PPT + pl + 1 < n_planes;
+            float dA_acc, dD_acc, dbias_acc;
+            l3_bwd_plane<HW, REV, MODE>((const bf16_t *)a.dts + ro, (bf16_t *)a.ddts + ro, Brow, Crow, chk_row, more, An, Dr,
+                                        bias, xq + pl * L, gq + pl * L, dxq + pl * L, ldsacc, rB, rC, dA_acc, dD_acc,
+                                        dbias_acc, lane, op, a.dbg);
+            for (int o = 32; o > 0; o >>= 1) {
+                dA_acc += __shfl_xor(dA_acc, o, 64);
+                dD_acc += __shfl_xor(dD_acc, o, 64);
+                dbias_acc += __shfl_xor(dbias_acc, o, 64);
+            }
+            if (lane == 0) {
+                atomicAdd(a.dA + row, dA_acc);
+                atomicAdd(a.dD + row, dD_acc);
+                atomicAdd(a.dbias + row, dbias_acc);
+            }
+        }
+        __syncthreads();
+        if (!(a.dbg & 4)) {
+            int tz2;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(tz2));
+            if constexpr (HW % 8 == 0) {
+                // the sums into the (now free) natural x image in the conflict-free order, then out in memory order
+                l3_merge_store<HW, PPT>(xN, DX, DX + PL, DX + 2 * PL, DX + 3 * PL, threadIdx.x + tz2);
+                __syncthreads();
+                for (int v = threadIdx.x + tz2; v < PL / 8; v += 256)
+                    *reinterpret_cast<uint4 *>((bf16_t *)a.dx + po + v * 8) = *reinterpret_cast<const uint4 *>(xN + v * 8);
+            } else {
+                l3_merge_store<HW, PPT>((bf16_t *)a.dx + po, DX, DX + PL, DX + 2 * PL, DX + 3 * PL, threadIdx.x + tz2);
+            }
+        }
+    }
+    // ---- flush: registers hold [chunk row][traversal element] of this lane.  Atomics are only fast when a wave
+    // instruction covers contiguous bytes, so the sums are first laid out by position in LDS (the plane region is free)
+    __syncthreads();
+    float *dBg = a.dBs + route * L, *dCg = a.dCs + route * L;
+    float *stage = smem + (size_t)wave * L;            // 4 waves x L floats <= 8 PL bf16 (PPT >= 1: 16 L bytes)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int s = 0; s < G::NREG; ++s) {
+            const int tp0 = s * G::ROW + ci * 8;
+            if (tp0 < L) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const l3f2 v = pass ? rC[s][q] : rB[s][q];
+                    stage[tp0 + (REV ? 7 - 2 * q : 2 * q)] = v.x;
+                    stage[tp0 + (REV ? 6 - 2 * q : 2 * q + 1)] = v.y;
+                }
+            }
+        }
+        // the LDS strip holds [chunk][traversal element]
+        for (int e = lane; e < G::LSZ; e += 64)
+            stage[G::NREG * G::ROW + (e & ~7) + (REV ? 7 - (e & 7) : (e & 7))] = ldsacc[pass * G::LSZ + e];
+        wave_sync();
+        float *dst = pass ? dCg : dBg;
+        for (int e = lane; e < L; e += 64) atomicAdd(dst + e, stage[e]);
+        wave_sync();
+    }
+}
+
+// kernel: wave w owns route {0,2,1,3}[w];
+// LDS: xN | xT | gN | gT (bf16, PPT planes) | 4 private dx planes (bf16) | 4 x [dB | dC] strips (LSZ fp32 each)
+template <int HW, int PPT, int MODE>
+__global__ void __launch_bounds__(256, L3_WPE) ss2d_l3_bwd_kernel(const LeanArgs a) {
+    static_assert(L3Geom<HW>::L % 8 == 0 && L3Geom<HW>::NSEG <= 8, "map size not covered");
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave & 1) l3_bwd_body<HW, PPT, MODE, true>(a, smem, wave, lane);
+    else l3_bwd_body<HW, PPT, MODE, false>(a, smem, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HW, int PPT> static int l3_launch_bwd(const xfm_ss2d_params_t &p, hipStream_t s) {
+    using G = L3Geom<HW>;
+    constexpr int L = G::L, PL = PPT * L;
+    const int D = p.d_inner;
+    if (D % PPT) return XFM_ELIMIT;
+    LeanArgs la{};
+    la.x = p.x; la.dts = p.dts; la.Bs = p.Bs; la.Cs = p.Cs;
+    la.A = p.A; la.D = p.D; la.bias = p.delta_bias;
+    la.y = p.y; la.chk = p.chk; la.dy = p.dy; la.dx = p.dx; la.ddts = p.ddts;
+    la.dBs = p.dBs; la.dCs = p.dCs; la.dA = p.dA; la.dD = p.dD; la.dbias = p.ddelta_bias;
+    la.batch = p.batch; la.D_ = D; la.H = HW; la.W = HW; la.L = L;
+    la.nseg = G::NSEG; la.ppt = PPT; la.softplus = p.delta_softplus;
+    la.magicW = (uint32_t)((0x100000000ull + HW - 1) / HW);
+    la.magicL = (uint32_t)((0x100000000ull + L - 1) / L);
+    la.magicH = la.magicW;
+    la.dbg = 0;                                        // timing-only switches: 1 skip sweeps, 2 skip plane staging, 4 skip merge,
+    if (const char *e = getenv("XFM_L3_DBG")) la.dbg = atoi(e);   // 16 no operand prefetch, 32 no ddts / dx stores
+    // tiles per workgroup: ONE round of the resident workgroups (2 per CU).  The dB / dC flush of a workgroup is 8 L
+    // float atomics; at the chip's ~1.3 TB/s of atomic bytes 1024 workgroups spend 79 us of a 56 x 56 launch there.
+    const int tiles_pb = D / PPT;
+    int pli = (int)(((int64_t)p.batch * tiles_pb + 511) / 512);
+    if (pli < 1) pli = 1;
+    if (pli > tiles_pb) pli = tiles_pb;
+    if (const char *e = getenv("XFM_L3_PLI")) pli = std::max(1, std::min(tiles_pb, atoi(e)));   // tuning hook
+    while (tiles_pb % pli) --pli;
+    la.pli = pli;
+    const size_t lds = (size_t)8 * PL * 2 + (size_t)4 * 2 * G::LSZ * sizeof(float);
+    const void *fn = p.delta_softplus == 2 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 2>
+                                           : (p.delta_softplus == 1 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 1>
+                                                                    : (const void *)ss2d_l3_bwd_kernel<HW, PPT, 0>);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const unsigned grid = (unsigned)((int64_t)p.batch * (tiles_pb / pli));
+    void *kargs[] = {&la};
+    const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, lds, s);
+    if (e != hipSuccess) {
+        set_last_hip_error(e);
+        return XFM_ELAUNCH;
+    }
+    return check_launch();
+}
+
+// XFM_ELIMIT: shape / dtype not covered here, the caller falls back to the lean / generic kernels
+int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s) {
+    static const bool enabled = [] {
+        const char *e = getenv("XFM_SS2D_L3");
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled || !bwd) return XFM_ELIMIT;
+    if (p->in_dtype != XFM_BF16 || p->out_dtype != XFM_F32 || p->dstate != 1 || p->H != p->W) return XFM_ELIMIT;
+    if (p->delta_softplus < 0 || p->delta_softplus > 2) return XFM_ELIMIT;
+    if ((p->H == 56 || p->H == 28) && !p->chk) return XFM_EINVAL;     // multi-chunk rows need the forward's checkpoints
+    switch (p->H) {
+        case 56: return l3_launch_bwd<56, 1>(*p, s);
+        case 28: return l3_launch_bwd<28, 4>(*p, s);
+    }
+    return XFM_ELIMIT;
+}
+
+}  // namespace xfm
