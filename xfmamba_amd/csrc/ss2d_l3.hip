@@ -23,6 +23,9 @@ namespace xfm {
 #ifndef L3_NREG
 #define L3_NREG 6
 #endif
+#ifndef L3_WPE_FWD
+#define L3_WPE_FWD 4
+#endif
 #ifndef L3_WPE
 #define L3_WPE 2
 #endif
@@ -134,6 +137,338 @@ __device__ __forceinline__ l3f2 l3_exp2(const l3f2 t) { return l3f2{exp2_fast(t.
 
 // operands of one chunk row, requested one row ahead
 struct L3Ops { uint4 d, b, c; float h; };
+struct L3Lds { uint4 x, g; };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plane staging (natural + transposed bf16 copies in LDS) and the merge of the four private planes, for a compile-time
+// map size.  `tid` is the thread index plus an opaque zero taken inside the tile loop: the per-thread element positions
+// are a handful of constant divisions, and hoisted out of the tile loop they would sit in ~40 registers through the sweeps.
+// ---------------------------------------------------------------------------------------------------------------------
+// element position of vector v (VS elements) of a tile: when the rows are whole vectors consecutive lanes take the SAME
+// column block of consecutive rows, so that the 2-byte writes of the transposed copy (and the 2-byte reads of the merge)
+// of a wave instruction fall on consecutive addresses (ss2d_lean.hpp: lean_vec_pos)
+template <int HW, int VS> __device__ __forceinline__ void l3_vec_pos(const int v, int &e0, int &pl, int &h, int &w) {
+    constexpr int L = HW * HW;
+    const int idx = v * VS;
+    pl = idx / L;
+    const int ep = idx - pl * L;
+    if constexpr (HW % VS == 0) {
+        const int r = ep / VS;
+        const int wb = r / HW;
+        h = r - wb * HW;
+        w = wb * VS;
+    } else {
+        h = ep / HW;
+        w = ep - h * HW;
+    }
+    e0 = pl * L + h * HW + w;
+}
+
+template <int HW, int PPT, typename S, int VS, int NV>
+__device__ __forceinline__ void l3_planes_issue(PlaneRegs<S, VS, NV> &r, const S *src, const int tid) {
+    constexpr int nvec = PPT * HW * HW / VS;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        const int v = tid + m * 256;
+        if (v < nvec) {
+            int e0, pl, h, w;
+            l3_vec_pos<HW, VS>(v, e0, pl, h, w);
+            r.v[m] = *reinterpret_cast<const typename VecIO<S, VS>::V *>(src + e0);
+        }
+    }
+}
+
+template <int HW, int PPT, typename S, int VS, int NV>
+__device__ __forceinline__ void l3_planes_commit(const PlaneRegs<S, VS, NV> &r, bf16_t *nat, bf16_t *tr, const int tid) {
+    constexpr int L = HW * HW, nvec = PPT * L / VS;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        const int v = tid + m * 256;
+        if (v >= nvec) continue;
+        int e0, pl, h, w;
+        l3_vec_pos<HW, VS>(v, e0, pl, h, w);
+        float f[VS];
+        VecIO<S, VS>::unpack(r.v[m], f);
+        *reinterpret_cast<typename VecIO<bf16_t, VS>::V *>(nat + e0) = VecIO<bf16_t, VS>::pack(f);
+#pragma unroll
+        for (int q = 0; q < VS; ++q) {
+            tr[pl * L + w * HW + h] = from_float<bf16_t>(f[q]);
+            if constexpr (HW % VS != 0) {
+                if (++w == HW) {
+                    w = 0;
+                    ++h;
+                }
+            } else {
+                ++w;
+            }
+        }
+    }
+}
+
+// Maps whose rows are whole 8-element vectors (56 x 56): two passes.  Pass A loads the tile in MEMORY order (1 KB per wave
+// instruction; the lean kernels' one-pass form asks for 16-byte pieces a row apart and spends 77 us of a 300 us launch
+// there) and writes the natural images; pass B re-reads them with consecutive lanes on the same column block of
+// consecutive rows (16-byte reads 112 bytes apart: conflict-free per 16-lane group) and scatters the transposed images
+// with 2-byte writes that fall on consecutive addresses.
+template <int HW, int PPT>
+__device__ __forceinline__ void l3_transpose_pass(const bf16_t *nat, bf16_t *tr, const int tid) {
+    constexpr int L = HW * HW, nvec = PPT * L / 8;
+    for (int v = tid; v < nvec; v += 256) {
+        int e0, pl, h, w;
+        l3_vec_pos<HW, 8>(v, e0, pl, h, w);
+        const uint4 r = *reinterpret_cast<const uint4 *>(nat + e0);
+        const uint32_t wd[4] = {r.x, r.y, r.z, r.w};
+        uint16_t *t = reinterpret_cast<uint16_t *>(tr) + pl * L + w * HW + h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t[(2 * q) * HW] = (uint16_t)(wd[q] & 0xffffu);
+            t[(2 * q + 1) * HW] = (uint16_t)(wd[q] >> 16);
+        }
+    }
+}
+
+// dx = sum of the four private planes (routes 0 / 2 natural, 1 / 3 transposed), fixed order, 16-byte stores
+template <int HW, int PPT>
+__device__ __forceinline__ void l3_merge_store(bf16_t *out, const bf16_t *P0, const bf16_t *P1, const bf16_t *P2,
+                                               const bf16_t *P3, const int tid) {
+    constexpr int L = HW * HW, PL = PPT * L;
+    for (int v = tid; v < PL / 8; v += 256) {
+        int e0, pl, h, w;
+        l3_vec_pos<HW, 8>(v, e0, pl, h, w);
+        float n0[8], n1[8], o[8];
+        VecIO<bf16_t, 8>::unpack(*reinterpret_cast<const uint4 *>(P0 + e0), n0);
+        VecIO<bf16_t, 8>::unpack(*reinterpret_cast<const uint4 *>(P1 + e0), n1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int t0 = pl * L + w * HW + h;
+            o[q] = (n0[q] + n1[q]) + (ldf<bf16_t>(P2 + t0) + ldf<bf16_t>(P3 + t0));
+            if constexpr (HW % 8 != 0) {
+                if (++w == HW) {
+                    w = 0;
+                    ++h;
+                }
+            } else {
+                ++w;
+            }
+        }
+        *reinterpret_cast<uint4 *>(out + e0) = VecIO<bf16_t, 8>::pack(o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward, one route over one plane
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HW, bool REV, int MODE>
+__device__ __forceinline__ void l3_fwd_plane(const bf16_t *__restrict__ dts_row, const bf16_t *__restrict__ Brow,
+                                             const bf16_t *__restrict__ Crow, float *__restrict__ chk_row,
+                                             const bool more_planes, const float A2, const float Dr, const float bias,
+                                             const bf16_t *xq, bf16_t *yq, const int lane, L3Ops &op) {
+    using G = L3Geom<HW>;
+    constexpr int L = G::L, NSEG = G::NSEG;
+    const int ci = REV ? 63 - lane : lane;
+    const bool tail_live = !G::HAS_TAIL || ci < G::TAILV;
+    float hc = 0.f;                                   // state entering the chunk row
+    uint4 xn;
+    {
+        const int sp0 = REV ? NSEG - 1 : 0;
+        xn = (G::HAS_TAIL && sp0 == NSEG - 1 && !tail_live) ? make_uint4(0, 0, 0, 0)
+                                                            : *reinterpret_cast<const uint4 *>(xq + sp0 * G::ROW + ci * 8);
+    }
+#pragma unroll 1
+    for (int i = 0; i < NSEG; ++i) {                  // chunk rows along the route
+        const int sp = REV ? NSEG - 1 - i : i;
+        const int tp0 = sp * G::ROW + ci * 8;
+        const bool is_tail = G::HAS_TAIL && sp == NSEG - 1;
+        const uint4 dv = op.d, bv = op.b, cv = op.c, xv = xn;
+        {   // request the next row (this plane's row i + 1, or the first row of the next plane)
+            const int in_ = i + 1 < NSEG ? i + 1 : 0;
+            const int spn = REV ? NSEG - 1 - in_ : in_;
+            const int tpn = spn * G::ROW + ci * 8;
+            const bf16_t *drow = i + 1 < NSEG ? dts_row : dts_row + L;
+            const bool dead = G::HAS_TAIL && spn == NSEG - 1 && !tail_live;
+            if (i + 1 < NSEG || more_planes) {
+                if (!dead) {
+                    op.d = *reinterpret_cast<const uint4 *>(drow + tpn);
+                    op.b = *reinterpret_cast<const uint4 *>(Brow + tpn);
+                    op.c = *reinterpret_cast<const uint4 *>(Crow + tpn);
+                } else {
+                    op.d = op.b = op.c = make_uint4(0, 0, 0, 0);
+                }
+            }
+            if (i + 1 < NSEG) xn = dead ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(xq + tpn);
+        }
+        l3f2 v[4], u[4], Bq[4], Cq[4];
+        l3_unpack<REV>(dv, v);
+        l3_unpack<REV>(xv, u);
+        l3_unpack<REV>(bv, Bq);
+        l3_unpack<REV>(cv, Cq);
+        if constexpr (MODE != 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v0 = v[q].x + bias, v1 = v[q].y + bias;
+                if constexpr (MODE == 1) {
+                    v0 = softplus20(v0);
+                    v1 = softplus20(v1);
+                }
+                v[q] = l3f2{v0, v1};
+            }
+            if (is_tail) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = tail_live ? v[q] : l3f2{0.f, 0.f};
+            }
+        }
+        l3f2 a[4], bb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = l3_exp2(v[q] * A2);
+            bb[q] = v[q] * u[q] * Bq[q];
+        }
+        float P = 1.f, S = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            S = fmaf(a[q].x, S, bb[q].x);
+            P *= a[q].x;
+            S = fmaf(a[q].y, S, bb[q].y);
+            P *= a[q].y;
+        }
+        l3_scan_up(P, S);
+        const float th = fmaf(P, hc, S);              // state after this lane's chunk
+        float hh = dpp_mov<kWaveShr1>(hc, th);
+        hc = bcast_lane<63>(th);
+        if (NSEG > 1 && lane == 63) chk_row[i] = hc;
+        l3f2 y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            hh = fmaf(a[q].x, hh, bb[q].x);
+            const float h0 = hh;
+            hh = fmaf(a[q].y, hh, bb[q].y);
+            y[q] = __builtin_elementwise_fma(Cq[q], l3f2{h0, hh}, u[q] * Dr);
+        }
+        if (!is_tail || tail_live) *reinterpret_cast<uint4 *>(yq + tp0) = l3_pack<REV>(y);
+    }
+}
+
+// y = sum of the four private planes (routes 0 / 2 natural, 1 / 3 transposed), fixed order, fp32 out
+template <int HW, int PPT>
+__device__ __forceinline__ void l3_merge_y(float *out, const bf16_t *P0, const bf16_t *P1, const bf16_t *P2,
+                                           const bf16_t *P3, const int tid) {
+    constexpr int L = HW * HW, PL = PPT * L;
+    for (int v = tid; v < PL / 8; v += 256) {
+        int e0, pl, h, w;
+        l3_vec_pos<HW, 8>(v, e0, pl, h, w);
+        float n0[8], n1[8], o[8];
+        VecIO<bf16_t, 8>::unpack(*reinterpret_cast<const uint4 *>(P0 + e0), n0);
+        VecIO<bf16_t, 8>::unpack(*reinterpret_cast<const uint4 *>(P1 + e0), n1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int t0 = pl * L + w * HW + h;
+            o[q] = (n0[q] + n1[q]) + (ldf<bf16_t>(P2 + t0) + ldf<bf16_t>(P3 + t0));
+            if constexpr (HW % 8 != 0) {
+                if (++w == HW) {
+                    w = 0;
+                    ++h;
+                }
+            } else {
+                ++w;
+            }
+        }
+        *reinterpret_cast<float4 *>(out + e0) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(out + e0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+template <int HW, int PPT, int MODE, bool REV>
+__device__ __forceinline__ void l3_fwd_body(const LeanArgs &a, float *smem, const int wave, const int lane) {
+    using G = L3Geom<HW>;
+    constexpr int L = G::L, PL = PPT * L, NSEG = G::NSEG;
+    const int D = a.D_;
+    const int tiles_pb = D / PPT;
+    const int groups_pb = tiles_pb / a.pli;
+    const int b = blockIdx.x / groups_pb, tg = blockIdx.x - b * groups_pb;
+    // LDS: xN | xT | 4 private y planes (bf16: the per-route partial sums are rounded to the I/O precision once, before
+    // the fixed-order fp32 merge, as in the lean kernels)
+    bf16_t *xN = reinterpret_cast<bf16_t *>(smem), *xT = xN + PL, *Y = xT + PL;
+    const bool col = wave >> 1;
+    const int k = (REV ? 2 : 0) + (wave >> 1);
+    const bf16_t *xq = col ? xT : xN;
+    bf16_t *yq = Y + (size_t)wave * PL;
+    const int64_t route = (int64_t)b * 4 + k;
+    const bf16_t *Brow = (const bf16_t *)a.Bs + route * L, *Crow = (const bf16_t *)a.Cs + route * L;
+    const int n_planes = a.pli * PPT;
+    const int ci = REV ? 63 - lane : lane;
+    L3Ops op;
+    {   // operands of the first chunk row of the first plane
+        const int64_t r0 = route * D + (int64_t)tg * a.pli * PPT;
+        const int sp = REV ? NSEG - 1 : 0;
+        const int tp = sp * G::ROW + ci * 8;
+        if (!(G::HAS_TAIL && sp == NSEG - 1) || ci < G::TAILV) {
+            op.d = *reinterpret_cast<const uint4 *>((const bf16_t *)a.dts + r0 * L + tp);
+            op.b = *reinterpret_cast<const uint4 *>(Brow + tp);
+            op.c = *reinterpret_cast<const uint4 *>(Crow + tp);
+        } else {
+            op.d = op.b = op.c = make_uint4(0, 0, 0, 0);
+        }
+        op.h = 0.f;
+    }
+    constexpr int NVX = 2;
+    static_assert(PL <= 4096, "tile beyond the staging registers");
+#pragma unroll 1
+    for (int it = 0; it < a.pli; ++it) {
+        const int d0 = (tg * a.pli + it) * PPT;
+        const int64_t po = ((int64_t)b * D + d0) * L;
+        int tz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(tz));
+        const int tid = threadIdx.x + tz;
+        if constexpr (HW % 8 == 0) {
+            uint4 px[NVX];
+            constexpr int nvx = PL / 8;
+#pragma unroll
+            for (int m = 0; m < NVX; ++m)
+                if (tid + m * 256 < nvx) px[m] = *reinterpret_cast<const uint4 *>((const bf16_t *)a.x + po + (tid + m * 256) * 8);
+            __syncthreads();                           // (the previous tile's output pass has read xN / xT)
+#pragma unroll
+            for (int m = 0; m < NVX; ++m)
+                if (tid + m * 256 < nvx) *reinterpret_cast<uint4 *>(xN + (tid + m * 256) * 8) = px[m];
+            __syncthreads();
+            l3_transpose_pass<HW, PPT>(xN, xT, tid);
+        } else {
+            PlaneRegs<bf16_t, 8, NVX> px;
+            l3_planes_issue<HW, PPT, bf16_t, 8, NVX>(px, (const bf16_t *)a.x + po, tid);
+            __syncthreads();
+            l3_planes_commit<HW, PPT, bf16_t, 8, NVX>(px, xN, xT, tid);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int pl = 0; pl < PPT; ++pl) {
+            const int d = d0 + pl, row = k * D + d;
+            const float A2 = a.A[row] * kLog2e, Dr = a.D[row], bias = MODE == 2 ? 0.f : a.bias[row];
+            const bool more = it * PPT + pl + 1 < n_planes;
+            l3_fwd_plane<HW, REV, MODE>((const bf16_t *)a.dts + (route * D + d) * L, Brow, Crow,
+                                        a.chk + (route * D + d) * NSEG, more, A2, Dr, bias, xq + pl * L, yq + pl * L, lane, op);
+        }
+        __syncthreads();
+        int tz2;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(tz2));
+        if constexpr (HW % 8 == 0 && PPT == 1) {
+            // the fp32 sums into the (now free) x images in the conflict-free order, then out in memory order
+            float *stage = reinterpret_cast<float *>(xN);                       // xN | xT = L floats
+            l3_merge_y<HW, PPT>(stage, Y, Y + PL, Y + 2 * PL, Y + 3 * PL, threadIdx.x + tz2);
+            __syncthreads();
+            for (int v = threadIdx.x + tz2; v < PL / 4; v += 256)
+                *reinterpret_cast<float4 *>((float *)a.y + po + v * 4) = *reinterpret_cast<const float4 *>(stage + v * 4);
+        } else {
+            l3_merge_y<HW, PPT>((float *)a.y + po, Y, Y + PL, Y + 2 * PL, Y + 3 * PL, threadIdx.x + tz2);
+        }
+    }
+}
+
+template <int HW, int PPT, int MODE>
+__global__ void __launch_bounds__(256, L3_WPE_FWD) ss2d_l3_fwd_kernel(const LeanArgs a) {
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave & 1) l3_fwd_body<HW, PPT, MODE, true>(a, smem, wave, lane);
+    else l3_fwd_body<HW, PPT, MODE, false>(a, smem, wave, lane);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward, one route over one plane
@@ -153,6 +488,18 @@ __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row,
     const bool tail_live = !G::HAS_TAIL || ci < G::TAILV;
     float Ec = 0.f;                                   // adjoint flowing in from the chunk row processed before
     l3f2 dA2 = {0.f, 0.f}, dD2 = dA2, db2 = dA2;
+    // x / dy of the chunk row to process, read from LDS one row ahead (a wave has one partner on its SIMD: an exposed LDS
+    // round trip at the head of every row is not covered by anything)
+    L3Lds ln;
+    {
+        const int sp0 = REV ? 0 : NSEG - 1;
+        if (G::HAS_TAIL && sp0 == NSEG - 1 && !tail_live) {
+            ln.x = ln.g = make_uint4(0, 0, 0, 0);
+        } else {
+            ln.x = *reinterpret_cast<const uint4 *>(xq + sp0 * G::ROW + ci * 8);
+            ln.g = *reinterpret_cast<const uint4 *>(gq + sp0 * G::ROW + ci * 8);
+        }
+    }
 #pragma unroll 1
     for (int i = NSEG - 1; i >= 0; --i) {             // chunk rows against the route
         const int sp = REV ? NSEG - 1 - i : i;        // physical chunk row
@@ -179,12 +526,15 @@ __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row,
                 op.h = in_ > 0 ? crow[in_ - 1] : 0.f;
             }
         }
-        uint4 xv, gv;
-        if (is_tail && !tail_live) {
-            xv = gv = make_uint4(0, 0, 0, 0);
-        } else {
-            xv = *reinterpret_cast<const uint4 *>(xq + tp0);
-            gv = *reinterpret_cast<const uint4 *>(gq + tp0);
+        const uint4 xv = ln.x, gv = ln.g;
+        if (i > 0) {
+            const int spn = REV ? NSEG - i : i - 1;
+            if (G::HAS_TAIL && spn == NSEG - 1 && !tail_live) {
+                ln.x = ln.g = make_uint4(0, 0, 0, 0);
+            } else {
+                ln.x = *reinterpret_cast<const uint4 *>(xq + spn * G::ROW + ci * 8);
+                ln.g = *reinterpret_cast<const uint4 *>(gq + spn * G::ROW + ci * 8);
+            }
         }
         l3f2 v[4], u[4], g[4], Bq[4], Cq[4], sg[4];
         l3_unpack<REV>(dv, v);
@@ -327,122 +677,6 @@ __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row,
     dA_acc = dA2.x + dA2.y;
     dD_acc = dD2.x + dD2.y;
     dbias_acc = db2.x + db2.y;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// plane staging (natural + transposed bf16 copies in LDS) and the merge of the four private planes, for a compile-time
-// map size.  `tid` is the thread index plus an opaque zero taken inside the tile loop: the per-thread element positions
-// are a handful of constant divisions, and hoisted out of the tile loop they would sit in ~40 registers through the sweeps.
-// ---------------------------------------------------------------------------------------------------------------------
-// element position of vector v (VS elements) of a tile: when the rows are whole vectors consecutive lanes take the SAME
-// column block of consecutive rows, so that the 2-byte writes of the transposed copy (and the 2-byte reads of the merge)
-// of a wave instruction fall on consecutive addresses (ss2d_lean.hpp: lean_vec_pos)
-template <int HW, int VS> __device__ __forceinline__ void l3_vec_pos(const int v, int &e0, int &pl, int &h, int &w) {
-    constexpr int L = HW * HW;
-    const int idx = v * VS;
-    pl = idx / L;
-    const int ep = idx - pl * L;
-    if constexpr (HW % VS == 0) {
-        const int r = ep / VS;
-        const int wb = r / HW;
-        h = r - wb * HW;
-        w = wb * VS;
-    } else {
-        h = ep / HW;
-        w = ep - h * HW;
-    }
-    e0 = pl * L + h * HW + w;
-}
-
-template <int HW, int PPT, typename S, int VS, int NV>
-__device__ __forceinline__ void l3_planes_issue(PlaneRegs<S, VS, NV> &r, const S *src, const int tid) {
-    constexpr int nvec = PPT * HW * HW / VS;
-#pragma unroll
-    for (int m = 0; m < NV; ++m) {
-        const int v = tid + m * 256;
-        if (v < nvec) {
-            int e0, pl, h, w;
-            l3_vec_pos<HW, VS>(v, e0, pl, h, w);
-            r.v[m] = *reinterpret_cast<const typename VecIO<S, VS>::V *>(src + e0);
-        }
-    }
-}
-
-template <int HW, int PPT, typename S, int VS, int NV>
-__device__ __forceinline__ void l3_planes_commit(const PlaneRegs<S, VS, NV> &r, bf16_t *nat, bf16_t *tr, const int tid) {
-    constexpr int L = HW * HW, nvec = PPT * L / VS;
-#pragma unroll
-    for (int m = 0; m < NV; ++m) {
-        const int v = tid + m * 256;
-        if (v >= nvec) continue;
-        int e0, pl, h, w;
-        l3_vec_pos<HW, VS>(v, e0, pl, h, w);
-        float f[VS];
-        VecIO<S, VS>::unpack(r.v[m], f);
-        *reinterpret_cast<typename VecIO<bf16_t, VS>::V *>(nat + e0) = VecIO<bf16_t, VS>::pack(f);
-#pragma unroll
-        for (int q = 0; q < VS; ++q) {
-            tr[pl * L + w * HW + h] = from_float<bf16_t>(f[q]);
-            if constexpr (HW % VS != 0) {
-                if (++w == HW) {
-                    w = 0;
-                    ++h;
-                }
-            } else {
-                ++w;
-            }
-        }
-    }
-}
-
-// Maps whose rows are whole 8-element vectors (56 x 56): two passes.  Pass A loads the tile in MEMORY order (1 KB per wave
-// instruction; the lean kernels' one-pass form asks for 16-byte pieces a row apart and spends 77 us of a 300 us launch
-// there) and writes the natural images; pass B re-reads them with consecutive lanes on the same column block of
-// consecutive rows (16-byte reads 112 bytes apart: conflict-free per 16-lane group) and scatters the transposed images
-// with 2-byte writes that fall on consecutive addresses.
-template <int HW, int PPT>
-__device__ __forceinline__ void l3_transpose_pass(const bf16_t *nat, bf16_t *tr, const int tid) {
-    constexpr int L = HW * HW, nvec = PPT * L / 8;
-    for (int v = tid; v < nvec; v += 256) {
-        int e0, pl, h, w;
-        l3_vec_pos<HW, 8>(v, e0, pl, h, w);
-        const uint4 r = *reinterpret_cast<const uint4 *>(nat + e0);
-        const uint32_t wd[4] = {r.x, r.y, r.z, r.w};
-        uint16_t *t = reinterpret_cast<uint16_t *>(tr) + pl * L + w * HW + h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            t[(2 * q) * HW] = (uint16_t)(wd[q] & 0xffffu);
-            t[(2 * q + 1) * HW] = (uint16_t)(wd[q] >> 16);
-        }
-    }
-}
-
-// dx = sum of the four private planes (routes 0 / 2 natural, 1 / 3 transposed), fixed order, 16-byte stores
-template <int HW, int PPT>
-__device__ __forceinline__ void l3_merge_store(bf16_t *out, const bf16_t *P0, const bf16_t *P1, const bf16_t *P2,
-                                               const bf16_t *P3, const int tid) {
-    constexpr int L = HW * HW, PL = PPT * L;
-    for (int v = tid; v < PL / 8; v += 256) {
-        int e0, pl, h, w;
-        l3_vec_pos<HW, 8>(v, e0, pl, h, w);
-        float n0[8], n1[8], o[8];
-        VecIO<bf16_t, 8>::unpack(*reinterpret_cast<const uint4 *>(P0 + e0), n0);
-        VecIO<bf16_t, 8>::unpack(*reinterpret_cast<const uint4 *>(P1 + e0), n1);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int t0 = pl * L + w * HW + h;
-            o[q] = (n0[q] + n1[q]) + (ldf<bf16_t>(P2 + t0) + ldf<bf16_t>(P3 + t0));
-            if constexpr (HW % 8 != 0) {
-                if (++w == HW) {
-                    w = 0;
-                    ++h;
-                }
-            } else {
-                ++w;
-            }
-        }
-        *reinterpret_cast<uint4 *>(out + e0) = VecIO<bf16_t, 8>::pack(o);
-    }
 }
 
 // the whole walk of a workgroup for one direction (a template parameter from the top: the ascending and the descending
@@ -617,7 +851,7 @@ __global__ void __launch_bounds__(256, L3_WPE) ss2d_l3_bwd_kernel(const LeanArgs
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-template <int HW, int PPT> static int l3_launch_bwd(const xfm_ss2d_params_t &p, hipStream_t s) {
+template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool bwd, hipStream_t s) {
     using G = L3Geom<HW>;
     constexpr int L = G::L, PL = PPT * L;
     const int D = p.d_inner;
@@ -637,16 +871,23 @@ template <int HW, int PPT> static int l3_launch_bwd(const xfm_ss2d_params_t &p, 
     // tiles per workgroup: ONE round of the resident workgroups (2 per CU).  The dB / dC flush of a workgroup is 8 L
     // float atomics; at the chip's ~1.3 TB/s of atomic bytes 1024 workgroups spend 79 us of a 56 x 56 launch there.
     const int tiles_pb = D / PPT;
-    int pli = (int)(((int64_t)p.batch * tiles_pb + 511) / 512);
+    const int resident = bwd ? 512 : 256 * L3_WPE_FWD;
+    int pli = (int)(((int64_t)p.batch * tiles_pb + resident - 1) / resident);
     if (pli < 1) pli = 1;
     if (pli > tiles_pb) pli = tiles_pb;
     if (const char *e = getenv("XFM_L3_PLI")) pli = std::max(1, std::min(tiles_pb, atoi(e)));   // tuning hook
     while (tiles_pb % pli) --pli;
     la.pli = pli;
-    const size_t lds = (size_t)8 * PL * 2 + (size_t)4 * 2 * G::LSZ * sizeof(float);
-    const void *fn = p.delta_softplus == 2 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 2>
-                                           : (p.delta_softplus == 1 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 1>
-                                                                    : (const void *)ss2d_l3_bwd_kernel<HW, PPT, 0>);
+    const size_t lds = bwd ? (size_t)8 * PL * 2 + (size_t)4 * 2 * G::LSZ * sizeof(float) : (size_t)6 * PL * 2;
+    const void *fn;
+    if (bwd)
+        fn = p.delta_softplus == 2 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 2>
+                                   : (p.delta_softplus == 1 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 1>
+                                                            : (const void *)ss2d_l3_bwd_kernel<HW, PPT, 0>);
+    else
+        fn = p.delta_softplus == 2 ? (const void *)ss2d_l3_fwd_kernel<HW, PPT, 2>
+                                   : (p.delta_softplus == 1 ? (const void *)ss2d_l3_fwd_kernel<HW, PPT, 1>
+                                                            : (const void *)ss2d_l3_fwd_kernel<HW, PPT, 0>);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const unsigned grid = (unsigned)((int64_t)p.batch * (tiles_pb / pli));
     void *kargs[] = {&la};
@@ -664,13 +905,18 @@ int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s) {
         const char *e = getenv("XFM_SS2D_L3");
         return !(e && e[0] == '0');
     }();
-    if (!enabled || !bwd) return XFM_ELIMIT;
+    if (!enabled) return XFM_ELIMIT;
+    static const bool fwd_enabled = [] {
+        const char *e = getenv("XFM_SS2D_L3_FWD");
+        return !(e && e[0] == '0');
+    }();
+    if (!bwd && !fwd_enabled) return XFM_ELIMIT;
     if (p->in_dtype != XFM_BF16 || p->out_dtype != XFM_F32 || p->dstate != 1 || p->H != p->W) return XFM_ELIMIT;
     if (p->delta_softplus < 0 || p->delta_softplus > 2) return XFM_ELIMIT;
     if ((p->H == 56 || p->H == 28) && !p->chk) return XFM_EINVAL;     // multi-chunk rows need the forward's checkpoints
     switch (p->H) {
-        case 56: return l3_launch_bwd<56, 1>(*p, s);
-        case 28: return l3_launch_bwd<28, 4>(*p, s);
+        case 56: return l3_launch<56, 1>(*p, bwd, s);
+        case 28: return l3_launch<28, 4>(*p, bwd, s);
     }
     return XFM_ELIMIT;
 }
