@@ -774,6 +774,548 @@ __global__ void __launch_bounds__(128) ss2dc_bwd_kernel(const ChanArgs a) {
     }
 }
 
+// =====================================================================================================================
+// d_state 16 on 7 x 7 maps -- the deep cross-fusion block (reference models/fusion_vmamba.py:483-576), second design.
+//
+// The kernels above give a lane one channel and its two halves a route and its reverse; with 16 states that needs the
+// B_n / C_n broadcasts of a step in 64 registers (MFMA results, one state ahead), 408 VGPRs in all, and ran the backward at
+// 1.5 % of the HBM peak (948 us).  Here a wave owns 64 channels of ONE route at a time:
+//   * B_n[t], C_n[t] are the same for all 64 lanes: the wave copies its route's rows once per pass into an fp32 LDS
+//     table in route order and a state takes its step with two 16-byte broadcast reads (no MFMA in the dependency
+//     chain of a state; as scalar operands they missed the scalar cache twice per state pair);
+//   * the states are walked in PAIRS (two independent recurrences in flight), the state / adjoint carries in LDS;
+//   * dt_proj of a step: one accumulator, the two 32-channel blocks of the tile stacked along k (rows of lane half h
+//     carry their x_proj slots in k-block h, the weights of block h sit in the same slots);
+//   * the step checkpoints are bf16 pairs (two states per dword): 132 MB instead of 264 MB each way;
+//   * wave 0 walks routes 0 then 2, wave 1 routes 1 then 3: every du plane has one owner, the second route adds.
+// =====================================================================================================================
+namespace deep {
+
+constexpr int HW = 7, L = 49, P = 7, NSTEP = 7, N = 16, LP = 50;   // LP: bf16 plane pitch (LP / 2 odd: conflict-free lanes)
+constexpr int TBL = 2 * N * NSTEP * 8;                           // floats of a wave's B / C table: [B | C][state][step][8]
+
+struct DeepArgs {
+    ChanArgs a;
+    uint32_t *chkp;          // (Bt, 4, NSTEP, N / 2, D) packed bf16 pairs: states (2 np, 2 np + 1) after each step
+    float *dAt;              // (4, N, D) fp32 scratch, zeroed per backward call: dA with the CHANNEL fastest, so that a wave's
+                             // atomic instruction covers 256 contiguous bytes (in the (4 D, N) layout of dA its 64 lanes hit
+                             // 64 different lines: ~17x slower per instruction, MI355X_MICROARCH.md "Global float atomics")
+};
+
+// natural position of sequence index s (0..48) of route k
+__host__ __device__ __forceinline__ int deep_nat(const int k, const int s) {
+    const int t = (k & 2) ? L - 1 - s : s;
+    return (k & 1) ? (t % HW) * HW + t / HW : t;
+}
+
+__device__ __forceinline__ float deep_lo(const uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float deep_hi(const uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// B_n[t] / C_n[t] of route k are the same for every channel: the wave copies them once per pass from the token-major x_proj
+// rows into its LDS table, fp32, in ROUTE order with eight slots per step (two aligned 16-byte broadcast reads hand a state
+// its step).  (As scalar operands -- s_load from a global table -- they shared lgkmcnt with the LDS reads of the state loop,
+// returned out of order and missed the scalar cache: two exposed L2 round trips per state pair, 3 k cycles of 4.)
+__device__ __forceinline__ void deep_fill_bc(const ChanArgs &a, const int sb, const int sbC, const int k, float *T,
+                                             const int lane) {
+    // a position's B (16 states) and C columns are 2 x 32 contiguous bytes of its x_proj row: 49 x 4 pieces of 16 bytes,
+    // all of a lane's loads in flight together (a rolled element-wise gather exposed 28 dependent L2 round trips per pass)
+    const uint16_t *src = a.xdbl + k * a.C2p + a.Rp8;
+    cu32x4_t r[4];
+    int slot[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int p = q * 64 + lane, s = p >> 2, part = p & 3, w = part >> 1, nb = 8 * (part & 1);
+        slot[q] = -1;
+        if (s < L) {
+            r[q] = *reinterpret_cast<const cu32x4_t *>(src + ((int64_t)(w ? sbC : sb) * L + deep_nat(k, s)) * a.XC + w * N + nb);
+            slot[q] = ((w * N + nb) * NSTEP + s / P) * 8 + s % P;
+        }
+    }
+    for (int e = lane; e < 2 * N * NSTEP; e += 64) T[e * 8 + 7] = 0.f;      // the pad slot of every row
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (slot[q] >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                T[slot[q] + (2 * j) * NSTEP * 8] = deep_lo(r[q][j]);
+                T[slot[q] + (2 * j + 1) * NSTEP * 8] = deep_hi(r[q][j]);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void deep_row(const float *T, const int w, const int n, const int st, float (&r)[8]) {
+    const float4 *q = reinterpret_cast<const float4 *>(T + ((w * N + n) * NSTEP + st) * 8);
+    const float4 lo = q[0], hi = q[1];
+    r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = lo.w; r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = hi.w;
+}
+
+// dt_proj of one step for the 64 channels of the tile: acc[i] = raw step size of position i of the step (i < 7).
+// One accumulator for both 32-channel blocks: the x_proj slots of lane half h sit in k-block h (the other block reads
+// zeros), the weights of channel block h in the same slots.  The x_proj fragments are requested one step ahead.
+template <int KS> struct DeepX { cbf16x8_t f[2 * KS]; };
+
+template <int KS>
+__device__ __forceinline__ void deep_load_x(const ChanArgs &a, const int sb, const int k, const int st, const int lane,
+                                            DeepX<KS> &x) {
+    const int row32 = lane & 31, kb = lane >> 5;
+    const int i = 4 * (row32 >> 3) + (row32 & 3), typ = (row32 >> 2) & 1;
+    const int nat = deep_nat(k, st * P + (i < P ? i : P - 1));
+    const uint16_t *xrow = a.xdbl + ((int64_t)sb * L + nat) * a.XC + k * a.C2p + 8 * kb;
+#pragma unroll
+    for (int m = 0; m < 2 * KS; ++m) {
+        const int ks = m % KS, blk = m / KS;
+        x.f[m] = chan_ld8((typ == blk && 16 * ks + 8 * kb < a.Rp8) ? xrow + 16 * ks : a.zeros);
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ cf32x16_t deep_dt_step(const ChanArgs &a, const int c0, const int k, const int lane,
+                                                  const float bv, const DeepX<KS> &x) {
+    const int row32 = lane & 31, kb = lane >> 5;
+    const uint16_t *w0 = a.wdt + ((int64_t)k * a.D + c0 + row32) * a.Rp8 + 8 * kb;
+    const uint16_t *w1 = w0 + (int64_t)32 * a.Rp8;
+    cbf16x8_t fb[2 * KS];
+#pragma unroll
+    for (int m = 0; m < 2 * KS; ++m) {
+        const int ks = m % KS, blk = m / KS;
+        fb[m] = chan_ld8(16 * ks + 8 * kb < a.Rp8 ? (blk ? w1 : w0) + 16 * ks : a.zeros);
+    }
+    cf32x16_t acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bv;
+#pragma unroll
+    for (int m = 0; m < 2 * KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.f[m], fb[m], acc, 0, 0, 0);
+    return acc;
+}
+
+// sum of eight per-lane values over the 64 channel lanes: the values (bf16) are the A operand of an MFMA whose selector
+// hands lane `col` value (col & 7) of 16 channel rows from each lane half; an in-lane sum and one cross-half add.
+// Lanes 0..7 (and their copies) return the totals.
+__device__ __forceinline__ float deep_colsum8(const float (&v)[8], const cbf16x8_t sel) {
+    cu32x4_t pk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pk[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+    const cf32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const cf32x16_t t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf16x8_t *>(&pk), sel, zero16, 0, 0, 0);
+    float s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    s += ((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]));
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const uint32_t sb = __float_as_uint(s);
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(sb, sb, false, false);
+    return s + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ uint16_t deep_bf16(const float v) { return (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu); }
+
+// ---- forward: one route over the 64 channel planes of the tile -------------------------------------------------------
+// yp: this wave's output planes [64][L] fp32 (FIRST: plain stores, else adds); T: B / C table
+struct DeepFwdLds {
+    static constexpr size_t xs = 0, dsum = xs + 64 * LP * 2, wave0 = dsum + 64 * 4;
+    static constexpr size_t yp = 0, T = yp + 64 * L * 4, wave_sz = T + TBL * 4;
+    static constexpr size_t total = wave0 + 2 * wave_sz;
+};
+
+template <int KS, bool FIRST>
+__device__ __forceinline__ void deep_fwd_pass(const DeepArgs &da, const int sb, const int c0, const int k, const uint16_t *xs,
+                                              char *wl) {
+    const ChanArgs &a = da.a;
+    const int lane = threadIdx.x & 63;
+    float *yp = reinterpret_cast<float *>(wl + DeepFwdLds::yp);
+    float *T = reinterpret_cast<float *>(wl + DeepFwdLds::T);
+    const int64_t wrow = (int64_t)k * a.D + c0 + lane;
+    const float bv = a.bias[wrow];
+    const float *Arow = a.A + wrow * N;
+    const int sbC = a.c_mod > 0 ? a.c_off + sb % a.c_mod : sb;
+    uint32_t *chk = da.chkp + (((int64_t)sb * 4 + k) * NSTEP) * (N / 2) * a.D + c0 + lane;
+    DeepX<KS> xf;
+    deep_load_x<KS>(a, sb, k, 0, lane, xf);
+    // the dt_proj weights of the tile (both channel blocks): the same for every step of the pass
+    cbf16x8_t fb[2 * KS];
+    {
+        const int row32 = lane & 31, kb = lane >> 5;
+        const uint16_t *w0 = a.wdt + ((int64_t)k * a.D + c0 + row32) * a.Rp8 + 8 * kb;
+        const uint16_t *w1 = w0 + (int64_t)32 * a.Rp8;
+#pragma unroll
+        for (int m = 0; m < 2 * KS; ++m) {
+            const int ks = m % KS, blk = m / KS;
+            fb[m] = chan_ld8(16 * ks + 8 * kb < a.Rp8 ? (blk ? w1 : w0) + 16 * ks : a.zeros);
+        }
+    }
+    wave_sync();                                      // (the previous pass of this wave has read the table)
+    deep_fill_bc(a, sb, sbC, k, T, lane);
+    // states and decay rates of the 16 states in registers: the state loop is unrolled (no LDS carries, no dynamic index)
+    float h[N], A2[N];
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4 *>(Arow + 4 * q);
+        A2[4 * q] = t.x * kLog2e; A2[4 * q + 1] = t.y * kLog2e; A2[4 * q + 2] = t.z * kLog2e; A2[4 * q + 3] = t.w * kLog2e;
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) h[n] = 0.f;
+    wave_sync();
+#pragma unroll 1
+    for (int st = 0; st < NSTEP; ++st) {
+        cf32x16_t acc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = bv;
+#pragma unroll
+        for (int m = 0; m < 2 * KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf.f[m], fb[m], acc, 0, 0, 0);
+        if (st + 1 < NSTEP) deep_load_x<KS>(a, sb, k, st + 1, lane, xf);
+        float dlu[P], dl[P], yv[P];
+        int nat[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            nat[i] = deep_nat(k, st * P + i);
+            dl[i] = chan_softplus(acc[i]);
+            dlu[i] = dl[i] * bf16_bits_to_float(xs[lane * LP + nat[i]]);
+            yv[i] = 0.f;
+        }
+        if (!(a.ct & 2)) {
+#pragma unroll
+            for (int np = 0; np < N / 2; ++np) {
+                float b0[8], b1[8], c0r[8], c1r[8];
+                deep_row(T, 0, 2 * np, st, b0);
+                deep_row(T, 0, 2 * np + 1, st, b1);
+                deep_row(T, 1, 2 * np, st, c0r);
+                deep_row(T, 1, 2 * np + 1, st, c1r);
+                float h0 = h[2 * np], h1 = h[2 * np + 1];
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    h0 = fmaf(exp2_fast(dl[i] * A2[2 * np]), h0, dlu[i] * b0[i]);
+                    h1 = fmaf(exp2_fast(dl[i] * A2[2 * np + 1]), h1, dlu[i] * b1[i]);
+                    yv[i] = fmaf(c0r[i], h0, yv[i]);
+                    yv[i] = fmaf(c1r[i], h1, yv[i]);
+                }
+                h[2 * np] = h0;
+                h[2 * np + 1] = h1;
+                if (!(a.ct & 1)) chk[((int64_t)st * (N / 2) + np) * a.D] = pack_bf16x2(h0, h1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            float *q = yp + lane * L + nat[i];
+            *q = FIRST ? yv[i] : *q + yv[i];
+        }
+    }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(128) deep_fwd_kernel(const DeepArgs da) {
+    const ChanArgs &a = da.a;
+    using LD = DeepFwdLds;
+    extern __shared__ float smem[];
+    char *sm = reinterpret_cast<char *>(smem);
+    uint16_t *xs = reinterpret_cast<uint16_t *>(sm + LD::xs);
+    float *dsum = reinterpret_cast<float *>(sm + LD::dsum);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *wl = sm + LD::wave0 + wave * LD::wave_sz;
+    const int tiles = a.D / 64;
+    const int sb = blockIdx.x / tiles, c0 = (blockIdx.x - sb * tiles) * 64;
+    {   // the 64 x L bf16 planes of this (sample, tile): one contiguous run in HBM
+        const uint16_t *src = a.x + ((int64_t)sb * a.D + c0) * L;
+        for (int v = threadIdx.x; v < 64 * L / 2; v += 128) {
+            const uint32_t r = *reinterpret_cast<const uint32_t *>(src + 2 * v);
+            const int e = 2 * v, c = e / L, l = e - c * L;
+            xs[c * LP + l] = (uint16_t)(r & 0xffffu);
+            const int e1 = e + 1, c1 = e1 / L, l1 = e1 - c1 * L;
+            xs[c1 * LP + l1] = (uint16_t)(r >> 16);
+        }
+        if (threadIdx.x < 64) {
+            const int q = threadIdx.x;
+            dsum[q] = (a.Dp[c0 + q] + a.Dp[a.D + c0 + q]) + (a.Dp[2 * a.D + c0 + q] + a.Dp[3 * a.D + c0 + q]);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        deep_fwd_pass<KS, true>(da, sb, c0, 0, xs, wl);
+        deep_fwd_pass<KS, false>(da, sb, c0, 2, xs, wl);
+    } else {
+        deep_fwd_pass<KS, true>(da, sb, c0, 1, xs, wl);
+        deep_fwd_pass<KS, false>(da, sb, c0, 3, xs, wl);
+    }
+    __syncthreads();
+    const float *y0 = reinterpret_cast<const float *>(sm + LD::wave0 + LD::yp);
+    const float *y1 = reinterpret_cast<const float *>(sm + LD::wave0 + LD::wave_sz + LD::yp);
+    float *dst = a.y + ((int64_t)sb * a.D + c0) * L;
+    for (int v = threadIdx.x; v < 64 * L / 4; v += 128) {
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = 4 * v + q, c = e / L, l = e - c * L;
+            o[q] = fmaf(dsum[c], bf16_bits_to_float(xs[c * LP + l]), y0[e] + y1[e]);
+        }
+        *reinterpret_cast<float4 *>(dst + 4 * v) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------------
+// LDS of a workgroup: xs | gs [64][LP] bf16 | dsum [64] fp32 | per wave: dup [64][LP] bf16 (du planes), T [2][N][NSTEP][8]
+// fp32 (the B / C table; a state's dB / dC sums of a step overwrite the slots it has just read), stg [P][64] bf16,
+// Es | dAs | As [N][64] fp32 (adjoint carries, dA sums, decay rates), hb [N / 2][64] packed entering states
+struct DeepBwdLds {
+    static constexpr size_t xs = 0, gs = xs + 64 * LP * 2, dsum = gs + 64 * LP * 2, wave0 = dsum + 64 * 4;
+    static constexpr size_t dup = 0, T = dup + 64 * LP * 2, stg = T + (size_t)TBL * 4;
+    static constexpr size_t Es = (stg + P * 64 * 2 + 15) / 16 * 16, dAs = Es + N * 64 * 4, As = dAs + N * 64 * 4;
+    static constexpr size_t hb = As + N * 64 * 4, wave_sz = hb + (N / 2) * 64 * 4;
+    static constexpr size_t total = wave0 + 2 * wave_sz;
+};
+
+template <int KS, bool FIRST>
+__device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, const int c0, const int k,
+                                              const uint16_t *xs, const uint16_t *gs, char *wl) {
+    const ChanArgs &a = da.a;
+    const int lane = threadIdx.x & 63;
+    uint16_t *dup = reinterpret_cast<uint16_t *>(wl + DeepBwdLds::dup);
+    float *T = reinterpret_cast<float *>(wl + DeepBwdLds::T);
+    uint16_t *stg = reinterpret_cast<uint16_t *>(wl + DeepBwdLds::stg);
+    float *Es = reinterpret_cast<float *>(wl + DeepBwdLds::Es), *dAs = reinterpret_cast<float *>(wl + DeepBwdLds::dAs);
+    float *As = reinterpret_cast<float *>(wl + DeepBwdLds::As);
+    uint32_t *hb = reinterpret_cast<uint32_t *>(wl + DeepBwdLds::hb);
+    const int64_t wrow = (int64_t)k * a.D + c0 + lane;
+    const float bv = a.bias[wrow];
+    const float *Arow = a.A + wrow * N;
+    const int sbC = a.c_mod > 0 ? a.c_off + sb % a.c_mod : sb;
+    const uint32_t *chk = da.chkp + (((int64_t)sb * 4 + k) * NSTEP) * (N / 2) * a.D + c0 + lane;
+    DeepX<KS> xf;
+    deep_load_x<KS>(a, sb, k, NSTEP - 1, lane, xf);
+    // states entering a step: requested one step ahead (eight loads in flight under a whole step of work: inside the
+    // state loop each would expose an HBM round trip), handed over through LDS
+    uint32_t hn[N / 2];
+#pragma unroll
+    for (int np = 0; np < N / 2; ++np) hn[np] = chk[((int64_t)(NSTEP - 2) * (N / 2) + np) * a.D];
+    deep_fill_bc(a, sb, sbC, k, T, lane);
+    {
+        float av[N];
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4 *>(Arow + 4 * q);
+            av[4 * q] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            Es[n * 64 + lane] = dAs[n * 64 + lane] = 0.f;
+            As[n * 64 + lane] = av[n];
+        }
+    }
+    wave_sync();
+    const cbf16x8_t sel = chan_indicator(0, lane & 7);
+    float dbacc = 0.f;
+#pragma unroll 1
+    for (int st = NSTEP - 1; st >= 0; --st) {
+#pragma unroll
+        for (int np = 0; np < N / 2; ++np) {
+            hb[np * 64 + lane] = st > 0 ? hn[np] : 0u;
+            if (st > 1) hn[np] = chk[((int64_t)(st - 2) * (N / 2) + np) * a.D];
+        }
+        const cf32x16_t acc = deep_dt_step<KS>(a, c0, k, lane, bv, xf);
+        if (st > 0) deep_load_x<KS>(a, sb, k, st - 1, lane, xf);
+        float dl[P], sg[P], u[P], g[P], dlu[P], sB[P], sA[P];
+        int nat[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            nat[i] = deep_nat(k, st * P + i);
+            dl[i] = chan_softplus_sig(acc[i], sg[i]);
+            u[i] = bf16_bits_to_float(xs[lane * LP + nat[i]]);
+            g[i] = bf16_bits_to_float(gs[lane * LP + nat[i]]);
+            dlu[i] = dl[i] * u[i];
+            sB[i] = sA[i] = 0.f;
+        }
+#pragma unroll 1
+        for (int np = 0; np < N / 2; ++np) {
+            const float2 An = {As[(2 * np) * 64 + lane], As[(2 * np + 1) * 64 + lane]};
+            const float A20 = An.x * kLog2e, A21 = An.y * kLog2e;
+            const uint32_t hp = hb[np * 64 + lane];
+            float b0[8], b1[8], c0r[8], c1r[8];
+            deep_row(T, 0, 2 * np, st, b0);
+            deep_row(T, 0, 2 * np + 1, st, b1);
+            deep_row(T, 1, 2 * np, st, c0r);
+            deep_row(T, 1, 2 * np + 1, st, c1r);
+            float E0 = Es[(2 * np) * 64 + lane], E1 = Es[(2 * np + 1) * 64 + lane];
+            float dA0 = dAs[(2 * np) * 64 + lane], dA1 = dAs[(2 * np + 1) * 64 + lane];
+            float av0[P], av1[P], hv0[P], hv1[P];
+            float h0 = deep_lo(hp), h1 = deep_hi(hp);
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                av0[i] = exp2_fast(dl[i] * A20);
+                av1[i] = exp2_fast(dl[i] * A21);
+                h0 = fmaf(av0[i], h0, dlu[i] * b0[i]);
+                h1 = fmaf(av1[i], h1, dlu[i] * b1[i]);
+                hv0[i] = h0;
+                hv1[i] = h1;
+            }
+            float dB0[8], dC0[8], dB1[8], dC1[8];
+            dB0[7] = dC0[7] = dB1[7] = dC1[7] = 0.f;
+#pragma unroll
+            for (int i = P - 1; i >= 0; --i) {
+                const float dh0 = fmaf(c0r[i], g[i], E0), dh1 = fmaf(c1r[i], g[i], E1);
+                E0 = av0[i] * dh0;
+                E1 = av1[i] * dh1;
+                const float dha0 = dh0 * fmaf(-dlu[i], b0[i], hv0[i]);      // dh * a_t h_{t-1}
+                const float dha1 = dh1 * fmaf(-dlu[i], b1[i], hv1[i]);
+                sB[i] = fmaf(dh0, b0[i], sB[i]);
+                sB[i] = fmaf(dh1, b1[i], sB[i]);
+                sA[i] = fmaf(dha0, An.x, sA[i]);
+                sA[i] = fmaf(dha1, An.y, sA[i]);
+                dA0 = fmaf(dha0, dl[i], dA0);
+                dA1 = fmaf(dha1, dl[i], dA1);
+                dB0[i] = dh0 * dlu[i];
+                dB1[i] = dh1 * dlu[i];
+                dC0[i] = g[i] * hv0[i];
+                dC1[i] = g[i] * hv1[i];
+            }
+            Es[(2 * np) * 64 + lane] = E0;
+            Es[(2 * np + 1) * 64 + lane] = E1;
+            dAs[(2 * np) * 64 + lane] = dA0;
+            dAs[(2 * np + 1) * 64 + lane] = dA1;
+            // dB / dC of the two states: sums over the 64 channel lanes, into the table slots just read
+            const float tB0 = deep_colsum8(dB0, sel), tC0 = deep_colsum8(dC0, sel);
+            const float tB1 = deep_colsum8(dB1, sel), tC1 = deep_colsum8(dC1, sel);
+            if (lane < P) {
+                T[((0 * N + 2 * np) * NSTEP + st) * 8 + lane] = tB0;
+                T[((0 * N + 2 * np + 1) * NSTEP + st) * 8 + lane] = tB1;
+                T[((1 * N + 2 * np) * NSTEP + st) * 8 + lane] = tC0;
+                T[((1 * N + 2 * np + 1) * NSTEP + st) * 8 + lane] = tC1;
+            }
+        }
+        // ---- per-position results: du of this route into the wave's planes, d raw step size to the staging rows
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const float du = dl[i] * sB[i];                          // (D g is added once, at the merge)
+            const float ddl = fmaf(u[i], sB[i], sA[i]) * sg[i];
+            dbacc += ddl;
+            stg[i * 64 + lane] = deep_bf16(ddl);
+            uint16_t *q = dup + lane * LP + nat[i];
+            *q = deep_bf16(FIRST ? du : bf16_bits_to_float(*q) + du);
+        }
+        wave_sync();
+        if (lane < P * 8) {                                          // ddts rows: [position][64 channels] bf16, 16-byte stores
+            const int i = lane >> 3, part = lane & 7;
+            const int nf = deep_nat(k, st * P + i);
+            const cu32x4_t v = *reinterpret_cast<const cu32x4_t *>(stg + i * 64 + 8 * part);
+            *reinterpret_cast<cu32x4_t *>(a.ddts + ((((int64_t)sb * 4 + k) * L + nf) * a.D + c0 + 8 * part)) = v;
+        }
+        wave_sync();
+    }
+    for (int n = 0; n < N; ++n) atomicAdd(da.dAt + ((int64_t)k * N + n) * a.D + c0 + lane, dAs[n * 64 + lane]);
+    atomicAdd(a.dbias + wrow, dbacc);
+    // dB / dC of this route over the tile: contiguous fp32 atomics in natural position order (the table is in route order)
+    for (int op = 0; op < 2; ++op) {
+        float *dst = a.dBC + ((((int64_t)(op ? sbC : sb) * 4 + k) * 2 + op) * N) * L;
+        for (int e = lane; e < N * L; e += 64) {
+            const int n = e / L, pnat = e - n * L;
+            int t = (k & 1) ? (pnat % HW) * HW + pnat / HW : pnat;           // sequence index of the position on route k
+            t = (k & 2) ? L - 1 - t : t;
+            atomicAdd(dst + e, T[((op * N + n) * NSTEP + t / P) * 8 + t % P]);
+        }
+    }
+    wave_sync();
+}
+
+template <int KS>
+__global__ void __launch_bounds__(128) deep_bwd_kernel(const DeepArgs da) {
+    const ChanArgs &a = da.a;
+    using LD = DeepBwdLds;
+    extern __shared__ float smem[];
+    char *sm = reinterpret_cast<char *>(smem);
+    uint16_t *xs = reinterpret_cast<uint16_t *>(sm + LD::xs), *gs = reinterpret_cast<uint16_t *>(sm + LD::gs);
+    float *dsum = reinterpret_cast<float *>(sm + LD::dsum);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *wl = sm + LD::wave0 + wave * LD::wave_sz;
+    const int tiles = a.D / 64;
+    const int sb = blockIdx.x / tiles, c0 = (blockIdx.x - sb * tiles) * 64;
+    {
+        const uint16_t *src = a.x + ((int64_t)sb * a.D + c0) * L;
+        const float *gsrc = a.dy + ((int64_t)sb * a.D + c0) * L;
+        for (int v = threadIdx.x; v < 64 * L / 2; v += 128) {
+            const uint32_t r = *reinterpret_cast<const uint32_t *>(src + 2 * v);
+            const float2 gr = *reinterpret_cast<const float2 *>(gsrc + 2 * v);
+            const uint32_t gp = pack_bf16x2(gr.x, gr.y);
+            const int e = 2 * v, c = e / L, l = e - c * L;
+            const int e1 = e + 1, c1 = e1 / L, l1 = e1 - c1 * L;
+            xs[c * LP + l] = (uint16_t)(r & 0xffffu);
+            xs[c1 * LP + l1] = (uint16_t)(r >> 16);
+            gs[c * LP + l] = (uint16_t)(gp & 0xffffu);
+            gs[c1 * LP + l1] = (uint16_t)(gp >> 16);
+        }
+        if (threadIdx.x < 64) {
+            const int q = threadIdx.x;
+            dsum[q] = (a.Dp[c0 + q] + a.Dp[a.D + c0 + q]) + (a.Dp[2 * a.D + c0 + q] + a.Dp[3 * a.D + c0 + q]);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        deep_bwd_pass<KS, true>(da, sb, c0, 0, xs, gs, wl);
+        deep_bwd_pass<KS, false>(da, sb, c0, 2, xs, gs, wl);
+    } else {
+        deep_bwd_pass<KS, true>(da, sb, c0, 1, xs, gs, wl);
+        deep_bwd_pass<KS, false>(da, sb, c0, 3, xs, gs, wl);
+    }
+    __syncthreads();
+    // ---- dx = rows + columns + (sum_k D_k) g ; dD_k[c] += sum_l g u (the same for every route k)
+    const uint16_t *d0 = reinterpret_cast<const uint16_t *>(sm + LD::wave0 + LD::dup);
+    const uint16_t *d1 = reinterpret_cast<const uint16_t *>(sm + LD::wave0 + LD::wave_sz + LD::dup);
+    uint16_t *dst = a.dx + ((int64_t)sb * a.D + c0) * L;
+    for (int v = threadIdx.x; v < 64 * L / 2; v += 128) {
+        float o[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = 2 * v + q, c = e / L, l = e - c * L, off = c * LP + l;
+            o[q] = fmaf(dsum[c], bf16_bits_to_float(gs[off]), bf16_bits_to_float(d0[off]) + bf16_bits_to_float(d1[off]));
+        }
+        *reinterpret_cast<uint32_t *>(dst + 2 * v) = pack_bf16x2(o[0], o[1]);
+    }
+    {
+        const int c = threadIdx.x >> 1, part = threadIdx.x & 1;      // two lanes per channel split the plane
+        float s = 0.f;
+        for (int l = part; l < L; l += 2) s = fmaf(bf16_bits_to_float(gs[c * LP + l]), bf16_bits_to_float(xs[c * LP + l]), s);
+        s += __shfl_xor(s, 1, 64);
+        if (part == 0)
+            for (int kk = 0; kk < 4; ++kk) atomicAdd(a.dD + kk * a.D + c0 + c, s);
+    }
+}
+
+__global__ void __launch_bounds__(256) deep_zero_kernel(float *p, const int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n) p[e] = 0.f;
+}
+
+// dA (4 D, N) += dAt (4, N, D)
+__global__ void __launch_bounds__(256) deep_dA_finish_kernel(const float *dAt, float *dA, const int D) {
+    const int e = blockIdx.x * 256 + threadIdx.x;                   // index into dA: (k D + c) N + n
+    if (e >= 4 * D * N) return;
+    const int n = e % N, r = e / N, k = r / D, c = r - k * D;
+    dA[e] += dAt[((int64_t)k * N + n) * D + c];
+}
+
+static int deep_supported(int H, int W, int N_, int NR, int D, int R) {
+    return H == 7 && W == 7 && N_ == 16 && NR == 4 && D % 64 == 0 && R >= 1 && R <= 48;
+}
+
+template <int KS> static int deep_launch(const DeepArgs &da, bool bwd, hipStream_t s) {
+    const size_t lds = bwd ? DeepBwdLds::total : DeepFwdLds::total;
+    const void *fn = bwd ? (const void *)deep_bwd_kernel<KS> : (const void *)deep_fwd_kernel<KS>;
+    static bool opted[2] = {false, false};
+    if (lds > 64 * 1024 && !opted[bwd]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
+        opted[bwd] = true;
+    }
+    DeepArgs args = da;
+    args.a.ct = 0;
+    if (const char *e = getenv("XFM_DEEP_DBG")) args.a.ct = atoi(e);    // timing-only switches
+    void *kargs[] = {&args};
+    // (a kernel, not a memset node: under stream capture the memset of this workspace slice replayed with stale contents)
+    if (bwd) hipLaunchKernelGGL(deep_zero_kernel, dim3((4 * N * da.a.D + 255) / 256), dim3(256), 0, s, da.dAt, 4 * N * da.a.D);
+    const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(da.a.Bt * (da.a.D / 64))), dim3(128), kargs, lds, s);
+    if (e != hipSuccess) {
+        set_last_hip_error(e);
+        return XFM_ELAUNCH;
+    }
+    if (bwd) hipLaunchKernelGGL(deep_dA_finish_kernel, dim3((4 * da.a.D * N + 255) / 256), dim3(256), 0, s, da.dAt, da.a.dA, da.a.D);
+    return check_launch();
+}
+
+}  // namespace deep
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -845,6 +1387,22 @@ static int chan_run(const xfm_ss2dc_params_t *p, bool bwd, void *stream) {
     a.zeros = (const uint16_t *)p->zeros;
     hipStream_t s = (hipStream_t)stream;
     const int HW = p->H;
+    static const bool deep_on = [] {
+        const char *e = getenv("XFM_SS2D_DEEP");
+        return !(e && e[0] == '0');
+    }();
+    if (deep_on && deep::deep_supported(p->H, p->W, N, p->n_routes, p->d_inner, p->dt_rank)) {
+        // workspace (xfm_ss2dc_nsteps = 7 steps): packed bf16 checkpoints in the first half, the dA scratch behind
+        deep::DeepArgs da;
+        da.a = a;
+        da.chkp = reinterpret_cast<uint32_t *>(p->chk);
+        da.dAt = p->chk + (size_t)p->batch * 4 * deep::NSTEP * (deep::N / 2) * p->d_inner;   // (64 D floats of the second half)
+        switch (a.Kp / 16) {
+            case 1: return deep::deep_launch<1>(da, bwd, s);
+            case 2: return deep::deep_launch<2>(da, bwd, s);
+            case 3: return deep::deep_launch<3>(da, bwd, s);
+        }
+    }
     if (N == 1) {
         if (HW == 7) return chan_dispatch_ks<7, 1>(a, bwd, s);
         if (HW == 12) return chan_dispatch_ks<12, 1>(a, bwd, s);
@@ -867,7 +1425,7 @@ int xfm_ss2dc_supported(int H, int W, int dstate, int n_routes, int d_inner, int
     return xfm::chan_supported(H, W, dstate, n_routes, d_inner, dt_rank);
 }
 int xfm_ss2dc_nsteps(int H, int W, int dstate) {
-    (void)dstate;
+    if (H == 7 && W == 7 && dstate == 16) return 7;      // one row / column per step (second design, namespace deep)
     const int P = H <= 8 ? 2 * H : H;
     return (H * W + P - 1) / P;
 }
