@@ -99,3 +99,32 @@ def test_model_tiny_fp8_config_close_to_reference():
     params = dict(m.named_parameters())
     assert sorted(k for k, p in params.items() if p.grad is None) == sorted(names["no_grad"])
     assert all(bool(torch.isfinite(p.grad).all()) for p in params.values() if p.grad is not None)
+
+
+def test_fp8_weight_cache_follows_the_fused_optimizer():
+    """FusedAdam writes the masters through raw pointers (no version bump); the quantised copy of an
+    fp8 projection must still be rebuilt after the step -- forward, step, forward == oracle with the UPDATED weight."""
+    from xfmamba_amd import fp8
+    from xfmamba_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    B, K, L, M = 2, 64, 49, 32
+    x = torch.randn(B, K, L, generator=g).to(DEV).bfloat16()
+    w = torch.nn.Parameter((torch.randn(M, K, generator=g) * K ** -0.5).to(DEV))
+    opt = FusedAdam([w], lr=5e-2)
+
+    def oracle():
+        wq, scale, wdq = fp8.quantize_weight(w)
+        xq = x.float().clamp(-448, 448).to(torch.float8_e4m3fn).float()
+        return torch.einsum("bkl,mk->blm", xq, wq.float() * scale)
+
+    y0 = fp8.fp8_planes_linear(x, w)
+    assert float((y0.float() - oracle()).abs().max()) <= 1e-2 * float(oracle().abs().max()) + 1e-6
+    w.grad = torch.randn(M, K, generator=g).to(DEV)
+    w_before = w.detach().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert float((w.detach() - w_before).abs().max()) > 1e-3, "the optimizer step must have moved the weight"
+    y1 = fp8.fp8_planes_linear(x, w)
+    ref1 = oracle()
+    assert float((y1.float() - ref1).abs().max()) <= 1e-2 * float(ref1.abs().max()) + 1e-6, "stale quantised weight served"
+    assert float((y1.float() - y0.float()).abs().max()) > 1e-3

@@ -128,7 +128,7 @@ def test_weight_cache_serves_current_shadows_only():
     assert cast_weight(lin.weight, torch.bfloat16).data_ptr() != a.data_ptr()
 
 
-def test_weight_cache_serves_current_shadows_only():
+def test_weight_cache_data_writes_need_explicit_invalidation():
     """amp.WeightCache: a shadow is served while the parameter is unchanged, dropped after an in-place update of the
     parameter, and -- the `.data` caveat -- must be invalidated explicitly after a write through ``p.data``."""
     from xfmamba_amd.amp import WeightCache, cast_weight, invalidate_shadows
@@ -147,4 +147,18 @@ def test_weight_cache_serves_current_shadows_only():
     assert float(cast_weight(m.weight, torch.bfloat16).float().mean()) == 7.0
     wc.refresh()
     assert float(cast_weight(m.weight, torch.bfloat16).float().mean()) == 7.0
+    wc.close()
+
+
+def test_mark_current_leaves_unwritten_parameters_to_the_version_check():
+    """``mark_current(written)`` re-registers only the shadows the optimizer kernel wrote; a parameter
+    changed in place that the step did not touch keeps its stale-shadow protection."""
+    from xfmamba_amd.amp import WeightCache, cast_weight
+    m = torch.nn.Linear(8, 4)
+    wc = WeightCache(m, torch.bfloat16)
+    with torch.no_grad():
+        m.bias.add_(1.0)                                                  # e.g. load_state_dict / broadcast
+    wc.mark_current([m.weight])                                           # the step wrote the weight only
+    assert torch.equal(cast_weight(m.bias, torch.bfloat16), m.bias.detach().to(torch.bfloat16))
+    assert cast_weight(m.weight, torch.bfloat16).data_ptr() == wc.shadows[0].data_ptr()
     wc.close()

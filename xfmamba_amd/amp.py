@@ -64,10 +64,14 @@ class WeightCache:
         for p, s in zip(self.params, self.shadows):
             _SHADOWS[id(p)] = (weakref.ref(p), s, p._version)
 
-    def mark_current(self):
-        """Register the shadows as current WITHOUT copying (they were just written by ``optim.FusedAdam``'s kernel)."""
+    def mark_current(self, written=None):
+        """Register the shadows as current WITHOUT copying (they were just written by ``optim.FusedAdam``'s kernel).
+        ``written``: the parameters the kernel actually updated; the others (frozen, no gradient this step) keep their
+        entry, so a shadow made stale by an in-place change stays subject to the version check."""
+        ids = None if written is None else {id(p) for p in written}
         for p, s in zip(self.params, self.shadows):
-            _SHADOWS[id(p)] = (weakref.ref(p), s, p._version)
+            if ids is None or id(p) in ids:
+                _SHADOWS[id(p)] = (weakref.ref(p), s, p._version)
 
     def close(self):
         for p in self.params:

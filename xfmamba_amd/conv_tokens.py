@@ -16,12 +16,16 @@ from . import _lib
 from .amp import cast_weight
 from .proj import split_k_wgrad
 
-__all__ = ["conv3x3s2_tokens_ok", "conv3x3s2_tokens_fn"]
+__all__ = ["conv3x3s2_tokens_ok", "conv3x3s2_tokens_fn", "conv3x3s2_tokens_enabled"]
 
 # Off by default: measured on the XFMamba-T step (hipGraph, batch 32) the implicit-GEMM path runs 1500 samples/s against
 # 1547 with MIOpen's tuned NHWC igemm kernels (the tile kernel reaches ~12 % of the bf16 MFMA peak on these shapes, the
 # library ~20-30 %).  XFM_CONV_TOKENS=1 selects it (read once at import).
 ENABLED = os.environ.get("XFM_CONV_TOKENS", "0") == "1"
+
+
+def conv3x3s2_tokens_enabled() -> bool:
+    return ENABLED
 
 
 def conv3x3s2_tokens_ok(conv: torch.nn.Conv2d, t: torch.Tensor) -> bool:

@@ -100,6 +100,15 @@ extern "C" int xfm_fp8_planes_gemm(const void *x_bf16, const void *wq_fp8, const
     const size_t lds = (size_t)32 * (K + 8);
     const unsigned grid = (unsigned)((a.T + 31) / 32);
     hipStream_t s = (hipStream_t)stream;
+    if (lds > 160 * 1024) return XFM_ELIMIT;
+    if (lds > 64 * 1024) {                                           // K > 2040 (XFMamba-B stage 3: d_inner 2048)
+        const void *fns[8] = {(const void *)fp8_planes_gemm_kernel<1>, (const void *)fp8_planes_gemm_kernel<2>,
+                              (const void *)fp8_planes_gemm_kernel<3>, (const void *)fp8_planes_gemm_kernel<4>,
+                              (const void *)fp8_planes_gemm_kernel<5>, (const void *)fp8_planes_gemm_kernel<6>,
+                              (const void *)fp8_planes_gemm_kernel<7>, (const void *)fp8_planes_gemm_kernel<8>};
+        if (mt < 1 || mt > 8) return XFM_ELIMIT;
+        if (hipFuncSetAttribute(fns[mt - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
+    }
     switch (mt) {
         case 1: hipLaunchKernelGGL(fp8_planes_gemm_kernel<1>, dim3(grid), dim3(256), lds, s, a); break;
         case 2: hipLaunchKernelGGL(fp8_planes_gemm_kernel<2>, dim3(grid), dim3(256), lds, s, a); break;

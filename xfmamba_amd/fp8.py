@@ -20,11 +20,19 @@ import torch
 
 from . import _lib
 
-__all__ = ["fp8_planes_linear", "quantize_weight", "ENABLED", "usable"]
+__all__ = ["fp8_planes_linear", "quantize_weight", "invalidate", "ENABLED", "usable"]
 
 ENABLED = False
 FP8_MAX = 448.0
-_WQ = {}          # id(weight) -> (weakref, version, wq uint8 view holder, scale tensor, dequantised bf16)
+_WQ = {}          # id(weight) -> (weakref, version, epoch, wq, scale tensor, dequantised bf16)
+_EPOCH = 0        # bumped by every optimizer step that writes parameters through raw pointers (optim.FusedAdam)
+
+
+def invalidate() -> None:
+    """Drop every cached quantised weight: ``optim.FusedAdam`` updates the masters through raw pointers, which does not
+    move ``Tensor._version`` -- the version check alone would keep serving the weights of the first forward pass."""
+    global _EPOCH
+    _EPOCH += 1
 
 
 def quantize_weight(w: torch.Tensor):
@@ -38,10 +46,13 @@ def quantize_weight(w: torch.Tensor):
 def _cached(w: torch.Tensor):
     src = w._base if w._base is not None else w
     ent = _WQ.get(id(src))
-    if ent is not None and ent[0]() is src and ent[1] == src._version and ent[2].shape == w.shape:
-        return ent[2], ent[3], ent[4]
+    # while a stream is being captured the weight is ALWAYS re-quantised: the graph must contain the quantisation, or every
+    # replay would multiply with the weights of the capture step
+    if (ent is not None and ent[0]() is src and ent[1] == src._version and ent[2] == _EPOCH and ent[3].shape == w.shape
+            and not torch.cuda.is_current_stream_capturing()):
+        return ent[3], ent[4], ent[5]
     wq, scale, wdq = quantize_weight(w)
-    _WQ[id(src)] = (weakref.ref(src), src._version, wq, scale, wdq)
+    _WQ[id(src)] = (weakref.ref(src), src._version, _EPOCH, wq, scale, wdq)
     return wq, scale, wdq
 
 

@@ -69,6 +69,10 @@ class FusedAdam:
         key = tuple((p.data_ptr(), g.data_ptr()) for p, g, _, _ in active)
         if key != sl["key"]:                        # rebuilt only when a tensor moved (eager steps allocate fresh gradients)
             h = sl["host"]
+            # the previous upload of this pinned table may still be in flight (the CPU can run a step ahead of the GPU):
+            # wait for it before the table is rewritten, or that step's kernel reads the NEXT step's pointers
+            if sl.get("evt") is not None and not capturing:
+                sl["evt"].synchronize()
             ct, co = [], []
             for ti, (p, g, m, v) in enumerate(active):
                 if not p.is_contiguous() or g.dtype != torch.float32:
@@ -87,6 +91,10 @@ class FusedAdam:
             sl["key"] = key
             sl["n"] = n
             sl["dev"][:6 * n + len(ct)].copy_(h[:6 * n + len(ct)], non_blocking=True)
+            if not capturing:
+                if sl.get("evt") is None:
+                    sl["evt"] = torch.cuda.Event()
+                sl["evt"].record()
         d, nn = sl["dev"], sl["n"]
         base = d.data_ptr()
         with torch.cuda.device(active[0][0].device):
@@ -97,7 +105,9 @@ class FusedAdam:
         # (the kernel wrote the parameters AND their bf16 shadows through raw pointers: the parameters' version counters
         #  did not move, so the shadows registered in amp.WeightCache stay the ones cast_weight serves -- and they are current)
         if self._cache is not None:
-            self._cache.mark_current()
+            self._cache.mark_current([p for p, _, _, _ in active])
+        from . import fp8 as _fp8
+        _fp8.invalidate()                            # quantised copies of the masters are stale now
 
     def state_dict(self):
         """torch.optim.Adam-compatible layout (state per parameter index)."""
