@@ -93,6 +93,7 @@ def test_ss2d_chan_equals_lean_fused_path_at_bench_shape():
 
 CASES16 = [  # B (per stream), D, HW, R   -- d_state 16: the deep cross-fusion block (three streams, C of the fused one)
     (2, 64, 5, 2), (2, 128, 7, 48), (1, 64, 12, 64), (3, 96, 7, 4),
+    (32, 1536, 7, 48),      # the deep block of XFMamba-T / S at the bench batch: the real launch shape
 ]
 
 

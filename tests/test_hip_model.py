@@ -333,6 +333,89 @@ def test_model_tiny_bf16_autocast_within_tolerance():
     assert d_hip < 2e-2, d_hip
 
 
+def _oracle_autocast_grads(ty_tag, sd, xa, xb, lab):
+    """Gradients of the CPU oracle under bf16 autocast (same GEMM precision as the bench configuration, fp32 scan): the
+    yardstick for what bf16 arithmetic itself does to the gradients."""
+    from oracle import c_scan
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in sd.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        out = O.xfmamba_top_ref(leaves, xa, xb, True, c_scan.selective_scan_c)
+    torch.nn.functional.cross_entropy(out.float(), lab).backward()
+    return {k: v.grad for k, v in leaves.items() if v.requires_grad and v.grad is not None}
+
+
+def test_model_tiny_bf16_autocast_gradients_track_the_oracle():
+    """bf16 GRADIENT parity of XFMamba-T at batch 2 (the bench arithmetic: autocast GEMMs, bf16 scan I/O
+    with fp32 state), with the same relative-yardstick rule as the logits test.  Every parameter gradient of the HIP path
+    is compared with the fp32 reference record; its error must stay within 1.5x the error of the CPU oracle run under
+    bf16 autocast (+ a floor), tensor by tensor for the gradient norms and in direction (cosine) for every tensor."""
+    z = load_npz("g5_model.npz")
+    names = load_json("g5_grad_names.json")
+    m = _tiny_with_synth_weights().train()
+    for mod in m.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    xa, xb, lab = g5_inputs()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m(xa.to(DEV), xb.to(DEV))
+    torch.nn.functional.cross_entropy(out.float(), lab.to(DEV)).backward()
+    hip = {k: p.grad.float().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    sd = O.synth_state_dict(load_json("g5_state_shapes.json")["tiny"], seed=0)
+    orc = _oracle_autocast_grads("tiny", sd, xa, xb, lab)
+    ref_norm = {k: float(row[2]) for k, row in zip(names["grad_names"], z["grad_stats"])}
+    worst = (0.0, None)
+    tot_h = tot_o = tot_r = 0.0
+    for k, rn in ref_norm.items():
+        assert k in hip and k in orc, k
+        gh, go = hip[k], orc[k].float()
+        eh = abs(float(gh.double().norm()) - rn) / (rn + 1e-12)
+        eo = abs(float(go.double().norm()) - rn) / (rn + 1e-12)
+        # norm error of the HIP path within 1.5x the oracle's own bf16 error, with a floor of 5e-2 for small tensors
+        assert eh <= 1.5 * eo + 5e-2, (k, eh, eo)
+        worst = max(worst, (eh, k))
+        if rn > 1e-6 * max(ref_norm.values()):
+            cos = float(torch.nn.functional.cosine_similarity(gh.flatten().double(), go.flatten().double(), dim=0))
+            assert cos > 0.97, (k, cos)
+        tot_h += float(gh.double().pow(2).sum()); tot_o += float(go.double().pow(2).sum()); tot_r += rn * rn
+    # the global gradient norm: the oracle's bf16 run and the HIP run must sit equally close to the fp32 record
+    eh, eo = abs(tot_h ** 0.5 - tot_r ** 0.5) / tot_r ** 0.5, abs(tot_o ** 0.5 - tot_r ** 0.5) / tot_r ** 0.5
+    assert eh <= 1.5 * eo + 1e-2, (eh, eo, worst)
+    # the sampled full tensors of the record: direction against the fp32 reference itself
+    for k in z.files:
+        if k.startswith("grad/") and k[5:] in hip:
+            ref = torch.from_numpy(z[k]).flatten().double()
+            if float(ref.norm()) > 0:
+                cos = float(torch.nn.functional.cosine_similarity(hip[k[5:]].flatten().double(), ref, dim=0))
+                assert cos > 0.97, (k, cos)
+
+
+def test_model_tiny_fp32_every_gradient_tensor_matches_the_oracle():
+    """the reference record holds ~10 full gradient tensors and the norm of every other one; here EVERY
+    parameter gradient of the fp32 HIP path is compared element-wise with the CPU oracle (itself pinned to the record by
+    tests/test_oracle_golden.py) at 2e-3 of the tensor's scale."""
+    from oracle import c_scan
+    m = _tiny_with_synth_weights().train()
+    for mod in m.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    xa, xb, lab = g5_inputs()
+    out = m(xa.to(DEV), xb.to(DEV))
+    torch.nn.functional.cross_entropy(out, lab.to(DEV)).backward()
+    sd = O.synth_state_dict(load_json("g5_state_shapes.json")["tiny"], seed=0)
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in sd.items()}
+    o = O.xfmamba_top_ref(leaves, xa, xb, True, c_scan.selective_scan_c)
+    torch.nn.functional.cross_entropy(o, lab).backward()
+    n = 0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        ref = leaves[k].grad
+        assert ref is not None, k
+        assert_close(p.grad.cpu(), ref, 5e-3, 2e-3 * float(ref.abs().max()) + 1e-8, k)
+        n += 1
+    assert n > 300
+
+
 @pytest.mark.parametrize("B,find,wstream", [
     (16, False, False), (32, True, False),
     (32, True, True),       # bench.py --wgrad-stream: weight-gradient kernels on a side stream = a parallel branch of the graph
