@@ -18,7 +18,7 @@ def per_kernel(path, counter):
     for row in csv.DictReader(open(path)):
         if row.get("Counter_Name") != counter:
             continue
-        m = re.search(r"xfm::(\w+)(<[^>]*>)?", row["Kernel_Name"])
+        m = re.search(r"xfm::(?:\w+::)?(\w+)(<[^>]*>)?", row["Kernel_Name"])
         if not m:
             continue
         keys = [m.group(1)]

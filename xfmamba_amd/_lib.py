@@ -193,16 +193,18 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
 
-    def add(self, name, start, end, nbytes):
-        self.records.setdefault(name, []).append((start, end, nbytes))
+    def add(self, name, start, end, nbytes, nbytes_alt=None):
+        self.records.setdefault(name, []).append((start, end, nbytes, nbytes_alt))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for name, recs in self.records.items():
-            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            ms = [r[0].elapsed_time(r[1]) for r in recs]
             out[name] = dict(launches=len(recs), total_ms=sum(ms), avg_us=1e3 * sum(ms) / len(recs),
-                             bytes=sum(b for _, _, b in recs))
+                             bytes=sum(r[2] for r in recs))
+            if all(r[3] is not None for r in recs):       # a second algorithmic boundary (dt_proj fused as well)
+                out[name]["bytes_alt"] = sum(r[3] for r in recs)
         return out
 
 
@@ -216,10 +218,10 @@ def set_timer(t):
 
 class timed:
     """``with timed(name, nbytes): launch`` -- free when no timer is installed."""
-    __slots__ = ("name", "nbytes", "s")
+    __slots__ = ("name", "nbytes", "nbytes_alt", "s")
 
-    def __init__(self, name, nbytes):
-        self.name, self.nbytes, self.s = name, nbytes, None
+    def __init__(self, name, nbytes, nbytes_alt=None):
+        self.name, self.nbytes, self.nbytes_alt, self.s = name, nbytes, nbytes_alt, None
 
     def __enter__(self):
         if _TIMER is not None:
@@ -230,7 +232,7 @@ class timed:
         if self.s is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
-            _TIMER.add(self.name, self.s, e, self.nbytes)
+            _TIMER.add(self.name, self.s, e, self.nbytes, self.nbytes_alt)
         return False
 
 

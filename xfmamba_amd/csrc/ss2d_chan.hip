@@ -40,6 +40,8 @@ struct ChanArgs {
     const float *Dp, *bias;  // (4*D)
     float *y;                // (Bt, D, L) fp32
     float *chk;              // (Bt, 4, NSTEP, N, D) fp32 states at step ends (written by fwd, read by bwd)
+    uint16_t *chk16;         // d_state 16 on 7 x 7 maps, when the backward is namespace deep's: the states after every ROW /
+                             // column as bf16, two states per dword: (Bt, 4, 7, N / 2, D, 2) -- written instead of chk
     const float *dy;         // (Bt, D, L) fp32
     uint16_t *dx;            // (Bt, D, L) bf16
     uint16_t *ddts;          // (Bt, 4, L, D) bf16, NATURAL position order, channel fastest: d loss / d raw step size
@@ -364,6 +366,7 @@ __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, c
     const int ybase = c * Lq * YS + (h ? YS * (L - 1) : 0);
     const int route = (COL ? 1 : 0) + 2 * h;
     float *chk = a.chk + (((int64_t)sb * 4 + route) * NSTEP) * N * a.D + c0 + c;
+    uint16_t *chk16 = a.chk16 + ((((int64_t)sb * 4 + route) * 7) * (N / 2) * a.D + c0 + c) * 2;
     ChanFrags<N, KS> fr;
     if constexpr (N == 1) chan_load_frags<HW, N, KS, COL>(a, ln, 0, fr);
     const cf32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -425,15 +428,23 @@ __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, c
                         bCn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fCc, ind, zero16, 0, 0, 0);
                     }
                     const float A2n = A2s[n * 64];
-                    float hh = hs[n * 64];
+                    float hh = hs[n * 64], hmid = 0.f;
 #pragma unroll
                     for (int i = 0; i < NV; ++i) {
                         const float av = exp2_fast(dl[i] * A2n);
                         hh = fmaf(av, hh, du[i] * bB[i]);
                         yv[i] = fmaf(bC[i], hh, yv[i]);
+                        if (i == HW - 1) hmid = hh;
                     }
                     hs[n * 64] = hh;
-                    chk[((int64_t)st * N + n) * a.D] = hh;
+                    if (HW == 7 && a.chk16) {
+                        // one checkpoint per row / column of the 7 x 7 map (this step covers two, the last one one)
+                        uint16_t *q = chk16 + ((int64_t)(2 * st) * (N / 2) + (n >> 1)) * a.D * 2 + (n & 1);
+                        *q = (uint16_t)(pack_bf16x2(NV > HW ? hmid : hh, 0.f) & 0xffffu);
+                        if (NV > HW) q[(int64_t)(N / 2) * a.D * 2] = (uint16_t)(pack_bf16x2(hh, 0.f) & 0xffffu);
+                    } else {
+                        chk[((int64_t)st * N + n) * a.D] = hh;
+                    }
                 }
             }
             chan_merge<YT, HW, N, COL, true, NV>(lds, yb, sgy, h, st, yv);
@@ -637,7 +648,11 @@ __device__ __forceinline__ void chan_bwd_pass(const ChanArgs &a, const int sb, c
                         const int i = 8 * m + jj;
                         if (lane < 16 && i < NV) {
                             const int nf = nb + (COL ? (i % HW) * HW + i / HW : i);
-                            atomicAdd(bcacc + ((hh2 * 2 + op) * N + n) * L + (hh2 ? L - 1 - nf : nf), tot);
+                            // one tile per workgroup (the default): every slot is written exactly once -- a plain store;
+                            // ds_add_f32 costs ~190 cycles per wave instruction (tools/ubench/lds_atomics.hip)
+                            float *slot = bcacc + ((hh2 * 2 + op) * N + n) * L + (hh2 ? L - 1 - nf : nf);
+                            if (a.ct == 1) *slot = tot;
+                            else atomicAdd(slot, tot);
                         }
                     }
             };
@@ -907,147 +922,6 @@ __device__ __forceinline__ float deep_colsum8(const float (&v)[8], const cbf16x8
 
 __device__ __forceinline__ uint16_t deep_bf16(const float v) { return (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu); }
 
-// ---- forward: one route over the 64 channel planes of the tile -------------------------------------------------------
-// yp: this wave's output planes [64][L] fp32 (FIRST: plain stores, else adds); T: B / C table
-struct DeepFwdLds {
-    static constexpr size_t xs = 0, dsum = xs + 64 * LP * 2, wave0 = dsum + 64 * 4;
-    static constexpr size_t yp = 0, T = yp + 64 * L * 4, wave_sz = T + TBL * 4;
-    static constexpr size_t total = wave0 + 2 * wave_sz;
-};
-
-template <int KS, bool FIRST>
-__device__ __forceinline__ void deep_fwd_pass(const DeepArgs &da, const int sb, const int c0, const int k, const uint16_t *xs,
-                                              char *wl) {
-    const ChanArgs &a = da.a;
-    const int lane = threadIdx.x & 63;
-    float *yp = reinterpret_cast<float *>(wl + DeepFwdLds::yp);
-    float *T = reinterpret_cast<float *>(wl + DeepFwdLds::T);
-    const int64_t wrow = (int64_t)k * a.D + c0 + lane;
-    const float bv = a.bias[wrow];
-    const float *Arow = a.A + wrow * N;
-    const int sbC = a.c_mod > 0 ? a.c_off + sb % a.c_mod : sb;
-    uint32_t *chk = da.chkp + (((int64_t)sb * 4 + k) * NSTEP) * (N / 2) * a.D + c0 + lane;
-    DeepX<KS> xf;
-    deep_load_x<KS>(a, sb, k, 0, lane, xf);
-    // the dt_proj weights of the tile (both channel blocks): the same for every step of the pass
-    cbf16x8_t fb[2 * KS];
-    {
-        const int row32 = lane & 31, kb = lane >> 5;
-        const uint16_t *w0 = a.wdt + ((int64_t)k * a.D + c0 + row32) * a.Rp8 + 8 * kb;
-        const uint16_t *w1 = w0 + (int64_t)32 * a.Rp8;
-#pragma unroll
-        for (int m = 0; m < 2 * KS; ++m) {
-            const int ks = m % KS, blk = m / KS;
-            fb[m] = chan_ld8(16 * ks + 8 * kb < a.Rp8 ? (blk ? w1 : w0) + 16 * ks : a.zeros);
-        }
-    }
-    wave_sync();                                      // (the previous pass of this wave has read the table)
-    deep_fill_bc(a, sb, sbC, k, T, lane);
-    // states and decay rates of the 16 states in registers: the state loop is unrolled (no LDS carries, no dynamic index)
-    float h[N], A2[N];
-#pragma unroll
-    for (int q = 0; q < N / 4; ++q) {
-        const float4 t = *reinterpret_cast<const float4 *>(Arow + 4 * q);
-        A2[4 * q] = t.x * kLog2e; A2[4 * q + 1] = t.y * kLog2e; A2[4 * q + 2] = t.z * kLog2e; A2[4 * q + 3] = t.w * kLog2e;
-    }
-#pragma unroll
-    for (int n = 0; n < N; ++n) h[n] = 0.f;
-    wave_sync();
-#pragma unroll 1
-    for (int st = 0; st < NSTEP; ++st) {
-        cf32x16_t acc;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = bv;
-#pragma unroll
-        for (int m = 0; m < 2 * KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf.f[m], fb[m], acc, 0, 0, 0);
-        if (st + 1 < NSTEP) deep_load_x<KS>(a, sb, k, st + 1, lane, xf);
-        float dlu[P], dl[P], yv[P];
-        int nat[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            nat[i] = deep_nat(k, st * P + i);
-            dl[i] = chan_softplus(acc[i]);
-            dlu[i] = dl[i] * bf16_bits_to_float(xs[lane * LP + nat[i]]);
-            yv[i] = 0.f;
-        }
-        if (!(a.ct & 2)) {
-#pragma unroll
-            for (int np = 0; np < N / 2; ++np) {
-                float b0[8], b1[8], c0r[8], c1r[8];
-                deep_row(T, 0, 2 * np, st, b0);
-                deep_row(T, 0, 2 * np + 1, st, b1);
-                deep_row(T, 1, 2 * np, st, c0r);
-                deep_row(T, 1, 2 * np + 1, st, c1r);
-                float h0 = h[2 * np], h1 = h[2 * np + 1];
-#pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    h0 = fmaf(exp2_fast(dl[i] * A2[2 * np]), h0, dlu[i] * b0[i]);
-                    h1 = fmaf(exp2_fast(dl[i] * A2[2 * np + 1]), h1, dlu[i] * b1[i]);
-                    yv[i] = fmaf(c0r[i], h0, yv[i]);
-                    yv[i] = fmaf(c1r[i], h1, yv[i]);
-                }
-                h[2 * np] = h0;
-                h[2 * np + 1] = h1;
-                if (!(a.ct & 1)) chk[((int64_t)st * (N / 2) + np) * a.D] = pack_bf16x2(h0, h1);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            float *q = yp + lane * L + nat[i];
-            *q = FIRST ? yv[i] : *q + yv[i];
-        }
-    }
-}
-
-template <int KS>
-__global__ void __launch_bounds__(128) deep_fwd_kernel(const DeepArgs da) {
-    const ChanArgs &a = da.a;
-    using LD = DeepFwdLds;
-    extern __shared__ float smem[];
-    char *sm = reinterpret_cast<char *>(smem);
-    uint16_t *xs = reinterpret_cast<uint16_t *>(sm + LD::xs);
-    float *dsum = reinterpret_cast<float *>(sm + LD::dsum);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *wl = sm + LD::wave0 + wave * LD::wave_sz;
-    const int tiles = a.D / 64;
-    const int sb = blockIdx.x / tiles, c0 = (blockIdx.x - sb * tiles) * 64;
-    {   // the 64 x L bf16 planes of this (sample, tile): one contiguous run in HBM
-        const uint16_t *src = a.x + ((int64_t)sb * a.D + c0) * L;
-        for (int v = threadIdx.x; v < 64 * L / 2; v += 128) {
-            const uint32_t r = *reinterpret_cast<const uint32_t *>(src + 2 * v);
-            const int e = 2 * v, c = e / L, l = e - c * L;
-            xs[c * LP + l] = (uint16_t)(r & 0xffffu);
-            const int e1 = e + 1, c1 = e1 / L, l1 = e1 - c1 * L;
-            xs[c1 * LP + l1] = (uint16_t)(r >> 16);
-        }
-        if (threadIdx.x < 64) {
-            const int q = threadIdx.x;
-            dsum[q] = (a.Dp[c0 + q] + a.Dp[a.D + c0 + q]) + (a.Dp[2 * a.D + c0 + q] + a.Dp[3 * a.D + c0 + q]);
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        deep_fwd_pass<KS, true>(da, sb, c0, 0, xs, wl);
-        deep_fwd_pass<KS, false>(da, sb, c0, 2, xs, wl);
-    } else {
-        deep_fwd_pass<KS, true>(da, sb, c0, 1, xs, wl);
-        deep_fwd_pass<KS, false>(da, sb, c0, 3, xs, wl);
-    }
-    __syncthreads();
-    const float *y0 = reinterpret_cast<const float *>(sm + LD::wave0 + LD::yp);
-    const float *y1 = reinterpret_cast<const float *>(sm + LD::wave0 + LD::wave_sz + LD::yp);
-    float *dst = a.y + ((int64_t)sb * a.D + c0) * L;
-    for (int v = threadIdx.x; v < 64 * L / 4; v += 128) {
-        float o[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = 4 * v + q, c = e / L, l = e - c * L;
-            o[q] = fmaf(dsum[c], bf16_bits_to_float(xs[c * LP + l]), y0[e] + y1[e]);
-        }
-        *reinterpret_cast<float4 *>(dst + 4 * v) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-}
-
 // ---- backward --------------------------------------------------------------------------------------------------------
 // LDS of a workgroup: xs | gs [64][LP] bf16 | dsum [64] fp32 | per wave: dup [64][LP] bf16 (du planes), T [2][N][NSTEP][8]
 // fp32 (the B / C table; a state's dB / dC sums of a step overwrite the slots it has just read), stg [P][64] bf16,
@@ -1291,17 +1165,16 @@ static int deep_supported(int H, int W, int N_, int NR, int D, int R) {
     return H == 7 && W == 7 && N_ == 16 && NR == 4 && D % 64 == 0 && R >= 1 && R <= 48;
 }
 
-template <int KS> static int deep_launch(const DeepArgs &da, bool bwd, hipStream_t s) {
-    const size_t lds = bwd ? DeepBwdLds::total : DeepFwdLds::total;
-    const void *fn = bwd ? (const void *)deep_bwd_kernel<KS> : (const void *)deep_fwd_kernel<KS>;
-    static bool opted[2] = {false, false};
-    if (lds > 64 * 1024 && !opted[bwd]) {
+template <int KS> static int deep_launch(const DeepArgs &da, hipStream_t s) {
+    constexpr bool bwd = true;
+    const size_t lds = DeepBwdLds::total;
+    const void *fn = (const void *)deep_bwd_kernel<KS>;
+    static bool opted = false;
+    if (lds > 64 * 1024 && !opted) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
-        opted[bwd] = true;
+        opted = true;
     }
     DeepArgs args = da;
-    args.a.ct = 0;
-    if (const char *e = getenv("XFM_DEEP_DBG")) args.a.ct = atoi(e);    // timing-only switches
     void *kargs[] = {&args};
     // (a kernel, not a memset node: under stream capture the memset of this workspace slice replayed with stale contents)
     if (bwd) hipLaunchKernelGGL(deep_zero_kernel, dim3((4 * N * da.a.D + 255) / 256), dim3(256), 0, s, da.dAt, 4 * N * da.a.D);
@@ -1392,15 +1265,21 @@ static int chan_run(const xfm_ss2dc_params_t *p, bool bwd, void *stream) {
         return !(e && e[0] == '0');
     }();
     if (deep_on && deep::deep_supported(p->H, p->W, N, p->n_routes, p->d_inner, p->dt_rank)) {
-        // workspace (xfm_ss2dc_nsteps = 7 steps): packed bf16 checkpoints in the first half, the dA scratch behind
-        deep::DeepArgs da;
-        da.a = a;
-        da.chkp = reinterpret_cast<uint32_t *>(p->chk);
-        da.dAt = p->chk + (size_t)p->batch * 4 * deep::NSTEP * (deep::N / 2) * p->d_inner;   // (64 D floats of the second half)
-        switch (a.Kp / 16) {
-            case 1: return deep::deep_launch<1>(da, bwd, s);
-            case 2: return deep::deep_launch<2>(da, bwd, s);
-            case 3: return deep::deep_launch<3>(da, bwd, s);
+        // workspace (xfm_ss2dc_nsteps = 7 steps): packed bf16 checkpoints in the first half, the dA scratch behind.
+        // Forward: the first-design kernel (two directions per wave; 222 us against 307 us for a 64-lane forward of the
+        // second design) writing one packed checkpoint per row / column; backward: namespace deep.
+        if (!bwd) {
+            a.chk16 = reinterpret_cast<uint16_t *>(p->chk);
+        } else {
+            deep::DeepArgs da;
+            da.a = a;
+            da.chkp = reinterpret_cast<uint32_t *>(p->chk);
+            da.dAt = p->chk + (size_t)p->batch * 4 * deep::NSTEP * (deep::N / 2) * p->d_inner;   // (64 D floats of the second half)
+            switch (a.Kp / 16) {
+                case 1: return deep::deep_launch<1>(da, s);
+                case 2: return deep::deep_launch<2>(da, s);
+                case 3: return deep::deep_launch<3>(da, s);
+            }
         }
     }
     if (N == 1) {

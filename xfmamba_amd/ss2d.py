@@ -179,7 +179,9 @@ class SS2DProjCoreHip(torch.autograd.Function):
         p.y = y.data_ptr()
         isz = x.element_size()
         nbytes = Bt * Dm * L * (5 * isz + 4) + 2 * Bt * 4 * N * L * isz
-        with torch.cuda.device(x.device), _lib.timed("ss2d_fwd", nbytes):
+        # SURVEY 8(d), "dt_proj also fused" boundary: x, y and the x_proj rows (2 B D L + 4 B (R + 2N) L elements)
+        nbytes_f = Bt * Dm * L * (isz + 4) + Bt * 4 * (R + 2 * N) * L * isz
+        with torch.cuda.device(x.device), _lib.timed("ss2d_fwd", nbytes, nbytes_f):
             _lib.check(_lib.lib().xfm_ss2d_fwd(ctypes.byref(p), _lib.stream_ptr()), "ss2d_fwd")
         ctx.hw = (H, W)
         ctx.mode = mode
@@ -216,7 +218,9 @@ class SS2DProjCoreHip(torch.autograd.Function):
                                                    dbias.data_ptr())
         isz = x.element_size()
         nbytes = Bt * Dm * L * (10 * isz + 4) + 2 * Bt * 4 * N * L * (isz + 4)
-        with torch.cuda.device(dev), _lib.timed("ss2d_bwd", nbytes):
+        # the same boundary for the backward: x, dy, dx and the x_proj rows with their gradient (8 B per element + small)
+        nbytes_f = Bt * Dm * L * (2 * isz + 4) + 2 * Bt * 4 * (R + 2 * N) * L * isz
+        with torch.cuda.device(dev), _lib.timed("ss2d_bwd", nbytes, nbytes_f):
             _lib.check(_lib.lib().xfm_ss2d_bwd(ctypes.byref(p), _lib.stream_ptr()), "ss2d_bwd")
         if mfma_bwd:
             # dt_proj backward on MFMA: ddts is read once for the data gradient and once for the weight gradient
