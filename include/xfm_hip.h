@@ -339,30 +339,6 @@ int xfm_adam_multi(const void *p_ptrs, const void *g_ptrs, const void *m_ptrs, c
                    float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
 
 /*
- * K-looped MFMA tile GEMM on the token-major stream (csrc/tile_gemm.hip), bf16 in / bf16 out, fp32 accumulation:
- *   y (T, N) = x (T, K) . w (N, K)^T (+ bias (N) fp32, may be null).  K % 8 == 0, N % 8 == 0, 16-byte aligned pointers.
- * Replaces the nn.Linear products of the reference's Mlp (models/fusion_vmamba.py:135-153) whose weight does not fit
- * LDS whole (the resident-weight kernel xfm_tokens_gemm covers the others).
- */
-int xfm_tile_gemm(const void *x, const void *w, const float *bias, void *y, int64_t T, int K, int N, void *stream);
-
-/*
- * The 3x3 / stride 2 / padding 1 convolutions of the patch embedding and the downsampling layers
- * (models/fusion_vmamba.py:1362-1390, nn.Conv2d on NCHW) as implicit GEMMs of the same kernel on channels-last maps:
- *   fwd:   y (batch, Ho, Wo, N) = conv(x (batch, H, W, C)) + bias;  w9 (N, 3, 3, C) bf16 (the OIHW weight permuted);
- *          Ho = (H + 1) / 2, Wo = (W + 1) / 2
- *   dgrad: dx (batch, H, W, C) from dy (batch, H/2, W/2, N);  wt (3, 3, C, N) bf16;  H, W even (four launches, one per
- *          input-pixel parity class, each contracting only over the taps that reach it)
- * C % 8 == 0, N % 8 == 0.  (The weight gradient is a token-contracting product of dy with the gathered taps.)
- */
-int xfm_conv3x3s2_fwd(const void *x, const void *w9, const float *bias, void *y, int batch, int H, int W, int C, int N,
-                      void *stream);
-int xfm_conv3x3s2_dgrad(const void *dy, const void *wt, void *dx, int batch, int H, int W, int C, int N, void *stream);
-/* col (batch * Ho * Wo, 9 * C) bf16 = the gathered taps of x (batch, H, W, C), zeros outside the map: the token-major
- * operand of the weight-gradient product dW[n][(kh, kw, c)] = sum_t dy[t][n] col[t][(kh, kw, c)]. */
-int xfm_im2col3x3s2(const void *x, void *col, int batch, int H, int W, int C, void *stream);
-
-/*
  * Token-contracting product on the matrix cores (csrc/wgrad_gemm.hip): the weight gradient of a channel projection,
  *   dw (M, N) fp32 += sum over samples b and tokens l of a[b, l, m] * b[b, l, n]
  * Each operand is token-major (batch, L, C) or plane-major (batch, C, L) (x_planes != 0), bf16, with sample stride

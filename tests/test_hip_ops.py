@@ -751,82 +751,6 @@ def test_planes_gemm_xproj_forward_and_accumulating_backward(B, L):
 
 
 # ---------------------------------------------------------------------------------------------
-# K-looped tile GEMM and the implicit-GEMM 3x3 stride-2 convolutions (csrc/tile_gemm.hip)
-# ---------------------------------------------------------------------------------------------
-@pytest.mark.gpu
-@pytest.mark.parametrize("T,K,N", [(12544, 384, 1536), (12544, 1536, 384), (3136, 768, 3072), (1000, 192, 768), (77, 40, 24),
-                                   (4099, 3072, 768)])
-@pytest.mark.parametrize("bias", [False, True])
-def test_tile_gemm_matches_torch_fp32(T, K, N, bias):
-    """y = x . w^T + b on bf16 operands against the fp32 product of the same (bf16-rounded) operands; tolerance: one bf16
-    rounding of the output (2^-8 relative) plus fp32 accumulation-order noise."""
-    from xfmamba_amd import _lib
-    g = torch.Generator().manual_seed(T + K + N)
-    x = torch.randn(T, K, generator=g).bfloat16().to(DEV)
-    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(DEV)
-    b = torch.randn(N, generator=g).to(DEV) if bias else None
-    y = torch.empty(T, N, dtype=torch.bfloat16, device=DEV)
-    _lib.check(_lib.lib().xfm_tile_gemm(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), T, K, N, _lib.stream_ptr()),
-               "tile_gemm")
-    ref = x.float() @ w.float().t() + (b if bias else 0.0)
-    assert_close(y.float().cpu(), ref.cpu(), 8e-3, 8e-3 * float(ref.abs().max()), "y")
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("B,H,C,N", [(2, 56, 96, 192), (3, 28, 192, 384), (2, 14, 384, 768), (2, 112, 48, 96), (1, 10, 8, 24)])
-def test_conv3x3s2_implicit_gemm_matches_torch(B, H, C, N):
-    """Forward and data gradient of the 3x3 / stride-2 / pad-1 convolution on channels-last maps against F.conv2d in fp32
-    on the same bf16-rounded operands."""
-    from xfmamba_amd import _lib
-    import torch.nn.functional as F
-    g = torch.Generator().manual_seed(B * H + C)
-    x = torch.randn(B, H, H, C, generator=g).bfloat16().to(DEV)
-    w = (torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5).bfloat16().to(DEV)
-    bias = torch.randn(N, generator=g).to(DEV)
-    Ho = (H + 1) // 2
-    w9 = w.permute(0, 2, 3, 1).contiguous()                        # (N, 3, 3, C)
-    wt = w.permute(2, 3, 1, 0).contiguous()                        # (3, 3, C, N)
-    y = torch.empty(B, Ho, Ho, N, dtype=torch.bfloat16, device=DEV)
-    lib = _lib.lib()
-    _lib.check(lib.xfm_conv3x3s2_fwd(x.data_ptr(), w9.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, H, C, N,
-                                     _lib.stream_ptr()), "conv fwd")
-    xr = x.float().permute(0, 3, 1, 2).requires_grad_()
-    ref = F.conv2d(xr, w.float(), bias, stride=2, padding=1)
-    assert_close(y.float().permute(0, 3, 1, 2).cpu(), ref.detach().cpu(), 8e-3, 8e-3 * float(ref.abs().max()), "y")
-    dy = torch.randn(B, Ho, Ho, N, generator=g).bfloat16().to(DEV)
-    ref.backward(dy.float().permute(0, 3, 1, 2))
-    dx = torch.full((B, H, H, C), float("nan"), dtype=torch.bfloat16, device=DEV)
-    _lib.check(lib.xfm_conv3x3s2_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), B, H, H, C, N, _lib.stream_ptr()),
-               "conv dgrad")
-    assert_close(dx.float().permute(0, 3, 1, 2).cpu(), xr.grad.cpu(), 8e-3, 8e-3 * float(xr.grad.abs().max()), "dx")
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("B,H,C,N", [(2, 56, 96, 192), (2, 14, 384, 768), (3, 12, 16, 24)])
-def test_conv3x3s2_tokens_autograd_matches_conv2d(B, H, C, N):
-    """conv3x3s2_tokens_fn (forward, data and weight gradients) against F.conv2d in fp32 on the same bf16-rounded
-    operands.  Tolerances: one bf16 rounding of each output / gradient."""
-    import torch.nn.functional as F
-    from xfmamba_amd.conv_tokens import conv3x3s2_tokens_fn      # (the op itself; the model only routes here with XFM_CONV_TOKENS=1)
-    g = torch.Generator().manual_seed(H + C)
-    x = torch.randn(B, H, H, C, generator=g).bfloat16()
-    w = (torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5).bfloat16().float()       # fp32 master, bf16-representable
-    dy = torch.randn(B, H // 2, H // 2, N, generator=g).bfloat16()
-    xh = x.to(DEV).requires_grad_()
-    wh = w.to(DEV).requires_grad_()
-    y = conv3x3s2_tokens_fn(xh, wh)
-    y.backward(dy.to(DEV))
-    xr = x.float().permute(0, 3, 1, 2).requires_grad_()
-    wr = w.clone().requires_grad_()
-    ref = F.conv2d(xr, wr, None, stride=2, padding=1)
-    ref.backward(dy.float().permute(0, 3, 1, 2))
-    assert_close(y.float().permute(0, 3, 1, 2).cpu(), ref.detach(), 8e-3, 8e-3 * float(ref.abs().max()), "y")
-    assert_close(xh.grad.float().permute(0, 3, 1, 2).cpu(), xr.grad, 8e-3, 8e-3 * float(xr.grad.abs().max()), "dx")
-    assert wh.grad.dtype == torch.float32
-    assert_close(wh.grad.cpu(), wr.grad, 8e-3, 8e-3 * float(wr.grad.abs().max()), "dw")
-
-
-# ---------------------------------------------------------------------------------------------
 # token-contracting weight-gradient kernel (csrc/wgrad_gemm.hip)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu

@@ -28,7 +28,7 @@ SYMBOLS = (
     "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd",
     "xfm_ss2dc_supported", "xfm_ss2dc_nsteps", "xfm_ss2dc_fwd", "xfm_ss2dc_bwd", "xfm_ss2dc_post",
     "xfm_fp8_planes_gemm_supported", "xfm_fp8_planes_gemm", "xfm_adam_multi",
-    "xfm_tile_gemm", "xfm_conv3x3s2_fwd", "xfm_conv3x3s2_dgrad", "xfm_im2col3x3s2", "xfm_wgrad_supported", "xfm_wgrad",
+    "xfm_wgrad_supported", "xfm_wgrad",
 )
 
 
@@ -115,10 +115,6 @@ def lib() -> C.CDLL:
         l.xfm_fp8_planes_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
         l.xfm_adam_multi.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p] + [C.c_float] * 5 + [C.c_void_p]
         l.xfm_ss2dc_post.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]
-        l.xfm_tile_gemm.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]
-        l.xfm_conv3x3s2_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
-        l.xfm_conv3x3s2_dgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]
-        l.xfm_im2col3x3s2.argtypes = [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]
         l.xfm_wgrad_supported.argtypes = [C.c_int] * 5
         l.xfm_wgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_int64] * 2 + [C.c_int] * 2 + [C.c_void_p]
         l.xfm_cross_scan.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]

@@ -41,7 +41,6 @@ from .mlp_tokens import linear_tokens_fn, mlp_tokens_fn
 from .proj import batched_proj
 from .rowln import add_layernorm_rows_fn, layernorm_rows_fn, rows_supported
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
-from .conv_tokens import conv3x3s2_tokens_enabled, conv3x3s2_tokens_fn, conv3x3s2_tokens_ok
 from .ss2d_chan import chan_supported, ss2d_chan_fn
 from . import fp8 as _fp8
 
@@ -529,19 +528,10 @@ def _conv_ln_tokens(conv: nn.Conv2d, norm: nn.Module, t: torch.Tensor, out_dtype
     fused = isinstance(norm, LayerNorm2d)
     if t.dtype != conv.weight.dtype and not torch.is_autocast_enabled():
         t = t.to(conv.weight.dtype)                      # fp32 residual stream into a reduced-precision model
-    # (the cheap static checks first: the bf16 copy of the map is only made when the token path will take it)
-    tc = None
-    if fused and conv3x3s2_tokens_enabled():
-        tc = t.to(torch.bfloat16) if (torch.is_autocast_enabled() and t.is_cuda
-                                      and torch.get_autocast_gpu_dtype() == torch.bfloat16) else t
-    if tc is not None and conv3x3s2_tokens_ok(conv, tc):
-        # implicit GEMM on the matrix cores straight from the channels-last map (csrc/tile_gemm.hip)
-        y = conv3x3s2_tokens_fn(tc, conv.weight)
-    else:
-        y = F.conv2d(t.permute(0, 3, 1, 2), conv.weight, None if fused else conv.bias, conv.stride, conv.padding,
-                     conv.dilation, conv.groups)
-        y = y.permute(0, 2, 3, 1)
-        y = y if y.is_contiguous() else y.contiguous()
+    y = F.conv2d(t.permute(0, 3, 1, 2), conv.weight, None if fused else conv.bias, conv.stride, conv.padding,
+                 conv.dilation, conv.groups)
+    y = y.permute(0, 2, 3, 1)
+    y = y if y.is_contiguous() else y.contiguous()
     if not fused:
         return y if out_dtype is None else y.to(out_dtype)
     if y.dtype not in (torch.float32, torch.bfloat16):
