@@ -265,6 +265,13 @@ typedef struct {
 int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, int in_dtype, xfm_scan_plan_t *plan);
 int xfm_ss2d_fwd(const xfm_ss2d_params_t *p, void *stream);
 int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream);
+/* The same backward with a caller-owned scratch buffer.  Where the kernel family supports it (the wide-map kernels of
+ * csrc/ss2d_l3.hip) each workgroup then STORES its partial dB / dC sums there and a second small kernel sums them into dBs /
+ * dCs (which need not be zeroed then) -- plain stores and one streaming pass instead of float atomics, which the chip
+ * retires at ~1.3 TB/s (51 MB per 56 x 56 launch).  xfm_ss2d_bwd_ws_bytes: the size to pass (0: no use for a workspace;
+ * xfm_ss2d_bwd_ws then behaves as xfm_ss2d_bwd).  Same adjoint as selective_scan_bwd_kernel.cuh:141-273. */
+size_t xfm_ss2d_bwd_ws_bytes(const xfm_ss2d_params_t *p);
+int xfm_ss2d_bwd_ws(const xfm_ss2d_params_t *p, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * "Channel-lane" fused SS2D core for short square maps (5x5 ... 14x14; csrc/ss2d_chan.hip): x_proj output ->

@@ -25,7 +25,7 @@ SYMBOLS = (
     "xfm_dwconv3x3_fwd", "xfm_dwconv3x3_bwd", "xfm_layernorm2d_fwd", "xfm_layernorm2d_bwd",
     "xfm_add_layernorm_rows_supported", "xfm_add_layernorm_rows_bwd_blocks", "xfm_add_layernorm_rows_fwd",
     "xfm_add_layernorm_rows_bwd", "xfm_colsum_blocks", "xfm_bias_gelu_fwd", "xfm_bias_gelu_bwd", "xfm_colsum", "xfm_tokens_gemm_supported", "xfm_tokens_gemm", "xfm_proj_gemm_supported", "xfm_proj_gemm", "xfm_planes_gemm_supported", "xfm_planes_gemm",
-    "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd",
+    "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd", "xfm_ss2d_bwd_ws_bytes", "xfm_ss2d_bwd_ws",
     "xfm_ss2dc_supported", "xfm_ss2dc_nsteps", "xfm_ss2dc_fwd", "xfm_ss2dc_bwd", "xfm_ss2dc_post",
     "xfm_fp8_planes_gemm_supported", "xfm_fp8_planes_gemm", "xfm_adam_multi",
     "xfm_wgrad_supported", "xfm_wgrad",
@@ -106,6 +106,10 @@ def lib() -> C.CDLL:
         for fn in (l.xfm_ss2d_fwd, l.xfm_ss2d_bwd):
             fn.argtypes = [C.POINTER(SS2DParams), C.c_void_p]
             fn.restype = C.c_int
+        l.xfm_ss2d_bwd_ws_bytes.argtypes = [C.POINTER(SS2DParams)]
+        l.xfm_ss2d_bwd_ws_bytes.restype = C.c_size_t
+        l.xfm_ss2d_bwd_ws.argtypes = [C.POINTER(SS2DParams), C.c_void_p, C.c_size_t, C.c_void_p]
+        l.xfm_ss2d_bwd_ws.restype = C.c_int
         for fn in (l.xfm_ss2dc_fwd, l.xfm_ss2dc_bwd):
             fn.argtypes = [C.POINTER(SS2DCParams), C.c_void_p]
             fn.restype = C.c_int

@@ -238,9 +238,10 @@ int ss2d_launch_lean(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bw
     return check_launch();
 }
 
-int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s);   // ss2d_l3.hip: wide maps, two waves per SIMD
+int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, size_t ws_bytes);   // ss2d_l3.hip: wide maps
+size_t ss2d_l3_ws_bytes(const xfm_ss2d_params_t *p);
 
-static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream) {
+static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream, float *ws = nullptr, size_t ws_bytes = 0) {
     if (!p || !p->x || !p->dts || !p->Bs || !p->Cs || !p->A || !p->D || !p->delta_bias) return XFM_EINVAL;
     if (!bwd && !p->y) return XFM_EINVAL;
     if (bwd && (!p->dy || !p->dx || !p->ddts || !p->dBs || !p->dCs || !p->dA || !p->dD || !p->ddelta_bias))
@@ -248,7 +249,7 @@ static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream) {
     if (p->in_dtype < 0 || p->in_dtype > 2) return XFM_EDTYPE;
     if (p->out_dtype != XFM_F32) return XFM_EDTYPE;          // the fused core always emits fp32 ("oflex")
     if (!getenv("XFM_SS2D_FORCE")) {
-        const int rc3 = ss2d_l3_run(p, bwd, (hipStream_t)stream);
+        const int rc3 = ss2d_l3_run(p, bwd, (hipStream_t)stream, ws, ws_bytes);
         if (rc3 != XFM_ELIMIT) return rc3;
     }
     Plan2 pl;
@@ -298,4 +299,12 @@ int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, int in_dtype
 }
 int xfm_ss2d_fwd(const xfm_ss2d_params_t *p, void *stream) { return xfm::run2(p, false, stream); }
 int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream) { return xfm::run2(p, true, stream); }
+size_t xfm_ss2d_bwd_ws_bytes(const xfm_ss2d_params_t *p) {
+    if (!p || getenv("XFM_SS2D_FORCE") || getenv("XFM_L3_ATOMICS")) return 0;
+    const char *e = getenv("XFM_SS2D_L3");
+    return (e && e[0] == '0') ? 0 : xfm::ss2d_l3_ws_bytes(p);
+}
+int xfm_ss2d_bwd_ws(const xfm_ss2d_params_t *p, void *workspace, size_t workspace_bytes, void *stream) {
+    return xfm::run2(p, true, stream, (float *)workspace, workspace_bytes);
+}
 }

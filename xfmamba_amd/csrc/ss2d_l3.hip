@@ -831,10 +831,33 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
         for (int e = lane; e < G::LSZ; e += 64)
             stage[G::NREG * G::ROW + (e & ~7) + (REV ? 7 - (e & 7) : (e & 7))] = ldsacc[pass * G::LSZ + e];
         wave_sync();
-        float *dst = pass ? dCg : dBg;
-        for (int e = lane; e < L; e += 64) atomicAdd(dst + e, stage[e]);
+        if (a.parts) {
+            // plain coalesced stores of this workgroup's sums; ss2d_l3_parts_kernel adds the groups of a sample up
+            float *dst = a.parts + ((((int64_t)b * groups_pb + tg) * 4 + k) * 2 + pass) * L;
+            for (int e = lane; e < L; e += 64) dst[e] = stage[e];
+        } else {
+            float *dst = pass ? dCg : dBg;
+            for (int e = lane; e < L; e += 64) atomicAdd(dst + e, stage[e]);
+        }
         wave_sync();
     }
+}
+
+// dBs / dCs (batch, 4, L) = sum over the workgroups of a sample of their partial sums (batch, groups, 4, 2, L)
+__global__ void __launch_bounds__(256) ss2d_l3_parts_kernel(const float *__restrict__ parts, float *__restrict__ dBs,
+                                                            float *__restrict__ dCs, const int groups, const int L) {
+    const int bk = blockIdx.y, b = bk >> 2, k = bk & 3;
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= L) return;
+    float4 sB = {0.f, 0.f, 0.f, 0.f}, sC = sB;
+    for (int g = 0; g < groups; ++g) {
+        const float *p = parts + ((((int64_t)b * groups + g) * 4 + k) * 2) * L + e;
+        const float4 vb = *reinterpret_cast<const float4 *>(p), vc = *reinterpret_cast<const float4 *>(p + L);
+        sB.x += vb.x; sB.y += vb.y; sB.z += vb.z; sB.w += vb.w;
+        sC.x += vc.x; sC.y += vc.y; sC.z += vc.z; sC.w += vc.w;
+    }
+    *reinterpret_cast<float4 *>(dBs + (int64_t)bk * L + e) = sB;
+    *reinterpret_cast<float4 *>(dCs + (int64_t)bk * L + e) = sC;
 }
 
 // kernel: wave w owns route {0,2,1,3}[w];
@@ -851,7 +874,19 @@ __global__ void __launch_bounds__(256, L3_WPE) ss2d_l3_bwd_kernel(const LeanArgs
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool bwd, hipStream_t s) {
+static int l3_pli(int batch, int tiles_pb, bool bwd) {
+    // tiles per workgroup: ONE round of the resident workgroups (2 per CU backward, 4 forward).  The dB / dC flush of a
+    // workgroup is 8 L floats; as float atomics (~1.3 TB/s chip-wide) 1024 workgroups spend 79 us of a 56 x 56 launch there.
+    const int resident = bwd ? 512 : 256 * L3_WPE_FWD;
+    int pli = (int)(((int64_t)batch * tiles_pb + resident - 1) / resident);
+    if (pli < 1) pli = 1;
+    if (pli > tiles_pb) pli = tiles_pb;
+    if (const char *e = getenv("XFM_L3_PLI")) pli = std::max(1, std::min(tiles_pb, atoi(e)));   // tuning hook
+    while (tiles_pb % pli) --pli;
+    return pli;
+}
+
+template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool bwd, hipStream_t s, float *ws, size_t ws_bytes) {
     using G = L3Geom<HW>;
     constexpr int L = G::L, PL = PPT * L;
     const int D = p.d_inner;
@@ -868,16 +903,12 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
     la.magicH = la.magicW;
     la.dbg = 0;                                        // timing-only switches: 1 skip sweeps, 2 skip plane staging, 4 skip merge,
     if (const char *e = getenv("XFM_L3_DBG")) la.dbg = atoi(e);   // 16 no operand prefetch, 32 no ddts / dx stores
-    // tiles per workgroup: ONE round of the resident workgroups (2 per CU).  The dB / dC flush of a workgroup is 8 L
-    // float atomics; at the chip's ~1.3 TB/s of atomic bytes 1024 workgroups spend 79 us of a 56 x 56 launch there.
     const int tiles_pb = D / PPT;
-    const int resident = bwd ? 512 : 256 * L3_WPE_FWD;
-    int pli = (int)(((int64_t)p.batch * tiles_pb + resident - 1) / resident);
-    if (pli < 1) pli = 1;
-    if (pli > tiles_pb) pli = tiles_pb;
-    if (const char *e = getenv("XFM_L3_PLI")) pli = std::max(1, std::min(tiles_pb, atoi(e)));   // tuning hook
-    while (tiles_pb % pli) --pli;
+    const int pli = l3_pli(p.batch, tiles_pb, bwd);
     la.pli = pli;
+    const int groups = tiles_pb / pli;
+    const size_t need = (size_t)p.batch * groups * 4 * 2 * L * sizeof(float);
+    la.parts = (bwd && ws && ws_bytes >= need && groups > 1 && L % 4 == 0) ? ws : nullptr;
     const size_t lds = bwd ? (size_t)8 * PL * 2 + (size_t)4 * 2 * G::LSZ * sizeof(float) : (size_t)6 * PL * 2;
     const void *fn;
     if (bwd)
@@ -896,11 +927,14 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
         set_last_hip_error(e);
         return XFM_ELAUNCH;
     }
+    if (la.parts)
+        hipLaunchKernelGGL(ss2d_l3_parts_kernel, dim3((L / 4 + 255) / 256, p.batch * 4), dim3(256), 0, s, la.parts, p.dBs, p.dCs,
+                           groups, L);
     return check_launch();
 }
 
 // XFM_ELIMIT: shape / dtype not covered here, the caller falls back to the lean / generic kernels
-int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s) {
+int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, size_t ws_bytes) {
     static const bool enabled = [] {
         const char *e = getenv("XFM_SS2D_L3");
         return !(e && e[0] == '0');
@@ -915,10 +949,20 @@ int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s) {
     if (p->delta_softplus < 0 || p->delta_softplus > 2) return XFM_ELIMIT;
     if ((p->H == 56 || p->H == 28) && !p->chk) return XFM_EINVAL;     // multi-chunk rows need the forward's checkpoints
     switch (p->H) {
-        case 56: return l3_launch<56, 1>(*p, bwd, s);
-        case 28: return l3_launch<28, 4>(*p, bwd, s);
+        case 56: return l3_launch<56, 1>(*p, bwd, s, ws, ws_bytes);
+        case 28: return l3_launch<28, 4>(*p, bwd, s, ws, ws_bytes);
     }
     return XFM_ELIMIT;
+}
+
+// bytes of the partial-sum workspace the backward can use (0: shape not covered here)
+size_t ss2d_l3_ws_bytes(const xfm_ss2d_params_t *p) {
+    if (p->in_dtype != XFM_BF16 || p->dstate != 1 || p->H != p->W || (p->H != 56 && p->H != 28)) return 0;
+    const int ppt = p->H == 56 ? 1 : 4;
+    if (p->d_inner % ppt) return 0;
+    const int tiles_pb = p->d_inner / ppt;
+    const int groups = tiles_pb / l3_pli(p->batch, tiles_pb, true);
+    return groups > 1 ? (size_t)p->batch * groups * 4 * 2 * p->H * p->W * sizeof(float) : 0;
 }
 
 }  // namespace xfm

@@ -220,8 +220,11 @@ class SS2DProjCoreHip(torch.autograd.Function):
         nbytes = Bt * Dm * L * (10 * isz + 4) + 2 * Bt * 4 * N * L * (isz + 4)
         # the same boundary for the backward: x, dy, dx and the x_proj rows with their gradient (8 B per element + small)
         nbytes_f = Bt * Dm * L * (2 * isz + 4) + 2 * Bt * 4 * (R + 2 * N) * L * isz
+        # scratch for the workgroups' partial dB / dC sums (wide-map kernels: stores + one summing pass instead of atomics)
+        wsb = lib.xfm_ss2d_bwd_ws_bytes(ctypes.byref(p))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         with torch.cuda.device(dev), _lib.timed("ss2d_bwd", nbytes, nbytes_f):
-            _lib.check(_lib.lib().xfm_ss2d_bwd(ctypes.byref(p), _lib.stream_ptr()), "ss2d_bwd")
+            _lib.check(lib.xfm_ss2d_bwd_ws(ctypes.byref(p), _lib.ptr(ws), wsb, _lib.stream_ptr()), "ss2d_bwd")
         if mfma_bwd:
             # dt_proj backward on MFMA: ddts is read once for the data gradient and once for the weight gradient
             dxr = torch.empty_like(xr)
