@@ -4,7 +4,7 @@
 # PMC pass for the matrix-core utilisation of the GEMM kernels.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/measure_$R
 rm -rf $O && mkdir -p $O
 python3 bench.py > $O/bench_line.json 2> $O/bench.err

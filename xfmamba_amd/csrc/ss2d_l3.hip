@@ -420,15 +420,15 @@ __device__ __forceinline__ void l3_fwd_body(const LeanArgs &a, float *smem, cons
         asm volatile("v_mov_b32 %0, 0" : "=v"(tz));
         const int tid = threadIdx.x + tz;
         if constexpr (HW % 8 == 0) {
-            uint4 px[NVX];
             constexpr int nvx = PL / 8;
-#pragma unroll
-            for (int m = 0; m < NVX; ++m)
-                if (tid + m * 256 < nvx) px[m] = *reinterpret_cast<const uint4 *>((const bf16_t *)a.x + po + (tid + m * 256) * 8);
+            static_assert(NVX == 2, "staging registers are spelled out");
+            const bf16_t *xs_ = (const bf16_t *)a.x + po;
+            const int v0 = tid, v1 = tid + 256;
+            const uint4 px0 = *reinterpret_cast<const uint4 *>(xs_ + (v0 < nvx ? v0 : 0) * 8);
+            const uint4 px1 = *reinterpret_cast<const uint4 *>(xs_ + (v1 < nvx ? v1 : 0) * 8);
             __syncthreads();                           // (the previous tile's output pass has read xN / xT)
-#pragma unroll
-            for (int m = 0; m < NVX; ++m)
-                if (tid + m * 256 < nvx) *reinterpret_cast<uint4 *>(xN + (tid + m * 256) * 8) = px[m];
+            if (v0 < nvx) *reinterpret_cast<uint4 *>(xN + v0 * 8) = px0;
+            if (v1 < nvx) *reinterpret_cast<uint4 *>(xN + v1 * 8) = px1;
             __syncthreads();
             l3_transpose_pass<HW, PPT>(xN, xT, tid);
         } else {
@@ -730,33 +730,31 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
         asm volatile("v_mov_b32 %0, 0" : "=v"(tz));    // opaque zero: keeps the per-thread tile positions out of registers
         const int tid = threadIdx.x + tz;
         if constexpr (HW % 8 == 0) {
-            uint4 px[NVX];
-            float4 pg[NVG];
+            // Register staging in memory order.  (Named scalars, not arrays: hipcc left a uint4 / float4 array as an alloca --
+            // 48 bytes of scratch per lane and plane, the vectors stored and re-read around the barrier: 1.9x the algorithmic
+            // HBM bytes in the PMC counters.  Requesting the NEXT tile's vectors before the sweeps was tried: the 24 live
+            // registers push the kernel over 256 and the spills cost what the hidden round trip gains.)
             constexpr int nvx = PL / 8, nvg = PL / 4;
-            if (!(a.dbg & 2)) {
-#pragma unroll
-                for (int m = 0; m < NVX; ++m)
-                    if (tid + m * 256 < nvx) px[m] = *reinterpret_cast<const uint4 *>((const bf16_t *)a.x + po + (tid + m * 256) * 8);
-#pragma unroll
-                for (int m = 0; m < NVG; ++m)
-                    if (tid + m * 256 < nvg) pg[m] = *reinterpret_cast<const float4 *>((const float *)a.dy + po + (tid + m * 256) * 4);
-            }
+            static_assert(NVX == 2 && NVG == 4, "staging registers are spelled out");
+            const bf16_t *xs_ = (const bf16_t *)a.x + po;
+            const float *gs_ = (const float *)a.dy + po;
+            const int v0 = tid, v1 = tid + 256, v2 = tid + 512, v3 = tid + 768;
+            const uint4 px0 = *reinterpret_cast<const uint4 *>(xs_ + (v0 < nvx ? v0 : 0) * 8);
+            const uint4 px1 = *reinterpret_cast<const uint4 *>(xs_ + (v1 < nvx ? v1 : 0) * 8);
+            const float4 pg0 = *reinterpret_cast<const float4 *>(gs_ + (v0 < nvg ? v0 : 0) * 4);
+            const float4 pg1 = *reinterpret_cast<const float4 *>(gs_ + (v1 < nvg ? v1 : 0) * 4);
+            const float4 pg2 = *reinterpret_cast<const float4 *>(gs_ + (v2 < nvg ? v2 : 0) * 4);
+            const float4 pg3 = *reinterpret_cast<const float4 *>(gs_ + (v3 < nvg ? v3 : 0) * 4);
             __syncthreads();                           // (the previous tile's merge has read the planes)
-            if (!(a.dbg & 2)) {
-#pragma unroll
-                for (int m = 0; m < NVX; ++m)
-                    if (tid + m * 256 < nvx) *reinterpret_cast<uint4 *>(xN + (tid + m * 256) * 8) = px[m];
-#pragma unroll
-                for (int m = 0; m < NVG; ++m)
-                    if (tid + m * 256 < nvg)
-                        *reinterpret_cast<uint2 *>(gN + (tid + m * 256) * 4) =
-                            make_uint2(pack_bf16x2(pg[m].x, pg[m].y), pack_bf16x2(pg[m].z, pg[m].w));
-            }
+            if (v0 < nvx) *reinterpret_cast<uint4 *>(xN + v0 * 8) = px0;
+            if (v1 < nvx) *reinterpret_cast<uint4 *>(xN + v1 * 8) = px1;
+            auto put_g = [&](const int v, const float4 g4) {
+                if (v < nvg) *reinterpret_cast<uint2 *>(gN + v * 4) = make_uint2(pack_bf16x2(g4.x, g4.y), pack_bf16x2(g4.z, g4.w));
+            };
+            put_g(v0, pg0); put_g(v1, pg1); put_g(v2, pg2); put_g(v3, pg3);
             __syncthreads();
-            if (!(a.dbg & 2)) {
-                l3_transpose_pass<HW, PPT>(xN, xT, tid);
-                l3_transpose_pass<HW, PPT>(gN, gT, tid);
-            }
+            l3_transpose_pass<HW, PPT>(xN, xT, tid);
+            l3_transpose_pass<HW, PPT>(gN, gT, tid);
         } else {
             PlaneRegs<bf16_t, 8, NVX> px;
             PlaneRegs<float, 4, NVG> pg;
