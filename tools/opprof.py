@@ -36,7 +36,11 @@ def main():
     from xfmamba_amd.amp import WeightCache
     buckets = GradBuckets(model, bucket_mb=48.0)
     wcache = WeightCache(model)                                   # as bench.py: bf16 weight shadows, one refresh per step
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
+    from xfmamba_amd.optim import FusedAdam
+    from xfmamba_amd.proj import WgradArena, set_wgrad_arena
+    opt = FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-5, weight_cache=wcache)      # as bench.py
+    arena = WgradArena(model.parameters())
+    set_wgrad_arena(arena)
     crit = torch.nn.CrossEntropyLoss()
     B = a.batch
     xa = torch.randn(B, 1, 224, 224, device=dev)
@@ -45,13 +49,13 @@ def main():
 
     def step():
         buckets.zero_grad()
+        arena.zero()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             out = model(xa, xb)
             loss = crit(out.float(), lab)
         loss.backward()
         buckets.finish()
         opt.step()
-        wcache.refresh()
 
     for _ in range(4):
         step()

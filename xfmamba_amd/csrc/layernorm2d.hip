@@ -164,6 +164,79 @@ __global__ void __launch_bounds__(64 * NW) ln2d_bwd_dx_kernel(const Tx *__restri
     }
 }
 
+// ---- short maps with wide rows (the 7 x 7 stage: 768 ... 1536 channels, a few thousand positions in all).  Lanes along the
+// positions leave the chip mostly idle there (64 x 49 positions = 49 workgroups) and the register-cached form needs 2 x 48
+// values per thread under the 128-register cap of a 16-wave workgroup (58 spills, 65 us for 24 MB).  Here a workgroup owns
+// 16 positions and splits the channels 16 ways across its threads; two passes over L2-resident data, no caching.
+template <typename Tx, typename Ty>
+__global__ void __launch_bounds__(256) ln2d_bwd_dx_short_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                                const Ty *__restrict__ dy, const float *__restrict__ mean,
+                                                                const float *__restrict__ rstd, Tx *__restrict__ dx, int C,
+                                                                int L, int NP) {
+    constexpr int UNR = 4;
+    __shared__ float red[2][16][17];
+    const int pi = threadIdx.x & 15, cs = threadIdx.x >> 4;
+    const int P = blockIdx.x * 16 + pi;
+    const bool ok = P < NP;
+    const int b = ok ? P / L : 0, p = ok ? P - b * L : 0;
+    const int64_t o = (int64_t)b * C * L + p;
+    const float mu = ok ? mean[(int64_t)b * L + p] : 0.f, rs = ok ? rstd[(int64_t)b * L + p] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok) {
+        int c = cs;
+        for (; c + (UNR - 1) * 16 < C; c += UNR * 16) {
+            float g[UNR], xv[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                g[q] = ldf<Ty>(dy + o + (int64_t)(c + q * 16) * L);
+                xv[q] = ldf<Tx>(x + o + (int64_t)(c + q * 16) * L);
+            }
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const float gg = g[q] * w[c + q * 16];
+                s1 += gg;
+                s2 = fmaf(gg, (xv[q] - mu) * rs, s2);
+            }
+        }
+        for (; c < C; c += 16) {
+            const float g = ldf<Ty>(dy + o + (int64_t)c * L) * w[c];
+            s1 += g;
+            s2 = fmaf(g, (ldf<Tx>(x + o + (int64_t)c * L) - mu) * rs, s2);
+        }
+    }
+    red[0][cs][pi] = s1;
+    red[1][cs][pi] = s2;
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        m1 += red[0][q][pi];
+        m2 += red[1][q][pi];
+    }
+    m1 /= (float)C;
+    m2 /= (float)C;
+    if (ok) {
+        int c = cs;
+        for (; c + (UNR - 1) * 16 < C; c += UNR * 16) {
+            float g[UNR], xv[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                g[q] = ldf<Ty>(dy + o + (int64_t)(c + q * 16) * L);
+                xv[q] = ldf<Tx>(x + o + (int64_t)(c + q * 16) * L);
+            }
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const int cc = c + q * 16;
+                stf<Tx>(dx + o + (int64_t)cc * L, rs * (g[q] * w[cc] - m1 - (xv[q] - mu) * rs * m2));
+            }
+        }
+        for (; c < C; c += 16) {
+            const float g = ldf<Ty>(dy + o + (int64_t)c * L) * w[c];
+            stf<Tx>(dx + o + (int64_t)c * L, rs * (g - m1 - (ldf<Tx>(x + o + (int64_t)c * L) - mu) * rs * m2));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // register-cached variants: C == CPT * NW.  The workgroup has NW waves (<= 16); lane = position, each thread
 // keeps its CPT channel values in registers, so x (and dy) are read from HBM exactly once.
@@ -540,6 +613,10 @@ static int ln_bwd(const void *x, const float *w, const void *dy, const float *me
         }
     }
     if (done) {
+    } else if (C >= 512 && (int64_t)B * L <= 16 * 1024) {
+        // short maps, wide rows (7 x 7 at 768 / 1536 channels): positions x channel slices instead of lanes along positions
+        hipLaunchKernelGGL((ln2d_bwd_dx_short_kernel<Tx, Ty>), dim3((B * L + 15) / 16), dim3(256), 0, s, (const Tx *)x, w,
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L);
     } else if (C % 24 == 0 && C / 24 <= 16) {
         const int NW = C / 24;
         hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 24>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,

@@ -73,8 +73,14 @@ struct WgOperand {
                 const int idx = tid + 256 * v, chn = idx >> 4, l = l0 + 4 * (idx & 15);
                 const int c = c0 + chn;
                 pv[v] = wg_u32x2_t{0, 0};
-                if (c < C && l < L) {                                   // (L % 4 == 0: a group of 4 tokens is in or out whole)
-                    pv[v] = *reinterpret_cast<const wg_u32x2_t *>(base + sample * bs + (int64_t)c * L + l);
+                if (c < C && l < L) {
+                    const uint16_t *p = base + sample * bs + (int64_t)c * L + l;
+                    if ((L & 3) == 0) {                                 // a group of 4 tokens is in or out whole, 8-byte aligned
+                        pv[v] = *reinterpret_cast<const wg_u32x2_t *>(p);
+                    } else {                                            // ragged rows (7 x 7 maps: 49 tokens): 2-byte loads
+                        const uint32_t e0 = p[0], e1 = l + 1 < L ? p[1] : 0u, e2 = l + 2 < L ? p[2] : 0u, e3 = l + 3 < L ? p[3] : 0u;
+                        pv[v] = wg_u32x2_t{e0 | (e1 << 16), e2 | (e3 << 16)};
+                    }
                 }
             }
         }
@@ -365,8 +371,8 @@ extern "C" {
 
 int xfm_wgrad_supported(int M, int N, int L, int a_planes, int b_planes) {
     if (M <= 0 || N <= 0 || L <= 0) return 0;
-    if (a_planes ? (L % 4 != 0) : (M % 8 != 0)) return 0;
-    if (b_planes ? (L % 4 != 0) : (N % 8 != 0)) return 0;
+    if (!a_planes && M % 8 != 0) return 0;                  // token-major rows are read in 16-byte vectors
+    if (!b_planes && N % 8 != 0) return 0;
     return 1;
 }
 
@@ -376,7 +382,10 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     if (!a || !b || !dw || batch <= 0) return XFM_EINVAL;
     if (!xfm_wgrad_supported(M, N, L, a_planes, b_planes)) return XFM_ELIMIT;
     if (((uintptr_t)a & 15) || ((uintptr_t)b & 15)) return XFM_EINVAL;
-    if ((!a_planes && (a_bs % 8)) || (!b_planes && (b_bs % 8)) || (a_planes && (a_bs % 4)) || (b_planes && (b_bs % 4))) return XFM_EINVAL;
+    const bool rag = (L & 3) != 0;                           // plane-major rows of ragged length: no alignment needed
+    if ((!a_planes && (a_bs % 8)) || (!b_planes && (b_bs % 8)) || (a_planes && !rag && (a_bs % 4)) || (b_planes && !rag && (b_bs % 4)))
+        return XFM_EINVAL;
+    if (rag && (((uintptr_t)a | (uintptr_t)b) & 1)) return XFM_EINVAL;
     WgradArgs w{};
     w.a = (const uint16_t *)a; w.b = (const uint16_t *)b; w.dw = dw;
     w.M = M; w.N = N; w.batch = batch; w.L = L; w.a_bs = a_bs; w.b_bs = b_bs;

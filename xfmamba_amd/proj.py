@@ -131,7 +131,8 @@ def wgrad_mfma(a: torch.Tensor, a_planes: bool, b: torch.Tensor, b_planes: bool,
             or not lib.xfm_wgrad_supported(M, N, L, int(a_planes), int(b_planes)):
         return None
     a_bs, b_bs = (a.stride(0) if Bt > 1 else a.shape[1] * a.shape[2]), (b.stride(0) if Bt > 1 else b.shape[1] * b.shape[2])
-    if (a_bs % (4 if a_planes else 8)) or (b_bs % (4 if b_planes else 8)):
+    rag = L % 4 != 0                                        # ragged plane rows (7 x 7 maps) are read element-wise
+    if (a_bs % ((1 if rag else 4) if a_planes else 8)) or (b_bs % ((1 if rag else 4) if b_planes else 8)):
         return None
     dw = torch.zeros((M, N), dtype=torch.float32, device=a.device) if out is None else out
 
