@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--drop-path", type=float, default=None, help="override the reference's DropPath rates (e.g. 0)")
     ap.add_argument("--comm-dtype", default=None, choices=["bf16", "fp32"],
                     help="dtype of the gradient all-reduce at N > 1 (default: the step's --dtype)")
+    ap.add_argument("--dp-cut", type=int, default=1, help="N > 1 with a captured step: the backward pass is cut after this "
+                    "trunk stage into two hipGraphs, the late layers' all-reduce runs under the second (-1: one graph, "
+                    "all-reduce after it)")
     ap.add_argument("--no-wgrad-arena", action="store_true",
                     help="a fresh zero-filled tensor per weight gradient (default: one arena, zeroed once per step)")
     ap.add_argument("--wgrad-stream", action="store_true",
@@ -117,7 +120,7 @@ def main():
     from xfmamba_amd import _lib, fusion_vmamba
     from xfmamba_amd.amp import WeightCache
     from xfmamba_amd.optim import FusedAdam
-    from xfmamba_amd.dp import GradBuckets, broadcast_parameters
+    from xfmamba_amd.dp import GradBuckets, PhasedGrads, broadcast_parameters
     from xfmamba_amd.proj import WgradArena, join_wgrad_stream, set_wgrad_arena, wgrad_stream
     wgrad_stream(a.wgrad_stream)
     from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
@@ -151,7 +154,8 @@ def main():
     # gradients cross xGMI in the step's compute dtype: bf16 buckets for the bf16 step (half the bytes of the ring
     # all-reduce; the optimizer still reads fp32), fp32 for --dtype fp32 or --comm-dtype fp32
     comm = torch.bfloat16 if (a.comm_dtype or a.dtype) == "bf16" else None
-    buckets = GradBuckets(model, bucket_mb=48.0, overlap=not use_graph, comm_dtype=comm)
+    use_phased = world > 1 and use_graph and scope != "step" and a.dp_cut >= 0
+    buckets = GradBuckets(model, bucket_mb=48.0, overlap=not use_graph, comm_dtype=comm, world=1 if use_phased else None)
     crit = torch.nn.CrossEntropyLoss()
     wcache = WeightCache(model) if a.dtype == "bf16" else None     # bf16 shadows of the GEMM weights
     # Adam of the reference loop (1_train_model.py:141) for all parameters in ONE launch that also rewrites the shadows
@@ -175,14 +179,47 @@ def main():
         arena = WgradArena(model.parameters())
         set_wgrad_arena(arena)
 
-    def fwd_bwd():
+    # N > 1 with a captured step: backward in two pieces around the activation entering trunk stage dp_cut + 1, one flat
+    # wire bucket per piece (bf16 for the bf16 step), the late piece's all-reduce under the early piece's graph, Adam reading
+    # the summed wire values in place (dp.PhasedGrads)
+    phased = None
+    if use_phased:
+        phased = PhasedGrads(model, wire_dtype=comm or torch.float32)
+        model.mamba_feature_extrac.cut_after = a.dp_cut
+
+    def forward_loss():
         buckets.zero_grad()
         if arena is not None:
             arena.zero()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
             out = model(xa, xb)
             loss = crit(out.float(), lab)
+        return loss
+
+    def fwd_bwd():
+        loss = forward_loss()
         loss.backward()
+        return loss
+
+    def phase_a():                                   # graph A: forward, loss, backward down to the cut, pack bucket 0
+        loss = forward_loss()
+        phased.backward_late(loss, model.mamba_feature_extrac.cut_tensor)
+        return loss
+
+    def phased_update():
+        phased.wait()
+        if a.torch_adam:
+            phased.materialize()
+            update()
+        else:
+            opt.step(grads=phased.grads(), grad_scale=phased.grad_scale)
+
+    def phased_step():                               # eager form of the two-graph step (warm-up, kernel timing)
+        loss = phase_a()
+        phased.reduce(0)
+        phased.backward_early()
+        phased.reduce(1)
+        phased_update()
         return loss
 
     def update():
@@ -192,6 +229,8 @@ def main():
             wcache.refresh()
 
     def step():                                      # one eager training step
+        if phased is not None:
+            return phased_step()
         loss = fwd_bwd()
         buckets.finish()
         update()
@@ -220,6 +259,7 @@ def main():
     # ---- the whole step (fwd + bwd + Adam) as ONE hipGraph: ~2800 launches per step are replayed by the
     # runtime instead of being issued one by one from Python ("HIP graphs instead of a tracing compiler")
     graph = None
+    graph_b = None
     loss_static = None
     if use_graph:
         try:
@@ -231,14 +271,29 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss_static = captured_part()
+            if phased is not None:
+                # two graphs over one memory pool, always replayed A then B: B reads the activations A's forward saved
+                with torch.cuda.graph(graph):
+                    loss_static = phase_a()
+                graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_b, pool=graph.pool()):
+                    phased.backward_early()
+            else:
+                with torch.cuda.graph(graph):
+                    loss_static = captured_part()
         except Exception as e:                       # noqa: BLE001  (report and fall back to eager launches)
             print(f"[bench] graph capture failed, running eager: {type(e).__name__}: {e}", file=sys.stderr)
-            graph = None
+            graph = graph_b = None
             torch.cuda.synchronize()
 
     def run_step():
+        if graph_b is not None:
+            graph.replay()
+            phased.reduce(0)                         # communication stream: runs under graph B
+            graph_b.replay()
+            phased.reduce(1)
+            phased_update()
+            return loss_static
         if graph is not None:
             graph.replay()
             after_replay()
@@ -351,7 +406,9 @@ def main():
                                    f"fwd+bwd+Adam, train mode" + cfg_label,
                        "note": "outnorm0-2 of the trunk are skipped: the reference computes them and discards the "
                                "results (net_fusionmamba.py:200-201); they carry no gradient",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_allreduce": ("bf16" if comm is not None else "fp32") if world > 1 else None, "ss2d_mode": fusion_vmamba.SS2D_MODE, "fp8_proj": bool(a.fp8),
+                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_allreduce": ("bf16" if comm is not None else "fp32") if world > 1 else None,
+                       "dp_step": (f"two hipGraphs cut after trunk stage {a.dp_cut}: the late layers' all-reduce runs under the early "
+                                   f"layers' backward; Adam reads the summed wire bucket in place" if graph_b is not None else None), "ss2d_mode": fusion_vmamba.SS2D_MODE, "fp8_proj": bool(a.fp8),
                        "single_view_images_per_s": round(2 * value, 2)},
             "roofline": roof,
             "roofline_scan_kernels": roofs,

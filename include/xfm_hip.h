@@ -344,6 +344,14 @@ int xfm_fp8_planes_gemm(const void *x_bf16, const void *wq_fp8, const float *sca
 int xfm_adam_multi(const void *p_ptrs, const void *g_ptrs, const void *m_ptrs, const void *v_ptrs, const void *shadow_ptrs,
                    const void *numel, const void *chunks, int nchunks, int chunk, float *step,
                    float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
+/*
+ * The same update with g * grad_scale in place of g, for data-parallel runs that hand in the all-reduced SUM of the ranks'
+ * gradients (grad_scale = 1 / world).  A numel entry with bit 62 set marks a bf16 gradient tensor (the wire bucket of
+ * xfmamba_amd/dp.py read in place: no widening copy).  xfm_adam_multi is this entry with grad_scale = 1.
+ */
+int xfm_adam_multi_scaled(const void *p_ptrs, const void *g_ptrs, const void *m_ptrs, const void *v_ptrs,
+                          const void *shadow_ptrs, const void *numel, const void *chunks, int nchunks, int chunk, float *step,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void *stream);
 
 /*
  * Token-contracting product on the matrix cores (csrc/wgrad_gemm.hip): the weight gradient of a channel projection,

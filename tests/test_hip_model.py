@@ -595,6 +595,36 @@ def test_fused_adam_matches_torch_adam_and_refreshes_shadows():
     wc.close()
 
 
+def test_fused_adam_reads_summed_bf16_wire_gradients_with_a_scale():
+    """Data-parallel form of the same update (dp.PhasedGrads): the gradient is the SUM over the ranks as bf16 values in a
+    flat wire bucket, read in place with grad_scale = 1 / world -- against torch.optim.Adam on fp32(bf16 sum) / world.
+    Slots at 16-byte AND at odd offsets (the scalar path), plus one fp32 external gradient."""
+    from xfmamba_amd.optim import FusedAdam
+    torch.manual_seed(5)
+    shapes = [(96, 96), (4, 8, 96), (383,), (33, 7), (768, 1024)]
+    net_a = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes])
+    net_b = torch.nn.ParameterList([torch.nn.Parameter(p.detach().clone()) for p in net_a])
+    opt_a = FusedAdam(net_a.parameters(), lr=1e-2, weight_decay=1e-2)
+    opt_b = torch.optim.Adam(net_b.parameters(), lr=1e-2, weight_decay=1e-2)
+    world = 8
+    flat = torch.zeros(sum(p.numel() for p in net_a) + 8, dtype=torch.bfloat16, device=DEV)
+    views, off = {}, 0
+    for p in net_a:
+        views[p] = flat[off:off + p.numel()].view(p.shape)          # (383 elements make the later slots unaligned)
+        off += p.numel()
+    f32 = torch.zeros_like(net_a[1])
+    views[net_a[1]] = f32                                           # a gradient handed over in fp32
+    for step in range(3):
+        for pa, pb in zip(net_a, net_b):
+            g = torch.randn_like(pa) * (step + 1) * world
+            views[pa].copy_(g)
+            pb.grad = views[pa].float() / world
+        opt_a.step(grads=views, grad_scale=1.0 / world)
+        opt_b.step()
+        for pa, pb in zip(net_a, net_b):
+            assert_close(pa.detach().cpu(), pb.detach().cpu(), 1e-5, 1e-6, f"step {step}")
+
+
 def test_checkpoint_round_trip_and_reference_format_load():
     """state_dict -> torch.save -> fresh model load_state_dict -> identical eval logits (what the reference's EarlyStopping
     writes every epoch, early_stop.py:43-51, and 2_inference_*.py read back); a checkpoint whose Linear2d weights are

@@ -480,17 +480,25 @@ class _NegExpAll(torch.autograd.Function):
 class _PrecomputedA:
     """Context: hand every SS2Dv2 of ``root`` its ``A = -exp(A_logs)`` from one batched evaluation."""
 
-    def __init__(self, root: nn.Module):
+    def __init__(self, root: nn.Module, split_after=None):
+        """``split_after``: index of the child of ``root`` (a stage) after which the backward pass will be cut
+        (``Backbone_VSSM.cut_after``): the blocks on either side get their own batched evaluation, so that no autograd
+        node spans the cut (dp.PhasedGrads)."""
         mods = root.__dict__.get("_ss2d_mods")           # (cached on the container: the module tree is static)
         if mods is None:
-            mods = [m for m in root.modules() if isinstance(m, SS2Dv2)]
+            mods = [[m for m in child.modules() if isinstance(m, SS2Dv2)] for child in root.children()]
             root.__dict__["_ss2d_mods"] = mods
-        self.mods = mods
+        if split_after is None:
+            self.groups = [[m for g in mods for m in g]]
+        else:
+            self.groups = [[m for g in mods[:split_after + 1] for m in g], [m for g in mods[split_after + 1:] for m in g]]
+        self.mods = [m for g in self.groups for m in g]
 
     def __enter__(self):
-        if self.mods and self.mods[0].A_logs.is_cuda:
-            for m, a in zip(self.mods, _NegExpAll.apply(*[m.A_logs for m in self.mods])):
-                m._As_pre = a
+        for grp in self.groups:
+            if grp and grp[0].A_logs.is_cuda:
+                for m, a in zip(grp, _NegExpAll.apply(*[m.A_logs for m in grp])):
+                    m._As_pre = a
         return self
 
     def __exit__(self, *exc):
@@ -551,6 +559,11 @@ def _norm_tokens_ok(norm: nn.Module) -> bool:
 
 class VSSM(nn.Module):
     """VMamba trunk in the one configuration XFMamba uses (patch-embed v2, downsample v3)."""
+
+    # data-parallel runs with a captured step cut the backward pass after stage ``cut_after`` (dp.PhasedGrads): the
+    # forward pass then leaves the activation entering the next stage in ``cut_tensor``.  None: no cut.
+    cut_after = None
+    cut_tensor = None
 
     def __init__(self, patch_size=4, in_chans=3, num_classes=2, depths=[2, 2, 9, 2], dims=[96, 192, 384, 768],
                  ssm_d_state=1, ssm_ratio=2.0, ssm_dt_rank="auto", ssm_act_layer="silu", ssm_conv=3,
@@ -650,10 +663,12 @@ class VSSM(nn.Module):
 
     def forward(self, x: torch.Tensor):
         if self.tokens_trunk_ok(x):
-            with _PrecomputedA(self.layers):
+            with _PrecomputedA(self.layers, self.cut_after):
                 t = self.stem_tokens(x)
                 for i in range(len(self.layers)):
                     o, t = self.stage_tokens(i, t)
+                    if i == self.cut_after:
+                        self.cut_tensor = t              # (the stream entering stage i + 1: dp.PhasedGrads' cut)
             x = o.permute(0, 3, 1, 2)
             return self.classifier(x)
         x = self.patch_embed(x)
@@ -721,10 +736,12 @@ class Backbone_VSSM(VSSM):
         last = len(self.layers) - 1
         if self.tokens_trunk_ok(x) and all(_norm_tokens_ok(getattr(self, f"outnorm{i}")) for i in self.out_indices):
             outs = []
-            with _PrecomputedA(self.layers):
+            with _PrecomputedA(self.layers, self.cut_after):
                 t = self.stem_tokens(x)
                 for i in range(len(self.layers)):
                     o, t = self.stage_tokens(i, t)
+                    if i == self.cut_after:
+                        self.cut_tensor = t              # (the stream entering stage i + 1: dp.PhasedGrads' cut)
                     if i in self.out_indices and (not only_last or i == last):
                         outs.append(_ln_tokens(getattr(self, f"outnorm{i}"), o, torch.float32).permute(0, 3, 1, 2).contiguous())
             return outs if len(self.out_indices) else o.permute(0, 3, 1, 2).contiguous()
@@ -733,6 +750,8 @@ class Backbone_VSSM(VSSM):
         for i, layer in enumerate(self.layers):
             o = _run_blocks(layer.blocks, x)
             x = layer.downsample(o)
+            if i == self.cut_after:
+                self.cut_tensor = x
             if i in self.out_indices and (not only_last or i == last):
                 outs.append(getattr(self, f"outnorm{i}")(o).contiguous())
         if len(self.out_indices) == 0:

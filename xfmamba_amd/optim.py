@@ -55,18 +55,24 @@ class FusedAdam:
         return self._slots["capture" if capturing else "eager"]
 
     @torch.no_grad()
-    def step(self):
+    def step(self, grads=None, grad_scale: float = 1.0):
+        """``grads``: {parameter: gradient tensor} to use instead of ``.grad`` -- fp32 or bf16, contiguous, e.g. the views
+        of ``dp.PhasedGrads``' wire buckets holding the all-reduced SUM over the ranks, with ``grad_scale = 1 / world``:
+        the kernel reads the bucket in place (parameters missing from the dict are skipped, like ``.grad is None``)."""
         from .proj import join_wgrad_stream
         join_wgrad_stream()                          # weight gradients launched on the side stream (proj.wgrad_stream)
-        # (gradients of the 3x3 convolutions may arrive channels_last: bring those few to the parameter's layout)
-        active = [(p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), m, v)
-                  for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq) if p.grad is not None]
+        if grads is not None:
+            active = [(p, grads[p], m, v) for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq) if p in grads]
+        else:
+            # (gradients of the 3x3 convolutions may arrive channels_last: bring those few to the parameter's layout)
+            active = [(p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), m, v)
+                      for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq) if p.grad is not None]
         if not active:
             return
         n = len(active)
         capturing = torch.cuda.is_current_stream_capturing()
         sl = self._slot(capturing)
-        key = tuple((p.data_ptr(), g.data_ptr()) for p, g, _, _ in active)
+        key = tuple((p.data_ptr(), g.data_ptr(), g.dtype) for p, g, _, _ in active)
         if key != sl["key"]:                        # rebuilt only when a tensor moved (eager steps allocate fresh gradients)
             h = sl["host"]
             # the previous upload of this pinned table may still be in flight (the CPU can run a step ahead of the GPU):
@@ -75,12 +81,13 @@ class FusedAdam:
                 sl["evt"].synchronize()
             ct, co = [], []
             for ti, (p, g, m, v) in enumerate(active):
-                if not p.is_contiguous() or g.dtype != torch.float32:
-                    raise RuntimeError("FusedAdam: contiguous fp32 parameters and fp32 gradients expected")
+                if not p.is_contiguous() or not g.is_contiguous() or g.dtype not in (torch.float32, torch.bfloat16) \
+                        or g.numel() != p.numel():
+                    raise RuntimeError("FusedAdam: contiguous fp32 parameters and contiguous fp32 / bf16 gradients expected")
                 sh = self.shadow_of.get(id(p))
                 h[ti], h[n + ti], h[2 * n + ti], h[3 * n + ti] = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
                 h[4 * n + ti] = sh.data_ptr() if sh is not None else 0
-                h[5 * n + ti] = p.numel()
+                h[5 * n + ti] = p.numel() | ((1 << 62) if g.dtype == torch.bfloat16 else 0)      # bit 62: bf16 gradient
                 for c in range((p.numel() + _CHUNK - 1) // _CHUNK):
                     ct.append(ti)
                     co.append(c)
@@ -98,10 +105,11 @@ class FusedAdam:
         d, nn = sl["dev"], sl["n"]
         base = d.data_ptr()
         with torch.cuda.device(active[0][0].device):
-            _lib.check(_lib.lib().xfm_adam_multi(base, base + 8 * nn, base + 16 * nn, base + 24 * nn, base + 32 * nn,
-                                                 base + 40 * nn, base + 48 * nn, sl["nchunks"], _CHUNK,
-                                                 self.step_count.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
-                                                 self.weight_decay, _lib.stream_ptr()), "adam_multi")
+            _lib.check(_lib.lib().xfm_adam_multi_scaled(base, base + 8 * nn, base + 16 * nn, base + 24 * nn, base + 32 * nn,
+                                                        base + 40 * nn, base + 48 * nn, sl["nchunks"], _CHUNK,
+                                                        self.step_count.data_ptr(), self.lr, self.betas[0], self.betas[1],
+                                                        self.eps, self.weight_decay, float(grad_scale), _lib.stream_ptr()),
+                       "adam_multi")
         # (the kernel wrote the parameters AND their bf16 shadows through raw pointers: the parameters' version counters
         #  did not move, so the shadows registered in amp.WeightCache stay the ones cast_weight serves -- and they are current)
         if self._cache is not None:
