@@ -162,3 +162,31 @@ def test_mark_current_leaves_unwritten_parameters_to_the_version_check():
     assert torch.equal(cast_weight(m.bias, torch.bfloat16), m.bias.detach().to(torch.bfloat16))
     assert cast_weight(m.weight, torch.bfloat16).data_ptr() == wc.shadows[0].data_ptr()
     wc.close()
+
+
+def test_wgrad_arena_scratch_region_is_sized_by_the_previous_step():
+    """proj.zeros_f32: pieces of the arena's scratch region (one zero fill per step for every fp32 accumulator); the first
+    step only records its demand and falls back to torch.zeros, the next one is served from the grown buffer."""
+    from xfmamba_amd.proj import WgradArena, set_wgrad_arena, zeros_f32
+    arena = WgradArena([])
+    set_wgrad_arena(arena)
+    try:
+        dev = arena.device
+        arena.zero()
+        a = zeros_f32(100, dev)
+        b = zeros_f32(30, dev)
+        assert a.untyped_storage().data_ptr() != arena.buf.untyped_storage().data_ptr()     # fallback tensors
+        assert arena.scratch_need == 128 + 64
+        arena.zero()                                                                        # grows the region
+        assert arena.scratch_cap >= 192
+        a, b = zeros_f32(100, dev), zeros_f32(30, dev)
+        base = arena.buf.data_ptr()
+        assert a.data_ptr() == base + 4 * arena.n_slots and b.data_ptr() == a.data_ptr() + 4 * 128
+        assert a.numel() == 100 and b.numel() == 30 and float(a.abs().sum() + b.abs().sum()) == 0.0
+        a.fill_(3.0)
+        big = zeros_f32(10_000, dev)                                                       # beyond the region: fresh tensor
+        assert big.untyped_storage().data_ptr() != arena.buf.untyped_storage().data_ptr()
+        arena.zero()
+        assert float(zeros_f32(100, dev).abs().sum()) == 0.0 and arena.scratch_cap >= 10_000
+    finally:
+        set_wgrad_arena(None)

@@ -19,6 +19,7 @@ import ctypes
 import torch
 
 from . import _lib
+from .proj import zeros_f32
 
 __all__ = ["selective_scan_fn", "SelectiveScanHip"]
 
@@ -104,7 +105,7 @@ class SelectiveScanHip(torch.autograd.Function):
         # fp32 accumulators (selective_scan.cpp:332-333,360), carved out of ONE zero-filled buffer: one fill kernel
         sizes = [A.numel(), B.numel(), C.numel(), D.numel() if D is not None else 0,
                  delta_bias.numel() if delta_bias is not None else 0]
-        acc = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        acc = zeros_f32(sum(sizes), dev)
         parts = torch.split(acc, sizes)
         dA, dB, dC = parts[0].view(A.shape), parts[1].view(B.shape), parts[2].view(C.shape)
         dD = parts[3].view(D.shape) if D is not None else None

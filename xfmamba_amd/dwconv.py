@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from .proj import zeros_f32
 
 __all__ = ["dwconv3x3_silu_fn", "DWConv3x3SiLUHip"]
 
@@ -41,7 +42,7 @@ class DWConv3x3SiLUHip(torch.autograd.Function):
         B, D, H, W = x.shape
         dy = dy.contiguous().to(x.dtype)
         dx = torch.empty_like(x)
-        acc = torch.zeros(w.numel() + (b.numel() if b is not None else 0), dtype=torch.float32, device=w.device)
+        acc = zeros_f32(w.numel() + (b.numel() if b is not None else 0), w.device)
         dw = acc[:w.numel()].view(w.shape)                              # one fill for both accumulators
         db = acc[w.numel():] if b is not None else None
         nbytes = 3 * x.numel() * x.element_size()

@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from .proj import zeros_f32
 
 __all__ = ["layernorm2d_fn", "LayerNorm2dHip"]
 
@@ -46,7 +47,7 @@ class LayerNorm2dHip(torch.autograd.Function):
         if dy.dtype != ctx.ydtype:
             dy = dy.to(ctx.ydtype)
         dx = torch.empty_like(x)
-        acc = torch.zeros(2 * w.numel() if ctx.has_bias else w.numel(), dtype=torch.float32, device=w.device)
+        acc = zeros_f32(2 * w.numel() if ctx.has_bias else w.numel(), w.device)
         dw = acc[:w.numel()]                                             # one fill for both accumulators
         db = acc[w.numel():] if ctx.has_bias else None
         nbytes = x.numel() * (2 * x.element_size() + dy.element_size())

@@ -17,7 +17,7 @@ import torch
 from .amp import cast_weight
 
 __all__ = ["batched_proj", "split_k_wgrad", "mfma_planes", "wgrad_mfma", "wgrad_stream", "join_wgrad_stream", "WgradArena",
-           "set_wgrad_arena", "wgrad_slot"]
+           "set_wgrad_arena", "wgrad_slot", "zeros_f32"]
 
 _F32_OUT = [None]      # does torch.bmm accept out_dtype on this build?  probed once
 
@@ -71,6 +71,13 @@ def join_wgrad_stream() -> None:
 # ``arena.zero()`` wipes, which is only sound for loops that drop ``.grad`` before every backward pass (bench.py does).  A
 # weight that receives a second gradient in the same pass (shared weights, two sequential trunk calls) falls back to a fresh
 # tensor for it -- the slot must not be handed to autograd twice.
+#
+# The same buffer serves the OTHER zero-initialised fp32 accumulators of the backward nodes (dA / dD / dbias / dB / dC sums
+# of the scan kernels, the weight / bias sums of the LayerNorm and depthwise-convolution kernels, weight gradients without a
+# slot: ~70 more fills per step) from a scratch region behind the slots: ``zeros_f32(n)`` hands out consecutive pieces of
+# it (a bump pointer reset by ``zero()``).  The region is sized by what the previous step asked for -- the first step
+# after construction falls back to ``torch.zeros`` and only records its demand -- and the same lifetime rule applies: what
+# a node returns from it lives until the next ``zero()``.
 class WgradArena:
     def __init__(self, params):
         ps = [p for p in params if p.requires_grad and p.dtype == torch.float32 and p.dim() >= 2 and p.is_cuda]
@@ -78,12 +85,31 @@ class WgradArena:
         for p in ps:
             self.offsets[id(p)] = (n, p.shape[0], p.numel() // p.shape[0])
             n += (p.numel() + 63) // 64 * 64                    # 256-byte aligned slots
-        self.buf = torch.zeros(max(n, 1), dtype=torch.float32, device=ps[0].device if ps else "cpu")
+        self.n_slots = n
+        self.device = ps[0].device if ps else torch.device("cpu")
+        self.buf = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
         self.used = set()
+        self.scratch_cap = 0          # elements behind the slots
+        self.scratch_off = 0          # bump pointer of this step
+        self.scratch_need = 0         # demand of this step (granted or not)
 
     def zero(self):
+        if self.scratch_need > self.scratch_cap and not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self.scratch_cap = self.scratch_need + self.scratch_need // 8
+            self.buf = torch.empty(self.n_slots + self.scratch_cap, dtype=torch.float32, device=self.device)
         self.buf.zero_()
         self.used.clear()
+        self.scratch_off = self.scratch_need = 0
+
+    def scratch(self, n: int):
+        """``n`` zeroed fp32 elements (256-byte aligned) from the scratch region, or None when it is exhausted."""
+        n64 = (n + 63) // 64 * 64
+        self.scratch_need += n64
+        if self.scratch_off + n64 > self.scratch_cap:
+            return None
+        o = self.n_slots + self.scratch_off
+        self.scratch_off += n64
+        return self.buf[o:o + n]
 
     def slot(self, weight, M, N):
         """The (M, N) fp32 slot of ``weight``, or None (unregistered, other shape, or already used in this pass)."""
@@ -105,6 +131,17 @@ def wgrad_slot(weight, M, N):
     return None if _ARENA[0] is None or weight is None else _ARENA[0].slot(weight, M, N)
 
 
+def zeros_f32(n: int, device) -> torch.Tensor:
+    """A zero-filled flat fp32 accumulator of ``n`` elements: a piece of the arena's scratch region when an arena is set
+    (valid until its next ``zero()``), else a fresh ``torch.zeros``."""
+    a = _ARENA[0]
+    if a is not None and a.device == device:
+        t = a.scratch(n)
+        if t is not None:
+            return t
+    return torch.zeros(n, dtype=torch.float32, device=device)
+
+
 def wgrad_mfma(a: torch.Tensor, a_planes: bool, b: torch.Tensor, b_planes: bool, out: torch.Tensor = None,
                deferred: bool = False):
     """``dW[m, n] = sum_{b, l} A[b, l, m] B[b, l, n]`` -> (M, N) fp32 through ``xfm_wgrad`` (csrc/wgrad_gemm.hip), or None
@@ -122,6 +159,16 @@ def wgrad_mfma(a: torch.Tensor, a_planes: bool, b: torch.Tensor, b_planes: bool,
     Lb, N = (b.shape[2], b.shape[1]) if b_planes else (b.shape[1], b.shape[2])
     if Lb != L or b.shape[0] != Bt:
         return None
+    if L % 4 and Bt * L * max(M, N) >= (1 << 20):
+        # 7 x 7 maps (49 tokens): the kernel reads ragged plane rows element by element (88 us for 64 x 49 x 768 x 768).
+        # Transposing such an operand to token-major first (a 5 MB copy) and contracting the samples as ONE token run
+        # on the LDS-direct token x token kernel is more than twice as fast.
+        if a_planes:
+            a, a_planes = a.transpose(1, 2).contiguous(), False
+        if b_planes:
+            b, b_planes = b.transpose(1, 2).contiguous(), False
+    if not a_planes and not b_planes and Bt > 1 and a.is_contiguous() and b.is_contiguous() and (Bt * L) % 64 == 0:
+        a, b, L, Bt = a.view(1, Bt * L, M), b.view(1, Bt * L, N), Bt * L, 1       # one long token run
 
     def dense(t):
         return t.stride(2) == 1 and t.stride(1) == t.shape[2]
@@ -134,7 +181,7 @@ def wgrad_mfma(a: torch.Tensor, a_planes: bool, b: torch.Tensor, b_planes: bool,
     rag = L % 4 != 0                                        # ragged plane rows (7 x 7 maps) are read element-wise
     if (a_bs % ((1 if rag else 4) if a_planes else 8)) or (b_bs % ((1 if rag else 4) if b_planes else 8)):
         return None
-    dw = torch.zeros((M, N), dtype=torch.float32, device=a.device) if out is None else out
+    dw = zeros_f32(M * N, a.device).view(M, N) if out is None else out
 
     def launch():
         with torch.cuda.device(a.device), _lib.timed("wgrad", (a.numel() + b.numel()) * 2):

@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from . import fp8 as _fp8
 from .amp import cast_weight
-from .proj import mfma_planes
+from .proj import mfma_planes, zeros_f32
 
 __all__ = ["ss2d_core_fn", "ss2d_proj_core_fn", "ss2d_xproj_core_fn", "SS2DCoreHip", "SS2DProjCoreHip", "to_route_order"]
 
@@ -83,9 +83,11 @@ class SS2DCoreHip(torch.autograd.Function):
         dy = dy.contiguous().float()
         dx = torch.empty_like(x)
         ddts = torch.empty_like(dts)
-        dBs = torch.zeros(Bs.shape, dtype=torch.float32, device=dev)
-        dCs = torch.zeros(Cs.shape, dtype=torch.float32, device=dev)
-        dA, dD, dbias = torch.zeros_like(A), torch.zeros_like(D), torch.zeros_like(bias)
+        nbc, na, nd = Bs.numel(), A.numel(), D.numel()
+        acc = zeros_f32(2 * nbc + na + 2 * nd, dev)                       # ONE fill (or none: the arena's scratch region)
+        dBs, dCs = acc[:nbc].view(Bs.shape), acc[nbc:2 * nbc].view(Cs.shape)
+        dA = acc[2 * nbc:2 * nbc + na].view(A.shape)
+        dD, dbias = acc[2 * nbc + na:2 * nbc + na + nd].view(D.shape), acc[2 * nbc + na + nd:].view(bias.shape)
         p = _lib.SS2DParams()
         _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk)
         p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
@@ -207,7 +209,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
         lib = _lib.lib()
         mfma_bwd = (x.dtype == torch.bfloat16 and L % 4 == 0 and Dm <= 1024 and lib.xfm_ss2d_dt_proj_mfma_rp(Dm, R, L) > 0)
         nw = w.numel() if mfma_bwd else 0
-        acc = torch.zeros(2 * nbc + na + 2 * nd + nw, dtype=torch.float32, device=dev)     # ONE fill for all accumulators
+        acc = zeros_f32(2 * nbc + na + 2 * nd + nw, dev)     # ONE fill for all accumulators
         dBs, dCs = acc[:nbc].view(Bs.shape), acc[nbc:2 * nbc].view(Cs.shape)
         dA = acc[2 * nbc:2 * nbc + na].view(A.shape)
         dD, dbias = acc[2 * nbc + na:2 * nbc + na + nd], acc[2 * nbc + na + nd:2 * nbc + na + 2 * nd]

@@ -17,6 +17,7 @@ import torch
 from . import _lib
 from . import fp8 as _fp8
 from .amp import cast_weight
+from .proj import zeros_f32
 
 __all__ = ["ss2d_chan_fn", "chan_supported", "SS2DChanHip"]
 
@@ -140,7 +141,7 @@ class SS2DChanHip(torch.autograd.Function):
         dx = torch.empty_like(x)
         ddts = torch.empty((Bt, K, L, Dm), dtype=x.dtype, device=dev)
         nbc, na, nd, nw = Bt * K * 2 * N * L, A.numel(), D.numel(), K * Dm * R
-        acc = torch.zeros(nbc + na + 2 * nd + nw, dtype=torch.float32, device=dev)       # ONE fill for all accumulators
+        acc = zeros_f32(nbc + na + 2 * nd + nw, dev)       # ONE fill for all accumulators
         dBC = acc[:nbc].view(Bt, K, 2, N, L)
         dA = acc[nbc:nbc + na].view(A.shape)
         dD, dbias = acc[nbc + na:nbc + na + nd], acc[nbc + na + nd:nbc + na + 2 * nd]
