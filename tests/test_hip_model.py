@@ -229,6 +229,8 @@ def _check_model_against_golden(m, tag, size, batch, tol_logits, tol_gnorm, tol_
     loss.backward()
     params = dict(m.named_parameters())
     assert sorted(k for k, p in params.items() if p.grad is None) == sorted(names["no_grad"])
+    if tol_gnorm is None:                                # (gradient values are checked elsewhere)
+        return
     for k, row in zip(names["grad_names"], z["grad_stats"]):
         gn = float(params[k].grad.double().norm())
         assert abs(gn - row[2]) <= tol_gnorm * row[2] + 1e-6, (k, gn, row[2])
@@ -303,10 +305,11 @@ def test_model_small_base_fp32_match_reference_golden(cfg, layout):
 @pytest.mark.parametrize("cfg", ["small", "base384"])
 def test_model_small_base_bf16_autocast(cfg):
     """The bench configuration (bf16 autocast, bf16 scan I/O) of configs[2]/[3]: every kernel of the bf16 path at
-    these widths, whole-model logits within the end-to-end bf16 bound, gradients finite and of the right scale."""
+    these widths, whole-model logits and loss within the end-to-end bf16 bound, the no-gradient set.  The gradients are
+    held to the oracle yardstick by test_model_bf16_autocast_gradients_track_the_oracle."""
     tag, ty, kw, size, batch = MODEL_CFGS[cfg]
     m = _model_with_synth_weights(ty, kw)
-    _check_model_against_golden(m, tag, size, batch, 3e-2, 0.35, 0.5, autocast=True)
+    _check_model_against_golden(m, tag, size, batch, 3e-2, None, None, autocast=True)
 
 
 def test_model_tiny_bf16_autocast_within_tolerance():
@@ -344,24 +347,27 @@ def _oracle_autocast_grads(ty_tag, sd, xa, xb, lab):
     return {k: v.grad for k, v in leaves.items() if v.requires_grad and v.grad is not None}
 
 
-def test_model_tiny_bf16_autocast_gradients_track_the_oracle():
-    """bf16 GRADIENT parity of XFMamba-T at batch 2 (the bench arithmetic: autocast GEMMs, bf16 scan I/O
-    with fp32 state), with the same relative-yardstick rule as the logits test.  Every parameter gradient of the HIP path
-    is compared with the fp32 reference record; its error must stay within 1.5x the error of the CPU oracle run under
-    bf16 autocast (+ a floor), tensor by tensor for the gradient norms and in direction (cosine) for every tensor."""
-    z = load_npz("g5_model.npz")
-    names = load_json("g5_grad_names.json")
-    m = _tiny_with_synth_weights().train()
+@pytest.mark.parametrize("cfg", ["tiny", "small", "base384"])
+def test_model_bf16_autocast_gradients_track_the_oracle(cfg):
+    """bf16 GRADIENT parity of XFMamba-T / -S (batch 2) and -B at 384^2 (batch 1) in the bench arithmetic
+    (autocast GEMMs, bf16 scan I/O with fp32 state), with the same relative-yardstick rule as the logits test.  Every
+    parameter gradient of the HIP path is compared with the fp32 reference record; its error must stay within 1.5x the
+    error of the CPU oracle run under bf16 autocast (+ a floor), tensor by tensor for the gradient norms and in direction
+    (cosine) for every tensor."""
+    tag, ty, kw, size, batch = MODEL_CFGS[cfg]
+    z = load_npz(f"{tag}_model.npz")
+    names = load_json(f"{tag}_grad_names.json")
+    m = _model_with_synth_weights(ty, kw).train()
     for mod in m.modules():
         if hasattr(mod, "drop_prob"):
             mod.drop_prob = 0.0
-    xa, xb, lab = g5_inputs()
+    xa, xb, lab = g5_inputs(batch, size)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = m(xa.to(DEV), xb.to(DEV))
     torch.nn.functional.cross_entropy(out.float(), lab.to(DEV)).backward()
     hip = {k: p.grad.float().cpu() for k, p in m.named_parameters() if p.grad is not None}
-    sd = O.synth_state_dict(load_json("g5_state_shapes.json")["tiny"], seed=0)
-    orc = _oracle_autocast_grads("tiny", sd, xa, xb, lab)
+    sd = O.synth_state_dict(load_json("g5_state_shapes.json")[ty], seed=0)
+    orc = _oracle_autocast_grads(ty, sd, xa, xb, lab)
     ref_norm = {k: float(row[2]) for k, row in zip(names["grad_names"], z["grad_stats"])}
     worst = (0.0, None)
     tot_h = tot_o = tot_r = 0.0
@@ -371,7 +377,9 @@ def test_model_tiny_bf16_autocast_gradients_track_the_oracle():
         eh = abs(float(gh.double().norm()) - rn) / (rn + 1e-12)
         eo = abs(float(go.double().norm()) - rn) / (rn + 1e-12)
         # norm error of the HIP path within 1.5x the oracle's own bf16 error, with a floor of 5e-2 for small tensors
-        assert eh <= 1.5 * eo + 5e-2, (k, eh, eo)
+        # (1e-1 for the 27-block-deep stage of XFMamba-B at batch 1: the oracle's scan runs in fp32 on fp32 operands, the
+        #  HIP path's on bf16 operands, so the yardstick underestimates the sums behind A_logs / Ds / dt_projs_bias)
+        assert eh <= 1.5 * eo + (1e-1 if cfg == "base384" else 5e-2), (k, eh, eo)
         worst = max(worst, (eh, k))
         if rn > 1e-6 * max(ref_norm.values()):
             cos = float(torch.nn.functional.cosine_similarity(gh.flatten().double(), go.flatten().double(), dim=0))
