@@ -660,3 +660,29 @@ def test_checkpoint_round_trip_and_reference_format_load():
     m3 = m3.to(DEV).eval()
     with torch.no_grad():
         assert_close(m3(xa, xb).cpu(), ref.cpu(), 1e-5, 1e-5, "conv-style checkpoint logits")
+
+
+def test_drop_path_bank_samples_every_layer_with_its_own_rate():
+    """fusion_vmamba._DropPathBank: one uniform draw serves all DropPath layers of a trunk pass.  Per layer the factor is
+    Bernoulli(keep) / keep with that layer's rate (timm 0.4.12's drop_path, which the reference imports), independent
+    across layers; a layer consumes its row exactly once and falls back to its own kernel afterwards."""
+    from xfmamba_amd import fusion_vmamba as fv
+    rates = [0.05, 0.2, 0.5]
+    root = torch.nn.ModuleList([fv.DropPath(r) for r in rates] + [fv.DropPath(0.0)]).train()
+    B = 20000
+    torch.manual_seed(0)
+    with fv._DropPathBank(root, B, torch.device(DEV)):
+        rows = [m._preset for m in root]
+        assert rows[3] is None and all(r is not None and r.shape == (B,) for r in rows[:3])
+        got = [m.sample_scale(B, torch.device(DEV)) for m in root]
+        assert all(g is r for g, r in zip(got[:3], rows[:3])) and got[3] is None
+        assert all(m._preset is None for m in root)                       # consumed
+    for r, g in zip(rates, got[:3]):
+        keep = 1.0 - r
+        vals = torch.unique(g).cpu()
+        assert len(vals) == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1.0 / keep) < 1e-6
+        assert abs(float((g == 0).float().mean()) - r) < 4 * (r * keep / B) ** 0.5 + 1e-3
+    c = float(torch.corrcoef(torch.stack([got[1], got[2]]))[0, 1])
+    assert abs(c) < 0.03                                                   # independent rows
+    again = root[1].sample_scale(B, torch.device(DEV))                    # no preset left: the per-layer kernel
+    assert again is not got[1] and abs(float((again == 0).float().mean()) - 0.2) < 0.02

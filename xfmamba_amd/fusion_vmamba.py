@@ -65,11 +65,15 @@ class DropPath(nn.Module):
         self.drop_prob = float(drop_prob)
         self.scale_by_keep = scale_by_keep
         self._ones = {}
+        self._preset = None          # a factor sampled ahead by _DropPathBank (one launch for all layers of a trunk)
 
     def sample_scale(self, batch: int, device):
         """The per-sample factor ``forward`` multiplies by, as a (B,) fp32 vector (None when it is the identity)."""
         if self.drop_prob == 0.0 or not self.training:
             return None
+        pre, self._preset = self._preset, None
+        if pre is not None and pre.shape[0] == batch and pre.device.type == torch.device(device).type:
+            return pre
         keep = 1.0 - self.drop_prob
         key = (batch, str(device))
         ones = self._ones.get(key)
@@ -477,6 +481,40 @@ class _NegExpAll(torch.autograd.Function):
         return tuple(res)
 
 
+class _DropPathBank:
+    """Context: sample the stochastic-depth factors of every ``DropPath`` under ``root`` for one forward pass with ONE
+    uniform draw (a (layers, B) matrix compared with the keep probabilities) instead of a dropout kernel per layer (26
+    launches in XFMamba-T).  Same distribution per layer and sample: Bernoulli(keep) / keep, independent across both."""
+
+    def __init__(self, root: nn.Module, batch: int, device):
+        mods = root.__dict__.get("_droppath_mods")
+        if mods is None:
+            mods = [m for m in root.modules() if isinstance(m, DropPath)]
+            root.__dict__["_droppath_mods"] = mods
+        self.mods = [m for m in mods if m.training and 0.0 < m.drop_prob < 1.0 and m.scale_by_keep]
+        self.root, self.batch, self.device = root, batch, device
+
+    def __enter__(self):
+        if len(self.mods) > 1 and self.device.type == "cuda":
+            key = (tuple(m.drop_prob for m in self.mods), str(self.device))
+            keep = self.root.__dict__.get("_droppath_keep")          # (layers, 1) keep probabilities, uploaded once
+            if keep is None or keep[0] != key:
+                if torch.cuda.is_current_stream_capturing():
+                    return self                                      # (no upload inside a capture: per-layer kernels)
+                keep = (key, torch.tensor([1.0 - p for p in key[0]], dtype=torch.float32).to(self.device)[:, None])
+                self.root.__dict__["_droppath_keep"] = keep
+            u = torch.rand(len(self.mods), self.batch, dtype=torch.float32, device=self.device)
+            bank = (u < keep[1]).to(torch.float32) / keep[1]
+            for m, row in zip(self.mods, bank.unbind(0)):
+                m._preset = row
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.mods:
+            m._preset = None
+        return False
+
+
 class _PrecomputedA:
     """Context: hand every SS2Dv2 of ``root`` its ``A = -exp(A_logs)`` from one batched evaluation."""
 
@@ -663,7 +701,7 @@ class VSSM(nn.Module):
 
     def forward(self, x: torch.Tensor):
         if self.tokens_trunk_ok(x):
-            with _PrecomputedA(self.layers, self.cut_after):
+            with _PrecomputedA(self.layers, self.cut_after), _DropPathBank(self.layers, x.shape[0], x.device):
                 t = self.stem_tokens(x)
                 for i in range(len(self.layers)):
                     o, t = self.stage_tokens(i, t)
@@ -736,7 +774,7 @@ class Backbone_VSSM(VSSM):
         last = len(self.layers) - 1
         if self.tokens_trunk_ok(x) and all(_norm_tokens_ok(getattr(self, f"outnorm{i}")) for i in self.out_indices):
             outs = []
-            with _PrecomputedA(self.layers, self.cut_after):
+            with _PrecomputedA(self.layers, self.cut_after), _DropPathBank(self.layers, x.shape[0], x.device):
                 t = self.stem_tokens(x)
                 for i in range(len(self.layers)):
                     o, t = self.stage_tokens(i, t)
