@@ -377,6 +377,23 @@ __device__ __forceinline__ void l3_merge_y(float *out, const bf16_t *P0, const b
     }
 }
 
+// Workgroup -> (sample, tile group).  Workgroups are handed to the 8 XCDs round-robin, and every workgroup re-reads its
+// sample's B / C rows (4 routes x 2 x L bf16 = 50 KB at 56 x 56) once per plane.  With consecutive ids walking the groups of
+// one sample, each XCD's L2 sees ALL samples at once (64 x 50 KB next to the streaming planes: the rows are evicted between
+// uses -- PMC traffic of the 56 x 56 kernels was 1.8x / 2.1x the algorithmic bytes).  With xmap the samples are dealt to the
+// XCDs (sample b lives on XCD b % 8): an XCD holds the rows of the batch / 8 samples its workgroups walk, fetched once.
+__device__ __forceinline__ void l3_block_map(const LeanArgs &a, const int groups_pb, int &b, int &tg) {
+    const int bid = blockIdx.x;
+    if (a.xmap) {
+        const int j = bid >> 3, q = j / groups_pb;
+        b = (bid & 7) + 8 * q;
+        tg = j - q * groups_pb;
+    } else {
+        b = bid / groups_pb;
+        tg = bid - b * groups_pb;
+    }
+}
+
 template <int HW, int PPT, int MODE, bool REV>
 __device__ __forceinline__ void l3_fwd_body(const LeanArgs &a, float *smem, const int wave, const int lane) {
     using G = L3Geom<HW>;
@@ -384,7 +401,8 @@ __device__ __forceinline__ void l3_fwd_body(const LeanArgs &a, float *smem, cons
     const int D = a.D_;
     const int tiles_pb = D / PPT;
     const int groups_pb = tiles_pb / a.pli;
-    const int b = blockIdx.x / groups_pb, tg = blockIdx.x - b * groups_pb;
+    int b, tg;
+    l3_block_map(a, groups_pb, b, tg);
     // LDS: xN | xT | 4 private y planes (bf16: the per-route partial sums are rounded to the I/O precision once, before
     // the fixed-order fp32 merge, as in the lean kernels)
     bf16_t *xN = reinterpret_cast<bf16_t *>(smem), *xT = xN + PL, *Y = xT + PL;
@@ -688,7 +706,8 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
     const int D = a.D_;
     const int tiles_pb = D / PPT;
     const int groups_pb = tiles_pb / a.pli;
-    const int b = blockIdx.x / groups_pb, tg = blockIdx.x - b * groups_pb;
+    int b, tg;
+    l3_block_map(a, groups_pb, b, tg);
     bf16_t *xN = reinterpret_cast<bf16_t *>(smem), *xT = xN + PL, *gN = xT + PL, *gT = gN + PL, *DX = gT + PL;
     float *ldsacc = smem + (8 * (size_t)PL * 2) / 4 + wave * 2 * G::LSZ;
     for (int e = lane; e < 2 * G::LSZ; e += 64) ldsacc[e] = 0.f;
@@ -904,6 +923,7 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
     const int tiles_pb = D / PPT;
     const int pli = l3_pli(p.batch, tiles_pb, bwd);
     la.pli = pli;
+    la.xmap = (p.batch % 8 == 0 && !getenv("XFM_L3_NO_XMAP")) ? 1 : 0;
     const int groups = tiles_pb / pli;
     const size_t need = (size_t)p.batch * groups * 4 * 2 * L * sizeof(float);
     la.parts = (bwd && ws && ws_bytes >= need && groups > 1 && L % 4 == 0) ? ws : nullptr;

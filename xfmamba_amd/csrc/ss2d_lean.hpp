@@ -34,6 +34,7 @@ struct LeanArgs {
     uint32_t magicL;   // ceil(2^32 / L): plane index of a tile element by multiply-high (tile elements < 2^16)
     uint32_t magicH;   // ceil(2^32 / H)
     float *parts;      // ss2d_l3.hip: (batch, groups, 4, 2, L) fp32 partial dB / dC sums of the workgroups (null: atomics)
+    int xmap;          // ss2d_l3.hip: 1 = XCD-local sample placement (batch % 8 == 0), see l3_block_map
 };
 
 // ---- DPP helpers -------------------------------------------------------------------------------
