@@ -51,7 +51,24 @@ struct ChanArgs {
     int c_mod, c_off;        // c_mod > 0: the C operand of sample sb is read from sample c_off + sb % c_mod
     const uint16_t *zeros;   // >= 2 * Kp zero bf16 (16-byte aligned): k-slots of the other route of a pair
     int ct;                  // consecutive 32-channel tiles walked by one workgroup (amortises the dB / dC flush)
+    int xmap;                // 1: samples are dealt to the XCDs (Bt % 8 == 0), see chan_block_map
 };
+
+// Workgroup -> (sample, first index inside the sample).  Every workgroup of a sample re-reads that sample's x_proj rows
+// (L x 4 C2p bf16: 37 KB at 14 x 14); workgroups go to the 8 XCDs round-robin, so with consecutive ids on one sample all
+// XCDs fetch all samples' rows -- and re-fetch them after the streaming planes evicted them: PMC traffic 1.9x (forward) /
+// 1.5x (backward) the algorithmic bytes at 14 x 14.  With xmap sample sb lives on XCD sb % 8 (as ss2d_l3.hip does).
+__device__ __forceinline__ void chan_block_map(const int xmap, const int per_sample, int &sb, int &idx) {
+    const int bid = blockIdx.x;
+    if (xmap) {
+        const int j = bid >> 3, q = j / per_sample;
+        sb = (bid & 7) + 8 * q;
+        idx = j - q * per_sample;
+    } else {
+        sb = bid / per_sample;
+        idx = bid - sb * per_sample;
+    }
+}
 
 // N (d_state) only sets the step length: a step of d_state > 1 works 16x longer per position, and its per-position
 // operands (not its state) fill the registers, so it takes ONE row / column where d_state 1 takes two on 5x5 / 7x7 maps
@@ -469,7 +486,9 @@ __global__ void __launch_bounds__(128) ss2dc_fwd_kernel(const ChanArgs a) {
     const int wave = threadIdx.x >> 6;
     float *scr = dsum + 32 + wave * 2 * N * 64;
     const int tiles = a.D / 32, groups = (tiles + a.ct - 1) / a.ct;
-    const int sb = blockIdx.x / groups, t0 = (blockIdx.x - sb * groups) * a.ct;
+    int sb, t0;
+    chan_block_map(a.xmap, groups, sb, t0);
+    t0 *= a.ct;
 #pragma unroll 1
     for (int t = t0; t < min(tiles, t0 + a.ct); ++t) {
         const int c0 = 32 * t;
@@ -736,7 +755,9 @@ __global__ void __launch_bounds__(128) ss2dc_bwd_kernel(const ChanArgs a) {
     float *red = reinterpret_cast<float *>(sm + LD::wave0 + wave * LD::wave_sz + LD::red_off);
     float *scr = reinterpret_cast<float *>(sm + LD::wave0 + wave * LD::wave_sz + LD::scr_off);
     const int tiles = a.D / 32, groups = (tiles + a.ct - 1) / a.ct;
-    const int sb = blockIdx.x / groups, t0 = (blockIdx.x - sb * groups) * a.ct;
+    int sb, t0;
+    chan_block_map(a.xmap, groups, sb, t0);
+    t0 *= a.ct;
     for (int e = lane; e < 2 * 2 * N * L; e += 64) bcacc[e] = 0.f;     // dB / dC of this wave's two routes, all tiles
 #pragma unroll 1
     for (int t = t0; t < min(tiles, t0 + a.ct); ++t) {
@@ -1096,7 +1117,9 @@ __global__ void __launch_bounds__(128) deep_bwd_kernel(const DeepArgs da) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *wl = sm + LD::wave0 + wave * LD::wave_sz;
     const int tiles = a.D / 64;
-    const int sb = blockIdx.x / tiles, c0 = (blockIdx.x - sb * tiles) * 64;
+    int sb, c0;
+    chan_block_map(a.xmap, tiles, sb, c0);
+    c0 *= 64;
     {
         const uint16_t *src = a.x + ((int64_t)sb * a.D + c0) * L;
         const float *gsrc = a.dy + ((int64_t)sb * a.D + c0) * L;
@@ -1258,6 +1281,7 @@ static int chan_run(const xfm_ss2dc_params_t *p, bool bwd, void *stream) {
     a.Kp = (p->dt_rank + 15) / 16 * 16;
     a.c_mod = p->c_mod; a.c_off = p->c_off;
     a.zeros = (const uint16_t *)p->zeros;
+    a.xmap = (p->batch % 8 == 0 && !getenv("XFM_CHAN_NO_XMAP")) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int HW = p->H;
     static const bool deep_on = [] {
