@@ -246,6 +246,8 @@ SS2D_SHAPES = [
     (2, 96, 56, 56, 1, torch.bfloat16),     # stage 0 in bf16: the two-waves-per-SIMD kernels (ss2d_l3.hip; 7 chunk rows, tail row of 8 lanes)
     (16, 8, 56, 56, 1, torch.bfloat16),     # batch % 8 == 0: XCD-local sample placement of ss2d_l3.hip (two samples per XCD)
     (8, 24, 28, 28, 1, torch.bfloat16),     # ... at 28 x 28 (four planes per tile, several tile groups per sample)
+    (2, 8, 48, 48, 1, torch.bfloat16),      # XFMamba-B @384 stage 1 on ss2d_l3.hip (5 chunk rows, 32-lane tail)
+    (8, 16, 24, 24, 1, torch.bfloat16),     # ... stage 2 (2 chunk rows, 8-lane tail, four planes per tile)
     (3, 96, 14, 14, 1, torch.float32),      # stage 2 (4 planes per wavefront)
     (2, 96, 7, 7, 1, torch.bfloat16),       # stage 3
     (2, 32, 7, 7, 16, torch.float32),       # deep fusion block shape (N = 16)

@@ -952,6 +952,9 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
 }
 
 // XFM_ELIMIT: shape / dtype not covered here, the caller falls back to the lean / generic kernels
+// planes per tile of the map sizes built here (0: not covered)
+static int l3_ppt(const int H) { return (H == 56 || H == 48) ? 1 : ((H == 28 || H == 24) ? 4 : 0); }
+
 int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, size_t ws_bytes) {
     static const bool enabled = [] {
         const char *e = getenv("XFM_SS2D_L3");
@@ -965,19 +968,23 @@ int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, 
     if (!bwd && !fwd_enabled) return XFM_ELIMIT;
     if (p->in_dtype != XFM_BF16 || p->out_dtype != XFM_F32 || p->dstate != 1 || p->H != p->W) return XFM_ELIMIT;
     if (p->delta_softplus < 0 || p->delta_softplus > 2) return XFM_ELIMIT;
-    if ((p->H == 56 || p->H == 28) && !p->chk) return XFM_EINVAL;     // multi-chunk rows need the forward's checkpoints
+    const int ppt = l3_ppt(p->H);
+    if (!ppt || p->d_inner % ppt) return XFM_ELIMIT;
+    if (!p->chk) return XFM_EINVAL;                                    // multi-chunk rows need the forward's checkpoints
     switch (p->H) {
         case 56: return l3_launch<56, 1>(*p, bwd, s, ws, ws_bytes);
         case 28: return l3_launch<28, 4>(*p, bwd, s, ws, ws_bytes);
+        case 48: return l3_launch<48, 1>(*p, bwd, s, ws, ws_bytes);   // XFMamba-B at 384 x 384: stages 1 and 2
+        case 24: return l3_launch<24, 4>(*p, bwd, s, ws, ws_bytes);
     }
     return XFM_ELIMIT;
 }
 
 // bytes of the partial-sum workspace the backward can use (0: shape not covered here)
 size_t ss2d_l3_ws_bytes(const xfm_ss2d_params_t *p) {
-    if (p->in_dtype != XFM_BF16 || p->dstate != 1 || p->H != p->W || (p->H != 56 && p->H != 28)) return 0;
-    const int ppt = p->H == 56 ? 1 : 4;
-    if (p->d_inner % ppt) return 0;
+    if (p->in_dtype != XFM_BF16 || p->dstate != 1 || p->H != p->W) return 0;
+    const int ppt = l3_ppt(p->H);
+    if (!ppt || p->d_inner % ppt) return 0;
     const int tiles_pb = p->d_inner / ppt;
     const int groups = tiles_pb / l3_pli(p->batch, tiles_pb, true);
     return groups > 1 ? (size_t)p->batch * groups * 4 * 2 * p->H * p->W * sizeof(float) : 0;
