@@ -547,6 +547,44 @@ def test_ss2d_xproj_core_matches_operator_chain(shape, dt):
         assert_close(a.float().cpu(), b.float().cpu(), tol, tol * float(b.float().abs().max()) + 1e-7, name)
 
 
+@pytest.mark.parametrize("shape", [(8, 24, 56, 56), (8, 48, 28, 28), (2, 16, 48, 48), (8, 32, 24, 24)])
+def test_ss2d_backward_workspace_entry_equals_the_atomics_entry(shape, monkeypatch):
+    """xfm_ss2d_bwd_ws (per-workgroup dB / dC partial rows in a caller workspace + one summing kernel, the default from
+    Python) against xfm_ss2d_bwd's flush by fp32 atomics (XFM_L3_ATOMICS=1 makes xfm_ss2d_bwd_ws_bytes return 0) on the
+    wide-map kernels: every gradient of the node, incl. the x_proj weight that consumes dB / dC."""
+    import ctypes
+    from xfmamba_amd import _lib
+    from xfmamba_amd.ss2d import ss2d_xproj_core_fn
+    B, D, H, W = shape
+    L, K, N = H * W, 4, 1
+    R = max(1, D // 16)
+    g = torch.Generator().manual_seed(D + H)
+    x = torch.randn(B, D, L, generator=g).bfloat16()
+    xw = torch.randn(K, R + 2 * N, D, generator=g) * D ** -0.5
+    dtw = torch.randn(K, D, R, generator=g) * R ** -0.5
+    A = -torch.rand(K * D, N, generator=g) - 0.1
+    Dp = torch.randn(K * D, generator=g)
+    bias = 0.1 * torch.rand(K * D, generator=g)
+    gy = torch.randn(B, D, L, generator=g)
+    p = _lib.SS2DParams()
+    p.batch, p.d_inner, p.H, p.W, p.dstate = B, D, H, W, N
+    p.in_dtype, p.out_dtype = _lib.dtype_code(torch.bfloat16), _lib.dtype_code(torch.float32)
+    outs = []
+    for atomics in (False, True):
+        if atomics:
+            monkeypatch.setenv("XFM_L3_ATOMICS", "1")
+        else:
+            monkeypatch.delenv("XFM_L3_ATOMICS", raising=False)
+        wsb = _lib.lib().xfm_ss2d_bwd_ws_bytes(ctypes.byref(p))
+        assert (wsb == 0) == atomics, (atomics, wsb)
+        t = [v.to(DEV).requires_grad_() for v in (x, xw, dtw, A, Dp, bias)]
+        y = ss2d_xproj_core_fn(t[0], t[1], t[2], t[3], t[4], t[5], H, W)
+        y.backward(gy.to(DEV))
+        outs.append([y.detach()] + [v.grad for v in t])
+    for name, a, b in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), outs[0], outs[1]):
+        assert_close(a.float().cpu(), b.float().cpu(), 2e-3, 2e-3 * float(b.float().abs().max()) + 1e-7, name)
+
+
 @pytest.mark.parametrize("B,D,R,H", [(2, 96, 6, 56), (2, 192, 12, 28), (3, 384, 24, 14), (2, 64, 5, 10), (1, 32, 3, 6)])
 @pytest.mark.parametrize("with_bias", [False, True])
 def test_dt_proj_kernels_match_torch_fp32(B, D, R, H, with_bias):
