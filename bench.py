@@ -202,6 +202,8 @@ def main():
         return loss
 
     def phase_a():                                   # graph A: forward, loss, backward down to the cut, pack bucket 0
+        if os.environ.get("XFM_BENCH_FAIL_PHASED"):  # (development hook: exercises the one-graph fallback below)
+            raise RuntimeError("forced by XFM_BENCH_FAIL_PHASED")
         loss = forward_loss()
         phased.backward_late(loss, model.mamba_feature_extrac.cut_tensor)
         return loss
@@ -261,30 +263,48 @@ def main():
     graph = None
     graph_b = None
     loss_static = None
+    def capture():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(3, min(a.warmup, 5))):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g, gb = torch.cuda.CUDAGraph(), None
+        if phased is not None:
+            # two graphs over one memory pool, always replayed A then B: B reads the activations A's forward saved
+            with torch.cuda.graph(g):
+                ls = phase_a()
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=g.pool()):
+                phased.backward_early()
+        else:
+            with torch.cuda.graph(g):
+                ls = captured_part()
+        return g, gb, ls
+
     if use_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(max(3, min(a.warmup, 5))):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
+            graph, graph_b, loss_static = capture()
+        except Exception as e:                       # noqa: BLE001
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
             if phased is not None:
-                # two graphs over one memory pool, always replayed A then B: B reads the activations A's forward saved
-                with torch.cuda.graph(graph):
-                    loss_static = phase_a()
-                graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_b, pool=graph.pool()):
-                    phased.backward_early()
+                # the two-graph data-parallel step did not come up (every rank runs the same code and fails alike): fall
+                # back to ONE graph for forward + backward + packing and the all-reduce after it
+                print(f"[bench] two-graph step failed ({type(e).__name__}: {e}); one graph + all-reduce after it", file=sys.stderr)
+                phased = None
+                model.mamba_feature_extrac.cut_after = None
+                buckets = GradBuckets(model, bucket_mb=48.0, overlap=False, comm_dtype=comm)
+                try:
+                    graph, graph_b, loss_static = capture()
+                except Exception as e2:              # noqa: BLE001  (report and fall back to eager launches)
+                    print(f"[bench] graph capture failed, running eager: {type(e2).__name__}: {e2}", file=sys.stderr)
+                    graph = graph_b = None
+                    torch.cuda.synchronize()
             else:
-                with torch.cuda.graph(graph):
-                    loss_static = captured_part()
-        except Exception as e:                       # noqa: BLE001  (report and fall back to eager launches)
-            print(f"[bench] graph capture failed, running eager: {type(e).__name__}: {e}", file=sys.stderr)
-            graph = graph_b = None
-            torch.cuda.synchronize()
+                print(f"[bench] graph capture failed, running eager: {type(e).__name__}: {e}", file=sys.stderr)
+                graph = graph_b = None
 
     def run_step():
         if graph_b is not None:
