@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--dp-cut", type=int, default=1, help="N > 1 with a captured step: the backward pass is cut after this "
                     "trunk stage into two hipGraphs, the late layers' all-reduce runs under the second (-1: one graph, "
                     "all-reduce after it)")
+    ap.add_argument("--no-deferred-sums", action="store_true",
+                    help="a finish kernel per LayerNorm / bias gradient (default: one fold launch per step, xfmamba_amd/deferred.py)")
     ap.add_argument("--no-wgrad-arena", action="store_true",
                     help="a fresh zero-filled tensor per weight gradient (default: one arena, zeroed once per step)")
     ap.add_argument("--wgrad-stream", action="store_true",
@@ -123,6 +125,8 @@ def main():
     from xfmamba_amd.dp import GradBuckets, PhasedGrads, broadcast_parameters
     from xfmamba_amd.proj import WgradArena, join_wgrad_stream, set_wgrad_arena, wgrad_stream
     wgrad_stream(a.wgrad_stream)
+    from xfmamba_amd.deferred import defer_partial_sums
+    defer_partial_sums(not a.no_deferred_sums)       # (every gradient reader below goes through join_wgrad_stream() first)
     from xfmamba_amd.net_fusionmamba import TwoViewXFMambaTop
     _lib.lib()                                                   # fail loudly if the HIP extension is missing
     if a.fp8:

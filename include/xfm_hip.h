@@ -192,6 +192,19 @@ int xfm_bias_gelu_bwd(const void *z, const float *bias, const void *dg, void *dz
 int xfm_colsum(const void *x, float *out, float *workspace, long long rows, int C, int dtype, void *stream);
 
 /*
+ * Deferred column sums.  xfm_add_layernorm_rows_bwd (dweight == NULL), xfm_bias_gelu_bwd (dbias == NULL) and xfm_colsum
+ * (out == NULL) then only leave their per-workgroup partial rows in `workspace` -- layout [block][parts][C] with
+ * parts = 2 (dw, db) or 3 (+ d pre_bias, whenever pre_bias is given) for the LayerNorm, 1 for the other two, `block`
+ * counts from xfm_add_layernorm_rows_bwd_blocks / xfm_colsum_blocks -- and ONE xfm_partial_sums_multi launch folds the
+ * partial rows of any number of such producers (the parameter gradients of autograd of nn.LayerNorm / nn.Linear biases,
+ * reference models/fusion_vmamba.py:135-153, 1325-1337: nothing reads them before the optimizer).
+ *   jobs:   device array, 6 int64 per job {part, out0, out1, out2 (device addresses; outs may be 0), nblk | (int64)C << 32,
+ *           parts}:  out_k[c] = sum over j < nblk of part[(j * parts + k) * C + c]
+ *   blocks: device int32 array, one entry per workgroup: job index | (64-column block of its parts * C columns) << 16
+ */
+int xfm_partial_sums_multi(const void *jobs, const void *blocks, int nblocks, void *stream);
+
+/*
  * Skinny token-major linear layer on MFMA (csrc/tokens_gemm.hip):  y[T, out] = x[T, con] . W^T (+ bias), bf16 in / out,
  * fp32 accumulation -- `F.linear` of Mlp.fc1 / fc2 (reference models/fusion_vmamba.py:135-153) and its backward data
  * product at the 56x56 stage, where the product is HBM-bound and the whole weight fits in LDS.

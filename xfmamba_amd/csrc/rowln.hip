@@ -341,12 +341,13 @@ int xfm_add_layernorm_rows_bwd(const void *x_new, const float *pre_bias, const f
                                void *dy, float *dweight, float *dbias, float *dpre_bias, float *workspace, int B, int rows_per_sample, int C,
                                int x_dtype, int dtype, void *stream) {
     using namespace xfm;
-    if (!x_new || !weight || !dh || !mean || !rstd || !dx || !dweight || !workspace || B <= 0 || rows_per_sample <= 0)
+    if (!x_new || !weight || !dh || !mean || !rstd || !dx || !workspace || B <= 0 || rows_per_sample <= 0)
         return XFM_EINVAL;
     int G, NV;
     if (!pick_shape(C, G, NV)) return XFM_ELIMIT;
     RowLnArgs a{};
-    a.x = x_new; a.pre_bias = pre_bias; a.nparts = dpre_bias ? 3 : 2; a.w = weight; a.dh = dh; a.dres = dres; a.mean = const_cast<float *>(mean); a.rstd = const_cast<float *>(rstd); a.scale = scale; a.dx = dx;
+    // (dweight == null: the partial rows stay in the workspace -- ALWAYS three parts wide then -- for xfm_partial_sums_multi)
+    a.x = x_new; a.pre_bias = pre_bias; a.nparts = (dpre_bias || (!dweight && pre_bias)) ? 3 : 2; a.w = weight; a.dh = dh; a.dres = dres; a.mean = const_cast<float *>(mean); a.rstd = const_cast<float *>(rstd); a.scale = scale; a.dx = dx;
     a.dy = dy; a.part = workspace;
     a.rows = B * rows_per_sample; a.rows_per_sample = rows_per_sample; a.C = C;
     const int nblk = xfm_add_layernorm_rows_bwd_blocks(a.rows, C);
@@ -354,6 +355,7 @@ int xfm_add_layernorm_rows_bwd(const void *x_new, const float *pre_bias, const f
     if ((dy || dres) && x_dtype != XFM_F32) return XFM_EINVAL;
     const int rc = launch_any(true, x_dtype, dtype, G, NV, a, nblk, s);
     if (rc != XFM_OK) return rc;
+    if (!dweight) return XFM_OK;
     hipLaunchKernelGGL(rowln_wb_kernel, dim3((a.nparts * C + 63) / 64), dim3(1024), 0, s, workspace, dweight, dbias,
                        dpre_bias, nblk, C, a.nparts);
     return check_launch();

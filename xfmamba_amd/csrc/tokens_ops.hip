@@ -114,6 +114,37 @@ template <typename T, int MODE> __global__ void tokens_kernel(TokArgs a) {
 
 // out[c] = sum_j part[j, c].  64 channels x 16 row slots per workgroup: the slots stride through the partial rows
 // (coalesced 256-byte reads, independent loads in flight), then fold through LDS.
+// many producers' partial rows in one launch (xfm_partial_sums_multi): 64 columns x 16 row slots per workgroup
+__global__ __launch_bounds__(1024) void partial_sums_multi_kernel(const int64_t *__restrict__ jobs, const int *__restrict__ blocks) {
+    __shared__ float red[16][64];
+    const int e = blocks[blockIdx.x];
+    const int64_t *jb = jobs + 6 * (e & 0xffff);
+    const float *part = reinterpret_cast<const float *>(jb[0]);
+    const int nblk = (int)(jb[4] & 0xffffffff), C = (int)(jb[4] >> 32), nparts = (int)jb[5];
+    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const int i = (e >> 16) * 64 + lane;
+    const int W = nparts * C;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < W) {
+        int j = slot;
+        for (; j + 16 < nblk; j += 32) {
+            s0 += part[(long)j * W + i];
+            s1 += part[(long)(j + 16) * W + i];
+        }
+        if (j < nblk) s0 += part[(long)j * W + i];
+    }
+    red[slot][lane] = s0 + s1;
+    __syncthreads();
+    if (slot == 0 && i < W) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][lane];
+        const int k = i / C;
+        float *out = reinterpret_cast<float *>(jb[1 + k]);
+        if (out) out[i - k * C] = s;
+    }
+}
+
 __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float *part, float *out, int nblk, int C) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
@@ -190,7 +221,7 @@ int xfm_bias_gelu_fwd(const void *z, const float *bias, void *g, long long rows,
 int xfm_bias_gelu_bwd(const void *z, const float *bias, const void *dg, void *dz, float *dbias, float *workspace,
                       long long rows, int C, int dtype, void *stream) {
     using namespace xfm;
-    if (!z || !dg || !dz || !dbias || !workspace || rows <= 0 || C <= 0) return XFM_EINVAL;
+    if (!z || !dg || !dz || !workspace || rows <= 0 || C <= 0) return XFM_EINVAL;
     TokArgs a{};
     a.z = z; a.bias = bias; a.dg = dg; a.out = dz; a.part = workspace; a.rows = rows; a.C = C;
     hipStream_t s = (hipStream_t)stream;
@@ -199,6 +230,7 @@ int xfm_bias_gelu_bwd(const void *z, const float *bias, const void *dg, void *dz
     else if (dtype == XFM_BF16) rc = tok_launch<bf16_t, 1>(a, s);
     else return XFM_EDTYPE;
     if (rc != XFM_OK) return rc;
+    if (!dbias) return XFM_OK;                       // the caller folds the partial rows itself (xfm_partial_sums_multi)
     const int nblk = xfm_colsum_blocks(rows, C, dtype);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, workspace, dbias, nblk, C);
     return check_launch();
@@ -206,7 +238,7 @@ int xfm_bias_gelu_bwd(const void *z, const float *bias, const void *dg, void *dz
 
 int xfm_colsum(const void *x, float *out, float *workspace, long long rows, int C, int dtype, void *stream) {
     using namespace xfm;
-    if (!x || !out || !workspace || rows <= 0 || C <= 0) return XFM_EINVAL;
+    if (!x || !workspace || rows <= 0 || C <= 0) return XFM_EINVAL;
     TokArgs a{};
     a.z = x; a.part = workspace; a.rows = rows; a.C = C;
     hipStream_t s = (hipStream_t)stream;
@@ -215,8 +247,23 @@ int xfm_colsum(const void *x, float *out, float *workspace, long long rows, int 
     else if (dtype == XFM_BF16) rc = tok_launch<bf16_t, 2>(a, s);
     else return XFM_EDTYPE;
     if (rc != XFM_OK) return rc;
+    if (!out) return XFM_OK;                         // partial rows only (xfm_partial_sums_multi folds them later)
     const int nblk = xfm_colsum_blocks(rows, C, dtype);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, workspace, out, nblk, C);
+    return check_launch();
+}
+
+// Fold the per-workgroup partial rows of MANY column-sum producers in one launch.  Every producer of this library that
+// ends in a small "finish" kernel (row-LayerNorm dw / db / d pre_bias, bias+GELU's bias gradient, xfm_colsum) can leave its
+// partial rows in its workspace instead (pass a null result pointer); a training step has ~50 of them, each a 6-7 us
+// kernel of a few workgroups whose results nobody reads before the optimizer.  jobs: device array of 6 int64 per job
+// {part, out0, out1, out2 (device addresses, outs may be 0), nblk | C << 32, nparts}: out_k[c] = sum_j part[j * nparts * C +
+// k * C + c].  blocks: device int32 array, one entry per workgroup: job | (64-column block << 16).
+int xfm_partial_sums_multi(const void *jobs, const void *blocks, int nblocks, void *stream) {
+    using namespace xfm;
+    if (!jobs || !blocks || nblocks <= 0) return XFM_EINVAL;
+    hipLaunchKernelGGL(partial_sums_multi_kernel, dim3((unsigned)nblocks), dim3(1024), 0, (hipStream_t)stream,
+                       (const int64_t *)jobs, (const int *)blocks);
     return check_launch();
 }
 

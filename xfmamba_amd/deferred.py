@@ -1,0 +1,114 @@
+"""Deferred column sums: one fold kernel per step for the partial rows of every LayerNorm / bias gradient.
+
+The row-LayerNorm backward, bias+GELU backward and the bias column sums end in a small "finish" kernel that folds
+per-workgroup partial rows into the parameter gradient: ~50 launches of 6-7 us per XFMamba-T step whose results nobody
+reads before the optimizer.  With ``defer_partial_sums(True)`` the producers leave their partial rows in their workspaces
+(null result pointer at the C ABI), register a job here, and ONE ``xfm_partial_sums_multi`` launch folds them all when
+``flush()`` runs -- ``proj.join_wgrad_stream()`` calls it, i.e. ``FusedAdam.step`` and the data-parallel packers do before
+they read a gradient.
+
+Opt-in (``bench.py`` turns it on): between ``backward()`` and the flush the affected ``.grad`` tensors are allocated but
+NOT yet filled, so code that reads gradients straight after ``backward()`` must call ``flush()`` (or leave this off).  A
+parameter that receives a second gradient in the same pass (shared weights) is flushed before its second producer runs and
+that producer is not deferred, so autograd never adds unfilled tensors.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = ["defer_partial_sums", "deferring", "add_job", "flush"]
+
+_MAX_JOBS, _MAX_BLOCKS = 512, 1 << 15
+_S = {"on": False, "jobs": [], "keys": set(), "slots": {}}
+
+
+def defer_partial_sums(enable: bool) -> None:
+    if not enable:
+        flush()
+    _S["on"] = bool(enable)
+
+
+def deferring() -> bool:
+    return _S["on"]
+
+
+def _slot(device, capturing):
+    """Pinned host tables + their device copies, one set for eager steps and one for a captured step (whose memcpy nodes
+    re-read the pinned buffer at every replay, so later eager steps must not overwrite it).  Both are allocated on the first
+    use, which has to be OUTSIDE a capture (the warm-up steps): nothing may be allocated on the host side while capturing."""
+    sl = _S["slots"].get((str(device), capturing))
+    if sl is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("xfmamba_amd.deferred: run a warm-up step with deferred sums before capturing")
+        for cap in (False, True):
+            _S["slots"][(str(device), cap)] = dict(
+                jobs_h=torch.empty(6 * _MAX_JOBS, dtype=torch.int64).pin_memory(),
+                blocks_h=torch.empty(_MAX_BLOCKS, dtype=torch.int32).pin_memory(),
+                jobs_d=torch.empty(6 * _MAX_JOBS, dtype=torch.int64, device=device),
+                blocks_d=torch.empty(_MAX_BLOCKS, dtype=torch.int32, device=device), key=None, evt=None)
+        sl = _S["slots"][(str(device), capturing)]
+    return sl
+
+
+def add_job(part: torch.Tensor, outs, nblk: int, C: int, nparts: int, key=None) -> bool:
+    """Register ``outs[k][c] = sum_j part[(j * nparts + k) * C + c]`` for the next flush.  False: deferral is off (the caller
+    runs its own finish kernel).  ``key``: identity of the parameter the result is a gradient of."""
+    if not _S["on"]:
+        return False
+    if key is not None and key in _S["keys"]:
+        # second gradient of the same parameter in one pass (shared weights, two trunk calls): autograd adds the two as
+        # soon as this one is returned, so the first must be complete NOW and this one is not deferred
+        flush(_end_of_pass=False)
+        return False
+    if len(_S["jobs"]) >= _MAX_JOBS:
+        flush(_end_of_pass=False)
+    # only the ADDRESSES of the results are kept: a second reference to a gradient tensor would make autograd's
+    # AccumulateGrad clone it instead of adopting it as .grad, and the fold would fill the orphan.  The tensors stay alive as
+    # the .grad of their parameters (or in the tuple torch.autograd.grad returns) until the flush.
+    ptrs = [0 if o is None else o.data_ptr() for o in outs] + [0] * (3 - len(outs))
+    _S["jobs"].append((part, ptrs, int(nblk), int(C), int(nparts)))
+    if key is not None:
+        _S["keys"].add(key)
+    return True
+
+
+@torch.no_grad()
+def flush(_end_of_pass: bool = True) -> None:
+    """Fold every registered job (one launch on the current stream).  No-op without jobs.  (The flushes ``add_job`` issues
+    in the middle of a backward pass keep the set of parameters seen in this pass: a later second gradient of any of them
+    must not be deferred either.)"""
+    jobs = _S["jobs"]
+    if _end_of_pass:
+        _S["keys"] = set()
+    if not jobs:
+        return
+    _S["jobs"] = []
+    dev = jobs[0][0].device
+    capturing = torch.cuda.is_current_stream_capturing()
+    sl = _slot(dev, capturing)
+    key = tuple((p.data_ptr(), tuple(outs), nblk, C, nparts) for p, outs, nblk, C, nparts in jobs)
+    if key != sl["key"]:
+        if sl["evt"] is not None and not capturing:
+            sl["evt"].synchronize()                  # the previous upload of this pinned table may still be in flight
+        jh, bh = sl["jobs_h"], sl["blocks_h"]
+        rows, blocks = [], []
+        for ji, (p, outs, nblk, C, nparts) in enumerate(jobs):
+            rows += [p.data_ptr()] + list(outs) + [nblk | (C << 32), nparts]
+            blocks += [ji | (cb << 16) for cb in range((nparts * C + 63) // 64)]
+        if len(blocks) > _MAX_BLOCKS:
+            raise RuntimeError("xfmamba_amd.deferred: too many column blocks in one flush")
+        jh[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
+        bh[:len(blocks)] = torch.tensor(blocks, dtype=torch.int32)
+        sl["jobs_d"][:len(rows)].copy_(jh[:len(rows)], non_blocking=True)
+        sl["blocks_d"][:len(blocks)].copy_(bh[:len(blocks)], non_blocking=True)
+        sl["key"], sl["nblocks"] = key, len(blocks)
+        if not capturing:
+            if sl["evt"] is None:
+                sl["evt"] = torch.cuda.Event()
+            sl["evt"].record()
+    with torch.cuda.device(dev), _lib.timed("partial_sums", 0):
+        _lib.check(_lib.lib().xfm_partial_sums_multi(sl["jobs_d"].data_ptr(), sl["blocks_d"].data_ptr(), sl["nblocks"],
+                                                     _lib.stream_ptr()), "partial_sums_multi")
+    # (the workspaces of `jobs` stay referenced until here: the launch is queued behind their producers)

@@ -11,6 +11,7 @@ import os
 import torch
 
 from . import _lib
+from . import deferred as _deferred
 from .amp import cast_weight
 from .proj import split_k_wgrad, wgrad_slot
 
@@ -22,8 +23,9 @@ def _rows(t):
     return t.numel() // C, C
 
 
-def colsum_fn(x: torch.Tensor) -> torch.Tensor:
-    """Sum over all axes but the last of a contiguous tensor -> (C,) fp32."""
+def colsum_fn(x: torch.Tensor, grad_of=None) -> torch.Tensor:
+    """Sum over all axes but the last of a contiguous tensor -> (C,) fp32.  ``grad_of``: the result is the gradient of that
+    parameter and nothing reads it before the optimizer -- with deferred column sums (deferred.py) it is filled at the flush."""
     _lib.require_cuda(x)
     x = x.contiguous()
     rows, C = _rows(x)
@@ -34,8 +36,10 @@ def colsum_fn(x: torch.Tensor) -> torch.Tensor:
         raise RuntimeError(f"xfmamba_amd: colsum does not support width {C} / dtype {x.dtype}")
     out = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = torch.empty(nblk * C, dtype=torch.float32, device=x.device)
+    later = grad_of is not None and _deferred.add_job(ws, [out], nblk, C, 1, key=grad_of.data_ptr())
     with torch.cuda.device(x.device), _lib.timed("colsum", x.numel() * x.element_size()):
-        _lib.check(lib.xfm_colsum(x.data_ptr(), out.data_ptr(), ws.data_ptr(), rows, C, code, _lib.stream_ptr()), "colsum")
+        _lib.check(lib.xfm_colsum(x.data_ptr(), None if later else out.data_ptr(), ws.data_ptr(), rows, C, code,
+                                  _lib.stream_ptr()), "colsum")
     return out
 
 
@@ -63,10 +67,14 @@ class BiasGeluHip(torch.autograd.Function):
         dg = dg.contiguous() if dg.dtype == z.dtype else dg.to(z.dtype).contiguous()
         dz = torch.empty_like(z)
         db = torch.empty(C, dtype=torch.float32, device=z.device)
-        ws = torch.empty(lib.xfm_colsum_blocks(rows, C, code) * C, dtype=torch.float32, device=z.device)
+        nblk = lib.xfm_colsum_blocks(rows, C, code)
+        ws = torch.empty(nblk * C, dtype=torch.float32, device=z.device)
+        later = (ctx.bdtype == torch.float32 and b is not None
+                 and _deferred.add_job(ws, [db], nblk, C, 1, key=b.data_ptr()))
         with torch.cuda.device(z.device), _lib.timed("bias_gelu_bwd", 3 * z.numel() * z.element_size()):
-            _lib.check(lib.xfm_bias_gelu_bwd(z.data_ptr(), _lib.ptr(b), dg.data_ptr(), dz.data_ptr(), db.data_ptr(),
-                                             ws.data_ptr(), rows, C, code, _lib.stream_ptr()), "bias_gelu_bwd")
+            _lib.check(lib.xfm_bias_gelu_bwd(z.data_ptr(), _lib.ptr(b), dg.data_ptr(), dz.data_ptr(),
+                                             None if later else db.data_ptr(), ws.data_ptr(), rows, C, code,
+                                             _lib.stream_ptr()), "bias_gelu_bwd")
         return dz, (None if ctx.bdtype is None else db.to(ctx.bdtype))
 
 
@@ -116,6 +124,7 @@ class LinearTokens(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
         ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None      # (identity only: the arena's slot key)
+        ctx.bparam = bias if isinstance(bias, torch.nn.Parameter) and bias.dtype == torch.float32 else None
         return y
 
     @staticmethod
@@ -134,7 +143,7 @@ class LinearTokens(torch.autograd.Function):
             slot = wgrad_slot(ctx.wparam, w.shape[0], w.shape[1]) if wdtype == torch.float32 else None
             dw = split_k_wgrad(dy2, x2, deferred=wdtype == torch.float32, out=slot).to(wdtype)
         if bdtype is not None and ctx.needs_input_grad[2]:
-            db = colsum_fn(dy2).to(bdtype)
+            db = colsum_fn(dy2, grad_of=ctx.bparam).to(bdtype)
         return dx, dw, db
 
 

@@ -57,7 +57,10 @@ def wgrad_stream(enable: bool) -> None:
 
 
 def join_wgrad_stream() -> None:
-    """Make the current stream wait for the weight-gradient launches issued so far (no-op when there are none)."""
+    """Make the current stream wait for the weight-gradient launches issued so far (no-op when there are none), and fold
+    the deferred column sums (deferred.py): every reader of parameter gradients calls this first."""
+    from . import deferred
+    deferred.flush()
     if _SIDE["pending"]:
         torch.cuda.current_stream().wait_stream(_SIDE["stream"])
         _SIDE["pending"] = False

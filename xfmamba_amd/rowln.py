@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from . import deferred as _deferred
 
 __all__ = ["add_layernorm_rows_fn", "layernorm_rows_fn", "rows_supported"]
 
@@ -44,14 +45,19 @@ def _bwd(x_new, w, dh, dres, mean, rstd, scale, want_dy, has_bias, dtype, pre=No
     dw = torch.empty_like(w)
     db = torch.empty_like(w) if has_bias else None
     dpre = torch.empty_like(w) if pre is not None else None
-    ws = torch.empty(3 * C * lib.xfm_add_layernorm_rows_bwd_blocks(B * rps, C), dtype=torch.float32, device=x_new.device)
+    nblk = lib.xfm_add_layernorm_rows_bwd_blocks(B * rps, C)
+    ws = torch.empty(3 * C * nblk, dtype=torch.float32, device=x_new.device)
     nbytes = x_new.numel() * (2 * x_new.element_size() + dh.element_size() + (0 if dres is None else 4)
                               + (dy.element_size() if want_dy else 0))
+    # with deferred column sums the kernel leaves its partial rows in ws and ONE launch per step folds them (deferred.py)
+    nparts = 3 if pre is not None else 2
+    later = _deferred.add_job(ws, [dw, db, dpre], nblk, C, nparts, key=w.data_ptr())
     with torch.cuda.device(x_new.device), _lib.timed("add_layernorm_rows_bwd", nbytes):
         _lib.check(lib.xfm_add_layernorm_rows_bwd(
             x_new.data_ptr(), _lib.ptr(pre), w.data_ptr(), dh.data_ptr(), _lib.ptr(dres), mean.data_ptr(), rstd.data_ptr(),
-            _lib.ptr(scale), dx.data_ptr(), _lib.ptr(dy), dw.data_ptr(), _lib.ptr(db), _lib.ptr(dpre), ws.data_ptr(), B, rps, C,
-            _lib.dtype_code(x_new.dtype), _lib.dtype_code(dtype), _lib.stream_ptr()), "add_layernorm_rows_bwd")
+            _lib.ptr(scale), dx.data_ptr(), _lib.ptr(dy), None if later else dw.data_ptr(), _lib.ptr(db), _lib.ptr(dpre),
+            ws.data_ptr(), B, rps, C, _lib.dtype_code(x_new.dtype), _lib.dtype_code(dtype), _lib.stream_ptr()),
+            "add_layernorm_rows_bwd")
     return dx, dy, dw, db, dpre
 
 
