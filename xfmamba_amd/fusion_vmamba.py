@@ -65,15 +65,16 @@ class DropPath(nn.Module):
         self.drop_prob = float(drop_prob)
         self.scale_by_keep = scale_by_keep
         self._ones = {}
-        self._preset = None          # a factor sampled ahead by _DropPathBank (one launch for all layers of a trunk)
+        self._preset = None          # factors sampled ahead by _DropPathBank (one launch for all layers of a trunk)
 
     def sample_scale(self, batch: int, device):
         """The per-sample factor ``forward`` multiplies by, as a (B,) fp32 vector (None when it is the identity)."""
         if self.drop_prob == 0.0 or not self.training:
             return None
-        pre, self._preset = self._preset, None
-        if pre is not None and pre.shape[0] == batch and pre.device.type == torch.device(device).type:
-            return pre
+        if self._preset:                                  # rows sampled ahead for this pass: one per use of the module
+            pre = self._preset.pop()
+            if pre.shape[0] == batch and pre.device.type == torch.device(device).type:
+                return pre
         keep = 1.0 - self.drop_prob
         key = (batch, str(device))
         ones = self._ones.get(key)
@@ -486,6 +487,8 @@ class _DropPathBank:
     uniform draw (a (layers, B) matrix compared with the keep probabilities) instead of a dropout kernel per layer (26
     launches in XFMamba-T).  Same distribution per layer and sample: Bernoulli(keep) / keep, independent across both."""
 
+    USES = 2
+
     def __init__(self, root: nn.Module, batch: int, device):
         mods = root.__dict__.get("_droppath_mods")
         if mods is None:
@@ -503,10 +506,12 @@ class _DropPathBank:
                     return self                                      # (no upload inside a capture: per-layer kernels)
                 keep = (key, torch.tensor([1.0 - p for p in key[0]], dtype=torch.float32).to(self.device)[:, None])
                 self.root.__dict__["_droppath_keep"] = keep
-            u = torch.rand(len(self.mods), self.batch, dtype=torch.float32, device=self.device)
+            # a VSSBlock applies its DropPath twice per pass (SS2D branch and Mlp branch): USES independent rows per module
+            n = len(self.mods)
+            u = torch.rand(self.USES, n, self.batch, dtype=torch.float32, device=self.device)
             bank = (u < keep[1]).to(torch.float32) / keep[1]
-            for m, row in zip(self.mods, bank.unbind(0)):
-                m._preset = row
+            for i, m in enumerate(self.mods):
+                m._preset = [bank[j, i] for j in range(self.USES)]
         return self
 
     def __exit__(self, *exc):
