@@ -733,3 +733,50 @@ def test_deferred_column_sums_fill_the_same_gradients():
             # (bf16 step with fp32 atomics elsewhere: run-to-run noise of a few % of a tiny gradient's scale; an unfilled
             #  or mis-addressed sum is off by ~100 %)
             assert float((grads[1][k] - ref).abs().max()) <= 5e-2 * scale + 1e-7, (merge, k)
+
+
+def test_padded_x_proj_copy_follows_the_fused_optimizer():
+    """amp.padded_shadow: the channel-lane SS2D blocks adopt the row-padded bf16 copy of x_proj_weight they build in their
+    first forward pass; FusedAdam.step (through WeightCache.mark_current -> amp.refresh_derived) rewrites it in place for all
+    blocks with one multi-tensor copy.  After a step the registered copy must equal pad(bf16(new weight)) and the next
+    forward must produce what a freshly padded weight produces; an in-place change of the parameter makes it stale."""
+    from xfmamba_amd import amp
+    from xfmamba_amd.amp import WeightCache
+    from xfmamba_amd.optim import FusedAdam
+    from xfmamba_amd.ss2d_chan import ss2d_chan_fn, _col_layout
+    torch.manual_seed(1)
+    B, D, H, R, N, K = 2, 64, 14, 8, 1, 4
+    L = H * H
+    xw = torch.nn.Parameter((torch.randn(K, R + 2 * N, D) * D ** -0.5).to(DEV))
+    dtw = torch.nn.Parameter((torch.randn(K, D, R) * R ** -0.5).to(DEV))
+    A = (-torch.rand(K * D, N) - 0.1).to(DEV)
+    Dp, bias = torch.randn(K * D).to(DEV), (0.1 * torch.rand(K * D) - 4.0).to(DEV)
+    x = torch.randn(B, D, L).bfloat16().to(DEV)
+    holder = torch.nn.ParameterList([xw, dtw])
+    wc = WeightCache(holder)
+    opt = FusedAdam(holder.parameters(), lr=1e-2, weight_cache=wc)
+    _, _, C2p, _ = _col_layout(R, N)
+    try:
+        assert amp.padded_shadow(xw, C2p, torch.bfloat16) is None
+        y = ss2d_chan_fn(x, xw, dtw, A, Dp, bias, H, H)
+        pad = amp.padded_shadow(xw, C2p, torch.bfloat16)
+        assert pad is not None and pad.shape == (K, C2p, D)
+        y.float().square().mean().backward()
+        opt.step()
+        torch.cuda.synchronize()
+        assert amp.padded_shadow(xw, C2p, torch.bfloat16) is pad                      # same storage, rewritten in place
+        want = torch.zeros(K, C2p, D, dtype=torch.bfloat16, device=DEV)
+        want[:, :R + 2 * N] = xw.detach().to(torch.bfloat16)
+        assert torch.equal(pad, want)
+        y1 = ss2d_chan_fn(x, xw, dtw, A, Dp, bias, H, H)                              # served from the registered copy
+        amp.invalidate_shadows(holder)
+        y2 = ss2d_chan_fn(x, xw, dtw, A, Dp, bias, H, H)                              # padded afresh from the master
+        assert torch.equal(y1, y2)
+        wc.refresh()
+        ss2d_chan_fn(x, xw, dtw, A, Dp, bias, H, H)
+        assert amp.padded_shadow(xw, C2p, torch.bfloat16) is not None
+        with torch.no_grad():
+            xw.mul_(0.5)                                                              # in-place change: the copy is stale
+        assert amp.padded_shadow(xw, C2p, torch.bfloat16) is None
+    finally:
+        wc.close()

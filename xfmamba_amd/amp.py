@@ -19,9 +19,52 @@ import weakref
 
 import torch
 
-__all__ = ["WeightCache", "cast_weight", "invalidate_shadows"]
+__all__ = ["WeightCache", "cast_weight", "invalidate_shadows", "padded_shadow", "adopt_padded", "refresh_derived"]
 
 _SHADOWS = {}          # id(parameter) -> (weakref(parameter), shadow tensor, version at refresh)
+# Row-padded copies of shadows (the channel-lane SS2D kernels read x_proj_weight with every route's rows padded from
+# R + 2N to a multiple of 8: ss2d_chan.py).  Padding the bf16 shadow inside every forward pass is a fill + a copy per block
+# and step; a registered padded copy is instead rewritten for ALL blocks by one multi-tensor copy right after the optimizer
+# step (refresh_derived), in place, so a captured step keeps reading the same storage.
+_PADDED = {}           # id(parameter) -> [weakref(parameter), padded (K, C2p, D) tensor, parameter version it was made from]
+
+
+def padded_shadow(w: torch.Tensor, rows_padded: int, dtype: torch.dtype):
+    """The registered (K, rows_padded, D) copy of the 3-D parameter ``w`` (rows beyond w.shape[1] zero), or None when there
+    is none or it is stale (the parameter was modified in place since)."""
+    ent = _PADDED.get(id(w))
+    if ent is None or ent[0]() is not w or ent[2] != w._version or ent[1].dtype != dtype or ent[1].shape[1] != rows_padded:
+        return None
+    return ent[1]
+
+
+def adopt_padded(w: torch.Tensor, padded: torch.Tensor) -> None:
+    """Register ``padded`` -- just computed from the CURRENT value of parameter ``w`` -- as its padded copy.  Only parameters
+    with a registered shadow are adopted: their copy is kept current by ``refresh_derived`` after every optimizer step."""
+    sh = _SHADOWS.get(id(w))
+    if sh is None or sh[0]() is not w or sh[2] != w._version or padded.dtype != sh[1].dtype:
+        return
+    _PADDED[id(w)] = [weakref.ref(w), padded, w._version]
+
+
+@torch.no_grad()
+def refresh_derived() -> None:
+    """Rewrite every padded copy from its parameter's shadow: ONE multi-tensor copy (per-route blocks are contiguous on both
+    sides).  Called by the writers of the shadows (FusedAdam.step, WeightCache.refresh)."""
+    dst, src = [], []
+    for key, ent in list(_PADDED.items()):
+        w = ent[0]()
+        sh = _SHADOWS.get(key)
+        if w is None or sh is None or sh[0]() is not w or sh[2] != w._version or sh[1].dtype != ent[1].dtype:
+            del _PADDED[key]                         # no current shadow to copy from: the next forward pads again
+            continue
+        K, C2 = w.shape[0], w.shape[1]
+        for k in range(K):
+            dst.append(ent[1][k, :C2])
+            src.append(sh[1][k])
+        ent[2] = w._version
+    if dst:
+        torch._foreach_copy_(dst, src)
 
 
 def cast_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -45,9 +88,11 @@ def invalidate_shadows(module: torch.nn.Module = None) -> None:
     fp32 master until ``WeightCache.refresh()`` registers fresh copies.  For code that wrote weights through ``.data``."""
     if module is None:
         _SHADOWS.clear()
+        _PADDED.clear()
         return
     for p in module.parameters():
         _SHADOWS.pop(id(p), None)
+        _PADDED.pop(id(p), None)
 
 
 class WeightCache:
@@ -63,6 +108,7 @@ class WeightCache:
             torch._foreach_copy_(self.shadows, self.params)
         for p, s in zip(self.params, self.shadows):
             _SHADOWS[id(p)] = (weakref.ref(p), s, p._version)
+        refresh_derived()
 
     def mark_current(self, written=None):
         """Register the shadows as current WITHOUT copying (they were just written by ``optim.FusedAdam``'s kernel).
@@ -72,9 +118,11 @@ class WeightCache:
         for p, s in zip(self.params, self.shadows):
             if ids is None or id(p) in ids:
                 _SHADOWS[id(p)] = (weakref.ref(p), s, p._version)
+        refresh_derived()
 
     def close(self):
         for p in self.params:
             ent = _SHADOWS.get(id(p))
             if ent is not None and ent[0]() is p:
                 del _SHADOWS[id(p)]
+            _PADDED.pop(id(p), None)

@@ -16,6 +16,7 @@ import torch
 
 from . import _lib
 from . import fp8 as _fp8
+from . import amp as _amp
 from .amp import cast_weight
 from .proj import zeros_f32
 
@@ -105,7 +106,15 @@ class SS2DChanHip(torch.autograd.Function):
                 _lib.check(_lib.lib().xfm_fp8_planes_gemm(x.data_ptr(), wq.data_ptr(), scale.data_ptr(), xdbl.data_ptr(), Bt, Dm,
                                                           L, XC, _lib.stream_ptr()), "fp8_planes_gemm")
         else:
-            xw_pad = padded(cast_weight(x_proj_w, x.dtype)).contiguous()
+            # the padded bf16 weight: a registered copy kept current by the optimizer step (amp.refresh_derived), else padded
+            # here (a fill + a copy) and handed over for the following steps
+            xw3 = _amp.padded_shadow(x_proj_w, C2p, x.dtype) if plain else None
+            if xw3 is not None:
+                xw_pad = xw3.view(XC, Dm)
+            else:
+                xw_pad = padded(cast_weight(x_proj_w, x.dtype)).contiguous()
+                if plain and isinstance(x_proj_w, torch.nn.Parameter):
+                    _amp.adopt_padded(x_proj_w, xw_pad.view(K, C2p, Dm))
             xdbl = torch.bmm(x.transpose(1, 2), xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC))     # (B, L, XC) token-major
         A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
         lib = _lib.lib()
