@@ -192,6 +192,18 @@ int xfm_bias_gelu_bwd(const void *z, const float *bias, const void *dg, void *dz
 int xfm_colsum(const void *x, float *out, float *workspace, long long rows, int C, int dtype, void *stream);
 
 /*
+ * End-of-stage residual settle on the token-major stream (reference models/fusion_vmamba.py:1325-1337: the last
+ * `x = x + self.drop_path(self.mlp(self.norm2(x)))` of a stage, whose result feeds the downsample convolution):
+ *   fwd: out[r, c] = x[r, c] + scale[b(r)] * (y[r, c] + y_bias[c])   x fp32, y / out bf16 or fp32 (out = the consumer's dtype)
+ *   bwd: dx = dout (fp32), dy = scale[b] * dout (y's dtype)            (d y_bias = column sum of dy: xfm_colsum)
+ * rows r = b * rows_per_sample + i; scale (B) and y_bias (C) may be NULL; C % 8 == 0.
+ */
+int xfm_residual_settle_fwd(const float *x, const void *y, const float *scale, const float *y_bias, void *out, int B,
+                            int rows_per_sample, int C, int y_dtype, int out_dtype, void *stream);
+int xfm_residual_settle_bwd(const void *dout, const float *scale, float *dx, void *dy, int B, int rows_per_sample, int C,
+                            int y_dtype, int out_dtype, void *stream);
+
+/*
  * Deferred column sums.  xfm_add_layernorm_rows_bwd (dweight == NULL), xfm_bias_gelu_bwd (dbias == NULL) and xfm_colsum
  * (out == NULL) then only leave their per-workgroup partial rows in `workspace` -- layout [block][parts][C] with
  * parts = 2 (dw, db) or 3 (+ d pre_bias, whenever pre_bias is given) for the LayerNorm, 1 for the other two, `block`

@@ -821,3 +821,38 @@ def test_wgrad_mfma_matches_torch_fp32(Bt, L, M, N, a_planes, b_planes):
     out = wgrad_mfma(wide[:, 1], a_planes, b, b_planes, out=acc)
     if out is not None:                                   # (sample stride must keep the vector alignment)
         assert_close((acc - 1.5).cpu(), ref, 2e-3, 2e-3 * float(ref.abs().max()), "dw (accumulated, strided)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ydt,odt", [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32),
+                                     (torch.float32, torch.float32), (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("mode", ["full", "noscale", "nobias"])
+def test_residual_settle_matches_torch_fp32(ydt, odt, mode):
+    """xfm_residual_settle_fwd/_bwd: out = x + scale[b] * (y + y_bias) in the consumer's dtype (the end-of-stage residual add
+    of VSSBlock._forward, reference fusion_vmamba.py:1325-1337, feeding the downsample convolution) vs plain PyTorch fp32:
+    output, dx, dy, d y_bias; ragged vector count (rows * C / 8 not a multiple of the block size)."""
+    from xfmamba_amd.rowln import residual_settle_fn
+    g = torch.Generator().manual_seed(9)
+    B, H, W, C = 3, 5, 7, 96
+    x = torch.randn(B, H, W, C, generator=g)
+    y = torch.randn(B, H, W, C, generator=g).to(ydt)
+    sc = None if mode == "noscale" else torch.tensor([0.0, 1.25, 1.25])
+    yb = None if mode == "nobias" else torch.randn(C, generator=g)
+    gy = torch.randn(B, H, W, C, generator=g).to(odt)
+    xr, yr = x.clone().requires_grad_(), y.float().clone().requires_grad_()
+    ybr = None if yb is None else yb.clone().requires_grad_()
+    ref = yr if ybr is None else yr + ybr
+    ref = xr + (ref if sc is None else ref * sc.view(B, 1, 1, 1))
+    ref.backward(gy.float())
+    xd, yd = x.to(DEV).requires_grad_(), y.to(DEV).requires_grad_()
+    ybd = None if yb is None else yb.to(DEV).requires_grad_()
+    out = residual_settle_fn(xd, yd, None if sc is None else sc.to(DEV), ybd, odt)
+    assert out.dtype == odt
+    out.backward(gy.to(DEV))
+    tol = 1e-6 if (ydt == torch.float32 and odt == torch.float32) else 1e-2
+    assert_close(out.float().cpu(), ref.detach(), tol, tol * float(ref.abs().max()), "out")
+    assert_close(xd.grad.cpu(), xr.grad, tol, tol * float(xr.grad.abs().max()), "dx")
+    assert yd.grad.dtype == ydt
+    assert_close(yd.grad.float().cpu(), yr.grad, tol, tol * float(yr.grad.abs().max()) + 1e-7, "dy")
+    if yb is not None:
+        assert_close(ybd.grad.cpu(), ybr.grad, tol, tol * float(ybr.grad.abs().max()) + 1e-6, "dyb")

@@ -11,6 +11,8 @@
 // HBM-bound: 2 tensor passes forward, 3 backward.
 #include "xfm_common.hpp"
 
+#include <algorithm>
+
 namespace xfm {
 
 constexpr float kInvSqrt2 = 0.70710678118654752f;
@@ -114,6 +116,69 @@ template <typename T, int MODE> __global__ void tokens_kernel(TokArgs a) {
 
 // out[c] = sum_j part[j, c].  64 channels x 16 row slots per workgroup: the slots stride through the partial rows
 // (coalesced 256-byte reads, independent loads in flight), then fold through LDS.
+// ---- end-of-stage residual settle: out = x + scale[b] * (y + y_bias), emitted in the consumer's dtype -----------------
+// (the last block of a trunk stage has no following LayerNorm to fold its residual add into; what follows is the
+// downsample convolution, which under autocast reads bf16 -- as framework ops this was bias add, scale, add and the
+// convolution's input cast: four passes over the stream instead of one)
+template <typename To> __device__ __forceinline__ void settle_store8(To *p, const float (&v)[8]);
+template <> __device__ __forceinline__ void settle_store8<float>(float *p, const float (&v)[8]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void settle_store8<bf16_t>(bf16_t *p, const float (&v)[8]) {
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4 *>(p) = o;
+}
+__device__ __forceinline__ void settle_load8(const float *p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void settle_load8(const bf16_t *p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4 *>(p);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[2 * q] = __uint_as_float(w[q] << 16);
+        v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+    }
+}
+
+// one thread = 8 consecutive channels of one row; rows = B * rows_per_sample, C % 8 == 0
+template <typename Ty, typename To>
+__global__ void __launch_bounds__(256) settle_fwd_kernel(const float *__restrict__ x, const Ty *__restrict__ y,
+                                                         const float *__restrict__ scale, const float *__restrict__ yb,
+                                                         To *__restrict__ out, long long nvec, int C8, int rows_per_sample) {
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        const long long row = v / C8;
+        const int c = (int)(v - row * C8) * 8;
+        const float s = scale ? scale[row / rows_per_sample] : 1.f;
+        float xv[8], yv[8], o[8];
+        settle_load8(x + v * 8, xv);
+        settle_load8(y + v * 8, yv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = fmaf(s, yv[q] + (yb ? yb[c + q] : 0.f), xv[q]);
+        settle_store8<To>(out + v * 8, o);
+    }
+}
+
+// dx = dout (fp32), dy = scale[b] * dout (y's dtype)
+template <typename Ty, typename To>
+__global__ void __launch_bounds__(256) settle_bwd_kernel(const To *__restrict__ dout, const float *__restrict__ scale,
+                                                         float *__restrict__ dx, Ty *__restrict__ dy, long long nvec, int C8,
+                                                         int rows_per_sample) {
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        const long long row = v / C8;
+        const float s = scale ? scale[row / rows_per_sample] : 1.f;
+        float g[8], o[8];
+        settle_load8(dout + v * 8, g);
+        settle_store8<float>(dx + v * 8, g);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = s * g[q];
+        settle_store8<Ty>(dy + v * 8, o);
+    }
+}
+
 // many producers' partial rows in one launch (xfm_partial_sums_multi): 64 columns x 16 row slots per workgroup
 __global__ __launch_bounds__(1024) void partial_sums_multi_kernel(const int64_t *__restrict__ jobs, const int *__restrict__ blocks) {
     __shared__ float red[16][64];
@@ -250,6 +315,46 @@ int xfm_colsum(const void *x, float *out, float *workspace, long long rows, int 
     if (!out) return XFM_OK;                         // partial rows only (xfm_partial_sums_multi folds them later)
     const int nblk = xfm_colsum_blocks(rows, C, dtype);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, workspace, out, nblk, C);
+    return check_launch();
+}
+
+int xfm_residual_settle_fwd(const float *x, const void *y, const float *scale, const float *y_bias, void *out, int B,
+                            int rows_per_sample, int C, int y_dtype, int out_dtype, void *stream) {
+    using namespace xfm;
+    if (!x || !y || !out || B <= 0 || rows_per_sample <= 0 || C <= 0) return XFM_EINVAL;
+    if (C % 8) return XFM_ELIMIT;
+    const long long nvec = (long long)B * rows_per_sample * (C / 8);
+    const unsigned grid = (unsigned)std::min<long long>((nvec + 255) / 256, 256 * 16);
+    hipStream_t s = (hipStream_t)stream;
+#define XFM_SETTLE_F(TY, TO)                                                                                        \
+    hipLaunchKernelGGL((settle_fwd_kernel<TY, TO>), dim3(grid), dim3(256), 0, s, x, (const TY *)y, scale, y_bias, \
+                       (TO *)out, nvec, C / 8, rows_per_sample)
+    if (y_dtype == XFM_BF16 && out_dtype == XFM_BF16) XFM_SETTLE_F(bf16_t, bf16_t);
+    else if (y_dtype == XFM_BF16 && out_dtype == XFM_F32) XFM_SETTLE_F(bf16_t, float);
+    else if (y_dtype == XFM_F32 && out_dtype == XFM_F32) XFM_SETTLE_F(float, float);
+    else if (y_dtype == XFM_F32 && out_dtype == XFM_BF16) XFM_SETTLE_F(float, bf16_t);
+    else return XFM_EDTYPE;
+#undef XFM_SETTLE_F
+    return check_launch();
+}
+
+int xfm_residual_settle_bwd(const void *dout, const float *scale, float *dx, void *dy, int B, int rows_per_sample, int C,
+                            int y_dtype, int out_dtype, void *stream) {
+    using namespace xfm;
+    if (!dout || !dx || !dy || B <= 0 || rows_per_sample <= 0 || C <= 0) return XFM_EINVAL;
+    if (C % 8) return XFM_ELIMIT;
+    const long long nvec = (long long)B * rows_per_sample * (C / 8);
+    const unsigned grid = (unsigned)std::min<long long>((nvec + 255) / 256, 256 * 16);
+    hipStream_t s = (hipStream_t)stream;
+#define XFM_SETTLE_B(TY, TO)                                                                                        \
+    hipLaunchKernelGGL((settle_bwd_kernel<TY, TO>), dim3(grid), dim3(256), 0, s, (const TO *)dout, scale, dx, (TY *)dy, \
+                       nvec, C / 8, rows_per_sample)
+    if (y_dtype == XFM_BF16 && out_dtype == XFM_BF16) XFM_SETTLE_B(bf16_t, bf16_t);
+    else if (y_dtype == XFM_BF16 && out_dtype == XFM_F32) XFM_SETTLE_B(bf16_t, float);
+    else if (y_dtype == XFM_F32 && out_dtype == XFM_F32) XFM_SETTLE_B(float, float);
+    else if (y_dtype == XFM_F32 && out_dtype == XFM_BF16) XFM_SETTLE_B(float, bf16_t);
+    else return XFM_EDTYPE;
+#undef XFM_SETTLE_B
     return check_launch();
 }
 

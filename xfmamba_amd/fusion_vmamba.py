@@ -39,7 +39,7 @@ from .dwconv import dwconv3x3_silu_fn
 from .layernorm2d import layernorm2d_fn
 from .mlp_tokens import linear_tokens_fn, mlp_tokens_fn
 from .proj import batched_proj
-from .rowln import add_layernorm_rows_fn, layernorm_rows_fn, rows_supported
+from .rowln import residual_settle_fn, add_layernorm_rows_fn, layernorm_rows_fn, rows_supported
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
 from .ss2d_chan import chan_supported, ss2d_chan_fn
 from . import fp8 as _fp8
@@ -390,16 +390,21 @@ def _norm_tokens(norm: nn.LayerNorm, x, pend):
     return add_layernorm_rows_fn(x, pend[0], pend[1], norm.weight, norm.bias, norm.eps, out_dtype, pend[2])
 
 
-def _settle(x, pend):
-    """Apply a pending ``x += scale * y`` with nothing to fuse it into (end of a stage)."""
+def _settle(x, pend, out_dtype=None):
+    """Apply a pending ``x += scale * y`` with nothing to fuse it into (end of a stage).  ``out_dtype``: what the only
+    consumer reads (the downsample convolution under autocast: bf16) -- the HIP kernel then emits that directly."""
     if pend is None:
-        return x
+        return x if out_dtype is None else x.to(out_dtype)
     y, s, yb = pend
+    if (x.is_cuda and x.dtype == torch.float32 and y.dtype in (torch.float32, torch.bfloat16) and y.shape == x.shape
+            and x.shape[-1] % 8 == 0):
+        return residual_settle_fn(x, y, s, yb, out_dtype)
     if yb is not None:
         y = y + yb.to(y.dtype)
     if s is not None:
         y = y * s.view(-1, *([1] * (y.ndim - 1))).to(y.dtype)
-    return x + y
+    x = x + y
+    return x if out_dtype is None else x.to(out_dtype)
 
 
 class VSSBlock(nn.Module):
@@ -554,12 +559,13 @@ def _blocks_tokens_ok(blocks) -> bool:
     return len(blocks) > 0 and all(isinstance(b, VSSBlock) and b.tokens_ok() for b in blocks)
 
 
-def _blocks_tokens(blocks, t):
-    """VSSBlocks of a stage on the token-major stream; the last residual add is settled here."""
+def _blocks_tokens(blocks, t, out_dtype=None):
+    """VSSBlocks of a stage on the token-major stream; the last residual add is settled here (in ``out_dtype`` when the
+    stage output has a single reduced-precision reader)."""
     pend = None
     for i, b in enumerate(blocks):
-        t, pend = b.forward_tokens(t, pend, defer_bias=i + 1 < len(blocks))
-    return _settle(t, pend)
+        t, pend = b.forward_tokens(t, pend, defer_bias=True)
+    return _settle(t, pend, out_dtype)
 
 
 def _run_blocks(blocks: nn.Sequential, x: torch.Tensor):
@@ -696,20 +702,27 @@ class VSSM(nn.Module):
         t = pe[4](_conv_ln_tokens(pe[0], pe[2], t, act_dtype))  # norm output feeds GELU -> conv: the conv's dtype
         return _conv_ln_tokens(pe[5], pe[7], t, torch.float32)
 
-    def stage_tokens(self, i: int, t: torch.Tensor):
-        """Stage i on tokens: returns (stage output, downsampled input of stage i+1 or None)."""
+    def stage_tokens(self, i: int, t: torch.Tensor, need_output: bool = True):
+        """Stage i on tokens: returns (stage output, downsampled input of stage i+1 or None).  ``need_output=False``: the
+        caller only wants the downsampled stream -- the stage output is then settled straight into the dtype the downsample
+        convolution reads (bf16 under autocast) and NOT returned."""
         layer = self.layers[i]
-        o = _blocks_tokens(layer.blocks, t)
-        if isinstance(layer.downsample, nn.Identity):
+        last = isinstance(layer.downsample, nn.Identity)
+        cd = None
+        if not need_output and not last and t.is_cuda and torch.is_autocast_enabled():
+            cd = torch.get_autocast_gpu_dtype()
+            cd = cd if cd == torch.bfloat16 else None
+        o = _blocks_tokens(layer.blocks, t, cd)
+        if last:
             return o, None
-        return o, _conv_ln_tokens(layer.downsample[1], layer.downsample[3], o, torch.float32)
+        return (None if cd is not None else o), _conv_ln_tokens(layer.downsample[1], layer.downsample[3], o, torch.float32)
 
     def forward(self, x: torch.Tensor):
         if self.tokens_trunk_ok(x):
             with _PrecomputedA(self.layers, self.cut_after), _DropPathBank(self.layers, x.shape[0], x.device):
                 t = self.stem_tokens(x)
                 for i in range(len(self.layers)):
-                    o, t = self.stage_tokens(i, t)
+                    o, t = self.stage_tokens(i, t, need_output=i + 1 == len(self.layers))
                     if i == self.cut_after:
                         self.cut_tensor = t              # (the stream entering stage i + 1: dp.PhasedGrads' cut)
             x = o.permute(0, 3, 1, 2)
@@ -782,7 +795,8 @@ class Backbone_VSSM(VSSM):
             with _PrecomputedA(self.layers, self.cut_after), _DropPathBank(self.layers, x.shape[0], x.device):
                 t = self.stem_tokens(x)
                 for i in range(len(self.layers)):
-                    o, t = self.stage_tokens(i, t)
+                    wanted = (i in self.out_indices and (not only_last or i == last)) or (i == last and not self.out_indices)
+                    o, t = self.stage_tokens(i, t, need_output=wanted)
                     if i == self.cut_after:
                         self.cut_tensor = t              # (the stream entering stage i + 1: dp.PhasedGrads' cut)
                     if i in self.out_indices and (not only_last or i == last):

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from . import deferred as _deferred
 
-__all__ = ["add_layernorm_rows_fn", "layernorm_rows_fn", "rows_supported"]
+__all__ = ["residual_settle_fn", "add_layernorm_rows_fn", "layernorm_rows_fn", "rows_supported"]
 
 
 def rows_supported(C: int) -> bool:
@@ -138,3 +138,53 @@ def add_layernorm_rows_fn(x, y, scale, weight, bias, eps=1e-5, out_dtype=None, y
     """``x_new = x + scale[b] * (y + y_bias)`` (scale (B,) or None; ``y_bias`` (C,) = the deferred bias of the linear
     layer that produced ``y``, or None) and ``LayerNorm(x_new)``: returns ``(x_new, h)``."""
     return AddLayerNormRowsHip.apply(x, y, scale, weight, bias, eps, out_dtype, y_bias)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# end-of-stage residual settle: x + scale[b] * (y + y_bias) in the consumer's dtype (xfm_residual_settle_fwd/_bwd)
+# ---------------------------------------------------------------------------------------------------------------------------
+class ResidualSettleHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, scale, y_bias, out_dtype):
+        _lib.require_cuda(x, y, scale, y_bias)
+        if x.dtype != torch.float32 or y.dtype not in (torch.float32, torch.bfloat16) or x.shape != y.shape:
+            raise RuntimeError("residual_settle: x fp32 and y (bf16 / fp32) of the same (B, ..., C) shape expected")
+        x, y = x.contiguous(), y.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        rps = x.numel() // (B * C)
+        sc = None if scale is None else scale.float().contiguous()
+        yb = None if y_bias is None else y_bias.float().contiguous()
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        nbytes = x.numel() * (4 + y.element_size() + out.element_size())
+        with torch.cuda.device(x.device), _lib.timed("residual_settle_fwd", nbytes):
+            _lib.check(_lib.lib().xfm_residual_settle_fwd(x.data_ptr(), y.data_ptr(), _lib.ptr(sc), _lib.ptr(yb), out.data_ptr(),
+                                                          B, rps, C, _lib.dtype_code(y.dtype), _lib.dtype_code(out_dtype),
+                                                          _lib.stream_ptr()), "residual_settle_fwd")
+        ctx.save_for_backward(sc)
+        ctx.meta = (B, rps, C, y.dtype, out_dtype, None if y_bias is None else y_bias.dtype)
+        ctx.bparam = y_bias if isinstance(y_bias, torch.nn.Parameter) and y_bias.dtype == torch.float32 else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (sc,) = ctx.saved_tensors
+        B, rps, C, ydt, odt, bdt = ctx.meta
+        dout = dout.contiguous() if dout.dtype == odt else dout.to(odt).contiguous()
+        dx = torch.empty(dout.shape, dtype=torch.float32, device=dout.device)
+        dy = torch.empty(dout.shape, dtype=ydt, device=dout.device)
+        nbytes = dout.numel() * (dout.element_size() + 4 + dy.element_size())
+        with torch.cuda.device(dout.device), _lib.timed("residual_settle_bwd", nbytes):
+            _lib.check(_lib.lib().xfm_residual_settle_bwd(dout.data_ptr(), _lib.ptr(sc), dx.data_ptr(), dy.data_ptr(), B, rps, C,
+                                                          _lib.dtype_code(ydt), _lib.dtype_code(odt), _lib.stream_ptr()),
+                       "residual_settle_bwd")
+        db = None
+        if bdt is not None and ctx.needs_input_grad[3]:
+            from .mlp_tokens import colsum_fn
+            db = colsum_fn(dy, grad_of=ctx.bparam).to(bdt)
+        return dx, dy, None, db, None
+
+
+def residual_settle_fn(x, y, scale=None, y_bias=None, out_dtype=None):
+    """``x + scale[b] * (y + y_bias)`` for the token-major fp32 stream ``x`` (B, ..., C) and a branch output ``y`` of the same
+    shape, emitted in ``out_dtype`` (default fp32): one pass instead of bias add, scale, add (and the consumer's cast)."""
+    return ResidualSettleHip.apply(x, y, scale, y_bias, out_dtype or torch.float32)
