@@ -37,7 +37,7 @@ from .csm import SwappingMerge_multiview, SwappingScan_multiview, cross_merge_fn
 from .csms6s import selective_scan_fn
 from .dwconv import dwconv3x3_silu_fn
 from .layernorm2d import layernorm2d_fn
-from .mlp_tokens import linear_tokens_fn, mlp_tokens_fn
+from .mlp_tokens import bias_gelu_fn, linear_tokens_fn, mlp_tokens_fn
 from .proj import batched_proj
 from .rowln import residual_settle_fn, add_layernorm_rows_fn, layernorm_rows_fn, rows_supported
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
@@ -699,7 +699,12 @@ class VSSM(nn.Module):
         pe = self.patch_embed
         act_dtype = _tokens_dtype(pe[0].weight)
         t = x.permute(0, 2, 3, 1).contiguous()                  # (B, H, W, 3): a channels_last image
-        t = pe[4](_conv_ln_tokens(pe[0], pe[2], t, act_dtype))  # norm output feeds GELU -> conv: the conv's dtype
+        t = _conv_ln_tokens(pe[0], pe[2], t, act_dtype)         # norm output feeds GELU -> conv: the conv's dtype
+        if isinstance(pe[4], nn.GELU) and getattr(pe[4], "approximate", "none") == "none" and t.is_cuda \
+                and t.dtype in (torch.float32, torch.bfloat16) and t.shape[-1] % 8 == 0:
+            t = bias_gelu_fn(t, None)                            # the exact-erf GELU kernel of the Mlp (streaming rate)
+        else:
+            t = pe[4](t)
         return _conv_ln_tokens(pe[5], pe[7], t, torch.float32)
 
     def stage_tokens(self, i: int, t: torch.Tensor, need_output: bool = True):
