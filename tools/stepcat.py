@@ -17,7 +17,7 @@ for r in csv.DictReader(open(f)):
     elif 'at::native' in n: fam = 'framework reduce' if 'reduce_kernel' in n else 'framework elementwise / copy / fill'
     elif 'igemm' in n or 'miopen' in n.lower() or 'ck::' in n or '_ZN2ck' in n or 'batched_transpose' in n or 'SubTensor' in n or 'naive_conv' in n: fam = 'MIOpen convolution (+ its casts)'
     elif 'partial_sums' in n: fam = 'deferred column sums (LayerNorm / bias gradients, folded per step)'
-    elif 'rowln' in n: fam = 'row LayerNorm (+residual)'
+    elif 'rowln' in n or 'settle_' in n: fam = 'row LayerNorm (+residual)'
     elif 'ln2d' in n: fam = 'LayerNorm2d'
     elif 'wgrad_kernel' in n or 'wgrad_tt' in n: fam = 'own MFMA weight-gradient GEMM'
     elif 'tokens_gemm' in n or 'planes_gemm' in n or 'proj_gemm' in n: fam = 'own MFMA GEMM'
