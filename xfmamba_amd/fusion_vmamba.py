@@ -39,7 +39,7 @@ from .dwconv import dwconv3x3_silu_fn
 from .layernorm2d import layernorm2d_fn
 from .mlp_tokens import bias_gelu_fn, linear_tokens_fn, mlp_tokens_fn
 from .proj import batched_proj
-from .rowln import residual_settle_fn, add_layernorm_rows_fn, layernorm_rows_fn, rows_supported
+from .rowln import residual_settle_fn, add_layernorm_rows_fn, layernorm_rows_fn, layernorm_rows_pass_fn, rows_supported
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
 from .ss2d_chan import chan_supported, ss2d_chan_fn
 from . import fp8 as _fp8
@@ -386,6 +386,9 @@ def _norm_tokens(norm: nn.LayerNorm, x, pend):
     """LayerNorm of the token-major stream, folding in a pending ``x += scale * y``.  Returns (x, normalised)."""
     out_dtype = _tokens_dtype(norm.weight)
     if pend is None:
+        if x.is_cuda and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled():
+            # (the stream goes on to the next add + LayerNorm kernel: hand it through this node, see LayerNormRowsPassHip)
+            return layernorm_rows_pass_fn(x, norm.weight, norm.bias, norm.eps, out_dtype)
         return x, layernorm_rows_fn(x, norm.weight, norm.bias, norm.eps, out_dtype)
     return add_layernorm_rows_fn(x, pend[0], pend[1], norm.weight, norm.bias, norm.eps, out_dtype, pend[2])
 

@@ -128,6 +128,38 @@ class AddLayerNormRowsHip(torch.autograd.Function):
                 (None if dyb is None else dyb.to(ybdtype)))
 
 
+class LayerNormRowsPassHip(torch.autograd.Function):
+    """``(x, LayerNorm(x))`` with ``x`` handed through as an OUTPUT of the node: the residual stream of the first block of a
+    stage feeds both this LayerNorm and the next add + LayerNorm kernel, and as two consumers of one tensor autograd summed
+    their two gradients with a stream-sized add; as outputs of one node both gradients arrive here and the backward kernel
+    adds the pass-through one itself (its ``dres`` operand)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        x, w, b, out_dtype = _prep(x, weight, bias, out_dtype, need_f32=True)
+        _, h, mean, rstd = _fwd(x, None, None, w, b, eps, out_dtype, None)
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.meta = (bias is not None, weight.dtype, out_dtype)
+        return x.view_as(x), h
+
+    @staticmethod
+    def backward(ctx, dres, dh):
+        x, w, mean, rstd = ctx.saved_tensors
+        has_bias, wdtype, dtype = ctx.meta
+        if dh is None:
+            return dres, None, None, None, None
+        dh = dh.contiguous() if dh.dtype == dtype else dh.to(dtype).contiguous()
+        if dres is not None:
+            dres = dres.float().contiguous()
+        dx, _, dw, db, _ = _bwd(x, w, dh, dres, mean, rstd, None, False, has_bias, dtype)
+        return dx, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None
+
+
+def layernorm_rows_pass_fn(x, weight, bias, eps=1e-5, out_dtype=None):
+    """``(x, LayerNorm(x))`` for the fp32 token-major stream, see LayerNormRowsPassHip."""
+    return LayerNormRowsPassHip.apply(x, weight, bias, eps, out_dtype)
+
+
 def layernorm_rows_fn(x, weight, bias, eps=1e-5, out_dtype=None, pre_bias=None):
     """LayerNorm over the last axis of a contiguous fp32 / bf16 (B, ..., C) tensor; output in ``out_dtype``.
     ``pre_bias`` (C,) is added to ``x`` first (the bias of the convolution that produced ``x``)."""
