@@ -459,6 +459,7 @@ static bool dw7_plan_shared(bool bwd, int B, int D, int H, int W, int lpr, int &
     const int ngrp = D / PP;
     bsplit = 1;
     while (ngrp * bsplit < 1024 && bsplit < B) bsplit *= 2;
+    if (const char *e = getenv("XFM_DW_BSPLIT")) bsplit = std::max(1, atoi(e));   // tuning hook
     if (bsplit > B) bsplit = B;
     return true;
 }
