@@ -106,7 +106,8 @@ class GradBuckets:
     def _pack(self, bi):
         """Copy the bucket's gradients into its flat buffer (one multi-tensor kernel) and re-point ``.grad``."""
         from .proj import join_wgrad_stream
-        join_wgrad_stream()                                 # (weight gradients launched on the side stream)
+        # (weight gradients launched on the side stream; deferred column sums.  A bucket hook runs in the middle of the pass)
+        join_wgrad_stream(end_of_pass=False)
         grp, views = self._groups[bi], self._views[bi]
         have = [(v, p.grad) for v, p in zip(views, grp) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if have:
@@ -181,6 +182,8 @@ class GradBuckets:
         self._work.clear()
         self._pending = list(self._sizes)
         self._launched = [False] * len(self.buckets)
+        from .proj import join_wgrad_stream
+        join_wgrad_stream()                                 # end of the pass
 
     def zero_grad(self):
         """Drop the gradients: the next backward pass assigns fresh tensors instead of accumulating."""
@@ -291,7 +294,7 @@ class PhasedGrads:
         late = self.pieces[0]
         out = torch.autograd.grad(loss, [cut] + late, allow_unused=True)
         self._cut, self._gcut = cut, out[0]
-        join_wgrad_stream()
+        join_wgrad_stream(end_of_pass=False)
         self._pack(0, out[1:])
 
     def backward_early(self):

@@ -56,11 +56,11 @@ def wgrad_stream(enable: bool) -> None:
     _SIDE["on"] = bool(enable)
 
 
-def join_wgrad_stream() -> None:
+def join_wgrad_stream(end_of_pass: bool = True) -> None:
     """Make the current stream wait for the weight-gradient launches issued so far (no-op when there are none), and fold
     the deferred column sums (deferred.py): every reader of parameter gradients calls this first."""
     from . import deferred
-    deferred.flush()
+    deferred.flush(_end_of_pass=end_of_pass)         # (False: a reader in the MIDDLE of a backward pass, e.g. a bucket hook)
     if _SIDE["pending"]:
         torch.cuda.current_stream().wait_stream(_SIDE["stream"])
         _SIDE["pending"] = False
