@@ -856,3 +856,32 @@ def test_residual_settle_matches_torch_fp32(ydt, odt, mode):
     assert_close(yd.grad.float().cpu(), yr.grad, tol, tol * float(yr.grad.abs().max()) + 1e-7, "dy")
     if yb is not None:
         assert_close(ybd.grad.cpu(), ybr.grad, tol, tol * float(ybr.grad.abs().max()) + 1e-6, "dyb")
+
+
+@pytest.mark.gpu
+def test_partial_sums_multi_folds_many_jobs_in_one_launch():
+    """xfm_partial_sums_multi at the C ABI: jobs with 1, 2 and 3 parts, widths that are not multiples of the 64-column
+    block, block counts around the 16 / 32 row-slot strides, a null output pointer -- against a plain sum."""
+    from xfmamba_amd import _lib
+    g = torch.Generator().manual_seed(17)
+    specs = [(1, 96, 7), (2, 100, 16), (3, 72, 33), (3, 1536, 130), (1, 8, 1), (2, 64, 48)]       # (parts, C, nblk)
+    parts, outs, refs, rows, blocks = [], [], [], [], []
+    for ji, (np_, C, nblk) in enumerate(specs):
+        p = torch.randn(nblk, np_, C, generator=g).to(DEV)
+        o = [torch.full((C,), 7.0, device=DEV) for _ in range(np_)]
+        skip = ji == 2                                                       # job 2: second output not wanted
+        ptrs = [0 if (skip and k == 1) else o[k].data_ptr() for k in range(np_)] + [0] * (3 - np_)
+        rows += [p.data_ptr()] + ptrs + [nblk | (C << 32), np_]
+        blocks += [ji | (cb << 16) for cb in range((np_ * C + 63) // 64)]
+        parts.append(p); outs.append(o); refs.append(p.double().sum(0).float().cpu())
+    jobs_d = torch.tensor(rows, dtype=torch.int64).to(DEV)
+    blocks_d = torch.tensor(blocks, dtype=torch.int32).to(DEV)
+    _lib.check(_lib.lib().xfm_partial_sums_multi(jobs_d.data_ptr(), blocks_d.data_ptr(), len(blocks), _lib.stream_ptr()),
+               "partial_sums_multi")
+    torch.cuda.synchronize()
+    for ji, (np_, C, nblk) in enumerate(specs):
+        for k in range(np_):
+            if ji == 2 and k == 1:
+                assert float((outs[ji][k] - 7.0).abs().max()) == 0.0      # untouched
+                continue
+            assert_close(outs[ji][k].cpu(), refs[ji][k], 1e-5, 1e-5 * float(refs[ji][k].abs().max()) + 1e-6, f"job {ji} part {k}")
