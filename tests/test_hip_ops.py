@@ -232,7 +232,8 @@ def test_dwconv3x3_silu_matches_torch_fp32(shape, dtype, has_bias):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(40, 96, 56, 56), (40, 192, 28, 28), (48, 384, 14, 14), (24, 768, 7, 7)])
+@pytest.mark.parametrize("shape", [(40, 96, 56, 56), (40, 192, 28, 28), (48, 384, 14, 14), (24, 768, 7, 7),
+                                   (11, 16, 56, 56), (9, 8, 28, 28)])       # strip kernels: a ragged last group of 8 samples
 def test_dwconv3x3_silu_plane_pipeline(shape):
     """Batches deep enough that one wave / workgroup walks several planes of its channel (the software-pipelined loop
     of dwconv7_kernel, both the shared-plane and the wave-private variant), against plain PyTorch fp32."""

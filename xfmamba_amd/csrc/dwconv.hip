@@ -17,7 +17,10 @@
 
 namespace xfm {
 
-__device__ __forceinline__ float sigmoidf_fast(float z) { return 1.f / (1.f + __expf(-z)); }
+// 1 / (1 + e^-z) on the raw v_exp_f32 / v_rcp_f32 (an IEEE division costs ~10 instructions: div_scale, div_fmas, div_fixup)
+__device__ __forceinline__ float sigmoidf_fast(float z) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
 
 template <typename T>
 __global__ void __launch_bounds__(256) dwconv_fwd_kernel(const T *__restrict__ x, const float *__restrict__ w,
@@ -439,6 +442,243 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Register-stencil backward for the WIDE maps (56 x 56: VEC = 8, 28 x 28: VEC = 4; rows of 7 vectors).  The LDS forms
+// above run these maps at ~1 TB/s: three LDS round trips and two or three hand-offs per plane.  Here nothing goes through
+// LDS and nothing is synchronised: a lane owns one column strip (one 16- / 8-byte vector wide) of one plane and walks DOWN
+// a band of RB rows with the 3 x (VEC + 2) windows of x and of dz rolling through its registers; the halo columns of a
+// window are the edge elements of the neighbouring strips = the neighbouring lanes (one-lane DPP shifts).  A wave holds
+// 8 planes x 7 strips (56 lanes): the same channel of 8 consecutive samples, so the weights are wave-uniform and the
+// 9 + 1 weight / bias gradient sums fold across the wave at the end (one atomic per tap and wave).  The rows of a plane
+// are cut into bands so that a launch has thousands of waves; a band recomputes dz for one row above and below it.
+template <int CTRL> __device__ __forceinline__ float dw_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+template <typename T, int VEC, int RB>
+__global__ void __launch_bounds__(256) dwconv_strip_bwd_kernel(const T *__restrict__ x, const float *__restrict__ w,
+                                                               const float *__restrict__ bias, const T *__restrict__ dy,
+                                                               T *__restrict__ dx, float *__restrict__ dw,
+                                                               float *__restrict__ dbias, int B, int D, int H, int act) {
+    constexpr int W = 7 * VEC, PPW = 8;
+    const int lane = threadIdx.x & 63;
+    const int nbands = H / RB, nbg = (B + PPW - 1) / PPW;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int band = gw % nbands, t1 = gw / nbands, bg = t1 % nbg, d = t1 / nbg;
+    if (d >= D) return;                                            // (whole wave)
+    const int pslot = lane / 7, sp = lane - pslot * 7;
+    const int b = bg * PPW + pslot;
+    const bool live = pslot < PPW && b < B;
+    const int64_t po = live ? (((int64_t)b * D + d) * H) * W + sp * VEC : 0;
+    const T *xg = x + po, *gg = dy + po;
+    T *og = dx + po;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = w[d * 9 + i];
+    const float bv = bias ? bias[d] : 0.f;
+    const int r0 = band * RB, r1 = r0 + RB;
+    const bool hasl = sp > 0, hasr = sp < 6;
+    // one row of a plane as VEC floats + the two halo columns from the neighbouring strips (zero outside the map)
+    auto load_raw = [&](const T *base, int r, uint32_t (&raw)[DwRaw<T, VEC>::NW]) {
+#pragma unroll
+        for (int i = 0; i < DwRaw<T, VEC>::NW; ++i) raw[i] = 0u;
+        if (live && r >= 0 && r < H) ld_raw<T, VEC>(base + (int64_t)r * W, raw);
+    };
+    auto widen = [&](const float (&v)[VEC], float (&q)[VEC + 2]) {
+        const float l = dw_dpp<0x138>(v[VEC - 1]), rr = dw_dpp<0x130>(v[0]);     // wave_shr:1 / wave_shl:1
+        q[0] = hasl ? l : 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) q[1 + i] = v[i];
+        q[VEC + 1] = hasr ? rr : 0.f;
+    };
+    float xw[3][VEC + 2], gz[3][VEC + 2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < VEC + 2; ++c) gz[i][c] = 0.f;
+    {
+        uint32_t raw[DwRaw<T, VEC>::NW];
+        float v[VEC];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            load_raw(xg, r0 - 2 + i, raw);
+            unpack_raw<T, VEC>(raw, v);
+            widen(v, xw[i]);
+        }
+    }
+    float acc[9], accb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    // operand rows are requested one iteration ahead (two ahead measured the same: the kernel is VALU-bound, SQ counters)
+    uint32_t xn[DwRaw<T, VEC>::NW], gn[DwRaw<T, VEC>::NW];
+    load_raw(gg, r0 - 1, gn);
+    load_raw(xg, r0 + 1, xn);
+    // one row: R0 / R1 / R2 name the window slots holding rows t-1, t, t+1 (x) resp. t-2, t-1, t (dz) -- the loop below is
+    // written out three times with the slots rotated, so the windows roll by renaming, not by 40 moves per row
+    auto step = [&](auto r0_tag, auto r1_tag, auto r2_tag, const int t) {
+        constexpr int R0 = decltype(r0_tag)::value, R1 = decltype(r1_tag)::value, R2 = decltype(r2_tag)::value;
+        // ---- dz of row t from the x window (rows t-1, t, t+1 in slots R0, R1, R2) and dy row t
+        float g[VEC];
+        unpack_raw<T, VEC>(gn, g);
+        uint32_t gnn[DwRaw<T, VEC>::NW], xnn[DwRaw<T, VEC>::NW];
+        load_raw(gg, t + 1, gnn);                                  // operands of the next iteration
+        load_raw(xg, t + 3, xnn);
+        const bool inmap = t >= 0 && t < H, own = t >= r0 && t < r1;
+        const float (*xr[3])[VEC + 2] = {&xw[R0], &xw[R1], &xw[R2]};
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            float z = bv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) z = fmaf(k[i * 3 + j], (*xr[i])[c + j], z);
+            if (act) {
+                const float sg = sigmoidf_fast(z);
+                g[c] *= sg * fmaf(z, 1.f - sg, 1.f);
+            }
+            if (!inmap) g[c] = 0.f;
+            if (own) {
+                accb += g[c];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i * 3 + j] = fmaf(g[c], (*xr[i])[c + j], acc[i * 3 + j]);
+            }
+        }
+        // ---- dz row t goes to the slot of the oldest dz row (t-3); dx of row t-1 from dz rows t-2, t-1, t
+        widen(g, gz[R0]);                                          // dz slots: rows t-2, t-1 in R1, R2, row t now in R0
+        if (t - 1 >= r0) {                                         // (t - 1 < r1 by the loop bound)
+            const float (*gr[3])[VEC + 2] = {&gz[R1], &gz[R2], &gz[R0]};
+            float o[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                float v = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) v = fmaf(k[8 - (i * 3 + j)], (*gr[i])[c + j], v);
+                o[c] = v;
+            }
+            if (live) st_vec<T, VEC>(og + (int64_t)(t - 1) * W, o);
+        }
+        // ---- x row t+2 replaces row t-1 (slot R0): the next iteration sees rows t, t+1, t+2 in R1, R2, R0
+        {
+            float v[VEC];
+            unpack_raw<T, VEC>(xn, v);
+            widen(v, xw[R0]);
+        }
+#pragma unroll
+        for (int i = 0; i < DwRaw<T, VEC>::NW; ++i) {
+            gn[i] = gnn[i];
+            xn[i] = xnn[i];
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+    for (int t = r0 - 1; t <= r1; t += 3) {
+        step(I0{}, I1{}, I2{}, t);
+        if (t + 1 <= r1) step(I1{}, I2{}, I0{}, t + 1);
+        if (t + 2 <= r1) step(I2{}, I0{}, I1{}, t + 2);
+    }
+    // ---- weight / bias gradient sums: all live lanes of the wave belong to channel d
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        float sm = i < 9 ? acc[i] : accb;
+        if (!live) sm = 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
+        if (lane == 0) {
+            if (i < 9) atomicAdd(dw + d * 9 + i, sm);
+            else if (dbias) atomicAdd(dbias + d, sm);
+        }
+    }
+}
+
+// forward of the same decomposition: y row t = silu(bias + 3 x 3 window of x rows t-1 .. t+1)
+template <typename T, int VEC, int RB>
+__global__ void __launch_bounds__(256) dwconv_strip_fwd_kernel(const T *__restrict__ x, const float *__restrict__ w,
+                                                               const float *__restrict__ bias, T *__restrict__ y, int B, int D,
+                                                               int H, int act) {
+    constexpr int W = 7 * VEC, PPW = 8;
+    const int lane = threadIdx.x & 63;
+    const int nbands = H / RB, nbg = (B + PPW - 1) / PPW;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int band = gw % nbands, t1 = gw / nbands, bg = t1 % nbg, d = t1 / nbg;
+    if (d >= D) return;
+    const int pslot = lane / 7, sp = lane - pslot * 7;
+    const int b = bg * PPW + pslot;
+    const bool live = pslot < PPW && b < B;
+    const int64_t po = live ? (((int64_t)b * D + d) * H) * W + sp * VEC : 0;
+    const T *xg = x + po;
+    T *og = y + po;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = w[d * 9 + i];
+    const float bv = bias ? bias[d] : 0.f;
+    const int r0 = band * RB, r1 = r0 + RB;
+    const bool hasl = sp > 0, hasr = sp < 6;
+    auto load_raw = [&](int r, uint32_t (&raw)[DwRaw<T, VEC>::NW]) {
+#pragma unroll
+        for (int i = 0; i < DwRaw<T, VEC>::NW; ++i) raw[i] = 0u;
+        if (live && r >= 0 && r < H) ld_raw<T, VEC>(xg + (int64_t)r * W, raw);
+    };
+    auto widen = [&](const uint32_t (&raw)[DwRaw<T, VEC>::NW], float (&q)[VEC + 2]) {
+        float v[VEC];
+        unpack_raw<T, VEC>(raw, v);
+        const float l = dw_dpp<0x138>(v[VEC - 1]), rr = dw_dpp<0x130>(v[0]);
+        q[0] = hasl ? l : 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) q[1 + i] = v[i];
+        q[VEC + 1] = hasr ? rr : 0.f;
+    };
+    float xw[3][VEC + 2];
+    uint32_t xn[DwRaw<T, VEC>::NW], xn2[DwRaw<T, VEC>::NW];
+    {
+        uint32_t raw[DwRaw<T, VEC>::NW];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            load_raw(r0 - 1 + i, raw);
+            widen(raw, xw[i]);
+        }
+    }
+    load_raw(r0 + 2, xn);
+    load_raw(r0 + 3, xn2);
+    auto step = [&](auto a_tag, auto b_tag, auto c_tag, const int t) {
+        constexpr int R0 = decltype(a_tag)::value, R1 = decltype(b_tag)::value, R2 = decltype(c_tag)::value;
+        uint32_t xnn[DwRaw<T, VEC>::NW];
+        load_raw(t + 4, xnn);                                      // two rows ahead of the row consumed next
+        const float (*xr[3])[VEC + 2] = {&xw[R0], &xw[R1], &xw[R2]};
+        float o[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            float z = bv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) z = fmaf(k[i * 3 + j], (*xr[i])[c + j], z);
+            o[c] = act ? z * sigmoidf_fast(z) : z;
+        }
+        if (live) st_vec<T, VEC>(og + (int64_t)t * W, o);
+        widen(xn, xw[R0]);                                         // row t + 2 replaces row t - 1
+#pragma unroll
+        for (int i = 0; i < DwRaw<T, VEC>::NW; ++i) {
+            xn[i] = xn2[i];
+            xn2[i] = xnn[i];
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+    for (int t = r0; t < r1; t += 3) {
+        step(I0{}, I1{}, I2{}, t);
+        if (t + 1 < r1) step(I1{}, I2{}, I0{}, t + 1);
+        if (t + 2 < r1) step(I2{}, I0{}, I1{}, t + 2);
+    }
+}
+
 // plan of the fast path: PP channels per workgroup (TP = 256 / PP threads each), batch split into `bsplit` slices
 static bool dw7_plan_shared(bool bwd, int B, int D, int H, int W, int lpr, int &vec, int &PP, int &bsplit, size_t &lds) {
     if (W % lpr != 0) return false;
@@ -531,6 +771,37 @@ static int pick_pp(int L) { return L >= 1024 ? 1 : (L >= 256 ? 2 : 4); }
 template <typename T>
 static int launch_dw(bool bwd, const void *x, const float *w, const float *bias, const void *dy, void *out, float *dw,
                      float *dbias, int B, int D, int H, int W, int act, hipStream_t s) {
+    // (14 x 14 maps measured no better on the strip kernels: forward 10.1 vs 11.6 us, backward 29.1 vs 24.7 us)
+    if (!bwd && sizeof(T) == 2 && H == W && (W == 56 || W == 28) && !getenv("XFM_DWCONV_NO_STRIP") && !getenv("XFM_DWCONV_GENERIC")) {
+        const int nwaves = D * ((B + 7) / 8) * (H / 14);
+        const dim3 grid((nwaves + 3) / 4);
+        if (W == 56)
+            hipLaunchKernelGGL((dwconv_strip_fwd_kernel<T, 8, 14>), grid, dim3(256), 0, s, (const T *)x, w, bias, (T *)out, B, D, H, act);
+        else
+            hipLaunchKernelGGL((dwconv_strip_fwd_kernel<T, 4, 14>), grid, dim3(256), 0, s, (const T *)x, w, bias, (T *)out, B, D, H, act);
+        return check_launch();
+    }
+    if (bwd && sizeof(T) == 2 && H == W && (W == 56 || W == 28) && !getenv("XFM_DWCONV_NO_STRIP") && !getenv("XFM_DWCONV_GENERIC")) {
+        // wide maps, backward: the register-stencil kernel (bands of 14 rows)
+        int rb = 14;
+        if (const char *e = getenv("XFM_DW_RB")) rb = atoi(e);    // tuning hook: 7 / 14 / 28
+        const int nwaves = D * ((B + 7) / 8) * (H / rb);
+        const dim3 grid((nwaves + 3) / 4);
+#define XFM_DW_STRIP(VEC, RB)                                                                                          \
+    hipLaunchKernelGGL((dwconv_strip_bwd_kernel<T, VEC, RB>), grid, dim3(256), 0, s, (const T *)x, w, bias, (const T *)dy, \
+                       (T *)out, dw, dbias, B, D, H, act)
+        if (W == 56) {
+            if (rb == 7) XFM_DW_STRIP(8, 7);
+            else if (rb == 28) XFM_DW_STRIP(8, 28);
+            else XFM_DW_STRIP(8, 14);
+        } else {
+            if (rb == 7) XFM_DW_STRIP(4, 7);
+            else if (rb == 28) XFM_DW_STRIP(4, 28);
+            else XFM_DW_STRIP(4, 14);
+        }
+#undef XFM_DW_STRIP
+        return check_launch();
+    }
     {
         int vec, PP, bsplit;
         size_t lds7;
