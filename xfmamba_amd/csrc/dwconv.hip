@@ -455,18 +455,18 @@ template <int CTRL> __device__ __forceinline__ float dw_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-template <typename T, int VEC, int RB>
+template <typename T, int VEC, int RB, int LPR = 7>
 __global__ void __launch_bounds__(256) dwconv_strip_bwd_kernel(const T *__restrict__ x, const float *__restrict__ w,
                                                                const float *__restrict__ bias, const T *__restrict__ dy,
                                                                T *__restrict__ dx, float *__restrict__ dw,
                                                                float *__restrict__ dbias, int B, int D, int H, int act) {
-    constexpr int W = 7 * VEC, PPW = 8;
+    constexpr int W = LPR * VEC, PPW = 64 / LPR > 8 ? 8 : 64 / LPR;    // strips per row, planes per wave
     const int lane = threadIdx.x & 63;
     const int nbands = H / RB, nbg = (B + PPW - 1) / PPW;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int band = gw % nbands, t1 = gw / nbands, bg = t1 % nbg, d = t1 / nbg;
     if (d >= D) return;                                            // (whole wave)
-    const int pslot = lane / 7, sp = lane - pslot * 7;
+    const int pslot = lane / LPR, sp = lane - pslot * LPR;
     const int b = bg * PPW + pslot;
     const bool live = pslot < PPW && b < B;
     const int64_t po = live ? (((int64_t)b * D + d) * H) * W + sp * VEC : 0;
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(256) dwconv_strip_bwd_kernel(const T *__restri
     for (int i = 0; i < 9; ++i) k[i] = w[d * 9 + i];
     const float bv = bias ? bias[d] : 0.f;
     const int r0 = band * RB, r1 = r0 + RB;
-    const bool hasl = sp > 0, hasr = sp < 6;
+    const bool hasl = sp > 0, hasr = sp < LPR - 1;
     // one row of a plane as VEC floats + the two halo columns from the neighbouring strips (zero outside the map)
     auto load_raw = [&](const T *base, int r, uint32_t (&raw)[DwRaw<T, VEC>::NW]) {
 #pragma unroll
@@ -597,17 +597,17 @@ __global__ void __launch_bounds__(256) dwconv_strip_bwd_kernel(const T *__restri
 }
 
 // forward of the same decomposition: y row t = silu(bias + 3 x 3 window of x rows t-1 .. t+1)
-template <typename T, int VEC, int RB>
+template <typename T, int VEC, int RB, int LPR = 7>
 __global__ void __launch_bounds__(256) dwconv_strip_fwd_kernel(const T *__restrict__ x, const float *__restrict__ w,
                                                                const float *__restrict__ bias, T *__restrict__ y, int B, int D,
                                                                int H, int act) {
-    constexpr int W = 7 * VEC, PPW = 8;
+    constexpr int W = LPR * VEC, PPW = 64 / LPR > 8 ? 8 : 64 / LPR;    // strips per row, planes per wave
     const int lane = threadIdx.x & 63;
     const int nbands = H / RB, nbg = (B + PPW - 1) / PPW;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int band = gw % nbands, t1 = gw / nbands, bg = t1 % nbg, d = t1 / nbg;
     if (d >= D) return;
-    const int pslot = lane / 7, sp = lane - pslot * 7;
+    const int pslot = lane / LPR, sp = lane - pslot * LPR;
     const int b = bg * PPW + pslot;
     const bool live = pslot < PPW && b < B;
     const int64_t po = live ? (((int64_t)b * D + d) * H) * W + sp * VEC : 0;
@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(256) dwconv_strip_fwd_kernel(const T *__restri
     for (int i = 0; i < 9; ++i) k[i] = w[d * 9 + i];
     const float bv = bias ? bias[d] : 0.f;
     const int r0 = band * RB, r1 = r0 + RB;
-    const bool hasl = sp > 0, hasr = sp < 6;
+    const bool hasl = sp > 0, hasr = sp < LPR - 1;
     auto load_raw = [&](int r, uint32_t (&raw)[DwRaw<T, VEC>::NW]) {
 #pragma unroll
         for (int i = 0; i < DwRaw<T, VEC>::NW; ++i) raw[i] = 0u;
@@ -772,35 +772,29 @@ template <typename T>
 static int launch_dw(bool bwd, const void *x, const float *w, const float *bias, const void *dy, void *out, float *dw,
                      float *dbias, int B, int D, int H, int W, int act, hipStream_t s) {
     // (14 x 14 maps measured no better on the strip kernels: forward 10.1 vs 11.6 us, backward 29.1 vs 24.7 us)
-    if (!bwd && sizeof(T) == 2 && H == W && (W == 56 || W == 28) && !getenv("XFM_DWCONV_NO_STRIP") && !getenv("XFM_DWCONV_GENERIC")) {
-        const int nwaves = D * ((B + 7) / 8) * (H / 14);
-        const dim3 grid((nwaves + 3) / 4);
-        if (W == 56)
-            hipLaunchKernelGGL((dwconv_strip_fwd_kernel<T, 8, 14>), grid, dim3(256), 0, s, (const T *)x, w, bias, (T *)out, B, D, H, act);
-        else
-            hipLaunchKernelGGL((dwconv_strip_fwd_kernel<T, 4, 14>), grid, dim3(256), 0, s, (const T *)x, w, bias, (T *)out, B, D, H, act);
-        return check_launch();
-    }
-    if (bwd && sizeof(T) == 2 && H == W && (W == 56 || W == 28) && !getenv("XFM_DWCONV_NO_STRIP") && !getenv("XFM_DWCONV_GENERIC")) {
-        // wide maps, backward: the register-stencil kernel (bands of 14 rows)
-        int rb = 14;
-        if (const char *e = getenv("XFM_DW_RB")) rb = atoi(e);    // tuning hook: 7 / 14 / 28
-        const int nwaves = D * ((B + 7) / 8) * (H / rb);
-        const dim3 grid((nwaves + 3) / 4);
-#define XFM_DW_STRIP(VEC, RB)                                                                                          \
-    hipLaunchKernelGGL((dwconv_strip_bwd_kernel<T, VEC, RB>), grid, dim3(256), 0, s, (const T *)x, w, bias, (const T *)dy, \
-                       (T *)out, dw, dbias, B, D, H, act)
-        if (W == 56) {
-            if (rb == 7) XFM_DW_STRIP(8, 7);
-            else if (rb == 28) XFM_DW_STRIP(8, 28);
-            else XFM_DW_STRIP(8, 14);
-        } else {
-            if (rb == 7) XFM_DW_STRIP(4, 7);
-            else if (rb == 28) XFM_DW_STRIP(4, 28);
-            else XFM_DW_STRIP(4, 14);
+    if (sizeof(T) == 2 && H == W && !getenv("XFM_DWCONV_NO_STRIP") && !getenv("XFM_DWCONV_GENERIC")) {
+        // wide maps: the register-stencil kernels.  (map, vector, band rows, strips per row); planes per wave = min(8, 64 / strips)
+#define XFM_DW_STRIP(VEC, RB, LPR)                                                                                        \
+    do {                                                                                                                  \
+        constexpr int ppw = 64 / LPR > 8 ? 8 : 64 / LPR;                                                                  \
+        const int nwaves = D * ((B + ppw - 1) / ppw) * (H / RB);                                                          \
+        const dim3 grid((nwaves + 3) / 4);                                                                                \
+        if (bwd)                                                                                                          \
+            hipLaunchKernelGGL((dwconv_strip_bwd_kernel<T, VEC, RB, LPR>), grid, dim3(256), 0, s, (const T *)x, w, bias,  \
+                               (const T *)dy, (T *)out, dw, dbias, B, D, H, act);                                         \
+        else                                                                                                              \
+            hipLaunchKernelGGL((dwconv_strip_fwd_kernel<T, VEC, RB, LPR>), grid, dim3(256), 0, s, (const T *)x, w, bias,  \
+                               (T *)out, B, D, H, act);                                                                   \
+        return check_launch();                                                                                            \
+    } while (0)
+        switch (W) {
+            case 56: XFM_DW_STRIP(8, 14, 7);
+            case 28: XFM_DW_STRIP(4, 14, 7);
+            case 48: XFM_DW_STRIP(8, 12, 6);                      // XFMamba-B at 384 x 384
+            case 24: XFM_DW_STRIP(4, 12, 6);
+            case 96: XFM_DW_STRIP(8, 12, 12);
         }
 #undef XFM_DW_STRIP
-        return check_launch();
     }
     {
         int vec, PP, bsplit;
