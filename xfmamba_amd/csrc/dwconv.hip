@@ -451,8 +451,20 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
 // 8 planes x 7 strips (56 lanes): the same channel of 8 consecutive samples, so the weights are wave-uniform and the
 // 9 + 1 weight / bias gradient sums fold across the wave at the end (one atomic per tap and wave).  The rows of a plane
 // are cut into bands so that a launch has thousands of waves; a band recomputes dz for one row above and below it.
-template <int CTRL> __device__ __forceinline__ float dw_dpp(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ float dw_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// sum over the 64 lanes on DPP adds (the total lands in lane 63): row-wise inclusive prefix (row_shr 1, 2, 4, 8), then the
+// row totals carried across rows (row_bcast:15 into rows 1 / 3, row_bcast:31 into rows 2 / 3).  Ten of these are 60 VALU
+// instructions; as __shfl_xor butterflies they were 60 ds_bpermute round trips at the end of every wave.
+__device__ __forceinline__ float dw_wave_sum(float v) {
+    v += dw_dpp<0x111>(v);
+    v += dw_dpp<0x112>(v);
+    v += dw_dpp<0x114>(v);
+    v += dw_dpp<0x118>(v);
+    v += dw_dpp<0x142, 0xa>(v);
+    v += dw_dpp<0x143, 0xc>(v);
+    return v;
 }
 
 template <typename T, int VEC, int RB, int LPR = 7>
@@ -587,9 +599,8 @@ __global__ void __launch_bounds__(256) dwconv_strip_bwd_kernel(const T *__restri
     for (int i = 0; i < 10; ++i) {
         float sm = i < 9 ? acc[i] : accb;
         if (!live) sm = 0.f;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
-        if (lane == 0) {
+        sm = dw_wave_sum(sm);
+        if (lane == 63) {
             if (i < 9) atomicAdd(dw + d * 9 + i, sm);
             else if (dbias) atomicAdd(dbias + d, sm);
         }
@@ -676,6 +687,128 @@ __global__ void __launch_bounds__(256) dwconv_strip_fwd_kernel(const T *__restri
         step(I0{}, I1{}, I2{}, t);
         if (t + 1 < r1) step(I1{}, I2{}, I0{}, t + 1);
         if (t + 2 < r1) step(I2{}, I0{}, I1{}, t + 2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 14 x 14 (12 x 12) maps: a lane owns one ROW of one plane (28 / 24 bytes), the rows above and below are the neighbouring
+// lanes (one-lane DPP shifts of the whole row), the columns left and right are its own registers.  No loop, no LDS: load the
+// row, take the two neighbour rows, compute, store.  A wave holds 64 / H planes of one channel (H consecutive lanes each).
+template <int HW> __device__ __forceinline__ void dwrow_load(const uint16_t *p, bool ok, float (&v)[HW + 2]) {
+    struct __attribute__((packed, aligned(4))) Raw { uint32_t w[HW / 2]; };
+    Raw r;
+#pragma unroll
+    for (int i = 0; i < HW / 2; ++i) r.w[i] = 0u;
+    if (ok) r = *reinterpret_cast<const Raw *>(p);
+    v[0] = 0.f;
+#pragma unroll
+    for (int i = 0; i < HW / 2; ++i) {
+        v[1 + 2 * i] = __uint_as_float(r.w[i] << 16);
+        v[2 + 2 * i] = __uint_as_float(r.w[i] & 0xffff0000u);
+    }
+    v[HW + 1] = 0.f;
+}
+template <int HW> __device__ __forceinline__ void dwrow_store(uint16_t *p, const float (&v)[HW]) {
+    struct __attribute__((packed, aligned(4))) Raw { uint32_t w[HW / 2]; };
+    Raw r;
+#pragma unroll
+    for (int i = 0; i < HW / 2; ++i) r.w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<Raw *>(p) = r;
+}
+// rows r-1 / r+1 of the same plane = lanes -1 / +1 (zero at the map's edge)
+template <int HW> __device__ __forceinline__ void dwrow_neigh(const float (&own)[HW + 2], bool hasu, bool hasd, float (&up)[HW + 2],
+                                                              float (&dn)[HW + 2]) {
+    up[0] = up[HW + 1] = dn[0] = dn[HW + 1] = 0.f;
+#pragma unroll
+    for (int c = 1; c <= HW; ++c) {
+        const float u = dw_dpp<0x138>(own[c]), d = dw_dpp<0x130>(own[c]);
+        up[c] = hasu ? u : 0.f;
+        dn[c] = hasd ? d : 0.f;
+    }
+}
+
+template <int HW, bool BWD>
+__global__ void __launch_bounds__(256) dwconv_rowlane_kernel(const uint16_t *__restrict__ x, const float *__restrict__ w,
+                                                             const float *__restrict__ bias, const uint16_t *__restrict__ dy,
+                                                             uint16_t *__restrict__ out, float *__restrict__ dw,
+                                                             float *__restrict__ dbias, int B, int D, int act) {
+    constexpr int PPW = 64 / HW, L = HW * HW;
+    const int lane = threadIdx.x & 63;
+    const int nbg = (B + PPW - 1) / PPW;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int bg = gw % nbg, d = gw / nbg;
+    if (d >= D) return;                                            // (whole wave)
+    const int pslot = lane / HW, r = lane - pslot * HW;
+    const int b = bg * PPW + pslot;
+    const bool live = pslot < PPW && b < B;
+    const int64_t po = live ? ((int64_t)b * D + d) * L + r * HW : 0;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = w[d * 9 + i];
+    const float bv = bias ? bias[d] : 0.f;
+    const bool hasu = r > 0, hasd = r < HW - 1;
+    float X[3][HW + 2];
+    dwrow_load<HW>(x + po, live, X[1]);
+    float g[HW + 2];
+    if constexpr (BWD) dwrow_load<HW>(dy + po, live, g);
+    dwrow_neigh<HW>(X[1], hasu, hasd, X[0], X[2]);
+    float z[HW];
+#pragma unroll
+    for (int c = 0; c < HW; ++c) {
+        float s = bv;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s = fmaf(k[i * 3 + j], X[i][c + j], s);
+        z[c] = s;
+    }
+    if constexpr (!BWD) {
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < HW; ++c) z[c] *= sigmoidf_fast(z[c]);
+        }
+        if (live) dwrow_store<HW>(out + po, z);
+    } else {
+        float acc[9], accb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+        float G[3][HW + 2];
+        G[1][0] = G[1][HW + 1] = 0.f;
+#pragma unroll
+        for (int c = 0; c < HW; ++c) {
+            float gv = g[1 + c];
+            if (act) {
+                const float sg = sigmoidf_fast(z[c]);
+                gv *= sg * fmaf(z[c], 1.f - sg, 1.f);
+            }
+            if (!live) gv = 0.f;
+            G[1][1 + c] = gv;
+            accb += gv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i * 3 + j] = fmaf(gv, X[i][c + j], acc[i * 3 + j]);
+        }
+        dwrow_neigh<HW>(G[1], hasu, hasd, G[0], G[2]);
+        float o[HW];
+#pragma unroll
+        for (int c = 0; c < HW; ++c) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v = fmaf(k[8 - (i * 3 + j)], G[i][c + j], v);
+            o[c] = v;
+        }
+        if (live) dwrow_store<HW>(out + po, o);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const float sm = dw_wave_sum(i < 9 ? acc[i] : accb);
+            if (lane == 63) {
+                if (i < 9) atomicAdd(dw + d * 9 + i, sm);
+                else if (dbias) atomicAdd(dbias + d, sm);
+            }
+        }
     }
 }
 
@@ -771,6 +904,25 @@ static int pick_pp(int L) { return L >= 1024 ? 1 : (L >= 256 ? 2 : 4); }
 template <typename T>
 static int launch_dw(bool bwd, const void *x, const float *w, const float *bias, const void *dy, void *out, float *dw,
                      float *dbias, int B, int D, int H, int W, int act, hipStream_t s) {
+    if (std::is_same<T, bf16_t>::value && H == W && (W == 14 || W == 12) && !getenv("XFM_DWCONV_NO_ROWLANE") && !getenv("XFM_DWCONV_GENERIC")) {
+        // 14 x 14 / 12 x 12: one lane per row
+        const int ppw = 64 / W;
+        const int nwaves = D * ((B + ppw - 1) / ppw);
+        const dim3 grid((nwaves + 3) / 4);
+#define XFM_DW_ROW(HW)                                                                                                 \
+    do {                                                                                                               \
+        if (bwd)                                                                                                       \
+            hipLaunchKernelGGL((dwconv_rowlane_kernel<HW, true>), grid, dim3(256), 0, s, (const uint16_t *)x, w, bias,  \
+                               (const uint16_t *)dy, (uint16_t *)out, dw, dbias, B, D, act);                           \
+        else                                                                                                           \
+            hipLaunchKernelGGL((dwconv_rowlane_kernel<HW, false>), grid, dim3(256), 0, s, (const uint16_t *)x, w, bias, \
+                               (const uint16_t *)nullptr, (uint16_t *)out, (float *)nullptr, (float *)nullptr, B, D, act); \
+        return check_launch();                                                                                         \
+    } while (0)
+        if (W == 14) XFM_DW_ROW(14);
+        else XFM_DW_ROW(12);
+#undef XFM_DW_ROW
+    }
     // (14 x 14 maps measured no better on the strip kernels: forward 10.1 vs 11.6 us, backward 29.1 vs 24.7 us)
     if (sizeof(T) == 2 && H == W && !getenv("XFM_DWCONV_NO_STRIP") && !getenv("XFM_DWCONV_GENERIC")) {
         // wide maps: the register-stencil kernels.  (map, vector, band rows, strips per row); planes per wave = min(8, 64 / strips)
