@@ -241,15 +241,20 @@ __global__ void __launch_bounds__(256) ln2d_bwd_dx_short_kernel(const Tx *__rest
 // register-cached variants: C == CPT * NW.  The workgroup has NW waves (<= 16); lane = position, each thread
 // keeps its CPT channel values in registers, so x (and dy) are read from HBM exactly once.
 // ---------------------------------------------------------------------------------------------
-template <typename Tx, typename Ty, int CPT>
+// HALF: a workgroup covers 32 positions instead of 64 -- the lower lanes take the even, the upper lanes the odd channels of
+// their wave -- so that maps with few positions (14 x 14: 12544 = 196 tiles of 64 for 256 CUs) launch twice the workgroups.
+template <typename Tx, typename Ty, int CPT, bool HALF = false>
 __global__ void __launch_bounds__(1024) ln2d_fwd_cached_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
                                                                const float *__restrict__ bias, Ty *__restrict__ y,
                                                                float *__restrict__ mean, float *__restrict__ rstd,
                                                                int C, int L, int tiles_pb, float eps, int NW) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = HALF ? (lane & 31) : lane, hh = HALF ? (lane >> 5) : 0;
+    constexpr int PPW = HALF ? 32 : 64;
+    auto chan = [&](int j) { return HALF ? (wave + j * NW) * 2 + hh : wave + j * NW; };
     // positions of all images form one index space (tiles_pb = B*L here): no ragged last tile per image
-    const int64_t P = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t P = (int64_t)blockIdx.x * PPW + pl;
     const bool ok = P < tiles_pb;
     const int b = ok ? (int)(P / L) : 0, p = ok ? (int)(P - (int64_t)b * L) : 0;
     const int64_t o = (int64_t)b * C * L + p;
@@ -257,13 +262,13 @@ __global__ void __launch_bounds__(1024) ln2d_fwd_cached_kernel(const Tx *__restr
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        v[j] = ok ? ldf<Tx>(x + o + (int64_t)(wave + j * NW) * L) : 0.f;
+        v[j] = ok ? ldf<Tx>(x + o + (int64_t)chan(j) * L) : 0.f;
         s += v[j];
     }
     red[wave][lane] = s;
     __syncthreads();
     float mu = 0.f;
-    for (int q = 0; q < NW; ++q) mu += red[q][lane];
+    for (int q = 0; q < NW; ++q) mu += red[q][pl] + (HALF ? red[q][pl + 32] : 0.f);
     mu /= (float)C;
     __syncthreads();
     float q2 = 0.f;
@@ -275,30 +280,33 @@ __global__ void __launch_bounds__(1024) ln2d_fwd_cached_kernel(const Tx *__restr
     red[wave][lane] = q2;
     __syncthreads();
     float var = 0.f;
-    for (int q = 0; q < NW; ++q) var += red[q][lane];
+    for (int q = 0; q < NW; ++q) var += red[q][pl] + (HALF ? red[q][pl + 32] : 0.f);
     const float rs = rsqrtf(var / (float)C + eps);
     if (ok) {
-        if (wave == 0) {
+        if (wave == 0 && hh == 0) {
             mean[(int64_t)b * L + p] = mu;
             rstd[(int64_t)b * L + p] = rs;
         }
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int c = wave + j * NW;
+            const int c = chan(j);
             stf<Ty>(y + o + (int64_t)c * L, fmaf(v[j] * rs, w[c], bias ? bias[c] : 0.f));
         }
     }
 }
 
-template <typename Tx, typename Ty, int CPT>
+template <typename Tx, typename Ty, int CPT, bool HALF = false>
 __global__ void __launch_bounds__(1024) ln2d_bwd_dx_cached_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
                                                                   const Ty *__restrict__ dy, const float *__restrict__ mean,
                                                                   const float *__restrict__ rstd, Tx *__restrict__ dx,
                                                                   int C, int L, int tiles_pb, int NW) {
     __shared__ float red[2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = HALF ? (lane & 31) : lane, hh = HALF ? (lane >> 5) : 0;
+    constexpr int PPW = HALF ? 32 : 64;
+    auto chan = [&](int j) { return HALF ? (wave + j * NW) * 2 + hh : wave + j * NW; };
     // positions of all images form one index space (tiles_pb = B*L here): no ragged last tile per image
-    const int64_t P = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t P = (int64_t)blockIdx.x * PPW + pl;
     const bool ok = P < tiles_pb;
     const int b = ok ? (int)(P / L) : 0, p = ok ? (int)(P - (int64_t)b * L) : 0;
     const int64_t o = (int64_t)b * C * L + p;
@@ -307,7 +315,7 @@ __global__ void __launch_bounds__(1024) ln2d_bwd_dx_cached_kernel(const Tx *__re
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        const int c = wave + j * NW;
+        const int c = chan(j);
         g[j] = ok ? ldf<Ty>(dy + o + (int64_t)c * L) * w[c] : 0.f;
         xh[j] = ok ? (ldf<Tx>(x + o + (int64_t)c * L) - mu) * rs : 0.f;
         s1 += g[j];
@@ -318,14 +326,14 @@ __global__ void __launch_bounds__(1024) ln2d_bwd_dx_cached_kernel(const Tx *__re
     __syncthreads();
     float m1 = 0.f, m2 = 0.f;
     for (int q = 0; q < NW; ++q) {
-        m1 += red[0][q][lane];
-        m2 += red[1][q][lane];
+        m1 += red[0][q][pl] + (HALF ? red[0][q][pl + 32] : 0.f);
+        m2 += red[1][q][pl] + (HALF ? red[1][q][pl + 32] : 0.f);
     }
     m1 /= (float)C;
     m2 /= (float)C;
     if (ok) {
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) stf<Tx>(dx + o + (int64_t)(wave + j * NW) * L, rs * (g[j] - m1 - xh[j] * m2));
+        for (int j = 0; j < CPT; ++j) stf<Tx>(dx + o + (int64_t)chan(j) * L, rs * (g[j] - m1 - xh[j] * m2));
     }
 }
 
@@ -563,7 +571,13 @@ static int ln_fwd(const void *x, const float *w, const float *b, void *y, float 
             return check_launch();
         }
     }
-    if (C % 24 == 0 && C / 24 <= 16) {
+    // few positions (a 14 x 14 stage: 196 tiles of 64 for 256 CUs): 32-position workgroups, the lane halves split the channels
+    // (the fp32 -> bf16 forward above measured the same either way: 14.1 vs 14.6 us; the backward 22.9 -> 17.8 us)
+    if ((B * L + 63) / 64 < 256 && !getenv("XFM_LN2D_NO_HALF") && C % 24 == 0 && C / 24 <= 16) {
+        const int NW = C / 24;
+        hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 12, true>), dim3((B * L + 31) / 32), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
+                           (Ty *)y, mean, rstd, C, L, B * L, eps, NW);
+    } else if (C % 24 == 0 && C / 24 <= 16) {
         const int NW = C / 24;
         hipLaunchKernelGGL((ln2d_fwd_cached_kernel<Tx, Ty, 24>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w, b,
                            (Ty *)y, mean, rstd, C, L, B * L, eps, NW);
@@ -617,6 +631,10 @@ static int ln_bwd(const void *x, const float *w, const void *dy, const float *me
         // short maps, wide rows (7 x 7 at 768 / 1536 channels): positions x channel slices instead of lanes along positions
         hipLaunchKernelGGL((ln2d_bwd_dx_short_kernel<Tx, Ty>), dim3((B * L + 15) / 16), dim3(256), 0, s, (const Tx *)x, w,
                            (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L);
+    } else if ((B * L + 63) / 64 < 256 && !getenv("XFM_LN2D_NO_HALF") && C % 24 == 0 && C / 24 <= 16) {
+        const int NW = C / 24;
+        hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 12, true>), dim3((B * L + 31) / 32), dim3(64 * NW), 0, s, (const Tx *)x, w,
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
     } else if (C % 24 == 0 && C / 24 <= 16) {
         const int NW = C / 24;
         hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 24>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
