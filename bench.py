@@ -267,6 +267,8 @@ def main():
     graph = None
     graph_b = None
     loss_static = None
+    dp_fallback = None                               # why the two-graph data-parallel step is not the one being timed
+
     def capture():
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -297,6 +299,7 @@ def main():
                 # the two-graph data-parallel step did not come up (every rank runs the same code and fails alike): fall
                 # back to ONE graph for forward + backward + packing and the all-reduce after it
                 print(f"[bench] two-graph step failed ({type(e).__name__}: {e}); one graph + all-reduce after it", file=sys.stderr)
+                dp_fallback = f"fallback: one graph (two-graph capture failed: {type(e).__name__}: {str(e)[:120]})"
                 phased = None
                 model.mamba_feature_extrac.cut_after = None
                 buckets = GradBuckets(model, bucket_mb=48.0, overlap=False, comm_dtype=comm)
@@ -304,6 +307,7 @@ def main():
                     graph, graph_b, loss_static = capture()
                 except Exception as e2:              # noqa: BLE001  (report and fall back to eager launches)
                     print(f"[bench] graph capture failed, running eager: {type(e2).__name__}: {e2}", file=sys.stderr)
+                    dp_fallback = f"fallback: eager launches (graph capture failed: {type(e2).__name__}: {str(e2)[:120]})"
                     graph = graph_b = None
                     torch.cuda.synchronize()
             else:
@@ -432,7 +436,10 @@ def main():
                                "results (net_fusionmamba.py:200-201); they carry no gradient",
                        "global_batch": B * world, "parallelism": f"dp{world}", "grad_allreduce": ("bf16" if comm is not None else "fp32") if world > 1 else None,
                        "dp_step": (f"two hipGraphs cut after trunk stage {a.dp_cut}: the late layers' all-reduce runs under the early "
-                                   f"layers' backward; Adam reads the summed wire bucket in place" if graph_b is not None else None), "ss2d_mode": fusion_vmamba.SS2D_MODE, "fp8_proj": bool(a.fp8),
+                                   f"layers' backward; Adam reads the summed wire bucket in place" if graph_b is not None else
+                                   (None if world == 1 else (dp_fallback or ("one graph (forward + backward + packing), all-reduce after it"
+                                                                             if graph is not None else "eager: bucket all-reduce overlapped with backward")))),
+                       "ss2d_mode": fusion_vmamba.SS2D_MODE, "fp8_proj": bool(a.fp8),
                        "single_view_images_per_s": round(2 * value, 2)},
             "roofline": roof,
             "roofline_scan_kernels": roofs,

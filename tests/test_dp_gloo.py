@@ -287,6 +287,10 @@ def _phased_gpu_worker(rank, world, port, q):
     from xfmamba_amd.proj import WgradArena, set_wgrad_arena
     arena = WgradArena(m.parameters())
     set_wgrad_arena(arena)
+    # ... and the LayerNorm / bias column sums are folded by one launch per GRAPH (deferred.py): graph A's flush (late piece)
+    # and graph B's (early piece) each replay a job table of their own (they used to share one pinned table)
+    from xfmamba_amd import deferred
+    deferred.defer_partial_sums(True)
     g = torch.Generator().manual_seed(5)
     B = 32        # (16 per rank: at tiny batches MIOpen's weight-gradient solver of the 384->768 stride-2 convolution returns
                   #  garbage under hipGraph replay -- library kernel, see test_captured_training_step_replays_like_eager)
@@ -317,6 +321,8 @@ def _phased_gpu_worker(rank, world, port, q):
     with torch.cuda.graph(gb, pool=ga.pool()):
         pg.backward_early()
     ok, worst, sizes = True, ("", 0.0), [sum(p.numel() for p in grp) for grp in pg.pieces]
+    used = deferred._S["cap_used"].get(str(dev), [])
+    ok &= len(used) >= 2 and all(t["nblocks"] > 0 for t in used[:2]) and used[0]["key"] != used[1]["key"]
     for xa_s, xb_s, lab_s in data:                                  # three replays on three batches
         xa.copy_(xa_s[sl]); xb.copy_(xb_s[sl]); lab.copy_(lab_s[sl])
         ga.replay()
@@ -344,6 +350,7 @@ def _phased_gpu_worker(rank, world, port, q):
                 if err > worst[1]:
                     worst = (k, err)
     set_wgrad_arena(None)
+    deferred.defer_partial_sums(False)
     # the late piece must hold most of the gradient bytes (it is the one whose all-reduce is hidden)
     ok &= sizes[0] > 4 * sizes[1]
     q.put((rank, bool(ok), worst, sizes))

@@ -54,6 +54,8 @@ def _oracle(x, xw, dtw, A, Dp, bias, gy, HW, N, c_mod=0, c_off=0):
 
 CASES = [  # B, D, HW, R       (trunk stage 2 / 3 of XFMamba-T/S, XFMamba-B@384 stage 3, odd batch, small widths)
     (2, 384, 14, 24), (3, 768, 7, 48), (2, 64, 12, 4), (1, 96, 14, 6), (5, 32, 7, 2), (2, 128, 12, 64), (2, 96, 7, 33),
+    # batch % 8 == 0: the XCD-local sample map (`chan_block_map`, csrc/ss2d_chan.hip) -- the launch mode of the bench
+    (8, 384, 14, 24), (16, 768, 7, 48), (8, 128, 12, 64), (64, 384, 14, 24),
 ]
 
 

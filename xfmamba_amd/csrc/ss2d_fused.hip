@@ -240,6 +240,11 @@ int ss2d_launch_lean(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bw
 
 int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, size_t ws_bytes);   // ss2d_l3.hip: wide maps
 size_t ss2d_l3_ws_bytes(const xfm_ss2d_params_t *p);
+int ss2d_l3_nseg(int batch, int D, int H, int W, int N, int in_dtype);
+static bool ss2d_forced() {
+    static const bool f = getenv("XFM_SS2D_FORCE") != nullptr;      // tuning hook, read once per process
+    return f;
+}
 
 static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream, float *ws = nullptr, size_t ws_bytes = 0) {
     if (!p || !p->x || !p->dts || !p->Bs || !p->Cs || !p->A || !p->D || !p->delta_bias) return XFM_EINVAL;
@@ -248,7 +253,7 @@ static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream, float *ws = 
         return XFM_EINVAL;
     if (p->in_dtype < 0 || p->in_dtype > 2) return XFM_EDTYPE;
     if (p->out_dtype != XFM_F32) return XFM_EDTYPE;          // the fused core always emits fp32 ("oflex")
-    if (!getenv("XFM_SS2D_FORCE")) {
+    if (!ss2d_forced()) {
         const int rc3 = ss2d_l3_run(p, bwd, (hipStream_t)stream, ws, ws_bytes);
         if (rc3 != XFM_ELIMIT) return rc3;
     }
@@ -267,9 +272,9 @@ static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream, float *ws = 
     a.kind = pl.kind;
     a.pli = pl.pli;
     a.bc_floats = pl.bc_floats;
-    a.dbg = 0;
-    if (const char *env = getenv("XFM_SS2D_DBG")) {
-        a.dbg = atoi(env);
+    static const int env_dbg = [] { const char *e = getenv("XFM_SS2D_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = env_dbg;
+    if (env_dbg) {
         static int once = 0;
         if (!once++) fprintf(stderr, "[xfm] ss2d timing switches dbg=%d kind=%d items=%d chunks=%d ppt=%d pli=%d lds=%zu/%zu\n", a.dbg, pl.kind, pl.items, pl.n_chunks, pl.ppt, pl.pli, pl.lds_fwd_block, pl.lds_bwd_block);
     }
@@ -295,12 +300,14 @@ int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, int in_dtype
     plan->lanes_per_row = 1 << pl.lg;
     plan->items = pl.items;
     plan->n_chunks = pl.n_chunks;
+    if (!xfm::ss2d_forced())                       // the wide-map kernels (ss2d_l3.hip) index chk by their own geometry
+        plan->n_chunks = std::max(plan->n_chunks, xfm::ss2d_l3_nseg(batch, d_inner, H, W, dstate, in_dtype));
     return XFM_OK;
 }
 int xfm_ss2d_fwd(const xfm_ss2d_params_t *p, void *stream) { return xfm::run2(p, false, stream); }
 int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream) { return xfm::run2(p, true, stream); }
 size_t xfm_ss2d_bwd_ws_bytes(const xfm_ss2d_params_t *p) {
-    if (!p || getenv("XFM_SS2D_FORCE") || getenv("XFM_L3_ATOMICS")) return 0;
+    if (!p || xfm::ss2d_forced() || getenv("XFM_L3_ATOMICS")) return 0;      // (A/B switch of the tests: read per call)
     const char *e = getenv("XFM_SS2D_L3");
     return (e && e[0] == '0') ? 0 : xfm::ss2d_l3_ws_bytes(p);
 }

@@ -898,7 +898,8 @@ static int l3_pli(int batch, int tiles_pb, bool bwd) {
     int pli = (int)(((int64_t)batch * tiles_pb + resident - 1) / resident);
     if (pli < 1) pli = 1;
     if (pli > tiles_pb) pli = tiles_pb;
-    if (const char *e = getenv("XFM_L3_PLI")) pli = std::max(1, std::min(tiles_pb, atoi(e)));   // tuning hook
+    static const int env_pli = [] { const char *e = getenv("XFM_L3_PLI"); return e ? atoi(e) : 0; }();   // tuning hook, read once
+    if (env_pli > 0) pli = std::max(1, std::min(tiles_pb, env_pli));
     while (tiles_pb % pli) --pli;
     return pli;
 }
@@ -919,11 +920,13 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
     la.magicL = (uint32_t)((0x100000000ull + L - 1) / L);
     la.magicH = la.magicW;
     la.dbg = 0;                                        // timing-only switches: 1 skip sweeps, 2 skip plane staging, 4 skip merge,
-    if (const char *e = getenv("XFM_L3_DBG")) la.dbg = atoi(e);   // 16 no operand prefetch, 32 no ddts / dx stores
+    static const int env_dbg = [] { const char *e = getenv("XFM_L3_DBG"); return e ? atoi(e) : 0; }();
+    la.dbg = env_dbg;                                  // 16 no operand prefetch, 32 no ddts / dx stores
     const int tiles_pb = D / PPT;
     const int pli = l3_pli(p.batch, tiles_pb, bwd);
     la.pli = pli;
-    la.xmap = (p.batch % 8 == 0 && !getenv("XFM_L3_NO_XMAP")) ? 1 : 0;
+    static const bool env_no_xmap = getenv("XFM_L3_NO_XMAP") != nullptr;
+    la.xmap = (p.batch % 8 == 0 && !env_no_xmap) ? 1 : 0;
     const int groups = tiles_pb / pli;
     const size_t need = (size_t)p.batch * groups * 4 * 2 * L * sizeof(float);
     la.parts = (bwd && ws && ws_bytes >= need && groups > 1 && L % 4 == 0) ? ws : nullptr;
@@ -970,7 +973,7 @@ int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, 
     if (p->delta_softplus < 0 || p->delta_softplus > 2) return XFM_ELIMIT;
     const int ppt = l3_ppt(p->H);
     if (!ppt || p->d_inner % ppt) return XFM_ELIMIT;
-    if (!p->chk) return XFM_EINVAL;                                    // multi-chunk rows need the forward's checkpoints
+    if (!p->chk) return XFM_ELIMIT;            // no checkpoint buffer: the generic path decides (EINVAL if it needs one too)
     switch (p->H) {
         case 56: return l3_launch<56, 1>(*p, bwd, s, ws, ws_bytes);
         case 28: return l3_launch<28, 4>(*p, bwd, s, ws, ws_bytes);
@@ -978,6 +981,18 @@ int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, 
         case 24: return l3_launch<24, 4>(*p, bwd, s, ws, ws_bytes);
     }
     return XFM_ELIMIT;
+}
+
+// checkpoints per (route, channel) row the kernels of this file write / read: chk[(route * D + d) * NSEG + i], NSEG from THEIR
+// geometry.  0: shape not dispatched here.  xfm_ss2d_plan reports at least this many chunks, so a caller that sizes chk
+// from the plan can never be short whichever kernel family the plan search itself would pick.
+int ss2d_l3_nseg(int batch, int D, int H, int W, int N, int in_dtype) {
+    (void)batch;
+    const char *e = getenv("XFM_SS2D_L3");
+    if ((e && e[0] == '0') || in_dtype != XFM_BF16 || N != 1 || H != W) return 0;
+    const int ppt = l3_ppt(H);
+    if (!ppt || D % ppt) return 0;
+    return (H * W + 511) / 512;
 }
 
 // bytes of the partial-sum workspace the backward can use (0: shape not covered here)

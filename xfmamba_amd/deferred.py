@@ -8,9 +8,20 @@ reads before the optimizer.  With ``defer_partial_sums(True)`` the producers lea
 they read a gradient.
 
 Opt-in (``bench.py`` turns it on): between ``backward()`` and the flush the affected ``.grad`` tensors are allocated but
-NOT yet filled, so code that reads gradients straight after ``backward()`` must call ``flush()`` (or leave this off).  A
-parameter that receives a second gradient in the same pass (shared weights) is flushed before its second producer runs and
-that producer is not deferred, so autograd never adds unfilled tensors.
+NOT yet filled, so code that reads gradients straight after ``backward()`` must call ``flush()`` (or leave this off).
+
+What is deferred, and what is not (``add_job`` decides; a refused job runs the producer's own finish kernel):
+* only results that are the gradient of an **fp32 ``nn.Parameter`` whose ``.grad`` is None** (``set_to_none`` semantics):
+  autograd then ADOPTS the result tensor as ``.grad`` and the fold fills it in place.  With an existing ``.grad``
+  (``zero_grad(set_to_none=False)``, micro-batch accumulation) autograd would add the unfilled tensor at once, and for a
+  reduced-precision parameter the producer's ``.to(dtype)`` would copy it -- neither is deferred;
+* a parameter that receives a second gradient in the same pass (shared weights) is flushed before its second producer
+  runs and that producer is not deferred, so autograd never adds unfilled tensors.
+
+Job tables.  The fold kernel reads a job table and a block table that are uploaded from pinned host memory.  A memcpy node
+of a captured graph re-reads its pinned source at EVERY replay, so every flush issued under capture takes a table pair of
+its own from a pool (allocated outside captures, topped up at every eager flush) and that pair is never written again:
+two graphs of one step (``dp.PhasedGrads``) or several flushes inside one graph each replay their own job set.
 """
 from __future__ import annotations
 
@@ -18,10 +29,11 @@ import torch
 
 from . import _lib
 
-__all__ = ["defer_partial_sums", "deferring", "add_job", "flush"]
+__all__ = ["defer_partial_sums", "deferring", "add_job", "flush", "reserve_capture_tables"]
 
 _MAX_JOBS, _MAX_BLOCKS = 512, 1 << 15
-_S = {"on": False, "jobs": [], "keys": set(), "slots": {}}
+_CAP_POOL_MIN = 8                           # free table pairs kept ready for flushes under capture
+_S = {"on": False, "jobs": [], "keys": set(), "eager": {}, "cap_free": {}, "cap_used": {}}
 
 
 def defer_partial_sums(enable: bool) -> None:
@@ -34,30 +46,58 @@ def deferring() -> bool:
     return _S["on"]
 
 
-def _slot(device, capturing):
-    """Pinned host tables + their device copies, one set for eager steps and one for a captured step (whose memcpy nodes
-    re-read the pinned buffer at every replay, so later eager steps must not overwrite it).  Both are allocated on the first
-    use, which has to be OUTSIDE a capture (the warm-up steps): nothing may be allocated on the host side while capturing."""
-    sl = _S["slots"].get((str(device), capturing))
-    if sl is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("xfmamba_amd.deferred: run a warm-up step with deferred sums before capturing")
-        for cap in (False, True):
-            _S["slots"][(str(device), cap)] = dict(
-                jobs_h=torch.empty(6 * _MAX_JOBS, dtype=torch.int64).pin_memory(),
+def _new_tables(device):
+    return dict(jobs_h=torch.empty(6 * _MAX_JOBS, dtype=torch.int64).pin_memory(),
                 blocks_h=torch.empty(_MAX_BLOCKS, dtype=torch.int32).pin_memory(),
                 jobs_d=torch.empty(6 * _MAX_JOBS, dtype=torch.int64, device=device),
-                blocks_d=torch.empty(_MAX_BLOCKS, dtype=torch.int32, device=device), key=None, evt=None)
-        sl = _S["slots"][(str(device), capturing)]
+                blocks_d=torch.empty(_MAX_BLOCKS, dtype=torch.int32, device=device), key=None, evt=None, nblocks=0)
+
+
+def reserve_capture_tables(device, n: int = _CAP_POOL_MIN) -> None:
+    """Make sure ``n`` unused table pairs exist for flushes under capture (call outside a capture; every eager flush does)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    free = _S["cap_free"].setdefault(str(device), [])
+    while len(free) < n:
+        free.append(_new_tables(device))
+
+
+def _tables(device, capturing):
+    """Eager flushes share one table pair per device (rewritten when the job set changes, behind an event).  A flush under
+    capture takes a pair from the pool and keeps it for the life of the process: the graph's memcpy nodes read it at replay."""
+    dev = str(device)
+    if not capturing:
+        sl = _S["eager"].get(dev)
+        if sl is None:
+            sl = _S["eager"][dev] = _new_tables(device)
+        reserve_capture_tables(device)
+        return sl
+    free = _S["cap_free"].get(dev)
+    if not free:
+        raise RuntimeError("xfmamba_amd.deferred: no job table left for a flush under capture -- run a warm-up step with "
+                           "deferred sums (or deferred.reserve_capture_tables(device, n)) before capturing")
+    sl = free.pop()
+    _S["cap_used"].setdefault(dev, []).append(sl)
     return sl
 
 
-def add_job(part: torch.Tensor, outs, nblk: int, C: int, nparts: int, key=None) -> bool:
-    """Register ``outs[k][c] = sum_j part[(j * nparts + k) * C + c]`` for the next flush.  False: deferral is off (the caller
-    runs its own finish kernel).  ``key``: identity of the parameter the result is a gradient of."""
+def _deferrable(p) -> bool:
+    return isinstance(p, torch.nn.Parameter) and p.dtype == torch.float32 and p.grad is None
+
+
+def add_job(part: torch.Tensor, outs, nblk: int, C: int, nparts: int, params=()) -> bool:
+    """Register ``outs[k][c] = sum_j part[(j * nparts + k) * C + c]`` for the next flush.  ``params[k]``: the parameter
+    ``outs[k]`` is the gradient of (None where ``outs[k]`` is None).  False: not deferred (the caller runs its own finish
+    kernel) -- deferral is off, a result is not the gradient of an fp32 parameter without ``.grad``, or a parameter already
+    got a gradient in this pass."""
     if not _S["on"]:
         return False
-    if key is not None and key in _S["keys"]:
+    params = list(params) + [None] * (len(outs) - len(params))
+    for o, p in zip(outs, params):
+        if o is not None and not _deferrable(p):
+            return False
+    keys = [id(p) for o, p in zip(outs, params) if o is not None]
+    if any(k in _S["keys"] for k in keys):
         # second gradient of the same parameter in one pass (shared weights, two trunk calls): autograd adds the two as
         # soon as this one is returned, so the first must be complete NOW and this one is not deferred
         flush(_end_of_pass=False)
@@ -69,8 +109,7 @@ def add_job(part: torch.Tensor, outs, nblk: int, C: int, nparts: int, key=None) 
     # the .grad of their parameters (or in the tuple torch.autograd.grad returns) until the flush.
     ptrs = [0 if o is None else o.data_ptr() for o in outs] + [0] * (3 - len(outs))
     _S["jobs"].append((part, ptrs, int(nblk), int(C), int(nparts)))
-    if key is not None:
-        _S["keys"].add(key)
+    _S["keys"].update(keys)
     return True
 
 
@@ -87,10 +126,10 @@ def flush(_end_of_pass: bool = True) -> None:
     _S["jobs"] = []
     dev = jobs[0][0].device
     capturing = torch.cuda.is_current_stream_capturing()
-    sl = _slot(dev, capturing)
+    sl = _tables(dev, capturing)
     key = tuple((p.data_ptr(), tuple(outs), nblk, C, nparts) for p, outs, nblk, C, nparts in jobs)
     if key != sl["key"]:
-        if sl["evt"] is not None and not capturing:
+        if sl["evt"] is not None:
             sl["evt"].synchronize()                  # the previous upload of this pinned table may still be in flight
         jh, bh = sl["jobs_h"], sl["blocks_h"]
         rows, blocks = [], []

@@ -36,7 +36,7 @@ def colsum_fn(x: torch.Tensor, grad_of=None) -> torch.Tensor:
         raise RuntimeError(f"xfmamba_amd: colsum does not support width {C} / dtype {x.dtype}")
     out = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = torch.empty(nblk * C, dtype=torch.float32, device=x.device)
-    later = grad_of is not None and _deferred.add_job(ws, [out], nblk, C, 1, key=grad_of.data_ptr())
+    later = grad_of is not None and _deferred.add_job(ws, [out], nblk, C, 1, params=(grad_of,))
     with torch.cuda.device(x.device), _lib.timed("colsum", x.numel() * x.element_size()):
         _lib.check(lib.xfm_colsum(x.data_ptr(), None if later else out.data_ptr(), ws.data_ptr(), rows, C, code,
                                   _lib.stream_ptr()), "colsum")
@@ -56,6 +56,7 @@ class BiasGeluHip(torch.autograd.Function):
                                                     _lib.dtype_code(z.dtype), _lib.stream_ptr()), "bias_gelu_fwd")
         ctx.save_for_backward(z, b)
         ctx.bdtype = None if bias is None else bias.dtype
+        ctx.bparam = bias                                   # (identity only: what deferred.add_job checks)
         return g
 
     @staticmethod
@@ -69,8 +70,7 @@ class BiasGeluHip(torch.autograd.Function):
         db = torch.empty(C, dtype=torch.float32, device=z.device)
         nblk = lib.xfm_colsum_blocks(rows, C, code)
         ws = torch.empty(nblk * C, dtype=torch.float32, device=z.device)
-        later = (ctx.bdtype == torch.float32 and b is not None
-                 and _deferred.add_job(ws, [db], nblk, C, 1, key=b.data_ptr()))
+        later = b is not None and _deferred.add_job(ws, [db], nblk, C, 1, params=(ctx.bparam,))
         with torch.cuda.device(z.device), _lib.timed("bias_gelu_bwd", 3 * z.numel() * z.element_size()):
             _lib.check(lib.xfm_bias_gelu_bwd(z.data_ptr(), _lib.ptr(b), dg.data_ptr(), dz.data_ptr(),
                                              None if later else db.data_ptr(), ws.data_ptr(), rows, C, code,
@@ -124,7 +124,7 @@ class LinearTokens(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
         ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None      # (identity only: the arena's slot key)
-        ctx.bparam = bias if isinstance(bias, torch.nn.Parameter) and bias.dtype == torch.float32 else None
+        ctx.bparam = bias
         return y
 
     @staticmethod

@@ -95,9 +95,12 @@ class WgradArena:
         self.scratch_cap = 0          # elements behind the slots
         self.scratch_off = 0          # bump pointer of this step
         self.scratch_need = 0         # demand of this step (granted or not)
+        self.frozen = False           # a captured graph holds raw addresses of ``buf``: it is never reallocated afterwards
 
     def zero(self):
-        if self.scratch_need > self.scratch_cap and not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            self.frozen = True
+        if self.scratch_need > self.scratch_cap and not self.frozen:
             self.scratch_cap = self.scratch_need + self.scratch_need // 8
             self.buf = torch.empty(self.n_slots + self.scratch_cap, dtype=torch.float32, device=self.device)
         self.buf.zero_()

@@ -36,7 +36,10 @@ def _fwd(x, y, scale, w, b, eps, out_dtype, pre=None):
     return x_new, h, mean, rstd
 
 
-def _bwd(x_new, w, dh, dres, mean, rstd, scale, want_dy, has_bias, dtype, pre=None):
+def _bwd(x_new, w, dh, dres, mean, rstd, scale, want_dy, has_bias, dtype, pre=None, params=()):
+    """``params``: the (weight, bias, pre_bias) PARAMETERS the three column sums are gradients of -- deferral (deferred.py)
+    needs fp32 parameters without a ``.grad`` so that the callers' ``.to(dtype)`` is the identity and autograd adopts the
+    result tensors; anything else takes the finish kernel."""
     B, C = x_new.shape[0], x_new.shape[-1]
     rps = x_new.numel() // (B * C)
     lib = _lib.lib()
@@ -51,7 +54,7 @@ def _bwd(x_new, w, dh, dres, mean, rstd, scale, want_dy, has_bias, dtype, pre=No
                               + (dy.element_size() if want_dy else 0))
     # with deferred column sums the kernel leaves its partial rows in ws and ONE launch per step folds them (deferred.py)
     nparts = 3 if pre is not None else 2
-    later = _deferred.add_job(ws, [dw, db, dpre], nblk, C, nparts, key=w.data_ptr())
+    later = _deferred.add_job(ws, [dw, db, dpre], nblk, C, nparts, params=params)
     with torch.cuda.device(x_new.device), _lib.timed("add_layernorm_rows_bwd", nbytes):
         _lib.check(lib.xfm_add_layernorm_rows_bwd(
             x_new.data_ptr(), _lib.ptr(pre), w.data_ptr(), dh.data_ptr(), _lib.ptr(dres), mean.data_ptr(), rstd.data_ptr(),
@@ -81,6 +84,7 @@ class LayerNormRowsHip(torch.autograd.Function):
         _, h, mean, rstd = _fwd(x, None, None, w, b, eps, out_dtype, pre)
         ctx.save_for_backward(x, w, mean, rstd, pre)
         ctx.meta = (bias is not None, weight.dtype, out_dtype, None if pre_bias is None else pre_bias.dtype)
+        ctx.params = (weight, bias, pre_bias)              # (identity only: what deferred.add_job checks)
         return h
 
     @staticmethod
@@ -88,7 +92,7 @@ class LayerNormRowsHip(torch.autograd.Function):
         x, w, mean, rstd, pre = ctx.saved_tensors
         has_bias, wdtype, dtype, pdtype = ctx.meta
         dh = dh.contiguous() if dh.dtype == dtype else dh.to(dtype).contiguous()
-        dx, _, dw, db, dpre = _bwd(x, w, dh, None, mean, rstd, None, False, has_bias, dtype, pre)
+        dx, _, dw, db, dpre = _bwd(x, w, dh, None, mean, rstd, None, False, has_bias, dtype, pre, ctx.params)
         return (dx, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None,
                 (None if dpre is None else dpre.to(pdtype)))
 
@@ -107,6 +111,7 @@ class AddLayerNormRowsHip(torch.autograd.Function):
         x_new, h, mean, rstd = _fwd(x, y, s, w, b, eps, out_dtype, yb)
         ctx.save_for_backward(x_new, w, mean, rstd, s, yb)
         ctx.meta = (bias is not None, weight.dtype, out_dtype, None if y_bias is None else y_bias.dtype)
+        ctx.params = (weight, bias, y_bias)
         return x_new, h
 
     @staticmethod
@@ -121,7 +126,7 @@ class AddLayerNormRowsHip(torch.autograd.Function):
         dh = dh.contiguous() if dh.dtype == dtype else dh.to(dtype).contiguous()
         if dres is not None:
             dres = dres.float().contiguous()
-        dx, dy, dw, db, dyb = _bwd(x_new, w, dh, dres, mean, rstd, s, True, has_bias, dtype, yb)
+        dx, dy, dw, db, dyb = _bwd(x_new, w, dh, dres, mean, rstd, s, True, has_bias, dtype, yb, ctx.params)
         if dy.dtype != ctx.ydtype:
             dy = dy.to(ctx.ydtype)
         return (dx, dy, None, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None,
@@ -140,6 +145,7 @@ class LayerNormRowsPassHip(torch.autograd.Function):
         _, h, mean, rstd = _fwd(x, None, None, w, b, eps, out_dtype, None)
         ctx.save_for_backward(x, w, mean, rstd)
         ctx.meta = (bias is not None, weight.dtype, out_dtype)
+        ctx.params = (weight, bias)
         return x.view_as(x), h
 
     @staticmethod
@@ -151,7 +157,7 @@ class LayerNormRowsPassHip(torch.autograd.Function):
         dh = dh.contiguous() if dh.dtype == dtype else dh.to(dtype).contiguous()
         if dres is not None:
             dres = dres.float().contiguous()
-        dx, _, dw, db, _ = _bwd(x, w, dh, dres, mean, rstd, None, False, has_bias, dtype)
+        dx, _, dw, db, _ = _bwd(x, w, dh, dres, mean, rstd, None, False, has_bias, dtype, None, ctx.params)
         return dx, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None
 
 
@@ -194,7 +200,7 @@ class ResidualSettleHip(torch.autograd.Function):
                                                           _lib.stream_ptr()), "residual_settle_fwd")
         ctx.save_for_backward(sc)
         ctx.meta = (B, rps, C, y.dtype, out_dtype, None if y_bias is None else y_bias.dtype)
-        ctx.bparam = y_bias if isinstance(y_bias, torch.nn.Parameter) and y_bias.dtype == torch.float32 else None
+        ctx.bparam = y_bias
         return out
 
     @staticmethod
