@@ -337,6 +337,7 @@ def _phased_gpu_worker(rank, world, port, q):
             ref_m.load_state_dict(m.state_dict())
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 torch.nn.functional.cross_entropy(ref_m(xa_s, xb_s).float(), lab_s).backward()
+            deferred.flush()                                        # (the eager reference defers its column sums too)
             torch.cuda.synchronize()
             for k, p in ref_m.named_parameters():
                 if p.grad is None:
