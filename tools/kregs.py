@@ -14,7 +14,7 @@ def main():
     src = sys.argv[1]
     pat = re.compile(sys.argv[2] if len(sys.argv) > 2 else ".")
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "xfmamba_amd", "csrc")
-    extra = ["-DXFM_CHAN_N16", "-mllvm", "-amdgpu-mfma-vgpr-form"] if src == "ss2d_chan.hip" else []
+    extra = ["-DXFM_CHAN_N16", "-mllvm", "-amdgpu-mfma-vgpr-form"] if src in ("ss2d_chan.hip", "ss2d_chan1.hip") else []
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", *extra,

@@ -19,7 +19,7 @@ import csv, glob, collections, re
 f = glob.glob('gpurun_out/sq_r01/p/**/*counter_collection.csv', recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.Counter()); n = collections.Counter()
 for r in csv.DictReader(open(f)):
-    m = re.search(r'xfm::(\w+_kernel<[^>]*>)', r['Kernel_Name'])
+    m = re.search(r'xfm::((?:\w+::)*\w+_kernel<[^>]*>)', r['Kernel_Name'])
     if not m: continue
     k = m.group(1) + ' grid=' + r.get('Grid_Size', r.get('Grid_Size_X', ''))
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])

@@ -21,6 +21,7 @@ struct ChanPostArgs {
     uint16_t *dxdbl;         // (Bt, L, XC) bf16 (every column written)
     float *dwdt;             // (4, D, R) fp32 ZEROED (atomics)
     int Bt, D, L, R, N, Rp8, C2p, XC, ptiles, bchunk;
+    int HW;                  // d_state 1: dBC is in WALKING order -- odd routes column-major on the HW x HW map (ss2d_chan1.hip)
 };
 
 __device__ __forceinline__ pbf16x8_t post_ld8(const uint16_t *p) {
@@ -92,8 +93,9 @@ template <int KT> __global__ void __launch_bounds__(256) chan_dxdbl_kernel(const
         }
     // B / C columns (and the zero padding after them) of this position
     if (kb == 0) {
-        const float *dB = a.dBC + (((int64_t)bk * 2 + 0) * a.N) * a.L + p;
-        const float *dC = a.dBC + (((int64_t)bk * 2 + 1) * a.N) * a.L + p;
+        const int pw = (a.N == 1 && (k & 1)) ? (p % a.HW) * a.HW + p / a.HW : p;
+        const float *dB = a.dBC + (((int64_t)bk * 2 + 0) * a.N) * a.L + pw;
+        const float *dC = a.dBC + (((int64_t)bk * 2 + 1) * a.N) * a.L + pw;
         if (a.N == 1) {
             pu32x4_t v = {pack_bf16x2(dB[0], dC[0]), 0u, 0u, 0u};
             *reinterpret_cast<pu32x4_t *>(orow + a.Rp8) = v;
@@ -181,6 +183,9 @@ extern "C" int xfm_ss2dc_post(const void *ddts, const void *xdbl, const void *wd
     a.C2p = a.Rp8 + (dstate == 1 ? 8 : 2 * dstate);
     a.XC = 4 * a.C2p;
     a.ptiles = (L + 31) / 32;
+    a.HW = 1;
+    while (a.HW * a.HW < L) ++a.HW;
+    if (dstate == 1 && a.HW * a.HW != L) return XFM_ELIMIT;         // (the d_state-1 scan kernels cover square maps only)
     const int KT = (a.Rp8 + 31) / 32;                                // 32-column tiles covering the dt_proj columns
     hipStream_t s = (hipStream_t)stream;
     const unsigned g1 = (unsigned)((batch * 4 * a.ptiles + 3) / 4);
