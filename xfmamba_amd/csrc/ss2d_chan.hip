@@ -630,6 +630,31 @@ __device__ __forceinline__ float deep_colsum8(const float (&v)[8], const cbf16x8
     return s + __uint_as_float(r[1]);
 }
 
+// the four value sets of a state pair (dB, dC of both states: 4 x 7 per-lane values) in ONE accumulator: set s lands in
+// columns 8 s .. 8 s + 7 through its own selector, so the in-lane sum of the 16 accumulator rows and the cross-half add are
+// paid once instead of four times.  Lane j < 32 returns the total of value (j & 7) of set (j >> 3).
+__device__ __forceinline__ float deep_colsum4(const float (&v0)[8], const float (&v1)[8], const float (&v2)[8], const float (&v3)[8],
+                                              const int lane) {
+    const float *vs[4] = {v0, v1, v2, v3};
+    const cf32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    cf32x16_t t = zero16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        cu32x4_t pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = pack_bf16x2(vs[q][2 * j], vs[q][2 * j + 1]);
+        // B operand: k-slot (lane & 7) of BOTH k-blocks (channels c and c + 32 of a row add up) for the columns of set q
+        const cbf16x8_t sel = chan_indicator(((lane >> 3) & 3) == q ? 0 : 1, lane & 7);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf16x8_t *>(&pk), sel, t, 0, 0, 0);
+    }
+    float s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    s += ((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]));
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const uint32_t sb = __float_as_uint(s);
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(sb, sb, false, false);
+    return s + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ uint16_t deep_bf16(const float v) { return (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu); }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
@@ -682,7 +707,6 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
         }
     }
     wave_sync();
-    const cbf16x8_t sel = chan_indicator(0, lane & 7);
     float dbacc = 0.f;
 #pragma unroll 1
     for (int st = NSTEP - 1; st >= 0; --st) {
@@ -717,7 +741,8 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
             float E0 = Es[(2 * np) * 64 + lane], E1 = Es[(2 * np + 1) * 64 + lane];
             float dA0 = dAs[(2 * np) * 64 + lane], dA1 = dAs[(2 * np + 1) * 64 + lane];
             float av0[P], av1[P], hv0[P], hv1[P];
-            float h0 = deep_lo(hp), h1 = deep_hi(hp);
+            const float hin0 = deep_lo(hp), hin1 = deep_hi(hp);
+            float h0 = hin0, h1 = hin1;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 av0[i] = exp2_fast(dl[i] * A20);
@@ -734,8 +759,8 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
                 const float dh0 = fmaf(c0r[i], g[i], E0), dh1 = fmaf(c1r[i], g[i], E1);
                 E0 = av0[i] * dh0;
                 E1 = av1[i] * dh1;
-                const float dha0 = dh0 * fmaf(-dlu[i], b0[i], hv0[i]);      // dh * a_t h_{t-1}
-                const float dha1 = dh1 * fmaf(-dlu[i], b1[i], hv1[i]);
+                const float dha0 = E0 * (i > 0 ? hv0[i - 1] : hin0);        // dh * a_t h_{t-1} = (a_t dh) h_{t-1}
+                const float dha1 = E1 * (i > 0 ? hv1[i - 1] : hin1);
                 sB[i] = fmaf(dh0, b0[i], sB[i]);
                 sB[i] = fmaf(dh1, b1[i], sB[i]);
                 sA[i] = fmaf(dha0, An.x, sA[i]);
@@ -752,14 +777,10 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
             dAs[(2 * np) * 64 + lane] = dA0;
             dAs[(2 * np + 1) * 64 + lane] = dA1;
             // dB / dC of the two states: sums over the 64 channel lanes, into the table slots just read
-            const float tB0 = deep_colsum8(dB0, sel), tC0 = deep_colsum8(dC0, sel);
-            const float tB1 = deep_colsum8(dB1, sel), tC1 = deep_colsum8(dC1, sel);
-            if (lane < P) {
-                T[((0 * N + 2 * np) * NSTEP + st) * 8 + lane] = tB0;
-                T[((0 * N + 2 * np + 1) * NSTEP + st) * 8 + lane] = tB1;
-                T[((1 * N + 2 * np) * NSTEP + st) * 8 + lane] = tC0;
-                T[((1 * N + 2 * np + 1) * NSTEP + st) * 8 + lane] = tC1;
-            }
+            // sets: 0 = dB of state 2 np, 1 = dC of it, 2 = dB of state 2 np + 1, 3 = dC of it
+            const float tot = deep_colsum4(dB0, dC0, dB1, dC1, lane);
+            if (lane < 32 && (lane & 7) < P)
+                T[(((lane >> 3) & 1) * N + 2 * np + (lane >> 4)) * NSTEP * 8 + st * 8 + (lane & 7)] = tot;
         }
         // ---- per-position results: du of this route into the wave's planes, d raw step size to the staging rows
 #pragma unroll
