@@ -42,6 +42,11 @@ struct WgradArgs {
     int steps_per_sample;               // ceil(L / 64)
     int total_steps, steps_per_slice;   // batch * steps_per_sample; steps a workgroup walks
     int dbg;                            // timing switches (XFM_WGRAD_DBG): 1 no atomics, 2 no MFMA / fragment reads, 4 no global loads
+    // register-staged kernel only: row pitches of token-major operands (elements; 0 = M / N: dense rows) and a GROUP axis of
+    // independent products in one launch (operand / result pointers advance by *_gs per group): the dt_proj weight gradient of
+    // the four routes of an SS2D block contracts ddts (B, 4, L, D) against column blocks of the x_proj rows (B, L, 4 C2p)
+    int lda, ldb, groups;
+    int64_t a_gs, b_gs, dw_gs;
 };
 
 // byte offset of 16-byte chunk ch (0..15) of token row `row` in a token-major tile (image (b) of the guide)
@@ -58,14 +63,14 @@ struct WgOperand {
     wg_u32x2_t pv[PL ? 8 : 1];
 
     __device__ __forceinline__ void load(const uint16_t *base, const int64_t bs, const int C, const int L, const int c0,
-                                         const int sample, const int l0, const int tid) {
+                                         const int sample, const int l0, const int tid, const int ld) {
         if constexpr (!PL) {
 #pragma unroll
             for (int v = 0; v < NTV; ++v) {
                 const int idx = tid + 256 * v, row = idx >> 4, ch = idx & 15;
                 const int l = l0 + row, c = c0 + 8 * ch;
                 tv[v] = wg_u32x4_t{0, 0, 0, 0};
-                if (l < L && c < C) tv[v] = *reinterpret_cast<const wg_u32x4_t *>(base + sample * bs + (int64_t)l * C + c);
+                if (l < L && c < C) tv[v] = *reinterpret_cast<const wg_u32x4_t *>(base + sample * bs + (int64_t)l * ld + c);
             }
         } else {
 #pragma unroll
@@ -144,11 +149,14 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
     auto Bt = [&](const int buf) { return wg_lds + 2 * ABYTES + buf * BBYTES; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbm = (a.M + kWgTile - 1) / kWgTile, nbn = (a.N + kWgTile - 1) / kWgTile;
-    const int tile_id = blockIdx.x % (nbm * nbn), slice = blockIdx.x / (nbm * nbn);
+    const int per_group = gridDim.x / a.groups, grp = blockIdx.x / per_group, bid = blockIdx.x - grp * per_group;
+    const int tile_id = bid % (nbm * nbn), slice = bid / (nbm * nbn);
     const int m0 = (tile_id / nbn) * kWgTile, n0 = (tile_id % nbn) * kWgTile;
     const int st0 = slice * a.steps_per_slice;
     const int st1 = min(st0 + a.steps_per_slice, a.total_steps);
     if (st0 >= st1) return;                                // (uniform per workgroup)
+    const uint16_t *const pa = a.a + grp * a.a_gs, *const pb = a.b + grp * a.b_gs;
+    float *const pdw = a.dw + grp * a.dw_gs;
     const int wm = wave >> 1, wn = wave & 1;               // wave -> 64 x 64 of the tile
     wg_f32x16_t acc[2][2];
 #pragma unroll
@@ -167,8 +175,8 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
         constexpr int P = decltype(par)::value;
         const int sample = st / a.steps_per_sample, l0 = (st - sample * a.steps_per_sample) * BK;
         if (a.dbg & 4) return;
-        ra[P].load(a.a, a.a_bs, a.M, a.L, m0, sample, l0, tid);
-        rb[P].load(a.b, a.b_bs, a.N, a.L, n0, sample, l0, tid);
+        ra[P].load(pa, a.a_bs, a.M, a.L, m0, sample, l0, tid, a.lda);
+        rb[P].load(pb, a.b_bs, a.N, a.L, n0, sample, l0, tid, a.ldb);
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -232,7 +240,7 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                if (m < a.M && n < a.N && !(a.dbg & 1)) atomicAdd(a.dw + (int64_t)m * a.N + n, acc[i][j][v]);
+                if (m < a.M && n < a.N && !(a.dbg & 1)) atomicAdd(pdw + (int64_t)m * a.N + n, acc[i][j][v]);
             }
         }
 }
@@ -367,6 +375,30 @@ static int wgrad_launch(const WgradArgs &a, int nslices, hipStream_t s) {
 
 }  // namespace xfm
 
+namespace xfm {
+// Token-major x token-major with row pitches and a group axis (see WgradArgs): dW[g] (M, N) += sum_{b, l} A[g][b, l, :M] (x)
+// B[g][b, l, :N].  Used by xfm_ss2dc_post for the dt_proj weight gradient of the four routes in ONE launch.  M, N % 8 == 0,
+// 16-byte aligned rows.  (xfm namespace, not part of the C ABI.)
+int wgrad_grouped(const void *a, const void *b, float *dw, int M, int N, int batch, int L, int64_t a_bs, int64_t b_bs, int lda,
+                  int ldb, int groups, int64_t a_gs, int64_t b_gs, int64_t dw_gs, hipStream_t s) {
+    if (M % 8 || N % 8 || lda % 8 || ldb % 8 || a_bs % 8 || b_bs % 8 || a_gs % 8 || b_gs % 8) return XFM_ELIMIT;
+    if (((uintptr_t)a & 15) || ((uintptr_t)b & 15)) return XFM_EINVAL;
+    WgradArgs w{};
+    w.a = (const uint16_t *)a; w.b = (const uint16_t *)b; w.dw = dw;
+    w.M = M; w.N = N; w.batch = batch; w.L = L; w.a_bs = a_bs; w.b_bs = b_bs;
+    w.lda = lda; w.ldb = ldb; w.groups = groups; w.a_gs = a_gs; w.b_gs = b_gs; w.dw_gs = dw_gs;
+    constexpr int BK = 64;
+    w.steps_per_sample = (L + BK - 1) / BK;
+    w.total_steps = batch * w.steps_per_sample;
+    const int tiles = ((M + kWgTile - 1) / kWgTile) * ((N + kWgTile - 1) / kWgTile);
+    // two workgroups per CU; a workgroup's atomic tail is its (128 x N) corner only, so short slices are fine
+    int nsl = std::max(1, std::min(512 / (tiles * groups), w.total_steps / 4));
+    w.steps_per_slice = (w.total_steps + nsl - 1) / nsl;
+    nsl = (w.total_steps + w.steps_per_slice - 1) / w.steps_per_slice;
+    return wgrad_launch<false, false, 64>(w, nsl * groups, s);
+}
+}  // namespace xfm
+
 extern "C" {
 
 int xfm_wgrad_supported(int M, int N, int L, int a_planes, int b_planes) {
@@ -389,6 +421,7 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     WgradArgs w{};
     w.a = (const uint16_t *)a; w.b = (const uint16_t *)b; w.dw = dw;
     w.M = M; w.N = N; w.batch = batch; w.L = L; w.a_bs = a_bs; w.b_bs = b_bs;
+    w.lda = M; w.ldb = N; w.groups = 1;
     const bool glds = !a_planes && !b_planes && batch == 1 && L % kGlBK == 0 && L >= 2048 && M >= 8 && N >= 8 &&
                       !getenv("XFM_WGRAD_NO_GLDS");
     const int BK = glds ? 64 : ((!a_planes && !b_planes && L >= 2048) ? 128 : 64);
