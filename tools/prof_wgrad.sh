@@ -20,11 +20,11 @@ for r in rows:
 i = 0
 while i < len(out):
     n, ds = out[i]
-    if 'wgrad_kernel' in n:
+    if 'wgrad' in n and 'kernel' in n:
         own = sorted(ds)[len(ds) // 2]
         lib = []
         j = i + 1
-        while j < len(out) and 'wgrad_kernel' not in out[j][0]:
+        while j < len(out) and not ('wgrad' in out[j][0] and 'kernel' in out[j][0]):
             lib += out[j][1]; j += 1
         per = sum(lib) / 5.0 if lib else 0.0
         print(f"own {own:7.1f} us   library gemm+sum {per:7.1f} us   {n[30:62]}")

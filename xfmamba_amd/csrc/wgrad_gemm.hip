@@ -47,7 +47,20 @@ struct WgradArgs {
     // the four routes of an SS2D block contracts ddts (B, 4, L, D) against column blocks of the x_proj rows (B, L, 4 C2p)
     int lda, ldb, groups;
     int64_t a_gs, b_gs, dw_gs;
+    // slices of UNEQUAL length (a linear ramp, +-stagger around the mean): equal slices all reach their 64 KB of atomic adds at
+    // the same moment and the chip retires those at ~1.3 TB/s -- the tail of every workgroup waits behind everyone else's;
+    // staggered ends put most of that traffic under the MFMA phase of the slices still running
+    int nslices;
+    float stagger;
 };
+
+// first step of slice i (i = nslices: one past the last step)
+__device__ __forceinline__ int wg_slice_start(const WgradArgs &a, const int i) {
+    if (a.stagger <= 0.f) return min(i * a.steps_per_slice, a.total_steps);
+    const float x = (float)i / (float)a.nslices;
+    const int v = (int)((float)a.total_steps * (x * (1.f - a.stagger) + a.stagger * x * x) + 0.5f);
+    return i >= a.nslices ? a.total_steps : min(v, a.total_steps);
+}
 
 // byte offset of 16-byte chunk ch (0..15) of token row `row` in a token-major tile (image (b) of the guide)
 __device__ __forceinline__ int wg_tok_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
@@ -152,8 +165,7 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
     const int per_group = gridDim.x / a.groups, grp = blockIdx.x / per_group, bid = blockIdx.x - grp * per_group;
     const int tile_id = bid % (nbm * nbn), slice = bid / (nbm * nbn);
     const int m0 = (tile_id / nbn) * kWgTile, n0 = (tile_id % nbn) * kWgTile;
-    const int st0 = slice * a.steps_per_slice;
-    const int st1 = min(st0 + a.steps_per_slice, a.total_steps);
+    const int st0 = wg_slice_start(a, slice), st1 = wg_slice_start(a, slice + 1);
     if (st0 >= st1) return;                                // (uniform per workgroup)
     const uint16_t *const pa = a.a + grp * a.a_gs, *const pb = a.b + grp * a.b_gs;
     float *const pdw = a.dw + grp * a.dw_gs;
@@ -262,8 +274,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
     const int nbm = (a.M + kWgTile - 1) / kWgTile, nbn = (a.N + kWgTile - 1) / kWgTile;
     const int tile_id = blockIdx.x % (nbm * nbn), slice = blockIdx.x / (nbm * nbn);
     const int m0 = (tile_id / nbn) * kWgTile, n0 = (tile_id % nbn) * kWgTile;
-    const int st0 = slice * a.steps_per_slice;
-    const int st1 = min(st0 + a.steps_per_slice, a.total_steps);
+    const int st0 = wg_slice_start(a, slice), st1 = wg_slice_start(a, slice + 1);
     if (st0 >= st1) return;
     const int wm = wave >> 1, wn = wave & 1;
     wg_f32x16_t acc[2][2];
@@ -395,6 +406,7 @@ int wgrad_grouped(const void *a, const void *b, float *dw, int M, int N, int bat
     int nsl = std::max(1, std::min(512 / (tiles * groups), w.total_steps / 4));
     w.steps_per_slice = (w.total_steps + nsl - 1) / nsl;
     nsl = (w.total_steps + w.steps_per_slice - 1) / w.steps_per_slice;
+    w.nslices = nsl;
     return wgrad_launch<false, false, 64>(w, nsl * groups, s);
 }
 }  // namespace xfm
@@ -437,6 +449,9 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     int nsl = std::max(1, std::min(cap / tiles, w.total_steps / (1024 / BK)));
     w.steps_per_slice = (w.total_steps + nsl - 1) / nsl;
     nsl = (w.total_steps + w.steps_per_slice - 1) / w.steps_per_slice;
+    w.nslices = nsl;
+    static const float stag = [] { const char *e = getenv("XFM_WGRAD_STAGGER"); return e ? (float)atof(e) : 0.25f; }();
+    w.stagger = (glds && nsl >= 4) ? stag : 0.f;      // (measured: 5 - 8 % on the LDS-direct kernel, nothing on the register-staged ones)
     hipStream_t s = (hipStream_t)stream;
     if (glds) {
         const size_t lds = (size_t)kGlStages * 2 * kGlTile;
