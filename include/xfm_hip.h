@@ -227,6 +227,18 @@ int xfm_partial_sums_multi(const void *jobs, const void *blocks, int nblocks, vo
 int xfm_tokens_gemm_supported(int con, int out);
 int xfm_tokens_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, long long T, int con, int out,
                     int weight_transposed, void *stream);
+/*
+ * The WIDE side of the Mlp at the later trunk stages (con -> out = 4 con: fc1's forward product and fc2's data gradient,
+ * reference models/fusion_vmamba.py:135-153) with the GELU fused into the product's epilogue; a workgroup keeps a chunk of
+ * output columns of the weight in LDS and walks the token rows.  epilogue:
+ *   0: y = x W^T + bias
+ *   1: y = z = x W^T (bf16, no bias: what the backward pass keeps) and y2 = gelu(z + bias), exact erf GELU (nn.GELU())
+ *   2: y = dz = bf16(x W^T) * gelu'(zin + bias)   (x = dy of fc2, weight = fc2's (con, out) weight with weight_transposed = 1)
+ * -- the values of the unfused chain (z / dg rounded to bf16 before the activation).  xfm_tokens_gemm2_supported(con, out).
+ */
+int xfm_tokens_gemm2_supported(int con, int out);
+int xfm_tokens_gemm2(const void *x, const void *weight_bf16, const float *bias, void *y, void *y2, const void *zin, long long T,
+                     int con, int out, int weight_transposed, int epilogue, void *stream);
 
 /*
  * The same kernel family for the layout-changing 1x1 projections of an SS2D block (in_proj: tokens -> planes, out_proj:

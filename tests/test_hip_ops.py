@@ -453,6 +453,48 @@ def test_mlp_tokens_matches_torch_fp32(dt):
         assert_close(a.grad.cpu(), r.grad, tol, 2 * tol * float(r.grad.abs().max()), name)
 
 
+@pytest.mark.parametrize("C,T", [(192, 2 * 28 * 28), (384, 8 * 14 * 14 + 5), (768, 32 * 7 * 7)])
+def test_mlp_fused_gelu_products_match_torch_fp32_and_the_unfused_chain(C, T):
+    """xfm_tokens_gemm2 (csrc/tokens_gemm.hip): fc1 with z / gelu(z + b1) out of the product's epilogue, fc2's data gradient
+    times gelu'(z + b1) out of its own -- reference models/fusion_vmamba.py:135-153 (fc1 -> GELU -> fc2) -- against torch fp32
+    at the bf16 bound, and bit for bit against the three-node chain (GEMM, bias + GELU kernel, GEMM) it replaces on the values
+    the two share (z, g, dz are rounded to bf16 at the same points)."""
+    import torch.nn.functional as F
+    from xfmamba_amd import mlp_tokens as M
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(T, C, generator=g)
+    w1, b1 = C ** -0.5 * torch.randn(4 * C, C, generator=g), 0.1 * torch.randn(4 * C, generator=g)
+    w2, b2 = (4 * C) ** -0.5 * torch.randn(C, 4 * C, generator=g), 0.1 * torch.randn(C, generator=g)
+    gy = torch.randn(T, C, generator=g)
+    ref = [t.clone().requires_grad_() for t in (x.bfloat16().float(), w1, b1, w2, b2)]
+    yr = F.linear(F.gelu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])
+    yr.backward(gy)
+    outs = []
+    for fused in (True, False):
+        old = M._FUSED
+        M._FUSED = fused
+        try:
+            dev = [t.to(DEV).requires_grad_() for t in (x, w1, b1, w2, b2)]
+            timer = None
+            from xfmamba_amd import _lib
+            timer = _lib.KernelTimer()
+            _lib.set_timer(timer)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = M.mlp_tokens_fn(dev[0].bfloat16(), *dev[1:])
+            y.float().backward(gy.to(DEV))
+            _lib.set_timer(None)
+            ran = set(timer.summary())
+            assert ("mlp_fc1_gelu" in ran and "mlp_fc2_dgrad_gelu" in ran) == fused, ran
+            outs.append([y.detach().float().cpu()] + [t.grad.float().cpu() for t in dev])
+        finally:
+            M._FUSED = old
+    names = ("y", "dx", "dw1", "db1", "dw2", "db2")
+    for name, a, r in zip(names, outs[0], [yr.detach()] + [t.grad for t in ref]):
+        assert_close(a, r, 1e-2, 2e-2 * float(r.abs().max()), name)
+    for name, a, b in zip(names, outs[0], outs[1]):                    # the unfused chain rounds at the same points
+        assert_close(a, b, 2e-3, 2e-3 * float(b.abs().max()) + 1e-7, name + " (fused vs chain)")
+
+
 @pytest.mark.parametrize("C,xdt,hdt", [(48, torch.bfloat16, torch.bfloat16), (96, torch.bfloat16, torch.float32),
                                        (192, torch.float32, torch.float32), (768, torch.bfloat16, torch.float32)])
 def test_layernorm_rows_with_conv_bias_and_bf16_input(C, xdt, hdt):

@@ -15,6 +15,9 @@
 // library).
 #include "xfm_common.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace xfm {
 
 typedef __bf16 tg_bf16x8_t __attribute__((ext_vector_type(8)));
@@ -330,6 +333,270 @@ static int proj_gemm_launch(const TokGemmArgs &a, hipStream_t s) {
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Chunked form for the WIDE side of the Mlp (fc1 forward x W1^T and fc2's data gradient dy W2: contraction over the
+// stream width C, output over the hidden width 4 C) at the 28 x 28 / 14 x 14 / 7 x 7 stages, with the GELU fused in.
+//
+// The weight no longer fits LDS as a whole (4 C x C: 1.2 MB at C = 384), so a workgroup owns a CHUNK of OCH output
+// columns ([OCH][CON + 8] bf16, ~100 KB) for its whole life and walks token tiles; the token rows are re-read once per
+// chunk from L2 (C is the narrow side: 9.6 MB at C = 384).  No staging pipeline, no barrier in the main loop: the only
+// traffic of a tile is its A fragments (global, requested a k-group ahead) and 16-byte LDS reads of the resident weight.
+// The library runs these products at 15 % of the bf16 MFMA peak (39 us at 12544 x 384 x 1536) and leaves bias + GELU to
+// a separate pass over the hidden activation (reference models/fusion_vmamba.py:135-153: fc1 -> act -> fc2).  Epilogues:
+//   EPI 0: y = x W^T + bias
+//   EPI 1: z = x W^T (bf16, kept for the backward pass) and g = gelu(z + bias)            (fc1 + GELU, forward)
+//   EPI 2: dz = bf16(dy W) * gelu'(z + bias)                                              (fc2 data gradient + GELU')
+// both exactly what the unfused chain computes (z / dg rounded to bf16 before the activation is applied).
+struct TokGemm2Args {
+    const uint16_t *x;      // (T, CON) bf16
+    const uint16_t *w;      // (OUT, CON) row-major, or (CON, OUT) when wt != 0
+    const float *bias;      // (OUT) or null
+    uint16_t *y;            // (T, OUT): EPI 0 result / EPI 1 z / EPI 2 dz
+    uint16_t *y2;           // (T, OUT): EPI 1 g
+    const uint16_t *zin;    // (T, OUT): EPI 2 the forward pass's z
+    int64_t T;
+    int OUT, wt, wgs_per_chunk;
+};
+
+constexpr float kTgInvSqrt2 = 0.70710678118654752f, kTgInvSqrt2Pi = 0.3989422804014327f;
+// erf by Abramowitz & Stegun 7.1.26 on the hardware exp2 / rcp (|error| <= 1.5e-7), as csrc/tokens_ops.hip; E = exp(-x^2)
+__device__ __forceinline__ float tg_erf(float x, float &E) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    E = __builtin_amdgcn_exp2f(-(x * x) * kLog2e);
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float r = fmaf(-(p * t), E, 1.0f);
+    return copysignf(r, x);
+}
+
+// timing-only switches (build with -DXFM_GEMM2_TIMING, then XFM_GEMM2_DBG=<bits>: 2 every tile reads the same rows, 4 no
+// epilogue, 8 no MFMA, 16 no token-row loads, 32 staging only); the production build compiles them away.  Measured with them
+// at 12544 x 384 -> 1536 (45 us): staging 4.5 us, the tile loop without MFMAs / loads / stores another 10, MFMAs + token rows
+// +9, the GELU epilogue and its two 38.5 MB stores +20.
+__device__ __forceinline__ bool tg2_dbg(const TokGemm2Args &a, const int bit) {
+#ifdef XFM_GEMM2_TIMING
+    return (a.wt & bit) != 0;
+#else
+    return false;
+#endif
+}
+
+template <int CON, int OCH, int EPI, int NT>
+__global__ void __launch_bounds__(NT) tokens_gemm2_kernel(const TokGemm2Args a) {
+    constexpr int P = CON + 8;             // LDS row pitch (halfwords): 16-byte rows, conflict-free 16-byte column reads
+    constexpr int KS = CON / 16, NB = OCH / 32, KG = KS % 8 == 0 ? 8 : 6, NG = KS / KG;
+    static_assert(KS % KG == 0 && OCH % 32 == 0, "shape");
+    extern __shared__ __align__(16) uint16_t wl[];              // [OCH][P] weight chunk, then OCH floats of bias
+    float *bl = reinterpret_cast<float *>(wl + OCH * P);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x / a.wgs_per_chunk, wg = blockIdx.x - chunk * a.wgs_per_chunk;
+    const int n0 = chunk * OCH;
+    for (int n = threadIdx.x; n < OCH; n += NT) bl[n] = a.bias ? a.bias[n0 + n] : 0.f;
+    // stage the weight chunk: ALL of a thread's loads are requested before the first LDS store (a load / store loop exposed
+    // one L2 round trip per 16 bytes: 12 of them, most of the kernel's time at these sizes)
+    constexpr int NVS = OCH * CON / 8 / NT;                         // 16-byte vectors per thread
+    static_assert(OCH * CON % (8 * NT) == 0, "staging vectors");
+    tg_u32x4_t sv[NVS];
+    if (!(a.wt & 1)) {
+        constexpr int VPR = CON / 8;                               // 16-byte vectors per row
+        const tg_u32x4_t *src = reinterpret_cast<const tg_u32x4_t *>(a.w + (int64_t)n0 * CON);
+#pragma unroll
+        for (int i = 0; i < NVS; ++i) sv[i] = src[threadIdx.x + i * NT];
+#pragma unroll
+        for (int i = 0; i < NVS; ++i) {
+            const int v = threadIdx.x + i * NT, n = v / VPR, q = v - n * VPR;
+            *reinterpret_cast<tg_u32x4_t *>(wl + n * P + 8 * q) = sv[i];
+        }
+    } else {                                                       // w is (CON, OUT): transpose while staging
+        constexpr int VPK = OCH / 8;                                // vectors of 8 output columns per k
+#pragma unroll
+        for (int i = 0; i < NVS; ++i) {
+            const int v = threadIdx.x + i * NT, k = v / VPK, n = 8 * (v - k * VPK);
+            sv[i] = *reinterpret_cast<const tg_u32x4_t *>(a.w + (int64_t)k * a.OUT + n0 + n);
+        }
+#pragma unroll
+        for (int i = 0; i < NVS; ++i) {
+            const int v = threadIdx.x + i * NT, k = v / VPK, n = 8 * (v - k * VPK);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wl[(n + 2 * q) * P + k] = (uint16_t)(sv[i][q] & 0xffffu);
+                wl[(n + 2 * q + 1) * P + k] = (uint16_t)(sv[i][q] >> 16);
+            }
+        }
+    }
+    __syncthreads();
+    if (tg2_dbg(a, 32)) return;                                    // (timing switch: staging only)
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t ntiles = (a.T + 31) / 32;
+    const int64_t stride = (int64_t)a.wgs_per_chunk * (NT / 64);
+    int64_t tile = (int64_t)wg * (NT / 64) + wave;
+    auto src_of = [&](int64_t tl) {
+        int64_t row = tl * 32 + c;
+        if (row >= a.T) row = a.T - 1;
+        if (tg2_dbg(a, 2)) row = c;                                // (timing switch: every tile reads the same 32 rows)
+        return reinterpret_cast<const tg_u32x4_t *>(a.x + row * CON + 8 * h);   // [2 s]: columns 16 s + 8 h .. + 7
+    };
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    // A fragments travel one k-group (KG k-steps) ahead of their MFMAs, across tile boundaries
+    tg_u32x4_t nx[KG];
+    if (tile < ntiles) {
+        const tg_u32x4_t *src = src_of(tile);
+#pragma unroll
+        for (int s = 0; s < KG; ++s) nx[s] = src[2 * s];
+    }
+    // weight fragments travel ONE k-step ahead of their MFMAs, also across k-groups and tiles (the weight does not depend on
+    // the tile: the step after a tile's last one reads the fragments of step 0 again); two register sets, KS even
+    static_assert(KS % 2 == 0, "fragment ping-pong");
+    tg_bf16x8_t wb[2][NB];
+    const uint16_t *wrow = wl + c * P + 8 * h;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) wb[0][b] = *reinterpret_cast<const tg_bf16x8_t *>(wrow + b * 32 * P);
+    for (; tile < ntiles; tile += stride) {
+        const int64_t t0 = tile * 32;
+        tg_f32x16_t acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+        tg_u32x4_t af[KG];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int g = ks / KG, sgi = ks % KG;
+            if (sgi == 0) {
+#pragma unroll
+                for (int q = 0; q < KG; ++q) af[q] = nx[q];
+                if (tg2_dbg(a, 16)) {                              // (timing switch: no token-row loads)
+                } else if (g + 1 < NG) {
+                    const tg_u32x4_t *src = src_of(tile);
+#pragma unroll
+                    for (int q = 0; q < KG; ++q) nx[q] = src[2 * ((g + 1) * KG + q)];
+                } else if (tile + stride < ntiles) {
+                    const tg_u32x4_t *src = src_of(tile + stride);
+#pragma unroll
+                    for (int q = 0; q < KG; ++q) nx[q] = src[2 * q];
+                }
+            }
+            const int kn = (ks + 1) % KS;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) wb[(ks + 1) & 1][b] = *reinterpret_cast<const tg_bf16x8_t *>(wrow + b * 32 * P + 16 * kn);
+            const tg_bf16x8_t afr = __builtin_bit_cast(tg_bf16x8_t, af[sgi]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (tg2_dbg(a, 8)) {                               // (timing switch: no matrix instruction)
+                    asm volatile("" :: "v"(wb[ks & 1][b]), "v"(afr));
+                } else {
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ks & 1][b], afr, acc[b], 0, 0, 0);   // D[n][t]
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue: D[n][t] -> a lane (token t0 + c) ends up with runs of eight consecutive output channels
+        const int64_t row = t0 + c;
+        const int64_t ro = row * a.OUT + n0 + 8 * h;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            __builtin_amdgcn_sched_barrier(0);                     // one accumulator's epilogue at a time (register pressure)
+            uint32_t pk[4][2];                                     // group g: channels 32 b + 8 g + 4 h .. + 3
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 bv = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (EPI == 0) bv = *reinterpret_cast<const float4 *>(bl + 32 * b + 8 * g + 4 * h);
+                pk[g][0] = pack_bf16x2(acc[b][4 * g] + bv.x, acc[b][4 * g + 1] + bv.y);
+                pk[g][1] = pack_bf16x2(acc[b][4 * g + 2] + bv.z, acc[b][4 * g + 3] + bv.w);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {                      // lower half gets channels +4..7 of group g, upper +0..3 of g+1
+                    const u32x2_t r = __builtin_amdgcn_permlane32_swap(pk[g][q], pk[g + 1][q], false, false);
+                    pk[g][q] = r[0];
+                    pk[g + 1][q] = r[1];
+                }
+            tg_u32x4_t v[2];
+            v[0][0] = pk[0][0]; v[0][1] = pk[0][1]; v[0][2] = pk[1][0]; v[0][3] = pk[1][1];      // channels 32 b + 8 h .. + 7
+            v[1][0] = pk[2][0]; v[1][1] = pk[2][1]; v[1][2] = pk[3][0]; v[1][3] = pk[3][1];      // channels 32 b + 16 + 8 h .. + 7
+            if (row < a.T && !tg2_dbg(a, 4)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int64_t off = ro + 32 * b + 16 * j;
+                    if constexpr (EPI == 0) {
+                        *reinterpret_cast<tg_u32x4_t *>(a.y + off) = v[j];
+                    } else {
+                        const float *bb = bl + 32 * b + 16 * j + 8 * h;
+                        tg_u32x4_t zi;
+                        if constexpr (EPI == 2) zi = *reinterpret_cast<const tg_u32x4_t *>(a.zin + off);
+                        tg_u32x4_t o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float r2[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const uint32_t wv = EPI == 1 ? v[j][q] : zi[q];
+                                const float zf = (e ? __uint_as_float(wv & 0xffff0000u) : __uint_as_float(wv << 16)) + bb[2 * q + e];
+                                float E;
+                                const float cdf = 0.5f * (1.0f + tg_erf(zf * kTgInvSqrt2, E));
+                                if constexpr (EPI == 1) {
+                                    r2[e] = zf * cdf;
+                                } else {
+                                    const float dgf = e ? __uint_as_float(v[j][q] & 0xffff0000u) : __uint_as_float(v[j][q] << 16);
+                                    r2[e] = dgf * fmaf(zf, kTgInvSqrt2Pi * E, cdf);
+                                }
+                            }
+                            o[q] = pack_bf16x2(r2[0], r2[1]);
+                        }
+                        if constexpr (EPI == 1) {
+                            *reinterpret_cast<tg_u32x4_t *>(a.y + off) = v[j];       // z
+                            *reinterpret_cast<tg_u32x4_t *>(a.y2 + off) = o;         // g
+                        } else {
+                            *reinterpret_cast<tg_u32x4_t *>(a.y + off) = o;          // dz
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int CON, int OCH, int EPI, int NT>
+static int tokens_gemm2_launch_nt(TokGemm2Args a, hipStream_t s) {
+    const size_t lds = (size_t)OCH * (CON + 8) * sizeof(uint16_t) + (size_t)OCH * sizeof(float);
+    auto fn = tokens_gemm2_kernel<CON, OCH, EPI, NT>;
+    static bool opted = false;
+    if (lds > 64 * 1024 && !opted) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return XFM_ELAUNCH;
+        opted = true;
+    }
+    const int chunks = a.OUT / OCH;
+    const int64_t ntiles = (a.T + 31) / 32;
+    // one workgroup per CU (the weight chunk takes ~100 KB of LDS): the CUs are split evenly over the chunks
+    int wgs = std::max(1, 256 / chunks);
+    wgs = (int)std::min<int64_t>(wgs, (ntiles + NT / 64 - 1) / (NT / 64));
+    a.wgs_per_chunk = wgs;
+    hipLaunchKernelGGL(fn, dim3(chunks * wgs), dim3(NT), lds, s, a);
+    return check_launch();
+}
+
+template <int CON, int OCH, int EPI>
+static int tokens_gemm2_launch(const TokGemm2Args &a, hipStream_t s) {
+    // waves per workgroup (tuning hook XFM_GEMM2_NT: 256 or 512 threads).  Four waves: the 32-row x 128-byte pieces the waves
+    // have in flight (4 KB each) stay inside the 32 KB L1, so a line of the token rows is fetched from L2 once, not once per
+    // k-step that touches it
+    static const int nt = [] { const char *e = getenv("XFM_GEMM2_NT"); return e ? atoi(e) : 256; }();
+    return nt == 512 ? tokens_gemm2_launch_nt<CON, OCH, EPI, 512>(a, s) : tokens_gemm2_launch_nt<CON, OCH, EPI, 256>(a, s);
+}
+
+template <int CON, int OCH>
+static int tokens_gemm2_epi(const TokGemm2Args &a, int epi, hipStream_t s) {
+    if (epi == 0) return tokens_gemm2_launch<CON, OCH, 0>(a, s);
+    if (epi == 1) return tokens_gemm2_launch<CON, OCH, 1>(a, s);
+    return tokens_gemm2_launch<CON, OCH, 2>(a, s);
+}
+
 template <int CON, int OUT, int OB>
 static int tokens_gemm_launch(const TokGemmArgs &a, hipStream_t s) {
     const size_t lds = (size_t)OUT * (CON + 8) * sizeof(uint16_t) + (size_t)OUT * sizeof(float);
@@ -367,6 +634,36 @@ int xfm_tokens_gemm(const void *x, const void *weight_bf16, const float *bias, v
     if (con == 96 && out == 96) return tokens_gemm_launch<96, 96, 96>(a, s);
     if (con == 96 && out == 192) return tokens_gemm_launch<96, 192, 96>(a, s);
     return XFM_ELIMIT;
+}
+
+/* Chunked form (weight chunk resident in LDS, GELU epilogues): con -> out = 4 con at the later trunk stages. */
+int xfm_tokens_gemm2_supported(int con, int out) {
+    return ((con == 192 && out == 768) || (con == 384 && out == 1536) || (con == 768 && out == 3072)) ? 1 : 0;
+}
+
+int xfm_tokens_gemm2(const void *x, const void *weight_bf16, const float *bias, void *y, void *y2, const void *zin, long long T,
+                     int con, int out, int weight_transposed, int epilogue, void *stream) {
+    using namespace xfm;
+    if (!x || !weight_bf16 || !y || T <= 0 || epilogue < 0 || epilogue > 2) return XFM_EINVAL;
+    if ((epilogue == 1 && !y2) || (epilogue == 2 && !zin)) return XFM_EINVAL;
+    if (!xfm_tokens_gemm2_supported(con, out)) return XFM_ELIMIT;
+    TokGemm2Args a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(weight_bf16);
+    a.bias = bias;
+    a.y = static_cast<uint16_t *>(y);
+    a.y2 = static_cast<uint16_t *>(y2);
+    a.zin = static_cast<const uint16_t *>(zin);
+    a.T = T;
+    a.OUT = out;
+    a.wt = weight_transposed ? 1 : 0;
+    static const int dbg = [] { const char *e = getenv("XFM_GEMM2_DBG"); return e ? atoi(e) : 0; }();   // timing switches: 2, 4
+    a.wt |= dbg & 62;
+    a.wgs_per_chunk = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (con == 192) return tokens_gemm2_epi<192, 128>(a, epilogue, s);
+    if (con == 384) return tokens_gemm2_epi<384, 128>(a, epilogue, s);
+    return tokens_gemm2_epi<768, 64>(a, epilogue, s);
 }
 
 int xfm_proj_gemm_supported(int con, int out, int L) {

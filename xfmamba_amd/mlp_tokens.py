@@ -151,10 +151,81 @@ def linear_tokens_fn(x, weight, bias=None):
     return LinearTokens.apply(x, weight, bias)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Mlp with the GELU inside the products (xfm_tokens_gemm2): fc1's forward epilogue emits z and gelu(z + b1), fc2's data
+# gradient comes out already multiplied by gelu'(z + b1) -- no pass over the hidden activation between the GEMMs, in either
+# direction.  XFM_MLP_FUSED=0 keeps the three-node chain (A/B switch, read once at import).
+# ---------------------------------------------------------------------------------------------------------------------------
+_FUSED = os.environ.get("XFM_MLP_FUSED", "1") == "1"
+
+
+def _gemm2_ok(x, con, out):
+    return bool(_FUSED and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == con and x.numel() >= con * 1024
+                and x.is_contiguous() and x.data_ptr() % 16 == 0 and _lib.lib().xfm_tokens_gemm2_supported(con, out))
+
+
+def _gemm2(x2, w, bias, out, transposed, epi, zin=None):
+    """xfm_tokens_gemm2 on (T, con) rows: epi 1 -> (z, g), epi 2 -> (dz, None), epi 0 -> (y, None)."""
+    T, con = x2.shape
+    y = torch.empty((T, out), dtype=x2.dtype, device=x2.device)
+    y2 = torch.empty_like(y) if epi == 1 else None
+    b = None if bias is None else bias.float().contiguous()
+    nbytes = T * (con + out * (2 if epi else 1)) * 2
+    with torch.cuda.device(x2.device), _lib.timed(("tokens_gemm2", "mlp_fc1_gelu", "mlp_fc2_dgrad_gelu")[epi], nbytes):
+        _lib.check(_lib.lib().xfm_tokens_gemm2(x2.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), _lib.ptr(y2), _lib.ptr(zin),
+                                               T, con, out, 1 if transposed else 0, epi, _lib.stream_ptr()), "tokens_gemm2")
+    return y, y2
+
+
+class MlpFusedHip(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) on token-major ``x`` (..., C) (reference models/fusion_vmamba.py:135-153) as ONE autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        cd = x.dtype
+        w1c, w2c = cast_weight(w1, cd), cast_weight(w2, cd)          # (H, C), (C, H)
+        H, C = w1c.shape
+        x2 = x.reshape(-1, C)
+        z, g = _gemm2(x2, w1c, b1, H, False, 1)
+        y = torch.nn.functional.linear(g, w2c, None if b2 is None else cast_weight(b2, cd))
+        ctx.save_for_backward(x2, z, g, w1c, w2c, b1)
+        ctx.meta = (x.shape, w1.dtype, w2.dtype, None if b1 is None else b1.dtype, None if b2 is None else b2.dtype)
+        ctx.params = (w1 if isinstance(w1, torch.nn.Parameter) else None, w2 if isinstance(w2, torch.nn.Parameter) else None,
+                      b1, b2)                                          # (identity only: arena slots, deferred column sums)
+        return y.view(*x.shape[:-1], C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, z, g, w1c, w2c, b1 = ctx.saved_tensors
+        xshape, w1dt, w2dt, b1dt, b2dt = ctx.meta
+        pw1, pw2, pb1, pb2 = ctx.params
+        H, C = w1c.shape
+        dy2 = dy.reshape(-1, C)
+        dy2 = dy2.contiguous() if dy2.dtype == w2c.dtype else dy2.to(w2c.dtype).contiguous()
+        # d z = (dy W2) * gelu'(z + b1): fc2's weight (C, H) IS the (con, out) layout of the transposed product
+        dz, _ = _gemm2(dy2, w2c, b1, H, True, 2, zin=z)
+        dx = dw1 = db1 = dw2 = db2 = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dz, w1c).view(xshape)
+        if ctx.needs_input_grad[1]:
+            slot = wgrad_slot(pw1, H, C) if w1dt == torch.float32 else None
+            dw1 = split_k_wgrad(dz, x2, deferred=w1dt == torch.float32, out=slot).to(w1dt)
+        if b1dt is not None and ctx.needs_input_grad[2]:
+            db1 = colsum_fn(dz, grad_of=pb1).to(b1dt)
+        if ctx.needs_input_grad[3]:
+            slot = wgrad_slot(pw2, C, H) if w2dt == torch.float32 else None
+            dw2 = split_k_wgrad(dy2, g, deferred=w2dt == torch.float32, out=slot).to(w2dt)
+        if b2dt is not None and ctx.needs_input_grad[4]:
+            db2 = colsum_fn(dy2, grad_of=pb2).to(b2dt)
+        return dx, dw1, db1, dw2, db2
+
+
 def mlp_tokens_fn(x, w1, b1, w2, b2, drop=None, defer_bias=False):
     """fc2(drop(gelu(fc1(x)))) on token-major ``x`` (..., C); weights are the (out, in) Linear2d / nn.Linear weights.
     ``defer_bias``: leave fc2's bias out -- the caller adds it inside the residual-add + LayerNorm kernel, whose backward
     pass then also yields its gradient (no column-sum pass over the fc2 output gradient)."""
+    if drop is None and b1 is not None and _gemm2_ok(x, w1.shape[1], w1.shape[0]) and tuple(w2.shape) == (w1.shape[1], w1.shape[0]):
+        return MlpFusedHip.apply(x, w1, b1, w2, None if defer_bias else b2)
     z = linear_tokens_fn(x, w1, None)
     g = bias_gelu_fn(z, b1)
     if drop is not None:
