@@ -12,7 +12,7 @@ def main():
     from xfmamba_amd import mlp_tokens as M
     dev = "cuda"
     fused = os.environ.get("XFM_MLP_FUSED", "1") == "1"
-    for name, B, HW, C in (("stage1", 64, 28, 192), ("stage2", 64, 14, 384), ("stage3", 64, 7, 768)):
+    for name, B, HW, C in (("stage0", 64, 56, 96), ("stage1", 64, 28, 192), ("stage2", 64, 14, 384), ("stage3", 64, 7, 768)):
         g = torch.Generator().manual_seed(0)
         x = torch.randn(B, HW, HW, C, generator=g).to(dev).bfloat16().requires_grad_()
         w1 = (C ** -0.5 * torch.randn(4 * C, C, generator=g)).to(dev).requires_grad_()

@@ -22,6 +22,9 @@ def per_kernel(path, counter):
         if not m:
             continue
         keys = [m.group(1)]
+        ns = re.search(r"xfm::(\w+)::\w+", row["Kernel_Name"])
+        if ns:
+            keys.append(ns.group(1) + "::" + m.group(1))         # e.g. chan1::bwd_kernel (the plain name is ambiguous)
         if m.group(2):
             keys.append(m.group(1) + m.group(2))                 # per template instantiation as well
             if m.group(1).startswith("ss2dc_"):                  # channel-lane kernels: d_state 1 / d_state 16 families

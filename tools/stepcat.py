@@ -11,7 +11,7 @@ for r in csv.DictReader(open(f)):
     if n.startswith('Cijk'):
         fam = 'hipBLASLt GEMM, fp32 out (wgrad)' if '_BSS_' in n or '_SB_' in n else 'hipBLASLt GEMM, bf16 out'
     elif 'xfm::deep' in n: fam = 'SS2D deep-fusion scan, backward (d_state 16)'
-    elif 'xfm::ss2dc' in n or 'xfm::chan_' in n: fam = 'SS2D channel-lane scan (+post)'
+    elif 'xfm::ss2dc' in n or 'xfm::chan_' in n or 'xfm::chan1' in n: fam = 'SS2D channel-lane scan (+post)'
     elif 'lean' in n or 'ss2d_l3' in n or 'dt_proj' in n or 'route_' in n: fam = 'SS2D wide-map scan + dt_proj + route split/merge'
     elif 'rowscan' in n or 'swap' in n or 'selective_scan' in n or 'xfm::scan_' in n: fam = 'shallow-fusion scan'
     elif 'at::native' in n: fam = 'framework reduce' if 'reduce_kernel' in n else 'framework elementwise / copy / fill'
@@ -20,6 +20,7 @@ for r in csv.DictReader(open(f)):
     elif 'rowln' in n or 'settle_' in n: fam = 'row LayerNorm (+residual)'
     elif 'ln2d' in n: fam = 'LayerNorm2d'
     elif 'wgrad_kernel' in n or 'wgrad_tt' in n: fam = 'own MFMA weight-gradient GEMM'
+    elif 'tokens_gemm2' in n: fam = 'own MFMA GEMM with GELU epilogue (Mlp fc1 / fc2 data gradient)'
     elif 'tokens_gemm' in n or 'planes_gemm' in n or 'proj_gemm' in n: fam = 'own MFMA GEMM'
     elif 'tokens_kernel' in n or 'colsum' in n: fam = 'bias+GELU / column sums'
     elif 'dwconv' in n: fam = 'depthwise conv + SiLU'

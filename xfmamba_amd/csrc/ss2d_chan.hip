@@ -964,7 +964,8 @@ template <int HW, int N> static int chan_dispatch_ks(const ChanArgs &a, bool bwd
     return XFM_ELIMIT;
 }
 
-int chan1_bwd(const ChanArgs &a, int HW, hipStream_t s);          // ss2d_chan1.hip
+int chan1_run(const ChanArgs &a, int HW, bool bwd, hipStream_t s);      // ss2d_chan1.hip: d_state 1, second generation
+int chan1_covers(int H, int W, int N, int n_routes);
 
 static int chan_supported(int HW_h, int HW_w, int N, int NR, int D, int R) {
     if (HW_h != HW_w || D % 32 || R < 1 || R > 64) return 0;
@@ -1018,8 +1019,10 @@ static int chan_run(const xfm_ss2dc_params_t *p, bool bwd, void *stream) {
             }
         }
     }
-    if (N == 1 && bwd && p->n_routes == 4) {                       // second-generation backward (ss2d_chan1.hip)
-        const int rc1 = chan1_bwd(a, HW, s);
+    if (chan1_covers(p->H, p->W, N, p->n_routes) && p->c_mod == 0) {      // second generation (ss2d_chan1.hip), both directions
+        // (XFM_ELIMIT -- dt_rank beyond four k-steps, a ddts tensor of 4 GB -- is the same answer for both directions of a
+        //  shape, so the generations never mix: their checkpoints differ at 7 x 7)
+        const int rc1 = chan1_run(a, HW, bwd, s);
         if (rc1 != XFM_ELIMIT) return rc1;
     }
     if (N == 1) {
@@ -1045,6 +1048,7 @@ int xfm_ss2dc_supported(int H, int W, int dstate, int n_routes, int d_inner, int
 }
 int xfm_ss2dc_nsteps(int H, int W, int dstate) {
     if (H == 7 && W == 7 && dstate == 16) return 7;      // one row / column per step (second design, namespace deep)
+    if (xfm::chan1_covers(H, W, dstate, 4)) return H;    // ss2d_chan1.hip: one row / column per step at every size
     const int P = H <= 8 ? 2 * H : H;
     return (H * W + P - 1) / P;
 }

@@ -25,14 +25,62 @@
 namespace xfm {
 namespace chan1 {
 
+// Geometry of this file: ONE row / column per step at every map size (the first generation takes two at 7 x 7), i.e. P = HW,
+// NSTEP = HW, no ragged last step; the forward kernel of this file writes one state checkpoint per step.
+template <int HW> struct Geom1 {
+    static constexpr int L = HW * HW, P = HW, NSTEP = HW;
+    static constexpr int Lp = L + 2 - (L & 1);               // bf16 plane pitch: Lp / 2 odd -> conflict-free channel lanes
+    static constexpr int Lq = L | 1;                          // 32-bit plane pitch (odd)
+    static constexpr int MIDSTEP = (L & 1) ? ((L - 1) / 2) / P : -1;   // step whose two directions touch the same row (odd maps)
+    template <bool COL> static __host__ __device__ constexpr int off(int i) { return COL ? i * HW : i; }
+    template <bool COL> static __device__ __forceinline__ int base(int st) { return COL ? st : st * P; }
+};
+
+// per-lane roles of a pass (COL: routes COL and COL + 2) and the operand fragments of a step, as ChanLane / ChanFrags of
+// ss2d_chan.hpp for this geometry and d_state 1 (B and C of a position are k-slots 0 and 1 of ONE fragment)
+template <int HW, int KS, bool COL> struct Lane1 {
+    using G = Geom1<HW>;
+    int c, h, kb, ha, offA, wrow, jB;
+    const uint16_t *rowA, *zeros;
+    __device__ __forceinline__ Lane1(const ChanArgs &a, int sb, int c0, int lane) {
+        c = lane & 31;
+        h = kb = lane >> 5;
+        const int rho = lane & 31;
+        ha = (rho >> 2) & 1;
+        const int ia = min(4 * (rho >> 3) + (rho & 3), G::P - 1);
+        offA = G::template off<COL>(ia);
+        rowA = a.xdbl + (int64_t)sb * G::L * a.XC + ((COL ? 1 : 0) + 2 * ha) * a.C2p;
+        wrow = ((COL ? 1 : 0) + 2 * h) * a.D + c0 + c;
+        jB = a.Rp8 >> 3;
+        zeros = a.zeros;
+    }
+    __device__ __forceinline__ int natA(int st) const {
+        const int nf = G::template base<COL>(st) + offA;
+        return ha ? G::L - 1 - nf : nf;
+    }
+};
+template <int KS> struct Frags1 { cbf16x8_t f0[KS], f1[KS], fB; };
+template <int HW, int KS, bool COL>
+__device__ __forceinline__ void load_frags(const ChanArgs &a, const Lane1<HW, KS, COL> &ln, const int st, Frags1<KS> &f) {
+    const uint16_t *ra = ln.rowA + (int64_t)ln.natA(st) * a.XC;
+    // rows of half 0 feed k-slots [0, Kp) (forward route), rows of half 1 feed [Kp, 2 Kp); the other k-slots of a row come
+    // from a block of zeros (an address select: the loads go straight into the MFMA operands)
+    const uint16_t *p0 = ln.ha == 0 ? ra : ln.zeros, *p1 = ln.ha == 0 ? ln.zeros : ra;
+#pragma unroll
+    for (int m = 0; m < KS; ++m) f.f0[m] = chan_ld8(p0 + 16 * m + 8 * ln.kb);
+#pragma unroll
+    for (int m = 0; m < KS; ++m) f.f1[m] = chan_ld8(p1 + 16 * m + 8 * ln.kb);
+    f.fB = chan_ld8(ra + 8 * ln.jB);
+}
+
 // LDS of a workgroup: two planes of 32-bit words, [32 channels][Lq] each (Lq odd: the 32 channel lanes of a half hit 32 banks):
 //   XG  word (c, p) = x[c][p] (bf16, low half) | dy[c][p] (bf16, high half): ONE read hands a position's u and g
 //   DD  word (c, p) = du of the row pass (low half) | du of the column pass (high half): each wave read-modify-writes its
 //       own 16 bits, the epilogue reads both partial sums at once
 // -> one per-position byte offset addresses everything (x, dy, both dx planes)
 template <int HW> struct Lds {
-    using G = ChanGeom<HW, 1>;
-    static constexpr int Lq = G::L | 1;
+    using G = Geom1<HW>;
+    static constexpr int Lq = G::Lq;
     static constexpr int PW = 32 * Lq * 4;
     static constexpr int XG = 0, DD = PW, DSUM = 2 * PW;
     static constexpr int total = 2 * PW + 32 * 4;
@@ -76,7 +124,7 @@ __device__ __forceinline__ float colsum2(const cu32x4_t pb, const cu32x4_t pc, c
 // second adds (ss2d_chan.hpp chan_merge, walking the steps downwards), addressed by the step's per-position byte offsets
 template <int HW, int NV>
 __device__ __forceinline__ void merge16(char *pl, const int (&ad)[NV], const int h, const int st, const float (&v)[NV]) {
-    using G = ChanGeom<HW, 1>;
+    using G = Geom1<HW>;
     constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP;
     auto put = [&](const int i, const float x) {
         *reinterpret_cast<uint16_t *>(pl + ad[i]) = (uint16_t)(pack_bf16x2(x, 0.f) & 0xffffu);
@@ -143,11 +191,11 @@ __device__ __forceinline__ void stage_tile(uint32_t *xg, const uint16_t *xsrc, c
 
 template <int HW, int KS, bool COL>
 __device__ __forceinline__ void bwd_pass(const ChanArgs &a, const int sb, const int c0, char *sm) {
-    using G = ChanGeom<HW, 1>;
+    using G = Geom1<HW>;
     using LD = Lds<HW>;
     constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP;
     const int lane = threadIdx.x & 63;
-    const ChanLane<HW, 1, KS, COL> ln(a, sb, c0, lane);
+    const Lane1<HW, KS, COL> ln(a, sb, c0, lane);
     const int c = ln.c, h = ln.h, kb = ln.kb;
     cbf16x8_t wf[2 * KS];
 #pragma unroll
@@ -180,8 +228,8 @@ __device__ __forceinline__ void bwd_pass(const ChanArgs &a, const int sb, const 
     // consumed inside ONE iteration: requested after the adjoint sweep (when its registers are free), in flight under the
     // merge / channel sums, consumed by the dt_proj MFMAs of the NEXT step -- their accumulator is what crosses the back
     // edge, in registers -- and only then come the iteration's stores and atomics.
-    ChanFrags<1, KS> fr;
-    chan_load_frags<HW, 1, KS, COL>(a, ln, NSTEP - 1, fr);
+    Frags1<KS> fr;
+    load_frags<HW, KS, COL>(a, ln, NSTEP - 1, fr);
     float hin = NSTEP > 1 ? chk[(int64_t)(NSTEP - 2) * a.D] : 0.f;
     const cf32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto dt_mfma = [&]() {
@@ -266,15 +314,12 @@ __device__ __forceinline__ void bwd_pass(const ChanArgs &a, const int sb, const 
             //   scheduler hoists the loads to the top of the iteration where they hold 24 registers through the sweeps)
             //   (and the sweep's results are pinned HERE: the compiler otherwise sinks the half of the sweep that only the
             //   stores need -- the sigmoid factors, dd, the packs -- below the MFMAs at the bottom, 100 live registers long)
-            if constexpr (NV == 14)
-                asm volatile("" : "+v"(ddp[0]), "+v"(ddp[1]), "+v"(ddp[2]), "+v"(ddp[3]), "+v"(ddp[4]), "+v"(ddp[5]), "+v"(ddp[6]),
-                             "+v"(pB[0]), "+v"(pB[1]), "+v"(pC[0]), "+v"(pC[1]), "+v"(dAacc), "+v"(dbacc));
-            else
 #pragma unroll
-                for (int k = 0; k < (NV + 1) / 2; ++k) asm volatile("" : "+v"(ddp[k]), "+v"(pB[0]), "+v"(pB[1]), "+v"(pC[0]), "+v"(pC[1]), "+v"(dAacc));
+            for (int k2 = 0; k2 < (NV + 1) / 2; ++k2) asm volatile("" : "+v"(ddp[k2]));
+            asm volatile("" : "+v"(pB[0]), "+v"(pB[1]), "+v"(pC[0]), "+v"(pC[1]), "+v"(dAacc), "+v"(dbacc));
             int stn = st - 1;
             asm volatile("" : "+s"(stn) : "v"(E));
-            if (st > 0) chan_load_frags<HW, 1, KS, COL>(a, ln, stn, fr);
+            if (st > 0) load_frags<HW, KS, COL>(a, ln, stn, fr);
             if (st > 1) hin_next = chk[(int64_t)(stn - 1) * a.D];
             //   LDS / ALU work under the loads: merge du into the pass-private plane, channel sums of dB / dC
             if (!dbg_on(a, 32)) merge16<HW, NV>(sm + LD::DD + (COL ? 2 : 0), ad, h, st, duv);
@@ -311,8 +356,7 @@ __device__ __forceinline__ void bwd_pass(const ChanArgs &a, const int sb, const 
                     if (lane < 32 && 8 + jt < NV) atomicAdd(bc0 + (jdir ? -8 : 8), t1);
             }
         };
-        if (G::TAIL == P || st + 1 < NSTEP) body(std::integral_constant<int, P>{});
-        else body(std::integral_constant<int, G::TAIL>{});
+        body(std::integral_constant<int, P>{});
         hin = hin_next;
     }
     atomicAdd(a.dA + ln.wrow, dAacc);
@@ -323,7 +367,7 @@ __device__ __forceinline__ void bwd_pass(const ChanArgs &a, const int sb, const 
 // (128, 2): at most 256 registers -- three workgroups per CU put two waves on two of its SIMDs
 template <int HW, int KS>
 __global__ void __launch_bounds__(128, 2) bwd_kernel(const ChanArgs a) {
-    using G = ChanGeom<HW, 1>;
+    using G = Geom1<HW>;
     using LD = Lds<HW>;
     constexpr int L = G::L, Lq = LD::Lq;
     extern __shared__ float smem[];
@@ -423,19 +467,245 @@ template <int HW> static int dispatch_bwd(const ChanArgs &a, hipStream_t s) {
     return XFM_ELIMIT;
 }
 
+// =====================================================================================================================
+// forward (same decomposition; one state checkpoint per step = per row / column: what bwd_pass above reads)
+// =====================================================================================================================
+// LDS: x [32][Lp] bf16 | pass-private y planes with 4-byte position stride: YT = bf16 (14 x 14: LDS capacity decides) ONE
+// plane of words, rows' partial sums in the low half, columns' in the high half; YT = float: two fp32 planes
+template <int HW, typename YT> struct FwdLds {
+    using G = Geom1<HW>;
+    static constexpr bool F32 = sizeof(YT) == 4;
+    static constexpr int XS = 0;
+    static constexpr int YR = (32 * G::Lp * 2 + 15) / 16 * 16;
+    static constexpr int YC = F32 ? YR + 32 * G::Lq * 4 : YR + 2;
+    static constexpr int DSUM = YR + (F32 ? 2 : 1) * 32 * G::Lq * 4;
+    static constexpr int total = DSUM + 32 * 4;
+};
+
+template <typename YT> __device__ __forceinline__ float y_ld(const char *p);
+template <> __device__ __forceinline__ float y_ld<float>(const char *p) { return *reinterpret_cast<const float *>(p); }
+template <> __device__ __forceinline__ float y_ld<uint16_t>(const char *p) { return lds_bf16(p); }
+template <typename YT> __device__ __forceinline__ void y_st(char *p, float v);
+template <> __device__ __forceinline__ void y_st<float>(char *p, float v) { *reinterpret_cast<float *>(p) = v; }
+template <> __device__ __forceinline__ void y_st<uint16_t>(char *p, float v) {
+    *reinterpret_cast<uint16_t *>(p) = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+}
+
+template <int HW, int KS, bool COL, typename YT>
+__device__ __forceinline__ void fwd_pass(const ChanArgs &a, const int sb, const int c0, char *sm) {
+    using G = Geom1<HW>;
+    using LD = FwdLds<HW, YT>;
+    constexpr int L = G::L, P = G::P, NSTEP = G::NSTEP, Lp = G::Lp, Lq = G::Lq;
+    const int lane = threadIdx.x & 63;
+    const Lane1<HW, KS, COL> ln(a, sb, c0, lane);
+    const int c = ln.c, h = ln.h, kb = ln.kb;
+    cbf16x8_t wf[2 * KS];
+#pragma unroll
+    for (int m = 0; m < 2 * KS; ++m) {
+        const int rm = (COL ? 1 : 0) + 2 * (m / KS);
+        wf[m] = chan_ld8(chan_w_ptr(a, rm, c0 + c, 16 * (m % KS) + 8 * kb));
+    }
+    const float A2 = a.A[ln.wrow] * kLog2e, bvl = a.bias[ln.wrow] * kLog2e;
+    // byte offset of sequence element (step nb, index i) in the bf16 x plane: pb + s2 (nb + off(i)); the same element of a y
+    // plane (4-byte stride, pitch Lq) sits at twice that plus a per-lane constant
+    const int s2 = h ? -2 : 2;
+    const int pb = c * Lp * 2 + (h ? 2 * (L - 1) : 0);
+    const int kfix = 4 * c * (Lq - Lp);
+    char *const yplane = sm + (COL ? LD::YC : LD::YR);
+    float *chk = a.chk + (((int64_t)sb * 4 + (COL ? 1 : 0) + 2 * h) * NSTEP) * a.D + c0 + c;
+    Frags1<KS> fr;
+    load_frags<HW, KS, COL>(a, ln, 0, fr);
+    const cf32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto dt_mfma = [&]() {
+        cf32x16_t r = zero16;
+#pragma unroll
+        for (int m = 0; m < KS; ++m) r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f0[m], wf[m], r, 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < KS; ++m) r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f1[m], wf[KS + m], r, 0, 0, 0);
+        return r;
+    };
+    cf32x16_t acc = dt_mfma();
+    cbf16x8_t fbc = fr.fB;
+    asm volatile("" : "+v"(fbc));                  // (nothing loaded is in flight at the loop head: see bwd_pass)
+    float hh = 0.f;
+#pragma unroll 1
+    for (int st = 0; st < NSTEP; ++st) {
+        const cf32x16_t bB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbc, chan_indicator(kb, 0), zero16, 0, 0, 0);
+        const cf32x16_t bC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbc, chan_indicator(kb, 1), zero16, 0, 0, 0);
+        const int bs = pb + s2 * G::template base<COL>(st);
+        int ad[P];
+        float u[P], yv[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            ad[i] = bs + s2 * G::template off<COL>(i);
+            u[i] = lds_bf16(sm + LD::XS + ad[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const float t = fmaf(acc[i], kLog2e, bvl);
+            const float z = __builtin_amdgcn_exp2f(fminf(t, 126.f));
+            const float dl = 0.6931471805599453f * fmaxf(__builtin_amdgcn_logf(1.0f + z), t);
+            const float av = exp2_fast(dl * A2);
+            hh = fmaf(av, hh, dl * u[i] * bB[i]);
+            yv[i] = bC[i] * hh;
+        }
+        // next step's operands: requested after the sweep, consumed by the MFMAs that close the iteration (bwd_pass)
+        int stn = st + 1;
+        asm volatile("" : "+s"(stn) : "v"(hh));
+        if (st + 1 < NSTEP) load_frags<HW, KS, COL>(a, ln, stn, fr);
+        // merge into the pass-private plane: the first visitor of a position stores, the second adds
+        {
+            auto yad = [&](const int i) { return yplane + 2 * ad[i] + kfix; };
+            if (G::MIDSTEP >= 0 && st == G::MIDSTEP) {
+                constexpr int SM = (L - 1) / 2 - (G::MIDSTEP < 0 ? 0 : G::MIDSTEP) * P;
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+                    if (h ? i < SM : i <= SM) y_st<YT>(yad(i), yv[i]);
+                wave_sync();
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+                    if (!(h ? i < SM : i <= SM)) y_st<YT>(yad(i), y_ld<YT>(yad(i)) + yv[i]);
+            } else if (2 * st + 1 < NSTEP) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) y_st<YT>(yad(i), yv[i]);
+            } else {
+                float o[P];
+#pragma unroll
+                for (int i = 0; i < P; ++i) o[i] = y_ld<YT>(yad(i));
+#pragma unroll
+                for (int i = 0; i < P; ++i) y_st<YT>(yad(i), o[i] + yv[i]);
+            }
+        }
+        if (st + 1 < NSTEP) {
+            acc = dt_mfma();
+            fbc = fr.fB;
+        }
+        float hs = hh;
+        asm volatile("" : "+v"(hs) : "v"(fbc));        // the checkpoint store is issued behind the loads' completion
+        chk[(int64_t)st * a.D] = hs;
+    }
+}
+
+template <int HW, int KS, typename YT>
+__global__ void __launch_bounds__(128, 2) fwd_kernel(const ChanArgs a) {
+    using G = Geom1<HW>;
+    using LD = FwdLds<HW, YT>;
+    constexpr int L = G::L, Lp = G::Lp, Lq = G::Lq;
+    extern __shared__ float smem[];
+    char *sm = reinterpret_cast<char *>(smem);
+    uint16_t *xs = reinterpret_cast<uint16_t *>(sm + LD::XS);
+    float *dsum = reinterpret_cast<float *>(sm + LD::DSUM);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int sb, t;
+    chan_block_map(a.xmap, a.D / 32, sb, t);
+    const int c0 = 32 * t;
+    {   // stage x: all loads of a thread first
+        constexpr int NX = 32 * L / 8, KX = (NX + 127) / 128;
+        const uint16_t *xsrc = a.x + ((int64_t)sb * a.D + c0) * L;
+        cu32x4_t xr[KX];
+#pragma unroll
+        for (int k = 0; k < KX; ++k)
+            if ((int)threadIdx.x + 128 * k < NX) xr[k] = *reinterpret_cast<const cu32x4_t *>(xsrc + 8 * (threadIdx.x + 128 * k));
+#pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            const int v = threadIdx.x + 128 * k;
+            if (v < NX) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = 8 * v + 2 * q, c = e / L, l = e - c * L;
+                    if constexpr ((L & 1) == 0) {
+                        *reinterpret_cast<uint32_t *>(xs + c * Lp + l) = xr[k][q];
+                    } else {
+                        xs[c * Lp + l] = (uint16_t)(xr[k][q] & 0xffffu);
+                        const int e1 = e + 1, c1 = e1 / L, l1 = e1 - c1 * L;
+                        xs[c1 * Lp + l1] = (uint16_t)(xr[k][q] >> 16);
+                    }
+                }
+            }
+        }
+    }
+    if (threadIdx.x < 32) {
+        const int q = threadIdx.x;
+        dsum[q] = (a.Dp[c0 + q] + a.Dp[a.D + c0 + q]) + (a.Dp[2 * a.D + c0 + q] + a.Dp[3 * a.D + c0 + q]);
+    }
+    __syncthreads();
+    if (wave == 0) fwd_pass<HW, KS, false, YT>(a, sb, c0, sm);
+    else fwd_pass<HW, KS, true, YT>(a, sb, c0, sm);
+    __syncthreads();
+    // y = rows + columns + (sum_k D_k) x: the contiguous run of 32 L floats of this (sample, channel tile)
+    float *dst = a.y + ((int64_t)sb * a.D + c0) * L;
+    const char *yr = sm + LD::YR, *yc = sm + LD::YC;
+    auto yval = [&](const int c, const int l) {
+        const int o = (c * Lq + l) * 4;
+        return fmaf(dsum[c], bf16_bits_to_float(xs[c * Lp + l]), y_ld<YT>(yr + o) + y_ld<YT>(yc + o));
+    };
+    if constexpr (L % 4 == 0) {
+        for (int v = threadIdx.x; v < 32 * L / 4; v += 128) {
+            const int e = 4 * v, c = e / L, l = e - c * L;
+            *reinterpret_cast<float4 *>(dst + e) = make_float4(yval(c, l), yval(c, l + 1), yval(c, l + 2), yval(c, l + 3));
+        }
+    } else {
+        for (int e = threadIdx.x; e < 32 * L; e += 128) {
+            const int c = e / L, l = e - c * L;
+            dst[e] = yval(c, l);
+        }
+    }
+}
+
+template <int HW, int KS> static int launch_fwd(const ChanArgs &a, hipStream_t s) {
+    // fp32 pass-private planes while the LDS allows four workgroups per CU, bf16 beyond (14 x 14): as the first generation
+    using YT = typename std::conditional<(HW > 12), uint16_t, float>::type;
+    const size_t lds = FwdLds<HW, YT>::total;
+    const void *fn = (const void *)fwd_kernel<HW, KS, YT>;
+    static bool opted = false;
+    if (lds > 64 * 1024 && !opted) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
+        opted = true;
+    }
+    ChanArgs args = a;
+    args.ct = 0;
+    void *kargs[] = {&args};
+    const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(a.Bt * (a.D / 32))), dim3(128), kargs, lds, s);
+    if (e != hipSuccess) {
+        set_last_hip_error(e);
+        return XFM_ELAUNCH;
+    }
+    return check_launch();
+}
+
+template <int HW> static int dispatch_fwd(const ChanArgs &a, hipStream_t s) {
+    switch (a.Kp / 16) {
+        case 1: return launch_fwd<HW, 1>(a, s);
+        case 2: return launch_fwd<HW, 2>(a, s);
+        case 3: return launch_fwd<HW, 3>(a, s);
+        case 4: return launch_fwd<HW, 4>(a, s);
+    }
+    return XFM_ELIMIT;
+}
+
 }  // namespace chan1
 
-// d_state 1, four routes, no borrowed C operand: the backward of this file.  XFM_ELIMIT: not covered (the caller falls back
-// to ss2d_chan.hip).  XFM_CHAN1=0 switches it off (A/B runs).
-int chan1_bwd(const ChanArgs &a, int HW, hipStream_t s) {
+// d_state 1, four routes, no borrowed C operand: the kernels of this file (forward AND backward: they share the checkpoint
+// layout -- one state per row / column -- so a shape is served by both or by neither).  XFM_ELIMIT: not covered (the caller
+// falls back to ss2d_chan.hip).  XFM_CHAN1=0 switches the file off (A/B runs).
+static bool chan1_on() {
     static const bool on = [] {
         const char *e = getenv("XFM_CHAN1");
         return !(e && e[0] == '0');
     }();
-    if (!on || a.c_mod > 0) return XFM_ELIMIT;
+    return on;
+}
+int chan1_covers(int H, int W, int N, int n_routes) {
+    return chan1_on() && N == 1 && n_routes == 4 && H == W && (H == 14 || H == 12 || H == 7);
+}
+int chan1_run(const ChanArgs &a, int HW, bool bwd, hipStream_t s) {
+    if (!chan1_on() || a.c_mod > 0) return XFM_ELIMIT;
     if ((int64_t)a.Bt * 4 * HW * HW * a.D * 2 >= ((int64_t)1 << 32)) return XFM_ELIMIT;     // 32-bit ddts offsets
-    if (HW == 14) return chan1::dispatch_bwd<14>(a, s);
-    if (HW == 12) return chan1::dispatch_bwd<12>(a, s);
+    if (HW == 14) return bwd ? chan1::dispatch_bwd<14>(a, s) : chan1::dispatch_fwd<14>(a, s);
+    // (12 x 12: the first-generation forward is faster -- 38.8 vs 42.9 us at XFMamba-B's stage 3 -- and writes the same
+    //  checkpoints: one row / column per step at that size in both generations)
+    if (HW == 12) return bwd ? chan1::dispatch_bwd<12>(a, s) : XFM_ELIMIT;
+    if (HW == 7) return bwd ? chan1::dispatch_bwd<7>(a, s) : chan1::dispatch_fwd<7>(a, s);
     return XFM_ELIMIT;
 }
 
