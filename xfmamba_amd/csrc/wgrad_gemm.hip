@@ -52,7 +52,19 @@ struct WgradArgs {
     // staggered ends put most of that traffic under the MFMA phase of the slices still running
     int nslices;
     float stagger;
+    // XCD-aware placement: the grid is rounded up to a multiple of 8 and workgroup b (dispatched to XCD b % 8) takes the
+    // virtual index (b % 8) * grid / 8 + b / 8, so an XCD runs CONSECUTIVE virtual indices -- tiles of the same token slice,
+    // whose operand rows then meet in that XCD's L2 instead of being fetched once per tile (wgs = workgroups with work)
+    int wgs, xcd_map;
+    long long *prof;                    // debugging: 4 timestamps per workgroup (xfm_dbg_wgrad_prof), or null
 };
+
+static long long *g_wgrad_prof = nullptr;
+
+__device__ __forceinline__ int wg_virtual_id(const WgradArgs &a) {
+    const int b = blockIdx.x;
+    return a.xcd_map ? (b & 7) * (int)(gridDim.x >> 3) + (b >> 3) : b;
+}
 
 // first step of slice i (i = nslices: one past the last step)
 __device__ __forceinline__ int wg_slice_start(const WgradArgs &a, const int i) {
@@ -162,7 +174,9 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
     auto Bt = [&](const int buf) { return wg_lds + 2 * ABYTES + buf * BBYTES; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbm = (a.M + kWgTile - 1) / kWgTile, nbn = (a.N + kWgTile - 1) / kWgTile;
-    const int per_group = gridDim.x / a.groups, grp = blockIdx.x / per_group, bid = blockIdx.x - grp * per_group;
+    const int vid = wg_virtual_id(a);
+    if (vid >= a.wgs) return;
+    const int per_group = a.wgs / a.groups, grp = vid / per_group, bid = vid - grp * per_group;
     const int tile_id = bid % (nbm * nbn), slice = bid / (nbm * nbn);
     const int m0 = (tile_id / nbn) * kWgTile, n0 = (tile_id % nbn) * kWgTile;
     const int st0 = wg_slice_start(a, slice), st1 = wg_slice_start(a, slice + 1);
@@ -268,11 +282,21 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
 // columns of the tile are never written back.
 constexpr int kGlStages = 4, kGlBK = 64, kGlTile = kGlBK * 256;     // bytes of one operand stage
 
+// transposed fragment read at a compile-time byte offset from a per-lane address
+template <int OFF> __device__ __forceinline__ void wg_tr_read(wg_bf16x4_t &d, const uint32_t ad) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(OFF) : "memory");
+}
+
+template <bool DBG>
 __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a) {
     extern __shared__ __align__(16) uint8_t wg_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dbg = DBG ? a.dbg : 0;                       // timing switches only in the debugging instance
     const int nbm = (a.M + kWgTile - 1) / kWgTile, nbn = (a.N + kWgTile - 1) / kWgTile;
-    const int tile_id = blockIdx.x % (nbm * nbn), slice = blockIdx.x / (nbm * nbn);
+    const int vid = wg_virtual_id(a);
+    if (vid >= a.wgs) return;
+    if (DBG && a.prof && tid == 0) a.prof[4 * blockIdx.x] = wall_clock64();
+    const int tile_id = vid % (nbm * nbn), slice = vid / (nbm * nbn);
     const int m0 = (tile_id / nbn) * kWgTile, n0 = (tile_id % nbn) * kWgTile;
     const int st0 = wg_slice_start(a, slice), st1 = wg_slice_start(a, slice + 1);
     if (st0 >= st1) return;
@@ -284,75 +308,126 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-    auto At = [&](const int buf) { return wg_lds + buf * 2 * kGlTile; };
-    auto Bt = [&](const int buf) { return wg_lds + buf * 2 * kGlTile + kGlTile; };
+    // stage buffer b: A tile at 2 b kGlTile, B tile kGlTile behind it
     // this lane's share of a stage: instruction i (0..3) of this wave fills rows 4 (4 wave + i) .. + 3 of the tile
-    int rowv[4];
     int64_t offa[4], offb[4];                             // element offsets inside a 64-token stage of A / B
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 4 * (4 * wave + i) + (lane >> 4);
         const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        rowv[i] = row;
         const int ca = min(m0 + 8 * ch, a.M - 8), cb = min(n0 + 8 * ch, a.N - 8);      // clamped: see above
         offa[i] = (int64_t)row * a.M + ca;
         offb[i] = (int64_t)row * a.N + cb;
     }
-    auto issue = [&](const int st) {
-        const int buf = (st - st0) % kGlStages;
-        const int64_t t0 = (int64_t)st * kGlBK;           // (batch == 1: the token axis is one run)
-        const uint16_t *pa = a.a + t0 * a.M, *pb = a.b + t0 * a.N;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa + offa[i]),
-                                             (__attribute__((address_space(3))) void *)(At(buf) + (4 * wave + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb + offb[i]),
-                                             (__attribute__((address_space(3))) void *)(Bt(buf) + (4 * wave + i) * 1024), 16, 0, 0);
-        }
+    // The loads of a stage are issued in FOUR parts, one per k16-step of the stage being multiplied: a 1 KB LDS-direct load
+    // keeps the CU's address path busy for 16 cycles (64 B / clk) -- the 32 of a stage (32 KB) for as long as the stage's 16
+    // MFMAs per wave take -- and a wave that issues its eight loads back to back sits in the issue queue for that long
+    // before its first MFMA (measured: 600 of 2400 cycles per stage).
+    // (scalar stage bases are carried by the loop: derived from the stage index at every use they cost ~25 scalar
+    //  instructions per part, and with one wave per SIMD every instruction of any kind takes an issue slot of ~4 cycles:
+    //  an MFMA covers 8 of them)
+    auto issue_part = [&](const uint16_t *pa, const uint16_t *pb, const int buf, const int i) {
+        if (dbg & 4) return;
+        uint8_t *dst = wg_lds + buf * 2 * kGlTile + (4 * wave + i) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa + offa[i]),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb + offb[i]),
+                                         (__attribute__((address_space(3))) void *)(dst + kGlTile), 16, 0, 0);
     };
-    (void)rowv;
+    const int64_t sa = (int64_t)kGlBK * a.M, sb = (int64_t)kGlBK * a.N;       // elements per stage (batch == 1: one token run)
+    const uint16_t *pan = a.a + (int64_t)st0 * sa, *pbn = a.b + (int64_t)st0 * sb;
+    int bufn = 0;                                         // pan / pbn / bufn: the next stage to request
 #pragma unroll
     for (int q = 0; q < kGlStages - 1; ++q)
-        if (st0 + q < st1) issue(st0 + q);
+        if (st0 + q < st1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_part(pan, pbn, bufn, i);
+            pan += sa; pbn += sb; bufn = (bufn + 1) & (kGlStages - 1);
+        }
+    if (DBG && a.prof && tid == 0) a.prof[4 * blockIdx.x + 1] = wall_clock64();
+    // fragment addresses of k16-step 0 in stage buffer 0 (wg_tok_off: the XOR term does not depend on the k16-step, so
+    // step s is a constant 4096 s bytes further and the B tile kGlTile: immediate offsets of the reads)
+    uint32_t fr[4][2];                                    // [0, 1: A channel tiles, 2, 3: B channel tiles][lo, hi]
+    {
+        const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)wg_lds;
+        const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+        const int r0 = 8 * (g >> 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ct = (t < 2 ? wm : wn) * 64 + (t & 1) * 32;
+            const int c0 = (ct + 16 * (g & 1)) >> 3;
+            fr[t][0] = base + wg_tok_off(r0 + q, c0 + (p >> 1)) + 8 * (p & 1);
+            fr[t][1] = base + wg_tok_off(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1);
+        }
+    }
+    static_assert((kGlStages & (kGlStages - 1)) == 0, "stage ring is a power of two");
+    int buf = 0;
     for (int st = st0; st < st1; ++st) {
-        const int buf = (st - st0) % kGlStages;
         // stage st has landed when at most the 8 loads of each later stage in flight remain outstanding
         const int later = min(st1 - 1 - st, kGlStages - 2);
         if (later >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                  // everyone's share of stage st is in LDS; everyone is done with st - 1
-        if (st + kGlStages - 1 < st1) issue(st + kGlStages - 1);      // refills the buffer stage st - 1 used
-        wg_bf16x4_t lo[2][4], hi[2][4];
-        auto frags = [&](const int ring, const int s) {
+        // everyone's share of stage st is in LDS; everyone is done with st - 1.  A BARE barrier: __syncthreads() carries a
+        // workgroup fence, and for LDS-direct loads the compiler turns that into s_waitcnt vmcnt(0) -- every stage would wait
+        // for ALL loads in flight, i.e. run with no prefetch at all (the fragment reads of st - 1 were drained by the last
+        // wg_wait<0>, the loads of st by the counted wait above)
+        __builtin_amdgcn_s_barrier();
+        const bool more = st + kGlStages - 1 < st1;       // stage st + 3 refills the buffer stage st - 1 used
+        if (dbg & 2) {
+            if (more)
+                for (int i = 0; i < 4; ++i) issue_part(pan, pbn, bufn, i);
+        } else {
+            uint32_t ad[4][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                WgOperand<false, 64>::frag(At(buf), wm * 64 + i * 32, s, lane, lo[ring][i], hi[ring][i]);
-                WgOperand<false, 64>::frag(Bt(buf), wn * 64 + i * 32, s, lane, lo[ring][2 + i], hi[ring][2 + i]);
+            for (int t = 0; t < 4; ++t) {
+                ad[t][0] = fr[t][0] + buf * 2 * kGlTile;
+                ad[t][1] = fr[t][1] + buf * 2 * kGlTile;
             }
-        };
-        frags(0, 0);
+            wg_bf16x4_t lo[2][4], hi[2][4];
+            auto frags = [&](const int ring, auto sc) {
+                constexpr int S = decltype(sc)::value;
+                wg_tr_read<4096 * S>(lo[ring][0], ad[0][0]);
+                wg_tr_read<4096 * S>(hi[ring][0], ad[0][1]);
+                wg_tr_read<4096 * S + kGlTile>(lo[ring][2], ad[2][0]);
+                wg_tr_read<4096 * S + kGlTile>(hi[ring][2], ad[2][1]);
+                wg_tr_read<4096 * S>(lo[ring][1], ad[1][0]);
+                wg_tr_read<4096 * S>(hi[ring][1], ad[1][1]);
+                wg_tr_read<4096 * S + kGlTile>(lo[ring][3], ad[3][0]);
+                wg_tr_read<4096 * S + kGlTile>(hi[ring][3], ad[3][1]);
+            };
+            auto k16 = [&](auto sc) {
+                constexpr int S = decltype(sc)::value, r = S & 1;
+                if constexpr (S + 1 < kGlBK / 16) {
+                    frags(r ^ 1, std::integral_constant<int, S + 1>{});
+                    if (more) issue_part(pan, pbn, bufn, S);
+                    wg_wait<8>(lo[r], hi[r]);
+                } else {
+                    if (more) issue_part(pan, pbn, bufn, S);
+                    wg_wait<0>(lo[r], hi[r]);
+                }
+                wg_bf16x8_t af[2], bf[2];
 #pragma unroll
-        for (int s = 0; s < kGlBK / 16; ++s) {
-            const int r = s & 1;
-            if (s + 1 < kGlBK / 16) {
-                frags(r ^ 1, s + 1);
-                wg_wait<8>(lo[r], hi[r]);
-            } else {
-                wg_wait<0>(lo[r], hi[r]);
-            }
-            wg_bf16x8_t af[2], bf[2];
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = __builtin_shufflevector(lo[r][i], hi[r][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                    bf[i] = __builtin_shufflevector(lo[r][2 + i], hi[r][2 + i], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = __builtin_shufflevector(lo[r][i], hi[r][i], 0, 1, 2, 3, 4, 5, 6, 7);
-                bf[i] = __builtin_shufflevector(lo[r][2 + i], hi[r][2 + i], 0, 1, 2, 3, 4, 5, 6, 7);
-            }
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            };
+            frags(0, std::integral_constant<int, 0>{});
+            k16(std::integral_constant<int, 0>{});
+            k16(std::integral_constant<int, 1>{});
+            k16(std::integral_constant<int, 2>{});
+            k16(std::integral_constant<int, 3>{});
         }
+        pan += sa; pbn += sb;
+        bufn = (bufn + 1) & (kGlStages - 1);
+        buf = (buf + 1) & (kGlStages - 1);
     }
+    if (DBG && a.prof && tid == 0) a.prof[4 * blockIdx.x + 2] = wall_clock64();
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -362,13 +437,22 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                if (m < a.M && n < a.N) atomicAdd(a.dw + (int64_t)m * a.N + n, acc[i][j][v]);
+                if (m < a.M && n < a.N && !(dbg & 1)) atomicAdd(a.dw + (int64_t)m * a.N + n, acc[i][j][v]);
             }
         }
+    if (DBG && a.prof && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.prof[4 * blockIdx.x + 3] = wall_clock64();
+    }
+}
+
+static bool wg_xcd_map() {
+    static const bool on = [] { const char *e = getenv("XFM_WGRAD_XCD"); return !e || atoi(e) != 0; }();
+    return on;
 }
 
 template <bool APL, bool BPL, int BK>
-static int wgrad_launch(const WgradArgs &a, int nslices, hipStream_t s) {
+static int wgrad_launch(WgradArgs a, int nslices, hipStream_t s) {
     constexpr int kWgTokBytes = BK * 256;
     constexpr int ABYTES = APL ? kWgPlaneBytes : kWgTokBytes, BBYTES = BPL ? kWgPlaneBytes : kWgTokBytes;
     const size_t lds = 2 * (ABYTES + BBYTES);
@@ -380,7 +464,10 @@ static int wgrad_launch(const WgradArgs &a, int nslices, hipStream_t s) {
             attr = true;
         }
     }
-    hipLaunchKernelGGL((wgrad_kernel<APL, BPL, BK>), dim3((unsigned)(nbm * nbn * nslices)), dim3(256), lds, s, a);
+    a.wgs = nbm * nbn * nslices;
+    a.xcd_map = wg_xcd_map() ? 1 : 0;
+    const int grid = a.xcd_map ? (a.wgs + 7) / 8 * 8 : a.wgs;
+    hipLaunchKernelGGL((wgrad_kernel<APL, BPL, BK>), dim3((unsigned)grid), dim3(256), lds, s, a);
     return check_launch();
 }
 
@@ -413,6 +500,10 @@ int wgrad_grouped(const void *a, const void *b, float *dw, int M, int N, int bat
 
 extern "C" {
 
+/* debugging (tools/wgradprof.py): device buffer of 4 x int64 per workgroup that the LDS-direct kernel stamps with the 100 MHz
+ * wall clock at entry, after its prologue loads, after its last stage and after its adds have drained; null switches it off */
+void xfm_dbg_wgrad_prof(void *buf) { xfm::g_wgrad_prof = (long long *)buf; }
+
 int xfm_wgrad_supported(int M, int N, int L, int a_planes, int b_planes) {
     if (M <= 0 || N <= 0 || L <= 0) return 0;
     if (!a_planes && M % 8 != 0) return 0;                  // token-major rows are read in 16-byte vectors
@@ -439,6 +530,7 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     const int BK = glds ? 64 : ((!a_planes && !b_planes && L >= 2048) ? 128 : 64);
     w.steps_per_sample = (L + BK - 1) / BK;
     if (const char *env = getenv("XFM_WGRAD_DBG")) w.dbg = atoi(env);
+    w.prof = g_wgrad_prof;
     w.total_steps = batch * w.steps_per_sample;
     // Slices of the token axis.  Every workgroup ends with 64 KB of fp32 atomic adds, and the chip retires those at
     // ~1.3 TB/s against ~5+ TB/s of operand streaming: the adds of ALL workgroups (tiles * slices * 64 KB) are the floor of
@@ -450,17 +542,25 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     w.steps_per_slice = (w.total_steps + nsl - 1) / nsl;
     nsl = (w.total_steps + w.steps_per_slice - 1) / w.steps_per_slice;
     w.nslices = nsl;
-    static const float stag = [] { const char *e = getenv("XFM_WGRAD_STAGGER"); return e ? (float)atof(e) : 0.25f; }();
-    w.stagger = (glds && nsl >= 4) ? stag : 0.f;      // (measured: 5 - 8 % on the LDS-direct kernel, nothing on the register-staged ones)
+    // (measured after the stage loop went from 40 to 28 us: many tiles x few slices -- 384 x 1536 over 12544 tokens -- 30.3 /
+    //  28.5 / 26.3 us at stagger 0 / 0.25 / 0.5; few tiles x many slices -- 96 x 384 over 200704 -- 37.0 / 36.0 / 40.4 at 0 /
+    //  0.15 / 0.5; nothing on the register-staged kernels)
+    static const float stag = [] { const char *e = getenv("XFM_WGRAD_STAGGER"); return e ? (float)atof(e) : -1.f; }();
+    w.stagger = (glds && nsl >= 4) ? (stag >= 0.f ? stag : (tiles >= 16 ? 0.5f : 0.2f)) : 0.f;
     hipStream_t s = (hipStream_t)stream;
     if (glds) {
         const size_t lds = (size_t)kGlStages * 2 * kGlTile;
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void *)wgrad_tt_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)wgrad_tt_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)wgrad_tt_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        hipLaunchKernelGGL(wgrad_tt_glds_kernel, dim3((unsigned)(tiles * nsl)), dim3(256), lds, s, w);
+        w.wgs = tiles * nsl;
+        w.xcd_map = wg_xcd_map() ? 1 : 0;
+        const int grid = w.xcd_map ? (w.wgs + 7) / 8 * 8 : w.wgs;
+        if (w.dbg || w.prof) hipLaunchKernelGGL(wgrad_tt_glds_kernel<true>, dim3((unsigned)grid), dim3(256), lds, s, w);
+        else hipLaunchKernelGGL(wgrad_tt_glds_kernel<false>, dim3((unsigned)grid), dim3(256), lds, s, w);
         return check_launch();
     }
     if (a_planes) return b_planes ? wgrad_launch<true, true, 64>(w, nsl, s) : wgrad_launch<true, false, 64>(w, nsl, s);
