@@ -15,28 +15,29 @@ def stages(st):
     for i in range(40):
         if st[i, 0, 0] == 0:
             break
-        print(f"  {i:2d} " + "  ".join("[" + " ".join(f"{int(st[i, w, k] - base):6d}" for k in range(4)) + "]" for w in range(4)))
+        print(f"  {i:2d} " + "  ".join("[" + " ".join(f"{int(st[i, w, k] - base):6d}" for k in range(5) if st[i, w, k]) + "]" for w in range(4)))
 
 
 def main():
     from xfmamba_amd import _lib
     from xfmamba_amd.proj import wgrad_mfma
     M, N, L = [int(v) for v in sys.argv[1:4]]
+    Bt, ap, bp = ([int(v) for v in sys.argv[4:7]] + [1, 0, 0])[:3] if len(sys.argv) > 4 else (1, 0, 0)
     lib = _lib.lib()
     lib.xfm_dbg_wgrad_prof.argtypes = [ctypes.c_void_p]
     lib.xfm_dbg_wgrad_prof.restype = None
     g = torch.Generator().manual_seed(0)
-    a = torch.randn(1, L, M, generator=g).bfloat16().cuda()
-    b = torch.randn(1, L, N, generator=g).bfloat16().cuda()
+    a = torch.randn((Bt, M, L) if ap else (Bt, L, M), generator=g).bfloat16().cuda()
+    b = torch.randn((Bt, N, L) if bp else (Bt, L, N), generator=g).bfloat16().cuda()
     out = torch.zeros(M, N, device="cuda")
     for _ in range(3):
-        wgrad_mfma(a, False, b, False, out=out)
-    prof = torch.zeros(4 * 512 + 40 * 16, dtype=torch.int64, device="cuda")
+        wgrad_mfma(a, bool(ap), b, bool(bp), out=out)
+    prof = torch.zeros(4 * 512 + 40 * 20, dtype=torch.int64, device="cuda")
     lib.xfm_dbg_wgrad_prof(prof.data_ptr())
-    wgrad_mfma(a, False, b, False, out=out)
+    wgrad_mfma(a, bool(ap), b, bool(bp), out=out)
     torch.cuda.synchronize()
     lib.xfm_dbg_wgrad_prof(None)
-    st = prof[2048:].view(40, 4, 4).cpu()
+    st = prof[2048:].view(40, 4, 5).cpu()
     p = prof[:2048].view(512, 4).cpu()
     p = p[p[:, 0] > 0]
     t0 = p[:, 0].min()

@@ -77,6 +77,21 @@ __device__ __forceinline__ int wg_slice_start(const WgradArgs &a, const int i) {
 // byte offset of 16-byte chunk ch (0..15) of token row `row` in a token-major tile (image (b) of the guide)
 __device__ __forceinline__ int wg_tok_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
+// Global loads the compiler does not see (saddr form: uniform 64-bit base + 32-bit byte offset per lane).  Its own counter
+// bookkeeping put a full s_waitcnt vmcnt(0) between the request for step st + 2 and the use of step st + 1 -- the operand
+// pipeline ran one step deep and every step exposed a whole memory round trip (1500 of 3300 cycles).  With these the waits
+// are explicit (wg_vm_wait) and counted: vector-memory operations return in order, each step requests the same number.
+__device__ __forceinline__ void wg_gload(wg_u32x4_t &d, const uint16_t *sbase, const uint32_t byte_off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(byte_off), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void wg_gload(wg_u32x2_t &d, const uint16_t *sbase, const uint32_t byte_off) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(byte_off), "s"(sbase) : "memory");
+}
+template <int N> __device__ __forceinline__ void wg_vm_wait() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <bool PL, int BK>
 struct WgOperand {
     static_assert(!PL || BK == 64, "plane-major tiles are 64 tokens");
@@ -87,15 +102,59 @@ struct WgOperand {
     wg_u32x4_t tv[PL ? 1 : NTV];
     wg_u32x2_t pv[PL ? 8 : 1];
 
-    __device__ __forceinline__ void load(const uint16_t *base, const int64_t bs, const int C, const int L, const int c0,
-                                         const int sample, const int l0, const int tid, const int ld) {
+    // byte offset of vector v from (sample base + first token of the step) -- lane constants, set once (channels clamped)
+    uint32_t boff[PL ? 8 : NTV];
+    __device__ __forceinline__ void init(const int C, const int L, const int c0, const int tid, const int ld) {
         if constexpr (!PL) {
 #pragma unroll
             for (int v = 0; v < NTV; ++v) {
                 const int idx = tid + 256 * v, row = idx >> 4, ch = idx & 15;
-                const int l = l0 + row, c = c0 + 8 * ch;
-                tv[v] = wg_u32x4_t{0, 0, 0, 0};
-                if (l < L && c < C) tv[v] = *reinterpret_cast<const wg_u32x4_t *>(base + sample * bs + (int64_t)l * ld + c);
+                boff[v] = 2u * (uint32_t)(row * ld + min(c0 + 8 * ch, C - 8));
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int idx = tid + 256 * v, chn = idx >> 4;
+                boff[v] = 2u * (uint32_t)(min(c0 + chn, C - 1) * L + 4 * (idx & 15));
+            }
+        }
+    }
+    // a step that lies inside its sample whole: `sl` = sample base + first token of the step (uniform)
+    __device__ __forceinline__ void load_full(const uint16_t *sl) {
+        if constexpr (!PL) {
+#pragma unroll
+            for (int v = 0; v < NTV; ++v) wg_gload(tv[v], sl, boff[v]);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) wg_gload(pv[v], sl, boff[v]);
+        }
+    }
+    // RAG: plane-major rows whose length is not a multiple of 4 (7 x 7 maps) -- element loads under per-element bounds.
+    // Otherwise the loads are UNCONDITIONAL at clamped addresses and rows past the end of the sample are zeroed by selects
+    // on the way to LDS (store(): a select next to the load would wait for it):
+    // with zero-fill-then-load-under-a-branch the compiler's counter bookkeeping gave up at the joins and put
+    // s_waitcnt vmcnt(0) in front of every step's loads -- the step in flight was drained before the next was requested
+    // (1500 of 3300 cycles per step).  Clamped channels (tiles past M / N) fill tile rows that are never written back.
+    template <bool RAG>
+    __device__ __forceinline__ void load(const uint16_t *base, const int64_t bs, const int C, const int L, const int c0,
+                                         const int sample, const int l0, const int tid, const int ld) {
+        const uint16_t *sb = base + sample * bs;
+        if constexpr (!PL) {
+#pragma unroll
+            for (int v = 0; v < NTV; ++v) {
+                const int idx = tid + 256 * v, row = idx >> 4, ch = idx & 15;
+                const int l = l0 + row, c = min(c0 + 8 * ch, C - 8);
+                const uint32_t off = (uint32_t)(min(l, L - 1) * ld + c);
+                if constexpr (RAG) tv[v] = *reinterpret_cast<const wg_u32x4_t *>(sb + off);      // (compiler-counted: see RAG)
+                else wg_gload(tv[v], sb, 2 * off);                         // (rows past L: zeroed in store())
+            }
+        } else if constexpr (!RAG) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int idx = tid + 256 * v, chn = idx >> 4, l = l0 + 4 * (idx & 15);
+                const int c = min(c0 + chn, C - 1);
+                const uint32_t off = (uint32_t)(c * L + min(l, L - 4));
+                wg_gload(pv[v], sb, 2 * off);                              // (L % 4 == 0: 4 tokens in or out whole)
             }
         } else {
 #pragma unroll
@@ -104,29 +163,101 @@ struct WgOperand {
                 const int c = c0 + chn;
                 pv[v] = wg_u32x2_t{0, 0};
                 if (c < C && l < L) {
-                    const uint16_t *p = base + sample * bs + (int64_t)c * L + l;
-                    if ((L & 3) == 0) {                                 // a group of 4 tokens is in or out whole, 8-byte aligned
-                        pv[v] = *reinterpret_cast<const wg_u32x2_t *>(p);
-                    } else {                                            // ragged rows (7 x 7 maps: 49 tokens): 2-byte loads
-                        const uint32_t e0 = p[0], e1 = l + 1 < L ? p[1] : 0u, e2 = l + 2 < L ? p[2] : 0u, e3 = l + 3 < L ? p[3] : 0u;
-                        pv[v] = wg_u32x2_t{e0 | (e1 << 16), e2 | (e3 << 16)};
-                    }
+                    const uint16_t *p = sb + (int64_t)c * L + l;
+                    const uint32_t e0 = p[0], e1 = l + 1 < L ? p[1] : 0u, e2 = l + 2 < L ? p[2] : 0u, e3 = l + 3 < L ? p[3] : 0u;
+                    pv[v] = wg_u32x2_t{e0 | (e1 << 16), e2 | (e3 << 16)};
                 }
             }
         }
     }
-    __device__ __forceinline__ void store(uint8_t *tile, const int tid) const {
+    // ---- the same in PARTS, one per k16-step of a step (token-major: one vector, plane-major: two): requests, LDS writes and
+    // MFMAs of a step interleave, so that the address path (64 B / clk), the LDS and the matrix pipe work at the same time
+    static constexpr int NS = BK / 16;                    // parts
+    static constexpr int VP = (PL ? 8 : NTV) / NS;        // vectors per part
+    uint32_t soff;                                        // LDS byte offset of vector 0 inside a tile (vector v: + SSTEP v)
+    static constexpr int SSTEP = PL ? 16 * kWgPlanePitch : 4096;
+    __device__ __forceinline__ void init_store(const int tid) {
+        soff = PL ? (uint32_t)((tid >> 4) * kWgPlanePitch + 8 * (tid & 15)) : (uint32_t)wg_tok_off(tid >> 4, tid & 15);
+    }
+    template <int PART> __device__ __forceinline__ void load_full_part(const uint16_t *sl) {
+#pragma unroll
+        for (int j = 0; j < VP; ++j) {
+            constexpr int v0 = PART * VP;
+            if constexpr (!PL) wg_gload(tv[v0 + j], sl, boff[v0 + j]);
+            else wg_gload(pv[v0 + j], sl, boff[v0 + j]);
+        }
+    }
+    // a step that runs past the end of its sample: token rows clamped to the last one (zeroed on the way to LDS)
+    template <int PART>
+    __device__ __forceinline__ void load_clamped_part(const uint16_t *sb, const int C, const int L, const int c0, const int l0,
+                                                      const int tid, const int ld) {
+#pragma unroll
+        for (int j = 0; j < VP; ++j) {
+            const int v = PART * VP + j, idx = tid + 256 * v;
+            if constexpr (!PL) {
+                const int row = idx >> 4, ch = idx & 15;
+                wg_gload(tv[v], sb, 2u * (uint32_t)(min(l0 + row, L - 1) * ld + min(c0 + 8 * ch, C - 8)));
+            } else {
+                const int chn = idx >> 4, l = l0 + 4 * (idx & 15);
+                wg_gload(pv[v], sb, 2u * (uint32_t)(min(c0 + chn, C - 1) * L + min(l, L - 4)));
+            }
+        }
+    }
+    template <int PART> __device__ __forceinline__ void landed_part() {
+#pragma unroll
+        for (int j = 0; j < VP; ++j) {
+            if constexpr (!PL) asm volatile("" : "+v"(tv[PART * VP + j]));
+            else asm volatile("" : "+v"(pv[PART * VP + j]));
+        }
+    }
+    // registers -> LDS (asm: the position of the writes among the fragment reads is what the counted lgkmcnt waits assume)
+    template <int PART, bool ZERO>
+    __device__ __forceinline__ void store_part(const uint32_t tile, const int tid, const int l0, const int L) const {
+        const uint32_t ad = tile + soff;
+#pragma unroll
+        for (int j = 0; j < VP; ++j) {
+            constexpr int v0 = PART * VP;
+            const int idx = tid + 256 * (v0 + j);
+            if constexpr (!PL) {
+                wg_u32x4_t t = tv[v0 + j];
+                if (ZERO && l0 + (idx >> 4) >= L) t = wg_u32x4_t{0, 0, 0, 0};
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ad), "v"(t), "n"(SSTEP * (v0 + j)) : "memory");
+            } else {
+                wg_u32x2_t t = pv[v0 + j];
+                if (ZERO && l0 + 4 * (idx & 15) >= L) t = wg_u32x2_t{0, 0};
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ad), "v"(t), "n"(SSTEP * (v0 + j)) : "memory");
+            }
+        }
+    }
+    // after wg_vm_wait: every later use of the registers is ordered behind it
+    __device__ __forceinline__ void landed() {
+        if constexpr (!PL) {
+#pragma unroll
+            for (int v = 0; v < NTV; ++v) asm volatile("" : "+v"(tv[v]));
+        } else {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) asm volatile("" : "+v"(pv[v]));
+        }
+    }
+    static constexpr int NLOADS = PL ? 8 : NTV;           // vector loads per thread and step
+    // l0: first token of the step these registers hold (tokens >= L of a sample's last step become zeros here)
+    template <bool RAG>
+    __device__ __forceinline__ void store(uint8_t *tile, const int tid, const int l0, const int L) const {
         if constexpr (!PL) {
 #pragma unroll
             for (int v = 0; v < NTV; ++v) {
                 const int idx = tid + 256 * v;
-                *reinterpret_cast<wg_u32x4_t *>(tile + wg_tok_off(idx >> 4, idx & 15)) = tv[v];
+                wg_u32x4_t t = tv[v];
+                if (l0 + (idx >> 4) >= L) t = wg_u32x4_t{0, 0, 0, 0};
+                *reinterpret_cast<wg_u32x4_t *>(tile + wg_tok_off(idx >> 4, idx & 15)) = t;
             }
         } else {
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
                 const int idx = tid + 256 * v;
-                *reinterpret_cast<wg_u32x2_t *>(tile + (idx >> 4) * kWgPlanePitch + 8 * (idx & 15)) = pv[v];
+                wg_u32x2_t t = pv[v];
+                if (!RAG && l0 + 4 * (idx & 15) >= L) t = wg_u32x2_t{0, 0};
+                *reinterpret_cast<wg_u32x2_t *>(tile + (idx >> 4) * kWgPlanePitch + 8 * (idx & 15)) = t;
             }
         }
     }
@@ -165,8 +296,8 @@ __device__ __forceinline__ void wg_wait(wg_bf16x4_t (&lo)[4], wg_bf16x4_t (&hi)[
                      : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
 }
 
-template <bool APL, bool BPL, int BK>
-__global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const WgradArgs a) {
+template <bool APL, bool BPL, int BK, bool RAG = false>
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
     extern __shared__ __align__(16) uint8_t wg_lds[];
     constexpr int kWgTokBytes = BK * 256;
     constexpr int ABYTES = APL ? kWgPlaneBytes : kWgTokBytes, BBYTES = BPL ? kWgPlaneBytes : kWgTokBytes;
@@ -181,6 +312,7 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
     const int m0 = (tile_id / nbn) * kWgTile, n0 = (tile_id % nbn) * kWgTile;
     const int st0 = wg_slice_start(a, slice), st1 = wg_slice_start(a, slice + 1);
     if (st0 >= st1) return;                                // (uniform per workgroup)
+    if (a.prof && tid == 0) a.prof[4 * blockIdx.x] = a.prof[4 * blockIdx.x + 1] = wall_clock64();
     const uint16_t *const pa = a.a + grp * a.a_gs, *const pb = a.b + grp * a.b_gs;
     float *const pdw = a.dw + grp * a.dw_gs;
     const int wm = wave >> 1, wn = wave & 1;               // wave -> 64 x 64 of the tile
@@ -201,20 +333,171 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
         constexpr int P = decltype(par)::value;
         const int sample = st / a.steps_per_sample, l0 = (st - sample * a.steps_per_sample) * BK;
         if (a.dbg & 4) return;
-        ra[P].load(pa, a.a_bs, a.M, a.L, m0, sample, l0, tid, a.lda);
-        rb[P].load(pb, a.b_bs, a.N, a.L, n0, sample, l0, tid, a.ldb);
+        if (!RAG && l0 + BK <= a.L) {                       // (uniform) the step lies inside its sample: lane-constant offsets
+            ra[P].load_full(pa + sample * a.a_bs + (int64_t)l0 * (APL ? 1 : a.lda));
+            rb[P].load_full(pb + sample * a.b_bs + (int64_t)l0 * (BPL ? 1 : a.ldb));
+        } else {
+            ra[P].template load<RAG>(pa, a.a_bs, a.M, a.L, m0, sample, l0, tid, a.lda);
+            rb[P].template load<RAG>(pb, a.b_bs, a.N, a.L, n0, sample, l0, tid, a.ldb);
+        }
     };
+    if constexpr (!RAG) {
+        ra[0].init(a.M, a.L, m0, tid, a.lda);
+        rb[0].init(a.N, a.L, n0, tid, a.ldb);
+#pragma unroll
+        for (int v = 0; v < WgOperand<APL, BK>::NLOADS; ++v) ra[1].boff[v] = ra[0].boff[v];
+#pragma unroll
+        for (int v = 0; v < WgOperand<BPL, BK>::NLOADS; ++v) rb[1].boff[v] = rb[0].boff[v];
+    }
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
-    issue(P0{}, st0);
-    if (st0 + 1 < st1) issue(P1{}, st0 + 1);
-    ra[0].store(At(0), tid);
-    rb[0].store(Bt(0), tid);
+    auto l0_of = [&](const int st) { return (st - (st / a.steps_per_sample) * a.steps_per_sample) * BK; };
+    constexpr int NLD = WgOperand<APL, BK>::NLOADS + WgOperand<BPL, BK>::NLOADS;     // loads per thread and step
+    // (requests in the part order of the step loop -- A part s, B part s -- which its counted waits assume)
+    auto issue_in_parts = [&](auto par, const int st) {
+        constexpr int P = decltype(par)::value;
+        const int sample = st / a.steps_per_sample, l0 = (st - sample * a.steps_per_sample) * BK;
+        if (a.dbg & 4) return;
+        const uint16_t *sa = pa + sample * a.a_bs, *sb = pb + sample * a.b_bs;
+        const bool full = l0 + BK <= a.L;
+        const uint16_t *sla = sa + (int64_t)l0 * (APL ? 1 : a.lda), *slb = sb + (int64_t)l0 * (BPL ? 1 : a.ldb);
+        auto one = [&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            if (full) {
+                ra[P].template load_full_part<S>(sla);
+                rb[P].template load_full_part<S>(slb);
+            } else {
+                ra[P].template load_clamped_part<S>(sa, a.M, a.L, m0, l0, tid, a.lda);
+                rb[P].template load_clamped_part<S>(sb, a.N, a.L, n0, l0, tid, a.ldb);
+            }
+        };
+        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+        one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+        if constexpr (BK == 128) {
+            one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+        }
+    };
+    if constexpr (RAG) {
+        issue(P0{}, st0);
+        if (st0 + 1 < st1) issue(P1{}, st0 + 1);
+    } else {
+        issue_in_parts(P0{}, st0);
+        if (st0 + 1 < st1) issue_in_parts(P1{}, st0 + 1);
+    }
+    if constexpr (!RAG) {
+        if (st0 + 1 < st1) wg_vm_wait<NLD>(); else wg_vm_wait<0>();
+        ra[0].landed();
+        rb[0].landed();
+    }
+    ra[0].template store<RAG>(At(0), tid, l0_of(st0), a.L);
+    rb[0].template store<RAG>(Bt(0), tid, l0_of(st0), a.L);
     __syncthreads();
+    auto stamp = [&](const int st, const int k) {
+        if (a.prof && blockIdx.x == 8 && lane == 0 && st - st0 < 40) a.prof[2048 + ((st - st0) * 4 + wave) * 5 + k] = clock64();
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)wg_lds;
+    if constexpr (!RAG) {
+        ra[0].init_store(tid); rb[0].init_store(tid);
+        ra[1].soff = ra[0].soff; rb[1].soff = rb[0].soff;
+    }
+    // ---- a step in parts (see WgOperand): per k16-step s -- fragment reads of s + 1, requests for part s of step st + 2,
+    // wait for the fragments of s, its four MFMAs, then part s of step st + 1 on its way to the other LDS buffer
+    // (sample, first token) of steps st + 1 and st + 2 and the sample bases of st + 2 are CARRIED by the loop: with one wave per
+    // SIMD every instruction costs an issue slot of >= 4 cycles and a step's 16 MFMAs cover 128 of them; derived from the step
+    // index every step, the scalar address arithmetic alone was 140 of a step's 360 instructions.  (Four specialised step bodies
+    // -- selects / clamps only where a step ends past its sample -- were tried: the accumulators changed register class at the
+    // joins, 64-128 copies per step, slower.)
+    int l0n = 0, l02 = 0;                                // first token of steps st + 1 / st + 2 inside their samples
+    const uint16_t *sa2 = pa, *sb2 = pb;                 // sample bases of step st + 2
+    {
+        const int s1 = (st0 + 1) / a.steps_per_sample, s2 = (st0 + 2) / a.steps_per_sample;
+        l0n = (st0 + 1 - s1 * a.steps_per_sample) * BK;
+        l02 = (st0 + 2 - s2 * a.steps_per_sample) * BK;
+        sa2 = pa + s2 * a.a_bs;
+        sb2 = pb + s2 * a.b_bs;
+    }
+    const int span = a.steps_per_sample * BK;
+    auto step_parts = [&](auto par, const bool c2, const int st) {
+        constexpr int P = decltype(par)::value, NS = BK / 16;
+        constexpr bool ZN = true;
+        constexpr int LP = NLD / NS;                        // loads per part
+        const int buf = P;
+        const bool req = st + 2 < st1 && !(a.dbg & 4), put = st + 1 < st1;
+        const uint16_t *sla = sa2 + (int64_t)l02 * (APL ? 1 : a.lda), *slb = sb2 + (int64_t)l02 * (BPL ? 1 : a.ldb);
+        const uint32_t At1 = lds0 + (buf ^ 1) * ABYTES, Bt1 = lds0 + 2 * ABYTES + (buf ^ 1) * BBYTES;
+        wg_bf16x4_t lo[2][4], hi[2][4];                     // [ring][0,1: A channel tiles, 2,3: B channel tiles]
+        auto frags = [&](const int ring, const int s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                WgOperand<APL, BK>::frag(At(buf), wm * 64 + i * 32, s, lane, lo[ring][i], hi[ring][i]);
+                WgOperand<BPL, BK>::frag(Bt(buf), wn * 64 + i * 32, s, lane, lo[ring][2 + i], hi[ring][2 + i]);
+            }
+        };
+        auto part = [&](auto sc) {
+            constexpr int S = decltype(sc)::value, r = S & 1;
+            if constexpr (S + 1 < NS) frags(r ^ 1, S + 1);
+            if (req) {
+                if (!c2) {
+                    ra[P].template load_full_part<S>(sla);
+                    rb[P].template load_full_part<S>(slb);
+                } else {
+                    ra[P].template load_clamped_part<S>(sa2, a.M, a.L, m0, l02, tid, a.lda);
+                    rb[P].template load_clamped_part<S>(sb2, a.N, a.L, n0, l02, tid, a.ldb);
+                }
+            }
+            if constexpr (S + 1 < NS) wg_wait<8>(lo[r], hi[r]);
+            else wg_wait<0>(lo[r], hi[r]);
+            wg_bf16x8_t af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = __builtin_shufflevector(lo[r][i], hi[r][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[i] = __builtin_shufflevector(lo[r][2 + i], hi[r][2 + i], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            if (put) {
+                // part S of step st + 1 has landed when only what was requested after it remains: its own later parts and,
+                // if this step requests, parts 0..S of step st + 2 -- together one step's worth
+                if (req) wg_vm_wait<NLD>(); else wg_vm_wait<LP * (NS - 1 - S)>();
+                ra[P ^ 1].template landed_part<S>();
+                rb[P ^ 1].template landed_part<S>();
+                ra[P ^ 1].template store_part<S, ZN>(At1, tid, l0n, a.L);
+                rb[P ^ 1].template store_part<S, ZN>(Bt1, tid, l0n, a.L);
+            }
+        };
+        frags(0, 0);
+        part(std::integral_constant<int, 0>{});
+        part(std::integral_constant<int, 1>{});
+        part(std::integral_constant<int, 2>{});
+        part(std::integral_constant<int, 3>{});
+        if constexpr (NS == 8) {
+            part(std::integral_constant<int, 4>{});
+            part(std::integral_constant<int, 5>{});
+            part(std::integral_constant<int, 6>{});
+            part(std::integral_constant<int, 7>{});
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the asm LDS writes are not in the compiler's books)
+        __syncthreads();
+    };
+    auto step_any = [&](auto par, const int st) {
+        step_parts(par, l02 + BK > a.L, st);                // (uniform) does step st + 2 run past the end of its sample?
+        l0n = l02;                                          // step st + 2 becomes st + 1; advance st + 2
+        l02 += BK;
+        if (l02 >= span) {
+            l02 = 0;
+            sa2 += a.a_bs;
+            sb2 += a.b_bs;
+        }
+    };
     auto step = [&](auto par, const int st) {
         constexpr int P = decltype(par)::value;               // parity of (st - st0): LDS buffer and register set of step st
         const int buf = P;
+        stamp(st, 0);
         if (st + 2 < st1) issue(par, st + 2);
+        stamp(st, 1);
         wg_bf16x4_t lo[2][4], hi[2][4];                     // [ring][0,1: A channel tiles, 2,3: B channel tiles]
         auto frags = [&](const int ring, const int s) {
 #pragma unroll
@@ -246,16 +529,31 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         }
+        stamp(st, 2);
         if (st + 1 < st1) {
-            ra[P ^ 1].store(At(buf ^ 1), tid);
-            rb[P ^ 1].store(Bt(buf ^ 1), tid);
+            const int l0n = l0_of(st + 1);
+            if constexpr (!RAG) {                           // step st + 1 has landed when only step st + 2's loads remain
+                if (st + 2 < st1 && !(a.dbg & 4)) wg_vm_wait<NLD>(); else wg_vm_wait<0>();
+                ra[P ^ 1].landed();
+                rb[P ^ 1].landed();
+            }
+            ra[P ^ 1].template store<RAG>(At(buf ^ 1), tid, l0n, a.L);
+            rb[P ^ 1].template store<RAG>(Bt(buf ^ 1), tid, l0n, a.L);
         }
+        stamp(st, 3);
         __syncthreads();
+        stamp(st, 4);
     };
     for (int st = st0; st < st1; st += 2) {
-        step(P0{}, st);
-        if (st + 1 < st1) step(P1{}, st + 1);
+        if constexpr (RAG) {
+            step(P0{}, st);
+            if (st + 1 < st1) step(P1{}, st + 1);
+        } else {
+            step_any(P0{}, st);
+            if (st + 1 < st1) step_any(P1{}, st + 1);
+        }
     }
+    if (a.prof && tid == 0) a.prof[4 * blockIdx.x + 2] = wall_clock64();
     // D[m][n]: column n = lane & 31, row m = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): 32 lanes = 128 contiguous bytes of a row
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -269,6 +567,10 @@ __global__ void __launch_bounds__(256, BK == 64 ? 2 : 1) wgrad_kernel(const Wgra
                 if (m < a.M && n < a.N && !(a.dbg & 1)) atomicAdd(pdw + (int64_t)m * a.N + n, acc[i][j][v]);
             }
         }
+    if (a.prof && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.prof[4 * blockIdx.x + 3] = wall_clock64();
+    }
 }
 
 // ---- token-major x token-major, operand tiles HBM -> LDS directly ------------------------------------------------------
@@ -451,7 +753,7 @@ static bool wg_xcd_map() {
     return on;
 }
 
-template <bool APL, bool BPL, int BK>
+template <bool APL, bool BPL, int BK, bool RAG = false>
 static int wgrad_launch(WgradArgs a, int nslices, hipStream_t s) {
     constexpr int kWgTokBytes = BK * 256;
     constexpr int ABYTES = APL ? kWgPlaneBytes : kWgTokBytes, BBYTES = BPL ? kWgPlaneBytes : kWgTokBytes;
@@ -460,14 +762,14 @@ static int wgrad_launch(WgradArgs a, int nslices, hipStream_t s) {
     if (lds > 64 * 1024) {
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void *)wgrad_kernel<APL, BPL, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)wgrad_kernel<APL, BPL, BK, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
     }
     a.wgs = nbm * nbn * nslices;
     a.xcd_map = wg_xcd_map() ? 1 : 0;
     const int grid = a.xcd_map ? (a.wgs + 7) / 8 * 8 : a.wgs;
-    hipLaunchKernelGGL((wgrad_kernel<APL, BPL, BK>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((wgrad_kernel<APL, BPL, BK, RAG>), dim3((unsigned)grid), dim3(256), lds, s, a);
     return check_launch();
 }
 
@@ -527,7 +829,9 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     w.lda = M; w.ldb = N; w.groups = 1;
     const bool glds = !a_planes && !b_planes && batch == 1 && L % kGlBK == 0 && L >= 2048 && M >= 8 && N >= 8 &&
                       !getenv("XFM_WGRAD_NO_GLDS");
-    const int BK = glds ? 64 : ((!a_planes && !b_planes && L >= 2048) ? 128 : 64);
+    // (128-token steps for long token-major runs were dropped with the step-in-parts pipeline: eight parts in four variants
+    //  spilled, and a spilled destination of an asynchronous asm load is saved before the data arrives)
+    const int BK = 64;
     w.steps_per_sample = (L + BK - 1) / BK;
     if (const char *env = getenv("XFM_WGRAD_DBG")) w.dbg = atoi(env);
     w.prof = g_wgrad_prof;
@@ -538,7 +842,8 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     const int tiles = ((M + kWgTile - 1) / kWgTile) * ((N + kWgTile - 1) / kWgTile);
     int cap = 256;
     if (const char *env = getenv("XFM_WGRAD_WGS")) cap = atoi(env);
-    int nsl = std::max(1, std::min(cap / tiles, w.total_steps / (1024 / BK)));
+    static const int min_tokens = [] { const char *e = getenv("XFM_WGRAD_MINTOK"); return e ? atoi(e) : 512; }();
+    int nsl = std::max(1, std::min(cap / tiles, w.total_steps / std::max(1, min_tokens / BK)));
     w.steps_per_slice = (w.total_steps + nsl - 1) / nsl;
     nsl = (w.total_steps + w.steps_per_slice - 1) / w.steps_per_slice;
     w.nslices = nsl;
@@ -563,9 +868,13 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
         else hipLaunchKernelGGL(wgrad_tt_glds_kernel<false>, dim3((unsigned)grid), dim3(256), lds, s, w);
         return check_launch();
     }
+    if (rag && (a_planes || b_planes)) {
+        if (a_planes) return b_planes ? wgrad_launch<true, true, 64, true>(w, nsl, s) : wgrad_launch<true, false, 64, true>(w, nsl, s);
+        return wgrad_launch<false, true, 64, true>(w, nsl, s);
+    }
     if (a_planes) return b_planes ? wgrad_launch<true, true, 64>(w, nsl, s) : wgrad_launch<true, false, 64>(w, nsl, s);
     if (b_planes) return wgrad_launch<false, true, 64>(w, nsl, s);
-    return BK == 128 ? wgrad_launch<false, false, 128>(w, nsl, s) : wgrad_launch<false, false, 64>(w, nsl, s);
+    return wgrad_launch<false, false, 64>(w, nsl, s);
 }
 
 }  // extern "C"
