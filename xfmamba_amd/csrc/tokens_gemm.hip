@@ -389,8 +389,10 @@ __global__ void __launch_bounds__(NT) tokens_gemm2_kernel(const TokGemm2Args a) 
     constexpr int P = CON + 8;             // LDS row pitch (halfwords): 16-byte rows, conflict-free 16-byte column reads
     constexpr int KS = CON / 16, NB = OCH / 32, KG = KS % 8 == 0 ? 8 : 6, NG = KS / KG;
     static_assert(KS % KG == 0 && OCH % 32 == 0, "shape");
-    extern __shared__ __align__(16) uint16_t wl[];              // [OCH][P] weight chunk, then OCH floats of bias
+    extern __shared__ __align__(16) uint16_t wl[];              // [OCH][P] weight chunk, OCH floats of bias, the waves' output images
     float *bl = reinterpret_cast<float *>(wl + OCH * P);
+    constexpr int SP = OCH + 8;                                  // row pitch of an output image (halfwords)
+    uint16_t *stage = reinterpret_cast<uint16_t *>(bl + OCH);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x / a.wgs_per_chunk, wg = blockIdx.x - chunk * a.wgs_per_chunk;
     const int n0 = chunk * OCH;
@@ -493,12 +495,15 @@ __global__ void __launch_bounds__(NT) tokens_gemm2_kernel(const TokGemm2Args a) 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- epilogue: D[n][t] -> a lane (token t0 + c) ends up with runs of eight consecutive output channels
-        const int64_t row = t0 + c;
-        const int64_t ro = row * a.OUT + n0 + 8 * h;
+        // ---- epilogue: D[n][t] -> a lane (token t0 + c) ends up with runs of eight consecutive output channels.  Written
+        // straight to memory that is 64 different 128-byte lines per store instruction (rows are OUT * 2 bytes apart): the
+        // address path takes 64 cycles for each, and the loads of z in the backward form are the same shape.  So the tile goes
+        // through a wave-private LDS image [32 tokens][OCH + 8] first and leaves in whole rows: 16 (8) lanes per row, four
+        // (eight) rows per instruction.
+        uint16_t *stg = stage + wave * (32 * SP);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            __builtin_amdgcn_sched_barrier(0);                     // one accumulator's epilogue at a time (register pressure)
+            __builtin_amdgcn_sched_barrier(0);                     // one accumulator at a time (register pressure)
             uint32_t pk[4][2];                                     // group g: channels 32 b + 8 g + 4 h .. + 3
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -515,55 +520,77 @@ __global__ void __launch_bounds__(NT) tokens_gemm2_kernel(const TokGemm2Args a) 
                     pk[g][q] = r[0];
                     pk[g + 1][q] = r[1];
                 }
-            tg_u32x4_t v[2];
-            v[0][0] = pk[0][0]; v[0][1] = pk[0][1]; v[0][2] = pk[1][0]; v[0][3] = pk[1][1];      // channels 32 b + 8 h .. + 7
-            v[1][0] = pk[2][0]; v[1][1] = pk[2][1]; v[1][2] = pk[3][0]; v[1][3] = pk[3][1];      // channels 32 b + 16 + 8 h .. + 7
-            if (row < a.T && !tg2_dbg(a, 4)) {
+            tg_u32x4_t v0, v1;
+            v0[0] = pk[0][0]; v0[1] = pk[0][1]; v0[2] = pk[1][0]; v0[3] = pk[1][1];      // channels 32 b + 8 h .. + 7
+            v1[0] = pk[2][0]; v1[1] = pk[2][1]; v1[2] = pk[3][0]; v1[3] = pk[3][1];      // channels 32 b + 16 + 8 h .. + 7
+            *reinterpret_cast<tg_u32x4_t *>(stg + c * SP + 32 * b + 8 * h) = v0;
+            *reinterpret_cast<tg_u32x4_t *>(stg + c * SP + 32 * b + 16 + 8 * h) = v1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (same wave, other lanes: LDS order, no barrier needed)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int CPR = OCH / 8, RPI = 64 / CPR, NIT = 32 / RPI;   // 16-byte chunks per row, rows per instruction
+        const int ck = lane % CPR, rl = lane / CPR;
+        float bbv[8];
+        if constexpr (EPI != 0) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int64_t off = ro + 32 * b + 16 * j;
-                    if constexpr (EPI == 0) {
-                        *reinterpret_cast<tg_u32x4_t *>(a.y + off) = v[j];
-                    } else {
-                        const float *bb = bl + 32 * b + 16 * j + 8 * h;
-                        tg_u32x4_t zi;
-                        if constexpr (EPI == 2) zi = *reinterpret_cast<const tg_u32x4_t *>(a.zin + off);
-                        tg_u32x4_t o;
+            for (int e = 0; e < 8; ++e) bbv[e] = bl[8 * ck + e];
+        }
+        tg_u32x4_t zi[EPI == 2 ? NIT : 1];
+        if constexpr (EPI == 2) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float r2[2];
+            for (int i = 0; i < NIT; ++i) {
+                int64_t row = t0 + RPI * i + rl;
+                if (row >= a.T) row = a.T - 1;
+                zi[i] = *reinterpret_cast<const tg_u32x4_t *>(a.zin + row * a.OUT + n0 + 8 * ck);
+            }
+        }
 #pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const uint32_t wv = EPI == 1 ? v[j][q] : zi[q];
-                                const float zf = (e ? __uint_as_float(wv & 0xffff0000u) : __uint_as_float(wv << 16)) + bb[2 * q + e];
-                                float E;
-                                const float cdf = 0.5f * (1.0f + tg_erf(zf * kTgInvSqrt2, E));
-                                if constexpr (EPI == 1) {
-                                    r2[e] = zf * cdf;
-                                } else {
-                                    const float dgf = e ? __uint_as_float(v[j][q] & 0xffff0000u) : __uint_as_float(v[j][q] << 16);
-                                    r2[e] = dgf * fmaf(zf, kTgInvSqrt2Pi * E, cdf);
-                                }
-                            }
-                            o[q] = pack_bf16x2(r2[0], r2[1]);
-                        }
+        for (int i = 0; i < NIT; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int r = RPI * i + rl;
+            const int64_t row = t0 + r;
+            const tg_u32x4_t v = *reinterpret_cast<const tg_u32x4_t *>(stg + r * SP + 8 * ck);
+            if (row >= a.T || tg2_dbg(a, 4)) continue;
+            const int64_t off = row * a.OUT + n0 + 8 * ck;
+            if constexpr (EPI == 0) {
+                *reinterpret_cast<tg_u32x4_t *>(a.y + off) = v;
+            } else {
+                tg_u32x4_t o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float r2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint32_t wv = EPI == 1 ? v[q] : zi[EPI == 2 ? i : 0][q];
+                        const float zf = (e ? __uint_as_float(wv & 0xffff0000u) : __uint_as_float(wv << 16)) + bbv[2 * q + e];
+                        float E;
+                        const float cdf = 0.5f * (1.0f + tg_erf(zf * kTgInvSqrt2, E));
                         if constexpr (EPI == 1) {
-                            *reinterpret_cast<tg_u32x4_t *>(a.y + off) = v[j];       // z
-                            *reinterpret_cast<tg_u32x4_t *>(a.y2 + off) = o;         // g
+                            r2[e] = zf * cdf;
                         } else {
-                            *reinterpret_cast<tg_u32x4_t *>(a.y + off) = o;          // dz
+                            const float dgf = e ? __uint_as_float(v[q] & 0xffff0000u) : __uint_as_float(v[q] << 16);
+                            r2[e] = dgf * fmaf(zf, kTgInvSqrt2Pi * E, cdf);
                         }
                     }
+                    o[q] = pack_bf16x2(r2[0], r2[1]);
+                }
+                if constexpr (EPI == 1) {
+                    *reinterpret_cast<tg_u32x4_t *>(a.y + off) = v;          // z
+                    *reinterpret_cast<tg_u32x4_t *>(a.y2 + off) = o;         // g
+                } else {
+                    *reinterpret_cast<tg_u32x4_t *>(a.y + off) = o;          // dz
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next tile's image is written after these reads
     }
 }
 
 template <int CON, int OCH, int EPI, int NT>
 static int tokens_gemm2_launch_nt(TokGemm2Args a, hipStream_t s) {
-    const size_t lds = (size_t)OCH * (CON + 8) * sizeof(uint16_t) + (size_t)OCH * sizeof(float);
+    const size_t lds = (size_t)OCH * (CON + 8) * sizeof(uint16_t) + (size_t)OCH * sizeof(float) +
+                       (size_t)(NT / 64) * 32 * (OCH + 8) * sizeof(uint16_t);
     auto fn = tokens_gemm2_kernel<CON, OCH, EPI, NT>;
     static bool opted = false;
     if (lds > 64 * 1024 && !opted) {
@@ -587,7 +614,11 @@ static int tokens_gemm2_launch(const TokGemm2Args &a, hipStream_t s) {
     // have in flight (4 KB each) stay inside the 32 KB L1, so a line of the token rows is fetched from L2 once, not once per
     // k-step that touches it
     static const int nt = [] { const char *e = getenv("XFM_GEMM2_NT"); return e ? atoi(e) : 256; }();
-    return nt == 512 ? tokens_gemm2_launch_nt<CON, OCH, EPI, 512>(a, s) : tokens_gemm2_launch_nt<CON, OCH, EPI, 256>(a, s);
+    constexpr size_t lds512 = (size_t)OCH * (CON + 8) * 2 + (size_t)OCH * 4 + (size_t)8 * 32 * (OCH + 8) * 2;
+    if constexpr (lds512 <= 160 * 1024) {                        // (eight output images next to the weight chunk)
+        if (nt == 512) return tokens_gemm2_launch_nt<CON, OCH, EPI, 512>(a, s);
+    }
+    return tokens_gemm2_launch_nt<CON, OCH, EPI, 256>(a, s);
 }
 
 template <int CON, int OCH>
