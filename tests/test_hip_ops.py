@@ -495,6 +495,47 @@ def test_mlp_fused_gelu_products_match_torch_fp32_and_the_unfused_chain(C, T):
         assert_close(a, b, 2e-3, 2e-3 * float(b.abs().max()) + 1e-7, name + " (fused vs chain)")
 
 
+@pytest.mark.parametrize("T,con,out", [(12544 + 37, 384, 1536), (3136, 768, 256), (640, 64, 128), (129, 1536, 384)])
+@pytest.mark.parametrize("wt", [0, 1])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_tokens_gemm2_tiled_form_every_epilogue_and_weight_layout(T, con, out, wt, epi):
+    """xfm_tokens_gemm2 at shapes only its tiled form covers (csrc/tokens_gemm.hip: 128 x 128 tiles, LDS-direct operand ring;
+    any con % 64 == 0, out % 128 == 0): plain product + bias, z / gelu(z + b) pair, dz = (x W) gelu'(z + b) -- reference
+    models/fusion_vmamba.py:135-153 -- for both weight layouts ((out, con) and (con, out)) against torch fp32 on the same bf16
+    operands; token counts that are not multiples of the tile, a single k-stage (con = 64), one n-tile."""
+    from xfmamba_amd import _lib
+    lib = _lib.lib()
+    if not lib.xfm_tokens_gemm2_supported(con, out):
+        pytest.skip("tiled form switched off (XFM_GEMM2_FORM)")
+    g = torch.Generator().manual_seed(T + con + out + 7 * wt + epi)
+    x = torch.randn(T, con, generator=g).bfloat16()
+    w = (con ** -0.5 * torch.randn(out, con, generator=g)).bfloat16()
+    b = 0.3 * torch.randn(out, generator=g)
+    zin = torch.randn(T, out, generator=g).bfloat16()
+    acc = x.float() @ w.float().t()
+    xd, bd, zd = x.to(DEV), b.to(DEV), zin.to(DEV)
+    wd = (w.t().contiguous() if wt else w).to(DEV)
+    y = torch.full((T, out), float("nan"), dtype=torch.bfloat16, device=DEV)
+    y2 = torch.full((T, out), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.xfm_tokens_gemm2(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), y2.data_ptr() if epi == 1 else None,
+                                    zd.data_ptr() if epi == 2 else None, T, con, out, wt, epi, _lib.stream_ptr()), "tokens_gemm2")
+    torch.cuda.synchronize()
+    tol = 1e-2
+    if epi == 0:
+        r = acc + b
+        assert_close(y.float().cpu(), r, tol, tol * float(r.abs().max()), "y")
+    elif epi == 1:
+        zr = acc.bfloat16().float()                                      # z is rounded before the bias and the GELU see it
+        assert_close(y.float().cpu(), acc, tol, tol * float(acc.abs().max()), "z")
+        gr = torch.nn.functional.gelu(y.float().cpu() + b)               # (from the z the kernel stored: same rounding point)
+        assert_close(y2.float().cpu(), gr, tol, tol * float(gr.abs().max()), "g")
+        assert zr.shape == acc.shape
+    else:
+        zb = (zin.float() + b).requires_grad_()
+        torch.nn.functional.gelu(zb).backward(acc.bfloat16().float())    # dg is rounded to bf16 before gelu' multiplies it
+        assert_close(y.float().cpu(), zb.grad, tol, tol * float(zb.grad.abs().max()), "dz")
+
+
 @pytest.mark.parametrize("C,xdt,hdt", [(48, torch.bfloat16, torch.bfloat16), (96, torch.bfloat16, torch.float32),
                                        (192, torch.float32, torch.float32), (768, torch.bfloat16, torch.float32)])
 def test_layernorm_rows_with_conv_bias_and_bf16_input(C, xdt, hdt):
