@@ -495,7 +495,7 @@ def test_mlp_fused_gelu_products_match_torch_fp32_and_the_unfused_chain(C, T):
         assert_close(a, b, 2e-3, 2e-3 * float(b.abs().max()) + 1e-7, name + " (fused vs chain)")
 
 
-@pytest.mark.parametrize("T,con,out", [(12544 + 37, 384, 1536), (3136, 768, 256), (640, 64, 128), (129, 1536, 384)])
+@pytest.mark.parametrize("T,con,out", [(12544 + 37, 384, 1536), (3136, 768, 256), (640, 64, 128), (129, 1536, 384), (3136 + 5, 96, 384), (777, 160, 128)])
 @pytest.mark.parametrize("wt", [0, 1])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_tokens_gemm2_tiled_form_every_epilogue_and_weight_layout(T, con, out, wt, epi):

@@ -638,6 +638,9 @@ static int tokens_gemm2_launch(const TokGemm2Args &a, hipStream_t s) {
 //     tile leaves through an LDS image [128 tokens][128 + 8] as whole rows (see the second form's epilogue).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kG3Stage = 32768, kG3Half = 16384;       // bytes of one stage (x tile | weight tile)
+// contraction widths that are not whole 64-wide stages (96 channels at trunk stage 0): the 16-byte chunks of the last stage that
+// lie past the row read this page instead -- zeros in both operands
+__device__ uint4 g3_zero_page[4];
 
 __device__ __forceinline__ int g3_off(const int r, const int c) { return 128 * r + 16 * (c ^ ((r >> 1) & 7)); }
 __device__ __forceinline__ int g3_tok_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
@@ -666,9 +669,11 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
     const int wm = wave >> 1, wn = wave & 1;               // wave -> outputs 64 wm .., tokens 64 wn ..
     // ---- global side of the LDS-direct loads (lane constants; k0 is added per stage through the scalar base)
     const uint16_t *gx[4], *gw[4];
+    int kch[4];                                            // first k of this lane's chunk inside a stage (k-contiguous images)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 8 * (4 * wave + i) + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+        kch[i] = 8 * ch;
         int64_t tr = t0 + row;
         if (tr >= a.T) tr = a.T - 1;
         gx[i] = a.x + tr * CON + 8 * ch;
@@ -680,12 +685,23 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
             gw[i] = a.w + (int64_t)kr * a.OUT + n0 + 8 * cw;
         }
     }
-    const int NST = CON / 64;
+    const int NST = (CON + 63) / 64;
+    const bool ragged = (CON & 63) != 0;                   // (uniform)
+    const uint16_t *zp = reinterpret_cast<const uint16_t *>(g3_zero_page);
     auto issue_part = [&](const int st, const int i) {
         uint8_t *dst = g3_lds + (st & 1) * kG3Stage + (4 * wave + i) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gx[i] + 64 * st),
+        const bool last = ragged && st == NST - 1;
+        const uint16_t *px = (last && 64 * st + kch[i] >= CON) ? zp : gx[i] + 64 * st;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)px,
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         const uint16_t *pw = WT ? gw[i] + (int64_t)64 * st * a.OUT : gw[i] + 64 * st;
+        if (last) {
+            if constexpr (!WT) {
+                if (64 * st + kch[i] >= CON) pw = zp;
+            } else {                                       // k-major weight: whole rows past CON
+                if (64 * st + 4 * (4 * wave + i) + (lane >> 4) >= CON) pw = zp;
+            }
+        }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pw,
                                          (__attribute__((address_space(3))) void *)(dst + kG3Half), 16, 0, 0);
     };
@@ -941,7 +957,7 @@ int xfm_tokens_gemm2_supported(int con, int out) {
     // the chunked form: con -> out = 4 con at the later trunk stages; the tiled form (LDS-direct, 128 x 128 tiles): any
     // con % 64 == 0, out % 128 == 0
     if ((con == 192 && out == 768) || (con == 384 && out == 1536) || (con == 768 && out == 3072)) return 1;
-    return (xfm::tokens_gemm2_form() == 3 && con >= 64 && con % 64 == 0 && out >= 128 && out % 128 == 0) ? 1 : 0;
+    return (xfm::tokens_gemm2_form() == 3 && con >= 64 && con % 32 == 0 && out >= 128 && out % 128 == 0) ? 1 : 0;
 }
 
 int xfm_tokens_gemm2(const void *x, const void *weight_bf16, const float *bias, void *y, void *y2, const void *zin, long long T,
@@ -966,7 +982,7 @@ int xfm_tokens_gemm2(const void *x, const void *weight_bf16, const float *bias, 
     hipStream_t s = (hipStream_t)stream;
     const int form = tokens_gemm2_form();
     // (192 -> 768 forward: three k-stages per tile, the chunked form is 2 us faster there -- 59.0 vs 60.8)
-    if (form == 3 && !(con == 192 && out == 768 && epilogue == 1) && con % 64 == 0 && out % 128 == 0 && !(dbg & 62) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)weight_bf16 & 15) == 0)
+    if (form == 3 && !(con == 192 && out == 768 && epilogue == 1) && con % 32 == 0 && out % 128 == 0 && !(dbg & 62) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)weight_bf16 & 15) == 0)
         return tokens_gemm3(a, con, epilogue, s);
     if (con == 192 && out == 768) return tokens_gemm2_epi<192, 128>(a, epilogue, s);
     if (con == 384 && out == 1536) return tokens_gemm2_epi<384, 128>(a, epilogue, s);

@@ -160,7 +160,9 @@ _FUSED = os.environ.get("XFM_MLP_FUSED", "1") == "1"
 
 
 def _gemm2_ok(x, con, out):
-    return bool(_FUSED and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == con and x.numel() >= con * 1024
+    # (con % 64: the kernel also takes 96 channels -- trunk stage 0 -- through a zero-filled last k-stage, but the fused Mlp
+    #  loses there: 77 M GELU evaluations per launch make the erf arithmetic of the epilogue the bound, 1918 vs 1936 samples/s)
+    return bool(_FUSED and con % 64 == 0 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == con and x.numel() >= con * 1024
                 and x.is_contiguous() and x.data_ptr() % 16 == 0 and _lib.lib().xfm_tokens_gemm2_supported(con, out))
 
 
