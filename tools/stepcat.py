@@ -20,7 +20,7 @@ for r in csv.DictReader(open(f)):
     elif 'rowln' in n or 'settle_' in n: fam = 'row LayerNorm (+residual)'
     elif 'ln2d' in n: fam = 'LayerNorm2d'
     elif 'wgrad_kernel' in n or 'wgrad_tt' in n: fam = 'own MFMA weight-gradient GEMM'
-    elif 'tokens_gemm2' in n: fam = 'own MFMA GEMM with GELU epilogue (Mlp fc1 / fc2 data gradient)'
+    elif 'tokens_gemm2' in n or 'tokens_gemm3' in n: fam = 'own MFMA GEMM with GELU epilogue (Mlp fc1 / fc2 data gradient)'
     elif 'tokens_gemm' in n or 'planes_gemm' in n or 'proj_gemm' in n: fam = 'own MFMA GEMM'
     elif 'tokens_kernel' in n or 'colsum' in n: fam = 'bias+GELU / column sums'
     elif 'dwconv' in n: fam = 'depthwise conv + SiLU'
