@@ -706,7 +706,9 @@ def test_dt_proj_kernels_match_torch_fp32(B, D, R, H, with_bias):
 
 
 @pytest.mark.parametrize("B,D,R,H", [(2, 96, 6, 56), (2, 192, 12, 28), (3, 384, 24, 14), (2, 64, 5, 10),
-                                     (1, 1024, 32, 24)])      # XFMamba-B stage 2: 66 KB of LDS (opt-in above 64 KB)
+                                     (1, 1024, 32, 24),       # XFMamba-B stage 2: 66 KB of LDS (opt-in above 64 KB)
+                                     # one pass over ddts for both products (a (b, k) slab per workgroup, B * 4 >= 128):
+                                     (32, 96, 6, 56), (32, 192, 12, 28), (33, 128, 8, 12), (32, 256, 16, 12)])
 def test_dt_proj_backward_mfma_matches_torch_fp32(B, D, R, H):
     """Backward of dt_proj on MFMA (bf16): data gradient W^T.ddts and weight gradient sum_{b,l} ddts.xr^T vs fp32."""
     from xfmamba_amd import _lib

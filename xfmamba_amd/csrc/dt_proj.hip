@@ -332,6 +332,179 @@ __global__ __launch_bounds__(256) void dt_proj_bwd_dw_kernel(DtProjBwdArgs a) {
     }
 }
 
+// ---- both products in ONE pass over ddts ----------------------------------------------------------------------------
+// A workgroup owns one (b, k) slab of ddts -- D rows of L positions, 154 MB per launch at the 56 x 56 stage in all -- and
+// walks it in tiles of 128 positions that arrive by LDS-direct loads (rows of 256 bytes, the chunk-XOR image of
+// csrc/wgrad_gemm.hip; two tiles ring).  The tile is read twice from LDS: transposed (ds_read_b64_tr_b16: column = position,
+// contraction over the channel rows) for d xr = W^T . ddts, and along its rows (lane = channel, eight consecutive positions) for
+// dW += ddts . xr^T, whose accumulators live in registers across the whole slab (one set of atomics per workgroup at the end).
+// The two separate kernels read ddts with 2-byte / 8-byte per-lane loads (32 different lines per instruction): 32 + 55 us at
+// 64 x 4 x 96 x 3136; this one is bound by the stream itself.
+constexpr int kDtmTL = 128;                                // positions per tile
+__device__ uint4 dtm_zero_page[4];
+
+__device__ __forceinline__ int dtm_off(const int row, const int ch) {      // 16-byte chunk ch (0..15) of row `row`
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <int DB>                                          // DB = D / 32
+__global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProjBwdArgs a) {
+    constexpr int D = 32 * DB;
+    constexpr int TILE = D * 256, XT = 32 * 256;           // bytes: ddts tile, xr tile (32 rank rows)
+    constexpr int P = D + 8;                               // row pitch of W^T (halfwords)
+    constexpr int NBUF = DB <= 4 ? 3 : 2;                  // tiles in the ring (3 x 40 KB at 128 channels; 2 x 56 KB at 192)
+    extern __shared__ __align__(16) uint8_t dl[];          // NBUF x (ddts tile | xr tile) | W^T [32][D + 8]
+    uint16_t *wt = reinterpret_cast<uint16_t *>(dl + NBUF * (TILE + XT));
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bk = blockIdx.x, k = bk & 3;
+    const int R = a.R, L = a.L;
+    {
+        const uint16_t *wg = reinterpret_cast<const uint16_t *>(a.w) + (int64_t)k * D * R;
+        for (int e = tid; e < 32 * D; e += 256) {
+            const int r = e / D, d = e - r * D;
+            wt[r * P + d] = r < R ? wg[d * R + r] : (uint16_t)0;
+        }
+    }
+    const uint16_t *g = reinterpret_cast<const uint16_t *>(a.ddts) + (int64_t)bk * D * L;
+    const uint16_t *x = reinterpret_cast<const uint16_t *>(a.xr) + (int64_t)bk * R * L;
+    const uint16_t *zp = reinterpret_cast<const uint16_t *>(dtm_zero_page);
+    const int ntile = (L + kDtmTL - 1) / kDtmTL;
+    // LDS-direct fill of tile t into buffer t & 1: instruction i of a wave covers rows 4 j .. 4 j + 3 (1 KB), j = wave + 4 i;
+    // lane l: row 4 j + (l >> 4), LDS position l & 15 = chunk (l & 15) ^ swz(row) of that row; chunks past L read zeros
+    auto issue = [&](const int t) {
+        uint8_t *dst = dl + (t % NBUF) * (TILE + XT);
+        const int l0 = t * kDtmTL;
+#pragma unroll
+        for (int i = 0; i < D / 16; ++i) {
+            const int j = wave + 4 * i, row = 4 * j + (lane >> 4);
+            const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            const uint16_t *src = (l0 + 8 * ch < L) ? g + (int64_t)row * L + l0 + 8 * ch : zp;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                      // xr: 32 rows (ranks >= R: zeros)
+            const int j = wave + 4 * i, row = 4 * j + (lane >> 4);
+            const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            const uint16_t *src = (row < R && l0 + 8 * ch < L) ? x + (int64_t)row * L + l0 + 8 * ch : zp;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + TILE + j * 1024), 16, 0, 0);
+        }
+    };
+    constexpr int NLD = D / 16 + 2;                        // loads per wave and tile
+    static_assert(NLD < 32, "vmcnt budget");
+    xfm_f32x16_t dwacc[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) dwacc[b][v] = 0.f;
+    const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)dl;
+    const int c = lane & 31, h = lane >> 5;
+    // transposed fragment addresses (tile buffer 0, channel rows 0..15; k16-step s adds 4096 s bytes): wave w owns positions 32 w ..
+    uint32_t trlo, trhi;
+    {
+        const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+        const int c0 = (32 * wave + 16 * (gq & 1)) >> 3, r0 = 8 * (gq >> 1);
+        trlo = base + dtm_off(r0 + q, c0 + (p >> 1)) + 8 * (p & 1);
+        trhi = base + dtm_off(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1);
+    }
+    typedef __bf16 dtm_bf16x4_t __attribute__((ext_vector_type(4)));
+    uint16_t *o = reinterpret_cast<uint16_t *>(a.dxr) + (int64_t)bk * R * L;
+    issue(0);
+    if (NBUF == 3 && ntile > 1) issue(1);
+    for (int t = 0; t < ntile; ++t) {
+        // this wave's share of tile t has landed.  Operations retire in issue order; younger than tile t's loads are, in a
+        // three-tile ring, the 16 d xr stores of tiles t - 2 and t - 1 and the loads of tile t + 1 (none of which is waited for),
+        // in a two-tile ring the 16 stores of tile t - 1.
+        if (NBUF == 3 && t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD + 32) : "memory");   // + the stores of two tiles
+        else if (NBUF == 2 && t > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                      // the previous tile's stores
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (first trip: W^T too) everyone's share landed, tile t - 1 is free.  A BARE barrier: __syncthreads() carries a fence
+        // that the compiler turns into s_waitcnt vmcnt(0) for LDS-direct loads -- the ring would run with nothing in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NBUF - 1 < ntile) issue(t + NBUF - 1);
+        const uint32_t so = (t % NBUF) * (TILE + XT);
+        // ---- d xr[r][l] for positions 32 wave .. + 31 of the tile: contraction over the channels; all fragment reads of (up to)
+        // six k16-steps are requested before the first MFMA waits
+        xfm_f32x16_t acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+        constexpr int KS = D / 16, KH = KS > 8 ? KS / 2 : KS;
+#pragma unroll
+        for (int s0 = 0; s0 < KS; s0 += KH) {
+            dtm_bf16x4_t lo[KH], hi[KH];
+            xfm_bf16x8_t afr[KH];
+#pragma unroll
+            for (int q = 0; q < KH; ++q) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[q]) : "v"(trlo + so + 4096 * (s0 + q)) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[q]) : "v"(trhi + so + 4096 * (s0 + q)) : "memory");
+                afr[q] = *reinterpret_cast<const xfm_bf16x8_t *>(wt + c * P + 16 * (s0 + q) + 8 * h);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < KH; ++q) {
+                asm volatile("" : "+v"(lo[q]), "+v"(hi[q]));
+                const xfm_bf16x8_t bfr = __builtin_shufflevector(lo[q], hi[q], 0, 1, 2, 3, 4, 5, 6, 7);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[q], bfr, acc, 0, 0, 0);
+            }
+        }
+        {
+            // 16 stores per tile, ALWAYS issued (lane mask in EXEC): the counted wait above needs a fixed number of
+            // vector-memory operations per tile
+            const int pos = t * kDtmTL + 32 * wave + c;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+                const bool live = pos < L && r < R;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(live);
+                const uint32_t val = pack_bf16x2(acc[v], 0.f);
+                const uint16_t *ptr = o + (live ? (int64_t)r * L + pos : 0);
+                uint64_t sv;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_and_b64 exec, exec, %[m]\n\t"
+                             "global_store_short %[p], %[v], off\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(sv) : [m] "s"(m), [p] "v"(ptr), [v] "v"(val) : "memory");
+            }
+        }
+        // ---- dW[d][r] += sum over the tile's positions: wave w takes k16-steps 2 w, 2 w + 1 (positions 32 w .. + 31)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int ch = 2 * (2 * wave + s2) + h;        // 16-byte chunk of 8 positions
+            const xfm_bf16x8_t xfr = *reinterpret_cast<const xfm_bf16x8_t *>(dl + so + TILE + dtm_off(c, ch));
+#pragma unroll
+            for (int b = 0; b < DB; ++b) {
+                const xfm_bf16x8_t gfr = *reinterpret_cast<const xfm_bf16x8_t *>(dl + so + dtm_off(32 * b + c, ch));
+                dwacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr, xfr, dwacc[b], 0, 0, 0);
+            }
+        }
+    }
+    if (c < R) {
+        float *dw = a.dw + (int64_t)k * D * R + c;         // column r = c
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = 32 * b + (v & 3) + 8 * (v >> 2) + 4 * h;
+                atomicAdd(dw + (int64_t)row * R, dwacc[b][v]);
+            }
+    }
+}
+
+template <int DB> static int dt_proj_bwd_merged_launch(const DtProjBwdArgs &a, int B, hipStream_t s) {
+    constexpr int D = 32 * DB;
+    const size_t lds = (size_t)(DB <= 4 ? 3 : 2) * (D * 256 + 32 * 256) + (size_t)32 * (D + 8) * 2;
+    auto fn = dt_proj_bwd_merged_kernel<DB>;
+    static bool opted = false;
+    if (lds > 64 * 1024 && !opted) {
+        if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
+        opted = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)(B * 4)), dim3(256), lds, s, a);
+    return check_launch();
+}
+
 }  // namespace xfm
 
 extern "C" {
@@ -363,6 +536,13 @@ int xfm_ss2d_dt_proj_bwd_mfma(const void *ddts, const void *xr, const void *weig
     a.ddts = static_cast<const bf16_t *>(ddts); a.xr = static_cast<const bf16_t *>(xr);
     a.w = static_cast<const bf16_t *>(weight_bf16); a.dxr = static_cast<bf16_t *>(dxr); a.dw = dweight;
     a.D = D; a.R = R; a.L = L;
+    // one pass over ddts for both products where a (b, k) slab per workgroup fills the chip and the ring fits LDS
+    static const bool merged_on = [] { const char *e = getenv("XFM_DTPROJ_MERGED"); return !e || atoi(e) != 0; }();
+    if (merged_on && B * 4 >= 128 && L % 8 == 0 && (((uintptr_t)ddts | (uintptr_t)xr) & 15) == 0) {
+        if (D == 96) return dt_proj_bwd_merged_launch<3>(a, B, s);
+        if (D == 128) return dt_proj_bwd_merged_launch<4>(a, B, s);
+        if (D == 192) return dt_proj_bwd_merged_launch<6>(a, B, s);      // (256 channels: the two-tile ring is 164 KB)
+    }
     a.ltiles = ((L + 31) / 32 + 3) / 4;
     const size_t lds = (size_t)32 * (D + 8) * sizeof(uint16_t);
     if (lds > 64 * 1024) {                                        // D = 1024 (XFMamba-B stage 2): 66 048 B, opt in
