@@ -480,16 +480,25 @@ __global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProj
             }
         }
     }
+    // ---- the four waves' partial dW (disjoint position ranges) are summed in LDS and leave as D * R / 64 full-wave atomic
+    // instructions per workgroup: a CU retires about one atomic wave-instruction per 120 cycles whatever its lane count, and
+    // 4 waves x 16 DB instructions of R lanes each were 11 us at the end of every workgroup
+    __syncthreads();                                       // (all tiles consumed: the ring is free)
+    float *red = reinterpret_cast<float *>(dl);            // [D][R]
+    for (int e = tid; e < D * R; e += 256) red[e] = 0.f;
+    __syncthreads();
     if (c < R) {
-        float *dw = a.dw + (int64_t)k * D * R + c;         // column r = c
 #pragma unroll
         for (int b = 0; b < DB; ++b)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int row = 32 * b + (v & 3) + 8 * (v >> 2) + 4 * h;
-                atomicAdd(dw + (int64_t)row * R, dwacc[b][v]);
+                atomicAdd(red + row * R + c, dwacc[b][v]);  // (LDS)
             }
     }
+    __syncthreads();
+    float *dw = a.dw + (int64_t)k * D * R;
+    for (int e = tid; e < D * R; e += 256) atomicAdd(dw + e, red[e]);
 }
 
 template <int DB> static int dt_proj_bwd_merged_launch(const DtProjBwdArgs &a, int B, hipStream_t s) {
