@@ -141,10 +141,13 @@ __global__ void __launch_bounds__(256) dwconv_bwd_kernel(const T *__restrict__ x
     for (int i = 0; i < 9; ++i)
         for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
     for (int off = 32; off > 0; off >>= 1) accb += __shfl_xor(accb, off, 64);
-    if (live && (threadIdx.x & 63) == 0) {
+    if (live) {                                                     // ONE atomic instruction: lane i adds total i
+        const int ln = threadIdx.x & 63;
+        float val = accb;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) atomicAdd(dw + d * 9 + i, acc[i]);
-        if (dbias) atomicAdd(dbias + d, accb);
+        for (int i = 0; i < 9; ++i) val = ln == i ? acc[i] : val;
+        float *p = ln < 9 ? dw + d * 9 + ln : dbias + d;
+        if (ln < 9 || (ln == 9 && dbias)) atomicAdd(p, val);
     }
 }
 
@@ -420,10 +423,12 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(Dw7Args a) {
             if (i < 9) acc[i] = s;
             else accb = s;
         }
-        if (tl == 0) {
+        {                                                           // ONE atomic instruction: lane i adds total i
+            float val = accb;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) atomicAdd(a.dw + d * 9 + i, acc[i]);
-            if (a.dbias) atomicAdd(a.dbias + d, accb);
+            for (int i = 0; i < 9; ++i) val = tl == i ? acc[i] : val;
+            float *p = tl < 9 ? a.dw + d * 9 + tl : a.dbias + d;
+            if (tl < 9 || (tl == 9 && a.dbias)) atomicAdd(p, val);
         }
     } else if constexpr (BWD) {
         // fold the TP partial sums of each channel through LDS (the plane buffers are free now)
