@@ -239,6 +239,12 @@ int xfm_tokens_gemm(const void *x, const void *weight_bf16, const float *bias, v
 int xfm_tokens_gemm2_supported(int con, int out);
 int xfm_tokens_gemm2(const void *x, const void *weight_bf16, const float *bias, void *y, void *y2, const void *zin, long long T,
                      int con, int out, int weight_transposed, int epilogue, void *stream);
+/* The same with epilogue 2 that ALSO leaves the column sums of dz (fc1's bias gradient, reference models/fusion_vmamba.py:135-153
+ * through autograd) as partial rows: colpart (xfm_tokens_gemm2_parts_blocks(T, con, out), out) fp32, one row per 128-token tile,
+ * every element written; 0 blocks = not available for the shape (use xfm_tokens_gemm2 + xfm_colsum). */
+int xfm_tokens_gemm2_parts_blocks(long long T, int con, int out);
+int xfm_tokens_gemm2_parts(const void *x, const void *weight_bf16, const float *bias, void *dz, const void *zin, float *colpart,
+                           long long T, int con, int out, int weight_transposed, void *stream);
 
 /*
  * The same kernel family for the layout-changing 1x1 projections of an SS2D block (in_proj: tokens -> planes, out_proj:

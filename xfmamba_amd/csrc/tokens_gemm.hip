@@ -356,6 +356,7 @@ struct TokGemm2Args {
     const uint16_t *zin;    // (T, OUT): EPI 2 the forward pass's z
     int64_t T;
     int OUT, wt, wgs_per_chunk;
+    float *colpart;         // tiled form, EPI 2: (ceil(T / 128), OUT) per-tile column sums of dz (the bias gradient's partial rows) or null
 };
 
 constexpr float kTgInvSqrt2 = 0.70710678118654752f, kTgInvSqrt2Pi = 0.3989422804014327f;
@@ -836,6 +837,9 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
             zi[i] = *reinterpret_cast<const tg_u32x4_t *>(a.zin + row * a.OUT + n0 + 8 * ck);
         }
     }
+    float csum[8];                                         // EPI 2: column sums of this thread's rows (dz as stored: bf16)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = 16 * i + rl;
@@ -870,6 +874,26 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
                 *reinterpret_cast<tg_u32x4_t *>(a.y2 + off) = o;         // g
             } else {
                 *reinterpret_cast<tg_u32x4_t *>(a.y + off) = o;          // dz
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    csum[2 * q] += __uint_as_float(o[q] << 16);
+                    csum[2 * q + 1] += __uint_as_float(o[q] & 0xffff0000u);
+                }
+            }
+        }
+    }
+    if constexpr (EPI == 2) {
+        // the bias gradient's partial row of this tile: the 16 row-lanes of a column chunk meet in LDS (past the image)
+        if (a.colpart) {
+            float *red = reinterpret_cast<float *>(g3_lds + 40960);          // [16][128]
+            *reinterpret_cast<float4 *>(red + rl * 128 + 8 * ck) = make_float4(csum[0], csum[1], csum[2], csum[3]);
+            *reinterpret_cast<float4 *>(red + rl * 128 + 8 * ck + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
+            __syncthreads();
+            if (tid < 128) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s += red[q * 128 + tid];
+                a.colpart[(int64_t)tm * a.OUT + n0 + tid] = s;
             }
         }
     }
@@ -966,7 +990,7 @@ int xfm_tokens_gemm2(const void *x, const void *weight_bf16, const float *bias, 
     if (!x || !weight_bf16 || !y || T <= 0 || epilogue < 0 || epilogue > 2) return XFM_EINVAL;
     if ((epilogue == 1 && !y2) || (epilogue == 2 && !zin)) return XFM_EINVAL;
     if (!xfm_tokens_gemm2_supported(con, out)) return XFM_ELIMIT;
-    TokGemm2Args a;
+    TokGemm2Args a{};
     a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(weight_bf16);
     a.bias = bias;
@@ -988,6 +1012,32 @@ int xfm_tokens_gemm2(const void *x, const void *weight_bf16, const float *bias, 
     if (con == 384 && out == 1536) return tokens_gemm2_epi<384, 128>(a, epilogue, s);
     if (con == 768 && out == 3072) return tokens_gemm2_epi<768, 64>(a, epilogue, s);
     return XFM_ELIMIT;
+}
+
+/* xfm_tokens_gemm2 with epilogue 2 (dz = (x W) gelu'(z + b)) that ALSO leaves the column sums of dz -- fc1's bias gradient --
+ * as partial rows: colpart (xfm_tokens_gemm2_parts_blocks(T, con, out), out) fp32, one row per 128-token tile, every
+ * element written (fold them with xfm_partial_sums_multi or a sum over rows).  0 blocks: not available for this shape. */
+int xfm_tokens_gemm2_parts_blocks(long long T, int con, int out) {
+    if (xfm::tokens_gemm2_form() != 3 || con % 32 != 0 || con < 64 || out % 128 != 0 || T <= 0) return 0;
+    return (int)((T + 127) / 128);
+}
+
+int xfm_tokens_gemm2_parts(const void *x, const void *weight_bf16, const float *bias, void *dz, const void *zin, float *colpart,
+                           long long T, int con, int out, int weight_transposed, void *stream) {
+    using namespace xfm;
+    if (!x || !weight_bf16 || !dz || !zin || !colpart || T <= 0) return XFM_EINVAL;
+    if (!xfm_tokens_gemm2_parts_blocks(T, con, out) || ((uintptr_t)x & 15) || ((uintptr_t)weight_bf16 & 15)) return XFM_ELIMIT;
+    TokGemm2Args a{};
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(weight_bf16);
+    a.bias = bias;
+    a.y = static_cast<uint16_t *>(dz);
+    a.zin = static_cast<const uint16_t *>(zin);
+    a.T = T;
+    a.OUT = out;
+    a.wt = weight_transposed ? 1 : 0;
+    a.colpart = colpart;
+    return tokens_gemm3(a, con, 2, (hipStream_t)stream);
 }
 
 int xfm_proj_gemm_supported(int con, int out, int L) {

@@ -205,14 +205,33 @@ class MlpFusedHip(torch.autograd.Function):
         dy2 = dy.reshape(-1, C)
         dy2 = dy2.contiguous() if dy2.dtype == w2c.dtype else dy2.to(w2c.dtype).contiguous()
         # d z = (dy W2) * gelu'(z + b1): fc2's weight (C, H) IS the (con, out) layout of the transposed product
-        dz, _ = _gemm2(dy2, w2c, b1, H, True, 2, zin=z)
+        # (the tiled form of the kernel also leaves the column sums of dz -- fc1's bias gradient -- as one partial row per
+        #  128-token tile: no second pass over the hidden-width tensor)
         dx = dw1 = db1 = dw2 = db2 = None
+        want_db1 = b1dt is not None and ctx.needs_input_grad[2]
+        lib = _lib.lib()
+        nblk = lib.xfm_tokens_gemm2_parts_blocks(dy2.shape[0], C, H) if want_db1 and dy2.data_ptr() % 16 == 0 else 0
+        if nblk > 0:
+            T = dy2.shape[0]
+            dz = torch.empty((T, H), dtype=dy2.dtype, device=dy2.device)
+            part = torch.empty(nblk * H, dtype=torch.float32, device=dy2.device)
+            bf = None if b1 is None else b1.float().contiguous()
+            with torch.cuda.device(dy2.device), _lib.timed("mlp_fc2_dgrad_gelu", T * (C + 2 * H) * 2):
+                _lib.check(lib.xfm_tokens_gemm2_parts(dy2.data_ptr(), w2c.data_ptr(), _lib.ptr(bf), dz.data_ptr(), z.data_ptr(),
+                                                      part.data_ptr(), T, C, H, 1, _lib.stream_ptr()), "tokens_gemm2_parts")
+            db1 = torch.empty(H, dtype=torch.float32, device=dy2.device)
+            if not _deferred.add_job(part, [db1], nblk, H, 1, params=(pb1,)):
+                db1 = part.view(nblk, H).sum(0)
+            db1 = db1.to(b1dt)
+            want_db1 = False
+        else:
+            dz, _ = _gemm2(dy2, w2c, b1, H, True, 2, zin=z)
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dz, w1c).view(xshape)
         if ctx.needs_input_grad[1]:
             slot = wgrad_slot(pw1, H, C) if w1dt == torch.float32 else None
             dw1 = split_k_wgrad(dz, x2, deferred=w1dt == torch.float32, out=slot).to(w1dt)
-        if b1dt is not None and ctx.needs_input_grad[2]:
+        if want_db1:
             db1 = colsum_fn(dz, grad_of=pb1).to(b1dt)
         if ctx.needs_input_grad[3]:
             slot = wgrad_slot(pw2, C, H) if w2dt == torch.float32 else None
