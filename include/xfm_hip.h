@@ -153,6 +153,13 @@ int xfm_layernorm2d_fwd(const void *x, const float *weight, const float *bias, v
 int xfm_layernorm2d_bwd(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,
                         void *dx, float *dweight, float *dbias, int B, int C, int L, int x_dtype, int y_dtype,
                         void *stream);
+/* The backward with the weight / bias gradient left as PARTIAL ROWS by the dx kernel (no second pass over x and dy): parts
+ * (xfm_layernorm2d_bwd_parts_blocks(B, C, L, x_dtype, y_dtype), 2, C) fp32, row pair j = [sum dy * xhat | sum dy] over the
+ * positions of workgroup j, every element written (fold with xfm_partial_sums_multi or a sum over j).  0 blocks: the kernel
+ * chosen for the shape cannot -- use xfm_layernorm2d_bwd. */
+int xfm_layernorm2d_bwd_parts_blocks(int B, int C, int L, int x_dtype, int y_dtype);
+int xfm_layernorm2d_bwd_parts(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,
+                              void *dx, float *parts, int B, int C, int L, int x_dtype, int y_dtype, void *stream);
 
 /* Residual add + DropPath scale + LayerNorm over C of a TOKEN-MAJOR stream (rows = B*rows_per_sample tokens of C
  * channels, contiguous), one pass:   x_new = x + scale[b]*y ;  h = LayerNorm_C(x_new)*weight + bias.

@@ -295,11 +295,30 @@ __global__ void __launch_bounds__(1024) ln2d_fwd_cached_kernel(const Tx *__restr
     }
 }
 
+// sums over the lanes of a wave on DPP adds: row-wise inclusive prefixes (row_shr 1, 2, 4, 8), row totals carried into the next
+// row (row_bcast:15) and, for the whole wave, into rows 2 / 3 (row_bcast:31).  HALVES: lane 31 ends with the total of lanes
+// 0..31, lane 63 with that of lanes 32..63; otherwise lane 63 with the total of all 64.
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ float ln2d_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <bool HALVES> __device__ __forceinline__ float ln2d_lane_sum(float v) {
+    v += ln2d_dpp<0x111>(v);
+    v += ln2d_dpp<0x112>(v);
+    v += ln2d_dpp<0x114>(v);
+    v += ln2d_dpp<0x118>(v);
+    v += ln2d_dpp<0x142, 0xa>(v);
+    if constexpr (!HALVES) v += ln2d_dpp<0x143, 0xc>(v);
+    return v;
+}
+
+// `parts` != null: the weight / bias gradient of the workgroup's positions as a partial row pair -- parts[(blk * 2 + k) * C + c],
+// k = 0: sum dy * xhat, k = 1: sum dy -- instead of a second kernel reading x and dy again (ln2d_bwd_wb_kernel); the rows are
+// folded by xfm_partial_sums_multi (deferred.py) or a sum over blocks.
 template <typename Tx, typename Ty, int CPT, bool HALF = false>
 __global__ void __launch_bounds__(1024) ln2d_bwd_dx_cached_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
                                                                   const Ty *__restrict__ dy, const float *__restrict__ mean,
                                                                   const float *__restrict__ rstd, Tx *__restrict__ dx,
-                                                                  int C, int L, int tiles_pb, int NW) {
+                                                                  int C, int L, int tiles_pb, int NW, float *__restrict__ parts) {
     __shared__ float red[2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = HALF ? (lane & 31) : lane, hh = HALF ? (lane >> 5) : 0;
@@ -311,15 +330,16 @@ __global__ void __launch_bounds__(1024) ln2d_bwd_dx_cached_kernel(const Tx *__re
     const int b = ok ? (int)(P / L) : 0, p = ok ? (int)(P - (int64_t)b * L) : 0;
     const int64_t o = (int64_t)b * C * L + p;
     const float mu = ok ? mean[(int64_t)b * L + p] : 0.f, rs = ok ? rstd[(int64_t)b * L + p] : 0.f;
-    float g[CPT], xh[CPT];
+    float gr[CPT], xh[CPT];                                        // RAW dy (the weight is applied at each use) and xhat
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int c = chan(j);
-        g[j] = ok ? ldf<Ty>(dy + o + (int64_t)c * L) * w[c] : 0.f;
+        gr[j] = ok ? ldf<Ty>(dy + o + (int64_t)c * L) : 0.f;
         xh[j] = ok ? (ldf<Tx>(x + o + (int64_t)c * L) - mu) * rs : 0.f;
-        s1 += g[j];
-        s2 = fmaf(g[j], xh[j], s2);
+        const float g = gr[j] * w[c];
+        s1 += g;
+        s2 = fmaf(g, xh[j], s2);
     }
     red[0][wave][lane] = s1;
     red[1][wave][lane] = s2;
@@ -333,7 +353,26 @@ __global__ void __launch_bounds__(1024) ln2d_bwd_dx_cached_kernel(const Tx *__re
     m2 /= (float)C;
     if (ok) {
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) stf<Tx>(dx + o + (int64_t)chan(j) * L, rs * (g[j] - m1 - xh[j] * m2));
+        for (int j = 0; j < CPT; ++j) {
+            const int c = chan(j);
+            stf<Tx>(dx + o + (int64_t)c * L, rs * (gr[j] * w[c] - m1 - xh[j] * m2));
+        }
+    }
+    if (parts) {                                                    // (uniform)
+        // a wave's channels over its positions: lane sums on DPP, gathered per workgroup in LDS, one coalesced row pair out
+        __shared__ float prow[2 * 1536];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const float a1 = ln2d_lane_sum<HALF>(gr[j] * xh[j]);
+            const float a2 = ln2d_lane_sum<HALF>(gr[j]);
+            if (lane == 63 || (HALF && lane == 31)) {
+                const int c = chan(j);
+                prow[c] = a1;
+                prow[C + c] = a2;
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) parts[(int64_t)blockIdx.x * 2 * C + e] = prow[e];
     }
 }
 
@@ -608,9 +647,21 @@ static int ln_fwd(const void *x, const float *w, const float *b, void *y, float 
     return check_launch();
 }
 
+// workgroups (= partial row pairs) of the register-cached dx kernels when they can emit the weight / bias gradient's partial
+// rows for this shape, else 0 (the vectorised / short / two-pass kernels do not: ln2d_bwd_wb_kernel follows them)
+static int ln2d_parts_blocks(int B, int C, int L, bool vec_path) {
+    if (C > 1536 || vec_path) return 0;
+    if (C >= 512 && (int64_t)B * L <= 16 * 1024) return 0;                         // the short-map kernel
+    if ((B * L + 63) / 64 < 256 && !getenv("XFM_LN2D_NO_HALF") && C % 24 == 0 && C / 24 <= 16) return (B * L + 31) / 32;
+    if ((C % 24 == 0 && C / 24 <= 16) || (C % 48 == 0 && C / 48 <= 16) || (C % 16 == 0 && C / 16 <= 16) ||
+        (C % 32 == 0 && C / 32 <= 16))
+        return (B * L + 63) / 64;
+    return 0;
+}
+
 template <typename Tx, typename Ty>
 static int ln_bwd(const void *x, const float *w, const void *dy, const float *mean, const float *rstd, void *dx,
-                  float *dw, float *db, int B, int C, int L, hipStream_t s) {
+                  float *dw, float *db, int B, int C, int L, hipStream_t s, float *parts = nullptr) {
     const int tiles = (L + 63) / 64;
     bool done = false;
     if constexpr (std::is_same<Tx, float>::value && std::is_same<Ty, bf16_t>::value) {
@@ -634,23 +685,23 @@ static int ln_bwd(const void *x, const float *w, const void *dy, const float *me
     } else if ((B * L + 63) / 64 < 256 && !getenv("XFM_LN2D_NO_HALF") && C % 24 == 0 && C / 24 <= 16) {
         const int NW = C / 24;
         hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 12, true>), dim3((B * L + 31) / 32), dim3(64 * NW), 0, s, (const Tx *)x, w,
-                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW, parts);
     } else if (C % 24 == 0 && C / 24 <= 16) {
         const int NW = C / 24;
         hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 24>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
-                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW, parts);
     } else if (C % 48 == 0 && C / 48 <= 16) {
         const int NW = C / 48;
         hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 48>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
-                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW, parts);
     } else if (C % 16 == 0 && C / 16 <= 16) {
         const int NW = C / 16;
         hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 16>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
-                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW, parts);
     } else if (C % 32 == 0 && C / 32 <= 16) {
         const int NW = C / 32;
         hipLaunchKernelGGL((ln2d_bwd_dx_cached_kernel<Tx, Ty, 32>), dim3((B * L + 63) / 64), dim3(64 * NW), 0, s, (const Tx *)x, w,
-                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW);
+                           (const Ty *)dy, mean, rstd, (Tx *)dx, C, L, B * L, NW, parts);
     } else {
         // (1024-channel rows, XFMamba-B stage 2: 2 x 64 values per thread do not fit the 128-register cap of a 16-wave
         //  workgroup -- measured 519 us with the spills against 183 us for the two-pass kernel below)
@@ -663,6 +714,7 @@ static int ln_bwd(const void *x, const float *w, const void *dy, const float *me
     }
     int rc = check_launch();
     if (rc) return rc;
+    if (parts) return XFM_OK;                   // (the dx kernel left the partial rows: no second pass)
     int bsplit = 2048 / C;                      // aim at >= ~2048 workgroups
     if (bsplit < 1) bsplit = 1;
     if (bsplit > B) bsplit = B;
@@ -687,6 +739,32 @@ int xfm_layernorm2d_fwd(const void *x, const float *weight, const float *bias, v
     if (x_dtype == XFM_BF16 && y_dtype == XFM_F32) return ln_fwd<bf16_t, float>(x, weight, bias, y, mean, rstd, B, C, L, eps, s);
     if (x_dtype == XFM_F16 && y_dtype == XFM_F16) return ln_fwd<f16_t, f16_t>(x, weight, bias, y, mean, rstd, B, C, L, eps, s);
     if (x_dtype == XFM_F16 && y_dtype == XFM_F32) return ln_fwd<f16_t, float>(x, weight, bias, y, mean, rstd, B, C, L, eps, s);
+    return XFM_EDTYPE;
+}
+
+/* Backward with the weight / bias gradient left as partial rows (no second pass over x and dy): parts
+ * (xfm_layernorm2d_bwd_parts_blocks(...), 2, C) fp32, row pair j = [sum dy * xhat | sum dy] over the positions of workgroup j,
+ * every element written.  0 blocks: the kernel chosen for this shape cannot (use xfm_layernorm2d_bwd). */
+static bool ln2d_takes_vec(int C, int L, int x_dtype, int y_dtype) {
+    int cpt, vp;
+    return x_dtype == XFM_F32 && y_dtype == XFM_BF16 && !getenv("XFM_LN2D_SCALAR") && xfm::ln2d_vec_plan(C, L, true, cpt, vp);
+}
+
+int xfm_layernorm2d_bwd_parts_blocks(int B, int C, int L, int x_dtype, int y_dtype) {
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    return xfm::ln2d_parts_blocks(B, C, L, ln2d_takes_vec(C, L, x_dtype, y_dtype));
+}
+
+int xfm_layernorm2d_bwd_parts(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,
+                              void *dx, float *parts, int B, int C, int L, int x_dtype, int y_dtype, void *stream) {
+    using namespace xfm;
+    if (!x || !weight || !dy || !mean || !rstd || !dx || !parts || B <= 0 || C <= 0 || L <= 0) return XFM_EINVAL;
+    if (!xfm_layernorm2d_bwd_parts_blocks(B, C, L, x_dtype, y_dtype)) return XFM_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == XFM_F32 && y_dtype == XFM_F32) return ln_bwd<float, float>(x, weight, dy, mean, rstd, dx, nullptr, nullptr, B, C, L, s, parts);
+    if (x_dtype == XFM_F32 && y_dtype == XFM_BF16) return ln_bwd<float, bf16_t>(x, weight, dy, mean, rstd, dx, nullptr, nullptr, B, C, L, s, parts);
+    if (x_dtype == XFM_BF16 && y_dtype == XFM_BF16) return ln_bwd<bf16_t, bf16_t>(x, weight, dy, mean, rstd, dx, nullptr, nullptr, B, C, L, s, parts);
+    if (x_dtype == XFM_BF16 && y_dtype == XFM_F32) return ln_bwd<bf16_t, float>(x, weight, dy, mean, rstd, dx, nullptr, nullptr, B, C, L, s, parts);
     return XFM_EDTYPE;
 }
 

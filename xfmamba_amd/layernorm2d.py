@@ -6,12 +6,17 @@ permute -> ``F.layer_norm`` -> permute).  The output may be emitted directly in 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
+from . import deferred as _deferred
 from .proj import zeros_f32
 
 __all__ = ["layernorm2d_fn", "LayerNorm2dHip"]
+
+_PARTS = os.environ.get("XFM_LN2D_PARTS", "1") == "1"     # weight / bias gradient as partial rows of the dx kernel
 
 
 class LayerNorm2dHip(torch.autograd.Function):
@@ -34,6 +39,7 @@ class LayerNorm2dHip(torch.autograd.Function):
                                                       _lib.dtype_code(out_dtype), _lib.stream_ptr()), "layernorm2d_fwd")
         ctx.save_for_backward(x, w, mean, rstd)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)                        # (identity only: what deferred.add_job checks)
         ctx.wdtype = weight.dtype
         ctx.ydtype = out_dtype
         return y
@@ -47,6 +53,22 @@ class LayerNorm2dHip(torch.autograd.Function):
         if dy.dtype != ctx.ydtype:
             dy = dy.to(ctx.ydtype)
         dx = torch.empty_like(x)
+        lib = _lib.lib()
+        xc, yc = _lib.dtype_code(x.dtype), _lib.dtype_code(ctx.ydtype)
+        nblk = lib.xfm_layernorm2d_bwd_parts_blocks(B, C, L, xc, yc) if ctx.has_bias and _PARTS else 0
+        if nblk > 0:
+            # the dx kernel leaves the weight / bias gradient as one partial row pair per workgroup: no second kernel reading x and
+            # dy again; folded with all the other column sums of the step (deferred.py) or summed here
+            part = torch.empty(nblk * 2 * C, dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device), _lib.timed("layernorm2d_bwd", x.numel() * (2 * x.element_size() + dy.element_size())):
+                _lib.check(lib.xfm_layernorm2d_bwd_parts(x.data_ptr(), w.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                         dx.data_ptr(), part.data_ptr(), B, C, L, xc, yc, _lib.stream_ptr()),
+                           "layernorm2d_bwd_parts")
+            dw, db = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
+            if not _deferred.add_job(part, [dw, db], nblk, C, 2, params=ctx.params):
+                pr = part.view(nblk, 2, C).sum(0)
+                dw, db = pr[0], pr[1]
+            return dx, dw.to(ctx.wdtype), db.to(ctx.wdtype), None, None
         acc = zeros_f32(2 * w.numel() if ctx.has_bias else w.numel(), w.device)
         dw = acc[:w.numel()]                                             # one fill for both accumulators
         db = acc[w.numel():] if ctx.has_bias else None
