@@ -481,7 +481,7 @@ template <int CPT, int VP>
 __global__ void __launch_bounds__(1024) ln2d_bwd_dx_vec_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                const bf16_t *__restrict__ dy, const float *__restrict__ mean,
                                                                const float *__restrict__ rstd, float *__restrict__ dx, int C,
-                                                               int L, int64_t NP) {
+                                                               int L, int64_t NP, float *__restrict__ parts) {
     constexpr int NW = 16;
     __shared__ float red[2][NW][64 * VP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(1024) ln2d_bwd_dx_vec_kernel(const float *__re
     float mu[VP], rs[VP];
     ldv_f32<VP>(mean + (int64_t)b * L + p, mu);
     ldv_f32<VP>(rstd + (int64_t)b * L + p, rs);
-    float g[CPT][VP], xh[CPT][VP], s1[VP], s2[VP];
+    float g[CPT][VP], xh[CPT][VP], s1[VP], s2[VP];            // g: RAW dy (the weight is applied at each use)
 #pragma unroll
     for (int i = 0; i < VP; ++i) s1[i] = s2[i] = 0.f;
 #pragma unroll
@@ -504,10 +504,10 @@ __global__ void __launch_bounds__(1024) ln2d_bwd_dx_vec_kernel(const float *__re
         ldv_f32<VP>(x + o + (int64_t)c * L, xh[j]);
 #pragma unroll
         for (int i = 0; i < VP; ++i) {
-            g[j][i] *= wc;
-            xh[j][i] = (xh[j][i] - mu[i]) * rs[i];
-            s1[i] += g[j][i];
-            s2[i] = fmaf(g[j][i], xh[j][i], s2[i]);
+            if (!ok) g[j][i] = 0.f;
+            xh[j][i] = ok ? (xh[j][i] - mu[i]) * rs[i] : 0.f;
+            s1[i] = fmaf(g[j][i], wc, s1[i]);
+            s2[i] = fmaf(g[j][i] * wc, xh[j][i], s2[i]);
         }
     }
     stv_f32<VP>(&red[0][wave][lane * VP], s1);
@@ -528,11 +528,32 @@ __global__ void __launch_bounds__(1024) ln2d_bwd_dx_vec_kernel(const float *__re
     if (ok) {
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
+            const float wc = w[wave + j * NW];
             float t[VP];
 #pragma unroll
-            for (int i = 0; i < VP; ++i) t[i] = rs[i] * (g[j][i] - s1[i] / (float)C - xh[j][i] * (s2[i] / (float)C));
+            for (int i = 0; i < VP; ++i) t[i] = rs[i] * (g[j][i] * wc - s1[i] / (float)C - xh[j][i] * (s2[i] / (float)C));
             stv_f32<VP>(dx + o + (int64_t)(wave + j * NW) * L, t);
         }
+    }
+    if (parts) {                                                    // (uniform) see ln2d_bwd_dx_cached_kernel
+        __shared__ float prow[2 * 16 * CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < VP; ++i) {
+                p1 = fmaf(g[j][i], xh[j][i], p1);
+                p2 += g[j][i];
+            }
+            p1 = ln2d_lane_sum<false>(p1);
+            p2 = ln2d_lane_sum<false>(p2);
+            if (lane == 63) {
+                prow[wave + j * NW] = p1;
+                prow[C + wave + j * NW] = p2;
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * C; e += 1024) parts[(int64_t)blockIdx.x * 2 * C + e] = prow[e];
     }
 }
 
@@ -647,10 +668,15 @@ static int ln_fwd(const void *x, const float *w, const float *b, void *y, float 
     return check_launch();
 }
 
-// workgroups (= partial row pairs) of the register-cached dx kernels when they can emit the weight / bias gradient's partial
-// rows for this shape, else 0 (the vectorised / short / two-pass kernels do not: ln2d_bwd_wb_kernel follows them)
+// workgroups (= partial row pairs) of the register-cached / vectorised dx kernels when they can emit the weight / bias gradient's
+// partial rows for this shape, else 0 (the short-map / two-pass kernels do not: ln2d_bwd_wb_kernel follows them)
 static int ln2d_parts_blocks(int B, int C, int L, bool vec_path) {
-    if (C > 1536 || vec_path) return 0;
+    if (vec_path) {                                                 // fp32 maps / bf16 gradients: the vectorised kernels
+        int cpt, vp;
+        if (!ln2d_vec_plan(C, L, true, cpt, vp)) return 0;
+        return (int)(((int64_t)B * L / vp + 63) / 64);
+    }
+    if (C > 1536) return 0;
     if (C >= 512 && (int64_t)B * L <= 16 * 1024) return 0;                         // the short-map kernel
     if ((B * L + 63) / 64 < 256 && !getenv("XFM_LN2D_NO_HALF") && C % 24 == 0 && C / 24 <= 16) return (B * L + 31) / 32;
     if ((C % 24 == 0 && C / 24 <= 16) || (C % 48 == 0 && C / 48 <= 16) || (C % 16 == 0 && C / 16 <= 16) ||
@@ -672,8 +698,8 @@ static int ln_bwd(const void *x, const float *w, const void *dy, const float *me
             const float *xf = (const float *)x;
             const bf16_t *dyb = (const bf16_t *)dy;
             float *dxf = (float *)dx;
-            if (cpt == 6) hipLaunchKernelGGL((ln2d_bwd_dx_vec_kernel<6, 4>), grid, block, 0, s, xf, w, dyb, mean, rstd, dxf, C, L, NP);
-            else hipLaunchKernelGGL((ln2d_bwd_dx_vec_kernel<12, 2>), grid, block, 0, s, xf, w, dyb, mean, rstd, dxf, C, L, NP);
+            if (cpt == 6) hipLaunchKernelGGL((ln2d_bwd_dx_vec_kernel<6, 4>), grid, block, 0, s, xf, w, dyb, mean, rstd, dxf, C, L, NP, parts);
+            else hipLaunchKernelGGL((ln2d_bwd_dx_vec_kernel<12, 2>), grid, block, 0, s, xf, w, dyb, mean, rstd, dxf, C, L, NP, parts);
             done = true;
         }
     }
