@@ -701,7 +701,13 @@ class VSSM(nn.Module):
         """patch_embed (conv s2 -> LN -> GELU -> conv s2 -> LN) -> fp32 tokens (B, H/4, W/4, C0)."""
         pe = self.patch_embed
         act_dtype = _tokens_dtype(pe[0].weight)
-        t = x.permute(0, 2, 3, 1).contiguous()                  # (B, H, W, 3): a channels_last image
+        if x.shape[1] > 1 and x.stride(1) == 0 and act_dtype is not None and not x.requires_grad:
+            # the image is a stride-0 broadcast of ONE channel (net_fusionmamba.py: x.expand(-1, 3, -1, -1)): cast the single
+            # channel to the convolution's dtype first and replicate it as the LAST step -- 6 + 19 MB moved instead of a 77 MB
+            # transposing copy of the broadcast followed by autocast's 58 MB cast
+            t = x[:, 0].unsqueeze(-1).to(act_dtype).expand(-1, -1, -1, x.shape[1]).contiguous()
+        else:
+            t = x.permute(0, 2, 3, 1).contiguous()              # (B, H, W, 3): a channels_last image
         t = _conv_ln_tokens(pe[0], pe[2], t, act_dtype)         # norm output feeds GELU -> conv: the conv's dtype
         if isinstance(pe[4], nn.GELU) and getattr(pe[4], "approximate", "none") == "none" and t.is_cuda \
                 and t.dtype in (torch.float32, torch.bfloat16) and t.shape[-1] % 8 == 0:
