@@ -826,7 +826,11 @@ def test_tokens_gemm_linear_matches_torch(T, K, N, bias):
 @pytest.mark.gpu
 @pytest.mark.parametrize("in_tokens,out_tokens", [(True, False), (False, True)])
 @pytest.mark.parametrize("bias", [False, True])
-@pytest.mark.parametrize("B,L,C", [(5, 1024, 96), (8, 784, 192), (128, 40, 96)])     # (128, 40): samples end inside tiles
+@pytest.mark.parametrize("B,L,C", [(5, 1024, 96), (8, 784, 192), (128, 40, 96),      # (128, 40): samples end inside tiles
+                                   # the tiled form (per-sample tiles of 128 positions, LDS-direct operand ring): the 14 x 14 stage
+                                   # (196 = 128 + 68: a ragged second tile whose last 16-byte chunk straddles the row end), a
+                                   # second tile of 4 positions, whole tiles only
+                                   (32, 196, 384), (32, 132, 128), (64, 64, 256)])
 def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias, B, L, C):
     """in_proj / out_proj of the 56x56 stage through xfm_proj_gemm (tokens -> planes, planes -> tokens; the backward data
     product is the same kernel with the roles swapped and the weight staged transposed) against an fp32 einsum."""

@@ -918,6 +918,251 @@ static int tokens_gemm3_launch(const TokGemm2Args &a, int con, hipStream_t s) {
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The tiled form for the LAYOUT-CHANGING projections of an SS2D block (in_proj: tokens -> planes, out_proj: planes -> tokens,
+// and their data gradients; reference models/fusion_vmamba.py:1190-1206 `Linear2d` / permutes): y[b] = W x[b] with one side
+// token-major (B, L, C) and the other plane-major (B, C, L).  Tiles are cut PER SAMPLE (a plane row of L positions is
+// contiguous only inside its sample): sample b, positions 128 lt .. + 127 (the last tile of a sample is ragged: 196 = 128 +
+// 68), 128 output channels.
+//   PIN (planes in, tokens out): the x tile is staged k-major -- [64 k][128 positions], rows of 256 bytes in the chunk-XOR
+//     image -- and read with ds_read_b64_tr_b16 (column = position); the 16-byte chunks that start past L read a zero page
+//     (a chunk that straddles L brings the next channel row's first positions into columns that are never stored).
+//   !PIN (tokens in, planes out): x as in the token -> token kernel; the accumulators D[n][t] (lane = position) leave by
+//     2-byte stores straight from registers: for one channel 32 lanes = 64 contiguous bytes of its plane row.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ProjTiledArgs {
+    const uint16_t *x, *w;
+    const float *bias;
+    uint16_t *y;
+    int B, L, CON, OUT, ltiles, ntn, ntiles;
+};
+
+template <bool PIN, bool WT>
+__global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs a) {
+    extern __shared__ __align__(16) uint8_t g3_lds[];      // 2 stages (64 KB) | bias (512 B); the token-major output image overlays
+    float *bl = reinterpret_cast<float *>(g3_lds + 2 * kG3Stage);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int vid = (blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (vid >= a.ntiles) return;
+    const int tn = vid % a.ntn, tm = vid / a.ntn;
+    const int b = tm / a.ltiles, l0 = (tm - b * a.ltiles) * 128;
+    const int n0 = tn * 128, L = a.L, CON = a.CON;
+    if (tid < 128) bl[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+    const int wm = wave >> 1, wn = wave & 1;               // wave -> outputs 64 wm .., positions 64 wn ..
+    const uint16_t *zp = reinterpret_cast<const uint16_t *>(g3_zero_page);
+    // ---- global side of the LDS-direct loads
+    const uint16_t *gx[4], *gw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (!PIN) {                              // x tile [128 positions][64 k]
+            const int row = 8 * (4 * wave + i) + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+            const int l = min(l0 + row, L - 1);
+            gx[i] = a.x + ((int64_t)b * L + l) * CON + 8 * ch;
+        } else {                                           // x tile [64 k][128 positions]: rows 4 (4 wave + i) .. + 3
+            const int kr = 4 * (4 * wave + i) + (lane >> 4);
+            const int cw = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+            // a chunk that straddles L is read 8 - Lrem % 8 positions EARLIER (inside the row: nothing is read past the tensor);
+            // its columns then hold positions Lrem - 8 .. Lrem - 1, which the epilogue's row map undoes
+            const int lrem = L - l0, lc = 8 * cw;
+            const int ls = lc + 8 <= lrem ? lc : lrem - 8;
+            gx[i] = lc < lrem ? a.x + ((int64_t)b * CON + kr) * L + l0 + ls : nullptr;
+        }
+        if constexpr (!WT) {
+            const int row = 8 * (4 * wave + i) + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+            gw[i] = a.w + (int64_t)(n0 + row) * CON + 8 * ch;
+        } else {
+            const int kr = 4 * (4 * wave + i) + (lane >> 4);
+            const int cw = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+            gw[i] = a.w + (int64_t)kr * a.OUT + n0 + 8 * cw;
+        }
+    }
+    const int NST = CON / 64;
+    auto issue_part = [&](const int st, const int i) {
+        uint8_t *dst = g3_lds + (st & 1) * kG3Stage + (4 * wave + i) * 1024;
+        const uint16_t *px;
+        if constexpr (!PIN) px = gx[i] + 64 * st;
+        else px = gx[i] ? gx[i] + (int64_t)64 * st * L : zp;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)px,
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        const uint16_t *pw = WT ? gw[i] + (int64_t)64 * st * a.OUT : gw[i] + 64 * st;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pw,
+                                         (__attribute__((address_space(3))) void *)(dst + kG3Half), 16, 0, 0);
+    };
+    // ---- fragment addresses (stage buffer 0)
+    const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)g3_lds;
+    const int c = lane & 31, kb = lane >> 5;
+    uint32_t ax[2][4], aw[2][4];                           // k-contiguous images: [32-row block][k16-step]; k-major: [block][lo, hi]
+    {
+        const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+        const int r0 = 8 * (g >> 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (!PIN) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) ax[j][s4] = base + g3_off(wn * 64 + j * 32 + c, 2 * s4 + kb);
+            } else {
+                const int ct = wn * 64 + j * 32, c0 = (ct + 16 * (g & 1)) >> 3;
+                ax[j][0] = base + g3_tok_off(r0 + q, c0 + (p >> 1)) + 8 * (p & 1);
+                ax[j][1] = base + g3_tok_off(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1);
+                ax[j][2] = ax[j][3] = 0;
+            }
+            if constexpr (!WT) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) aw[j][s4] = base + kG3Half + g3_off(wm * 64 + j * 32 + c, 2 * s4 + kb);
+            } else {
+                const int ct = wm * 64 + j * 32, c0 = (ct + 16 * (g & 1)) >> 3;
+                aw[j][0] = base + kG3Half + g3_tok_off(r0 + q, c0 + (p >> 1)) + 8 * (p & 1);
+                aw[j][1] = base + kG3Half + g3_tok_off(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1);
+                aw[j][2] = aw[j][3] = 0;
+            }
+        }
+    }
+    tg_f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_part(0, i);
+    for (int st = 0; st < NST; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more = st + 1 < NST;
+        const uint32_t so = (st & 1) * kG3Stage;
+        tg_u32x4_t xf[2][2], wf[2][2];
+        g3_bf16x4_t xlo[2][2], xhi[2][2], wlo[2][2], whi[2][2];
+        auto frags = [&](const int ring, auto sc) {
+            constexpr int S = decltype(sc)::value;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (!PIN) g3_read16<0>(xf[ring][j], ax[j][S] + so);
+                else {
+                    g3_read_tr<4096 * S>(xlo[ring][j], ax[j][0] + so);
+                    g3_read_tr<4096 * S>(xhi[ring][j], ax[j][1] + so);
+                }
+                if constexpr (!WT) g3_read16<0>(wf[ring][j], aw[j][S] + so);
+                else {
+                    g3_read_tr<4096 * S>(wlo[ring][j], aw[j][0] + so);
+                    g3_read_tr<4096 * S>(whi[ring][j], aw[j][1] + so);
+                }
+            }
+        };
+        constexpr int NRD = (PIN ? 4 : 2) + (WT ? 4 : 2);  // LDS reads of one k16-step
+        auto k16 = [&](auto sc) {
+            constexpr int S = decltype(sc)::value, r = S & 1;
+            if constexpr (S + 1 < 4) frags(r ^ 1, std::integral_constant<int, S + 1>{});
+            if (more) issue_part(st + 1, S);
+            if constexpr (S + 1 < 4) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tg_bf16x8_t wop[2], xop[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (!PIN) {
+                    asm volatile("" : "+v"(xf[r][j]));
+                    xop[j] = __builtin_bit_cast(tg_bf16x8_t, xf[r][j]);
+                } else {
+                    asm volatile("" : "+v"(xlo[r][j]), "+v"(xhi[r][j]));
+                    xop[j] = __builtin_shufflevector(xlo[r][j], xhi[r][j], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                if constexpr (!WT) {
+                    asm volatile("" : "+v"(wf[r][j]));
+                    wop[j] = __builtin_bit_cast(tg_bf16x8_t, wf[r][j]);
+                } else {
+                    asm volatile("" : "+v"(wlo[r][j]), "+v"(whi[r][j]));
+                    wop[j] = __builtin_shufflevector(wlo[r][j], whi[r][j], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop[i], xop[j], acc[i][j], 0, 0, 0);
+        };
+        frags(0, std::integral_constant<int, 0>{});
+        k16(std::integral_constant<int, 0>{});
+        k16(std::integral_constant<int, 1>{});
+        k16(std::integral_constant<int, 2>{});
+        k16(std::integral_constant<int, 3>{});
+    }
+    const int h = kb;
+    if constexpr (!PIN) {
+        // ---- planes out: D[n][position]: for one register 32 lanes hold 32 consecutive positions of one channel's plane row
+        __syncthreads();                                   // (bias)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int l = l0 + wn * 64 + j * 32 + c;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int nl = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    if (l < L)
+                        a.y[((int64_t)b * a.OUT + n0 + nl) * L + l] = (uint16_t)(pack_bf16x2(acc[i][j][v] + bl[nl], 0.f) & 0xffffu);
+                }
+            }
+    } else {
+        // ---- tokens out: through the image [128 positions][136], whole rows (as the token -> token kernel)
+        __builtin_amdgcn_s_barrier();
+        constexpr int SP = 136;
+        uint16_t *img = reinterpret_cast<uint16_t *>(g3_lds);
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t pk[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(bl + wm * 64 + i * 32 + 8 * g + 4 * h);
+                    pk[g][0] = pack_bf16x2(acc[i][j][4 * g] + bv.x, acc[i][j][4 * g + 1] + bv.y);
+                    pk[g][1] = pack_bf16x2(acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const u32x2_t r = __builtin_amdgcn_permlane32_swap(pk[g][q], pk[g + 1][q], false, false);
+                        pk[g][q] = r[0];
+                        pk[g + 1][q] = r[1];
+                    }
+                tg_u32x4_t v0, v1;
+                v0[0] = pk[0][0]; v0[1] = pk[0][1]; v0[2] = pk[1][0]; v0[3] = pk[1][1];
+                v1[0] = pk[2][0]; v1[1] = pk[2][1]; v1[2] = pk[3][0]; v1[3] = pk[3][1];
+                uint16_t *row = img + (wn * 64 + j * 32 + c) * SP + wm * 64 + i * 32;
+                *reinterpret_cast<tg_u32x4_t *>(row + 8 * h) = v0;
+                *reinterpret_cast<tg_u32x4_t *>(row + 16 + 8 * h) = v1;
+            }
+        __syncthreads();
+        const int ck = tid & 15, rl = tid >> 4;
+        const int lrem = L - l0, tail0 = lrem & ~7, shift = (8 - (lrem & 7)) & 7;     // (see the straddling chunk above)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 16 * i + rl;
+            const int lr = (shift && r >= tail0) ? r - shift : r;               // position this image row holds
+            if (lr < 0 || lr >= lrem || r >= tail0 + 8) continue;
+            const tg_u32x4_t v = *reinterpret_cast<const tg_u32x4_t *>(img + r * SP + 8 * ck);
+            *reinterpret_cast<tg_u32x4_t *>(a.y + ((int64_t)b * L + l0 + lr) * a.OUT + n0 + 8 * ck) = v;
+        }
+    }
+}
+
+template <bool PIN, bool WT> static int proj_tiled_launch(ProjTiledArgs a, hipStream_t s) {
+    const size_t lds = 2 * kG3Stage + 512;
+    auto fn = proj_tiled_kernel<PIN, WT>;
+    static bool opted = false;
+    if (!opted) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return XFM_ELAUNCH;
+        opted = true;
+    }
+    a.ltiles = (a.L + 127) / 128;
+    a.ntn = a.OUT / 128;
+    a.ntiles = a.B * a.ltiles * a.ntn;
+    hipLaunchKernelGGL(fn, dim3((unsigned)((a.ntiles + 7) / 8 * 8)), dim3(256), lds, s, a);
+    return check_launch();
+}
+
 int tokens_gemm2_form() {
     static const int form = [] { const char *e = getenv("XFM_GEMM2_FORM"); return e ? atoi(e) : 3; }();
     return form;
@@ -1040,8 +1285,14 @@ int xfm_tokens_gemm2_parts(const void *x, const void *weight_bf16, const float *
     return tokens_gemm3(a, con, 2, (hipStream_t)stream);
 }
 
+static int proj_tiled_ok(int con, int out, int L) {
+    static const bool on = [] { const char *e = getenv("XFM_PROJ_TILED"); return !e || atoi(e) != 0; }();
+    return on && con >= 64 && con % 64 == 0 && out % 128 == 0 && L >= 64 && L % 4 == 0;
+}
+
 int xfm_proj_gemm_supported(int con, int out, int L) {
-    return (((con == 96 && out == 96) || (con == 192 && out == 192)) && L > 0 && L % 8 == 0) ? 1 : 0;
+    if (((con == 96 && out == 96) || (con == 192 && out == 192)) && L > 0 && L % 8 == 0) return 1;
+    return proj_tiled_ok(con, out, L);
 }
 
 int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, int B, int L, int con, int out,
@@ -1049,6 +1300,15 @@ int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, voi
     using namespace xfm;
     if (!x || !weight_bf16 || !y || B <= 0) return XFM_EINVAL;
     if (!xfm_proj_gemm_supported(con, out, L) || ((int64_t)B * L) % 32 != 0) return XFM_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    if (!((con == 96 && out == 96) || (con == 192 && out == 192))) {      // the tiled form (csrc: proj_tiled_kernel)
+        if (((uintptr_t)x | (uintptr_t)weight_bf16 | (uintptr_t)y) & 15) return XFM_EINVAL;
+        ProjTiledArgs t{};
+        t.x = static_cast<const uint16_t *>(x); t.w = static_cast<const uint16_t *>(weight_bf16); t.bias = bias;
+        t.y = static_cast<uint16_t *>(y); t.B = B; t.L = L; t.CON = con; t.OUT = out;
+        if (in_planes) return weight_transposed ? proj_tiled_launch<true, true>(t, s) : proj_tiled_launch<true, false>(t, s);
+        return weight_transposed ? proj_tiled_launch<false, true>(t, s) : proj_tiled_launch<false, false>(t, s);
+    }
     TokGemmArgs a;
     a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(weight_bf16);
@@ -1057,7 +1317,6 @@ int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, voi
     a.T = (int64_t)B * L;
     a.wt = weight_transposed;
     a.L = L;
-    hipStream_t s = (hipStream_t)stream;
     if (con == 96) return in_planes ? proj_gemm_launch<96, 96, true>(a, s) : proj_gemm_launch<96, 96, false>(a, s);
     return in_planes ? proj_gemm_launch<192, 192, true>(a, s) : proj_gemm_launch<192, 192, false>(a, s);
 }
