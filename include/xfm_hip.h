@@ -263,6 +263,10 @@ int xfm_tokens_gemm2_parts(const void *x, const void *weight_bf16, const float *
 int xfm_proj_gemm_supported(int con, int out, int L);
 int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, int B, int L, int con, int out,
                   int in_planes, int weight_transposed, void *stream);
+/* tokens -> planes with accumulation, y (B, out, L) += W . x (B, L, con): the x_proj data gradient of a channel-lane SS2D
+ * block (dx += Wx^T . d x_dbl^T); tiled form only: con % 64 == 0, out % 128 == 0, L % 4 == 0, L >= 64. */
+int xfm_proj_gemm_accumulate(const void *x, const void *weight_bf16, void *y, int B, int L, int con, int out,
+                             int weight_transposed, void *stream);
 
 /*
  * Plane-major on both sides: y (B, out, L) = W . x (B, con, L), or y += W . x when accumulate != 0 (the existing bf16

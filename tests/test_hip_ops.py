@@ -862,6 +862,34 @@ def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias, B, L, C)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,L,D,XC", [(32, 196, 384, 128), (24, 196, 384, 128), (32, 132, 256, 128)])
+def test_tiled_xproj_forward_and_accumulating_backward(B, L, D, XC):
+    """x_proj of a channel-lane SS2D block at 14 x 14 on the tiled form: planes -> tokens (D -> XC) through xfm_proj_gemm,
+    and its data gradient dx += Wx^T . d x_dbl^T (tokens -> planes, XC -> D) through xfm_proj_gemm_accumulate, against
+    fp32 matmuls; the accumulation adds in fp32 and rounds once, so it is compared with (dx0 + product) rounded to bf16."""
+    from xfmamba_amd import _lib
+    from xfmamba_amd.proj import _mfma_proj
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, D, L, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(XC, D, generator=g) / D ** 0.5).to(torch.bfloat16).to(DEV)
+    y = _mfma_proj(x, w, None, False, True, False)
+    assert y is not None and y.shape == (B, L, XC)
+    yr = torch.einsum("cd,bdl->blc", w.float(), x.float())
+    assert_close(y.float().cpu(), yr.cpu(), 1e-2, 1e-2 * float(yr.abs().max()), "x_dbl")
+    dy = torch.randn(B, L, XC, generator=g).to(torch.bfloat16).to(DEV)
+    dx0 = torch.randn(B, D, L, generator=g).to(torch.bfloat16).to(DEV)
+    dx = dx0.clone()
+    lib = _lib.lib()
+    assert lib.xfm_proj_gemm_supported(XC, D, L)
+    _lib.check(lib.xfm_proj_gemm_accumulate(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, L, XC, D, 1, _lib.stream_ptr()),
+               "proj_gemm_accumulate")
+    ref = dx0.float() + torch.einsum("cd,blc->bdl", w.float(), dy.float())
+    assert_close(dx.float().cpu(), ref.cpu(), 1e-2, 1e-2 * float(ref.abs().max()), "dx")
+    # shapes outside the tiled form are refused, not computed some other way
+    assert lib.xfm_proj_gemm_accumulate(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, L, 96, 96, 1, _lib.stream_ptr()) != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,L", [(4, 3136), (128, 40)])
 def test_planes_gemm_xproj_forward_and_accumulating_backward(B, L):
     """x_proj on the natural map at the 56x56 stage (planes -> planes, 96 -> 32) and its backward data product

@@ -935,6 +935,7 @@ struct ProjTiledArgs {
     const float *bias;
     uint16_t *y;
     int B, L, CON, OUT, ltiles, ntn, ntiles;
+    int accumulate;         // planes out: y += W x (the existing bf16 values are widened, added in fp32 and rounded once)
 };
 
 template <bool PIN, bool WT>
@@ -1097,8 +1098,12 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int nl = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                    if (l < L)
-                        a.y[((int64_t)b * a.OUT + n0 + nl) * L + l] = (uint16_t)(pack_bf16x2(acc[i][j][v] + bl[nl], 0.f) & 0xffffu);
+                    if (l < L) {
+                        uint16_t *dst = a.y + ((int64_t)b * a.OUT + n0 + nl) * L + l;
+                        float val = acc[i][j][v] + bl[nl];
+                        if (a.accumulate) val += __uint_as_float((uint32_t)*dst << 16);
+                        *dst = (uint16_t)(pack_bf16x2(val, 0.f) & 0xffffu);
+                    }
                 }
             }
     } else {
@@ -1319,6 +1324,22 @@ int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, voi
     a.L = L;
     if (con == 96) return in_planes ? proj_gemm_launch<96, 96, true>(a, s) : proj_gemm_launch<96, 96, false>(a, s);
     return in_planes ? proj_gemm_launch<192, 192, true>(a, s) : proj_gemm_launch<192, 192, false>(a, s);
+}
+
+/* tokens -> planes with accumulation: y (B, out, L) += W . x (B, L, con) -- the x_proj data gradient of a channel-lane SS2D
+ * block, dx += Wx^T . d x_dbl^T (reference models/fusion_vmamba.py:1150-1152 through autograd), on the tiled form only
+ * (xfm_proj_gemm_supported(con, out, L) with con % 64 == 0, out % 128 == 0). */
+int xfm_proj_gemm_accumulate(const void *x, const void *weight_bf16, void *y, int B, int L, int con, int out,
+                             int weight_transposed, void *stream) {
+    using namespace xfm;
+    if (!x || !weight_bf16 || !y || B <= 0) return XFM_EINVAL;
+    if (!proj_tiled_ok(con, out, L)) return XFM_ELIMIT;
+    if (((uintptr_t)x | (uintptr_t)weight_bf16) & 15) return XFM_EINVAL;
+    ProjTiledArgs t{};
+    t.x = static_cast<const uint16_t *>(x); t.w = static_cast<const uint16_t *>(weight_bf16);
+    t.y = static_cast<uint16_t *>(y); t.B = B; t.L = L; t.CON = con; t.OUT = out; t.accumulate = 1;
+    hipStream_t s = (hipStream_t)stream;
+    return weight_transposed ? proj_tiled_launch<false, true>(t, s) : proj_tiled_launch<false, false>(t, s);
 }
 
 /* planes -> planes: y (B, out, L) (+)= W . x (B, con, L); (con, out) = (96, 32): x_proj of the 56x56 stage on the natural

@@ -39,6 +39,9 @@ def _col_layout(R: int, N: int):
     return Rp8, NBo, C2p, idx
 
 
+# x_proj (and its accumulating data gradient) on the tiled layout-changing kernel where it covers the shape; 0: the library
+_XPROJ_TILED = os.environ.get("XFM_XPROJ_TILED", "1") == "1"
+
 _IDX_CACHE = {}
 
 
@@ -115,7 +118,11 @@ class SS2DChanHip(torch.autograd.Function):
                 xw_pad = padded(cast_weight(x_proj_w, x.dtype)).contiguous()
                 if plain and isinstance(x_proj_w, torch.nn.Parameter):
                     _amp.adopt_padded(x_proj_w, xw_pad.view(K, C2p, Dm))
-            xdbl = torch.bmm(x.transpose(1, 2), xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC))     # (B, L, XC) token-major
+            from .proj import _mfma_proj
+            # (the tiled layout-changing projection where it covers the shape -- 14 x 14: 384 -> 128 -- else the library)
+            xdbl = _mfma_proj(x, xw_pad, None, False, True, False) if _XPROJ_TILED else None      # (B, L, XC) token-major
+            if xdbl is None:
+                xdbl = torch.bmm(x.transpose(1, 2), xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC))
         A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
         lib = _lib.lib()
         nst = lib.xfm_ss2dc_nsteps(H, W, N)
@@ -169,7 +176,17 @@ class SS2DChanHip(torch.autograd.Function):
             _lib.check(lib.xfm_ss2dc_post(ddts.data_ptr(), xdbl.data_ptr(), wdt.data_ptr(), dBC.data_ptr(), dxdbl.data_ptr(),
                                           dwdt.data_ptr(), Bt, Dm, L, R, N, _lib.stream_ptr()), "ss2dc_post")
         # x_proj backward on the natural map
-        dx.baddbmm_(xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC), dxdbl.transpose(1, 2))   # dx += Wx^T . d x_dbl^T
+        lib2 = _lib.lib()
+        if (_XPROJ_TILED and XC % 64 == 0 and Dm % 128 == 0 and Bt * L >= 4096 and lib2.xfm_proj_gemm_supported(XC, Dm, L)
+                and xw_pad.dtype == torch.bfloat16 and dxdbl.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16
+                and dx.is_contiguous()
+                and dxdbl.data_ptr() % 16 == 0 and xw_pad.data_ptr() % 16 == 0 and xw_pad.is_contiguous()):
+            # dx += Wx^T . d x_dbl^T: tokens in, planes out, accumulating; xw_pad (XC, D) IS the (con, out) layout
+            with torch.cuda.device(dev), _lib.timed("proj_gemm", Bt * L * (XC + 2 * Dm) * 2):
+                _lib.check(lib2.xfm_proj_gemm_accumulate(dxdbl.data_ptr(), xw_pad.data_ptr(), dx.data_ptr(), Bt, L, XC, Dm, 1,
+                                                         _lib.stream_ptr()), "proj_gemm_accumulate")
+        else:
+            dx.baddbmm_(xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC), dxdbl.transpose(1, 2))   # dx += Wx^T . d x_dbl^T
         dxw_pad = wgrad_mfma(dxdbl, False, x, True)                                       # (XC, D) fp32
         if dxw_pad is None:
             dxw_pad = _bmm_f32(dxdbl.transpose(1, 2), x.transpose(1, 2)).sum(0)
