@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--wgrad-stream", action="store_true",
                     help="weight-gradient kernels on a side stream = a parallel branch of the graph (measured: 1520 vs 1571 "
                          "samples/s on the main stream -- the branch competes for the CUs it was meant to fill; off by default)")
+    ap.add_argument("--aten-profile", action="store_true", help="development: after the warm-up, one eager step under "
+                    "torch.profiler; prints the framework (aten) operators that still launch kernels, by input shapes and "
+                    "innermost package frame, to stderr")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave MIOpen's default solver heuristics (default: "
                     "torch.backends.cudnn.benchmark = True, i.e. MIOpen's own find pass during warm-up; +5 %% measured)")
@@ -96,6 +99,27 @@ def cpu_baseline(batch=2, size=224):
     return dict(value=batch / dt, unit="two-view samples/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{nstep} fwd+bwd steps, XFMamba-T fp32, batch {batch}, 2x{size}x{size} (BASELINE configs[0]); "
                        f"oracle = restatement of the reference CPU selective-scan path; {dt:.1f} s/step")
+
+
+def _aten_profile(step):
+    """Which framework operators still launch kernels in one eager step (development aid for the element-wise tail)."""
+    from torch.profiler import profile, ProfilerActivity
+    step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+        step()
+        torch.cuda.synchronize()
+    rows = []
+    for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12):
+        t = e.self_device_time_total
+        if t <= 0 or not e.key.startswith("aten::"):
+            continue
+        where = next((fr.split("xfmamba_amd/")[-1][:70] for fr in e.stack if "xfmamba_amd" in fr), "")
+        rows.append((t, e.count, e.key, str(e.input_shapes)[:100], where))
+    rows.sort(reverse=True)
+    print(f"[aten-profile] {sum(r[0] for r in rows) / 1e3:.3f} ms in {sum(r[1] for r in rows)} calls", file=sys.stderr)
+    for t, n, k, shp, where in rows[:120]:
+        print(f"[aten-profile] {t:8.1f} us {n:4d}  {k:30s} {shp}  {where}", file=sys.stderr)
 
 
 def main():
@@ -330,6 +354,8 @@ def main():
 
     for _ in range(a.warmup):
         run_step()
+    if a.aten_profile and rank == 0:
+        _aten_profile(step)
     timer = None
     if not a.no_kernel_timer and graph is None:
         timer = _lib.KernelTimer()

@@ -27,6 +27,15 @@ with open('gpurun_out/prof_step/s_kernel_stats.csv', 'w') as out:
     T = sum(tot.values())
     for n, t in tot.most_common():
         w.writerow([n, cnt[n], t, t / cnt[n], 100.0 * t / T])
+# launch order of the last step (name, start offset, duration): which kernels sit between which
+with open('gpurun_out/prof_step/s_last_step_order.csv', 'w') as out:
+    w = csv.writer(out)
+    w.writerow(['Index', 'Name', 'StartUs', 'DurationUs'])
+    i = 0
+    for s, e, n in rows:
+        if s >= adam[-2] and e <= adam[-1]:
+            w.writerow([i, n[:140], round((s - adam[-2]) / 1e3, 1), round((e - s) / 1e3, 1)])
+            i += 1
 print("steady-state window: %d steps, wall %.2f ms/step, kernel time %.2f ms/step" % (NS, (hi - lo) / 1e6 / NS, T / 1e6 / NS))
 for n, t in tot.most_common(45):
     print(f"{n[:95]:95s} {cnt[n] / NS:6.1f} {t / 1e6 / NS:8.3f} ms/step {t / cnt[n] / 1e3:8.1f} us")

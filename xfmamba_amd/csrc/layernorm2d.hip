@@ -237,6 +237,127 @@ __global__ void __launch_bounds__(256) ln2d_bwd_dx_short_kernel(const Tx *__rest
     }
 }
 
+// ---- the same maps, register-cached (round 4).  A workgroup owns EIGHT positions and splits the channels 32 ways: thread
+// (position pi, slice cs) keeps channels cs + 32 j, j < CPT = C / 32, in registers, so x (and dy) are read once and 1568
+// positions make 196 workgroups (the lanes-along-positions forms launch 25 for a 32 x 768 x 7 x 7 map: 27 us for 4.8 MB).
+// The backward kernel can leave the weight / bias gradient's partial rows ([sum dy * xhat | sum dy] over its 8 positions).
+template <typename Tx, typename Ty, int CPT>
+__global__ void __launch_bounds__(256) ln2d_fwd_short_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                             const float *__restrict__ bias, Ty *__restrict__ y,
+                                                             float *__restrict__ mean, float *__restrict__ rstd, int C, int L,
+                                                             int NP, float eps) {
+    __shared__ float red[32][9];
+    const int pi = threadIdx.x & 7, cs = threadIdx.x >> 3;
+    const int P = blockIdx.x * 8 + pi;
+    const bool ok = P < NP;
+    const int b = ok ? P / L : 0, p = ok ? P - b * L : 0;
+    const int64_t o = (int64_t)b * C * L + p;
+    float v[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        v[j] = ok ? ldf<Tx>(x + o + (int64_t)(cs + 32 * j) * L) : 0.f;
+        s += v[j];
+    }
+    red[cs][pi] = s;
+    __syncthreads();
+    float mu = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) mu += red[q][pi];
+    mu /= (float)C;
+    __syncthreads();
+    float q2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        v[j] -= mu;
+        q2 = fmaf(v[j], v[j], q2);
+    }
+    red[cs][pi] = q2;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) var += red[q][pi];
+    const float rs = rsqrtf(var / (float)C + eps);
+    if (!ok) return;
+    if (cs == 0) {
+        mean[(int64_t)b * L + p] = mu;
+        rstd[(int64_t)b * L + p] = rs;
+    }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = cs + 32 * j;
+        stf<Ty>(y + o + (int64_t)c * L, fmaf(v[j] * rs, w[c], bias ? bias[c] : 0.f));
+    }
+}
+
+template <typename Tx, typename Ty, int CPT>
+__global__ void __launch_bounds__(256) ln2d_bwd_dx_short8_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                                 const Ty *__restrict__ dy, const float *__restrict__ mean,
+                                                                 const float *__restrict__ rstd, Tx *__restrict__ dx, int C,
+                                                                 int L, int NP, float *__restrict__ parts) {
+    __shared__ float red[2][32][9];
+    const int pi = threadIdx.x & 7, cs = threadIdx.x >> 3;
+    const int P = blockIdx.x * 8 + pi;
+    const bool ok = P < NP;
+    const int b = ok ? P / L : 0, p = ok ? P - b * L : 0;
+    const int64_t o = (int64_t)b * C * L + p;
+    const float mu = ok ? mean[(int64_t)b * L + p] : 0.f, rs = ok ? rstd[(int64_t)b * L + p] : 0.f;
+    float g[CPT], xh[CPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int64_t a = o + (int64_t)(cs + 32 * j) * L;
+        g[j] = ok ? ldf<Ty>(dy + a) : 0.f;
+        xh[j] = ok ? (ldf<Tx>(x + a) - mu) * rs : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const float gw = g[j] * w[cs + 32 * j];
+        s1 += gw;
+        s2 = fmaf(gw, xh[j], s2);
+    }
+    red[0][cs][pi] = s1;
+    red[1][cs][pi] = s2;
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        m1 += red[0][q][pi];
+        m2 += red[1][q][pi];
+    }
+    m1 /= (float)C;
+    m2 /= (float)C;
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = cs + 32 * j;
+            stf<Tx>(dx + o + (int64_t)c * L, rs * (g[j] * w[c] - m1 - xh[j] * m2));
+        }
+    }
+    if (parts) {
+        // the eight positions of a channel are eight adjacent lanes: three exchange steps, lane pi == 0 writes the pair
+        float *pr = parts + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            float a1 = g[j] * xh[j], a2 = g[j];
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                a1 += __shfl_xor(a1, off, 64);
+                a2 += __shfl_xor(a2, off, 64);
+            }
+            if (pi == 0) {
+                pr[cs + 32 * j] = a1;
+                pr[C + cs + 32 * j] = a2;
+            }
+        }
+    }
+}
+
+static bool ln2d_short8_ok(int B, int C, int L) {
+    return C >= 512 && (int64_t)B * L <= 16 * 1024 && C % 32 == 0 && (C == 512 || C == 768 || C == 1024 || C == 1536) &&
+           !getenv("XFM_LN2D_NO_SHORT8");
+}
+
 // ---------------------------------------------------------------------------------------------
 // register-cached variants: C == CPT * NW.  The workgroup has NW waves (<= 16); lane = position, each thread
 // keeps its CPT channel values in registers, so x (and dy) are read from HBM exactly once.
@@ -631,6 +752,18 @@ static int ln_fwd(const void *x, const float *w, const float *b, void *y, float 
             return check_launch();
         }
     }
+    if (ln2d_short8_ok(B, C, L)) {                          // 7 x 7 maps with 512 ... 1536 channels
+        const dim3 grid((B * L + 7) / 8), block(256);
+#define XFM_LN2D_S8(CPT)                                                                                                    \
+    hipLaunchKernelGGL((ln2d_fwd_short_kernel<Tx, Ty, CPT>), grid, block, 0, s, (const Tx *)x, w, b, (Ty *)y, mean, rstd, C, L,  \
+                       B * L, eps)
+        if (C == 512) XFM_LN2D_S8(16);
+        else if (C == 768) XFM_LN2D_S8(24);
+        else if (C == 1024) XFM_LN2D_S8(32);
+        else XFM_LN2D_S8(48);
+#undef XFM_LN2D_S8
+        return check_launch();
+    }
     // few positions (a 14 x 14 stage: 196 tiles of 64 for 256 CUs): 32-position workgroups, the lane halves split the channels
     // (the fp32 -> bf16 forward above measured the same either way: 14.1 vs 14.6 us; the backward 22.9 -> 17.8 us)
     if ((B * L + 63) / 64 < 256 && !getenv("XFM_LN2D_NO_HALF") && C % 24 == 0 && C / 24 <= 16) {
@@ -677,7 +810,8 @@ static int ln2d_parts_blocks(int B, int C, int L, bool vec_path) {
         return (int)(((int64_t)B * L / vp + 63) / 64);
     }
     if (C > 1536) return 0;
-    if (C >= 512 && (int64_t)B * L <= 16 * 1024) return 0;                         // the short-map kernel
+    if (ln2d_short8_ok(B, C, L)) return (B * L + 7) / 8;                           // the register-cached short-map kernel
+    if (C >= 512 && (int64_t)B * L <= 16 * 1024) return 0;                         // the two-pass short-map kernel
     if ((B * L + 63) / 64 < 256 && !getenv("XFM_LN2D_NO_HALF") && C % 24 == 0 && C / 24 <= 16) return (B * L + 31) / 32;
     if ((C % 24 == 0 && C / 24 <= 16) || (C % 48 == 0 && C / 48 <= 16) || (C % 16 == 0 && C / 16 <= 16) ||
         (C % 32 == 0 && C / 32 <= 16))
@@ -704,6 +838,16 @@ static int ln_bwd(const void *x, const float *w, const void *dy, const float *me
         }
     }
     if (done) {
+    } else if (ln2d_short8_ok(B, C, L)) {
+        const dim3 grid((B * L + 7) / 8), block(256);
+#define XFM_LN2D_S8(CPT)                                                                                                    \
+    hipLaunchKernelGGL((ln2d_bwd_dx_short8_kernel<Tx, Ty, CPT>), grid, block, 0, s, (const Tx *)x, w, (const Ty *)dy, mean,  \
+                       rstd, (Tx *)dx, C, L, B * L, parts)
+        if (C == 512) XFM_LN2D_S8(16);
+        else if (C == 768) XFM_LN2D_S8(24);
+        else if (C == 1024) XFM_LN2D_S8(32);
+        else XFM_LN2D_S8(48);
+#undef XFM_LN2D_S8
     } else if (C >= 512 && (int64_t)B * L <= 16 * 1024) {
         // short maps, wide rows (7 x 7 at 768 / 1536 channels): positions x channel slices instead of lanes along positions
         hipLaunchKernelGGL((ln2d_bwd_dx_short_kernel<Tx, Ty>), dim3((B * L + 15) / 16), dim3(256), 0, s, (const Tx *)x, w,

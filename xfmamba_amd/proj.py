@@ -290,10 +290,17 @@ def mfma_planes(x, w, out, transposed=False, accumulate_into=None):
     return y
 
 
+_CAST_IN = os.environ.get("XFM_PROJ_CAST_IN", "1") == "1"
+
+
 class BatchedProj(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, in_tokens, out_tokens):
         # x: (B, L, K) tokens or (B, K, L) planes; weight (M, K); result (B, L, M) tokens or (B, M, L) planes
+        if _CAST_IN and x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled():
+            # an fp32 operand under autocast: the products below would cast it per call (and the backward pass, which
+            # runs outside autocast, would contract the SAVED fp32 tensors in fp32): cast once, save the cast
+            x = x.to(torch.get_autocast_gpu_dtype())
         x = x.contiguous()
         B = x.shape[0]
         cd = x.dtype
