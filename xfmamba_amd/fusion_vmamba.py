@@ -800,11 +800,15 @@ class Backbone_VSSM(VSSM):
         except Exception as e:  # same tolerant behaviour as the reference (fusion_vmamba.py:1692-1702)
             print(f"Failed loading checkpoint form {ckpt}: {e}")
 
-    def forward(self, x, only_last: bool = False):
+    def tokens_path_ok(self, x: torch.Tensor) -> bool:
+        return self.tokens_trunk_ok(x) and all(_norm_tokens_ok(getattr(self, f"outnorm{i}")) for i in self.out_indices)
+
+    def forward(self, x, only_last: bool = False, tokens_out: bool = False):
         """``only_last=True`` skips the out-norms whose results ``TwoViewXFMambaTop`` discards
-        (outnorm0-2, net_fusionmamba.py:200-201); values of the last output are unchanged."""
+        (outnorm0-2, net_fusionmamba.py:200-201); values of the last output are unchanged.  ``tokens_out`` (with the
+        token-major trunk only, see ``tokens_trunk_ok``): the outputs stay (B, H, W, C) -- no NCHW copy."""
         last = len(self.layers) - 1
-        if self.tokens_trunk_ok(x) and all(_norm_tokens_ok(getattr(self, f"outnorm{i}")) for i in self.out_indices):
+        if self.tokens_path_ok(x):
             outs = []
             with _PrecomputedA(self.layers, self.cut_after), _DropPathBank(self.layers, x.shape[0], x.device):
                 t = self.stem_tokens(x)
@@ -814,8 +818,11 @@ class Backbone_VSSM(VSSM):
                     if i == self.cut_after:
                         self.cut_tensor = t              # (the stream entering stage i + 1: dp.PhasedGrads' cut)
                     if i in self.out_indices and (not only_last or i == last):
-                        outs.append(_ln_tokens(getattr(self, f"outnorm{i}"), o, torch.float32).permute(0, 3, 1, 2).contiguous())
-            return outs if len(self.out_indices) else o.permute(0, 3, 1, 2).contiguous()
+                        on = _ln_tokens(getattr(self, f"outnorm{i}"), o, torch.float32)
+                        outs.append(on if tokens_out else on.permute(0, 3, 1, 2).contiguous())
+            return outs if len(self.out_indices) else (o if tokens_out else o.permute(0, 3, 1, 2).contiguous())
+        if tokens_out:
+            raise RuntimeError("tokens_out needs the token-major trunk (tokens_trunk_ok)")
         x = self.patch_embed(x)
         outs = []
         for i, layer in enumerate(self.layers):
@@ -828,6 +835,17 @@ class Backbone_VSSM(VSSM):
         if len(self.out_indices) == 0:
             return x
         return outs
+
+
+def _bn_rows(bn: nn.BatchNorm2d, rows: torch.Tensor) -> torch.Tensor:
+    """``bn`` applied to the (B H W, C) token matrix of an NCHW map: what ``nn.BatchNorm2d.forward`` does (batch statistics
+    in training mode, running statistics updated with ``momentum``, the step counter), on the 2-D view."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+    keep = not bn.training or bn.track_running_stats
+    return F.batch_norm(rows, bn.running_mean if keep else None, bn.running_var if keep else None, bn.weight, bn.bias,
+                        use_batch, bn.momentum, bn.eps)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -883,10 +901,43 @@ class ShallowFuse_SS2Dv4(nn.Module):
         y, y2 = yy.chunk(2, dim=0)                      # (chunk, not slices: its backward is one cat, not zeros + adds)
         return y, y2
 
+    def stacked_ok(self, n: torch.Tensor) -> bool:
+        return (n.is_cuda and isinstance(self.out_act, nn.Identity) and self.out_proj.bias is None
+                and isinstance(self.out_norm, nn.LayerNorm) and self.out_norm.elementwise_affine)
+
+    def forward_stacked(self, n: torch.Tensor) -> torch.Tensor:
+        """Both views as ONE token-major batch ``n`` = [view 1 | view 2] (2B, H, W, C) -> (B, 2, H, W, C): ``[:, 0]`` is the
+        reference's first output, ``[:, 1]`` its second (fusion_vmamba.py:853-876).  Same operator chain as ``forward``
+        with the layout copies taken out: the scan output (B, 2, D, L) IS a plane-major batch of 2B maps in (sample, view)
+        order, so out_norm runs on it as LayerNorm2d (no merge copies, no transposes), the squeeze gates are re-ordered
+        instead of the maps (a (2B, D) tensor), and out_proj reads planes and writes tokens."""
+        B2, H, W, _ = n.shape
+        B, L = B2 // 2, H * W
+        K, R, N = self.k_group, self.dt_rank, self.d_state
+        xp = self.in_proj(n).permute(0, 3, 1, 2).contiguous()                              # (2B, D, H, W)
+        D = xp.shape[1]
+        xc = _dwconv_act(self.conv2d, self.act, xp) if self.with_dconv else self.act(xp)
+        xs = SwappingScan_multiview.apply(xc[:B], xc[B:])                                    # (B, 2, D, L)
+        x_dbl = torch.matmul(self.x_proj_weight.to(xs.dtype), xs)                            # (B, 2, R + 2N, L)
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.matmul(self.dt_projs_weight.to(xs.dtype), dts)                           # (B, 2, D, L)
+        ys = selective_scan_fn(xs.view(B, -1, L), dts.view(B, -1, L), -self.A_logs.float().exp(), Bs.contiguous(),
+                               Cs.contiguous(), self.Ds.float(), self.dt_projs_bias.reshape(-1).float(), True, True, None)
+        # (slices of ys are what SwappingMerge_multiview returns, and their gradient is its stack)
+        yy = layernorm2d_fn(ys.view(B * 2, D, H, W), self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, xp.dtype)
+        gate = self.fc1(self.avg_pool(xp).view(B2, D))                                       # [gate 1 | gate 2]
+        # view 1's map is gated by view 2's squeeze and the other way round (:870-871): (sample, view) order, swapped
+        gate = torch.stack([gate[B:], gate[:B]], dim=1).view(B * 2, D, 1)
+        o = batched_proj(yy.view(B * 2, D, L) * gate, self.out_proj.weight, None, in_tokens=False, out_tokens=True)
+        return self.dropout(o).view(B, 2, H, W, -1)
+
     def forward(self, x: torch.Tensor, x2: torch.Tensor):
         # both views share every weight here: they run as one batch of 2B wherever the reference makes two calls
         # (in_proj, conv, squeeze gate, out_norm, out_proj act per sample, so the values are the same)
         B = x.shape[0]
+        if self.stacked_ok(x):
+            o = self.forward_stacked(torch.cat([x, x2], dim=0))
+            return o[:, 0], o[:, 1]
         xp = self.in_proj(torch.cat([x, x2], dim=0)).permute(0, 3, 1, 2).contiguous()        # (2B, D, H, W)
         xc = _dwconv_act(self.conv2d, self.act, xp) if self.with_dconv else self.act(xp)
         y1, y2 = self.forward_corev2(*xc.chunk(2, dim=0))
@@ -906,6 +957,22 @@ class ShallowFusionBlock_v4(nn.Module):
         self.shallowfuseSS2D = ShallowFuse_SS2Dv4(d_model=hidden_dim, d_state=d_state, ssm_ratio=ssm_ratio,
                                                   dt_rank=dt_rank, dropout=attn_drop_rate, **kwargs)
         self.drop_path = DropPath(drop_path)
+
+    def stacked_ok(self, xt: torch.Tensor) -> bool:
+        bn = self.norm
+        return (isinstance(bn, nn.BatchNorm2d) and bn.momentum is not None and bn.affine
+                and self.shallowfuseSS2D.stacked_ok(xt))
+
+    def forward_stacked(self, xt: torch.Tensor) -> torch.Tensor:
+        """[view 1 | view 2] as one token-major (2B, H, W, C) stream in and out.  BatchNorm2d over an NCHW map is a
+        per-column normalisation of its (B H W, C) token matrix: the same module state (running statistics, view 1 then
+        view 2, :906-907) through ``F.batch_norm`` on the 2-D view, no NCHW copies."""
+        B2, H, W, C = xt.shape
+        B = B2 // 2
+        x2d = xt.reshape(2, B * H * W, C)
+        n = torch.cat([_bn_rows(self.norm, x2d[0]), _bn_rows(self.norm, x2d[1])], dim=0).view(B2, H, W, C)
+        o = self.shallowfuseSS2D.forward_stacked(n)                                          # (B, 2, H, W, C)
+        return (xt.view(2, B, H, W, C) + o.transpose(0, 1)).view(B2, H, W, C)            # x1 + o1 | x2 + o2 (:914)
 
     def forward(self, x1, x2):
         n1 = self.norm(x1).permute(0, 2, 3, 1)      # the same BatchNorm sees view 1 then view 2 (:906-907)
@@ -990,9 +1057,17 @@ class Cross_SS2Dv5(nn.Module):
         y = cross_merge_fn(ys.view(B3, K, -1, H, W), in_channel_first=True, out_channel_first=True, scans=0)
         return self.out_norm(y.view(B3, -1, L).transpose(1, 2).reshape(B3, H, W, -1)).to(cd)
 
+    def forward_stacked(self, n: torch.Tensor) -> torch.Tensor:
+        """``forward`` on the two views as one token-major batch ``n`` = [view 1 | view 2] (2B, H, W, C)."""
+        B = n.shape[0] // 2
+        return self._from_x3(self.in_proj_sec(torch.cat([n, (n[:B] + n[B:]) / 2], dim=0)), B, n.shape[1], n.shape[2])
+
     def forward(self, x, x2: torch.Tensor, **kwargs):
         B, H, W = x.shape[0], x.shape[1], x.shape[2]
         x3 = self.in_proj_sec(torch.cat([x, x2, (x + x2) / 2], dim=0))                 # one GEMM for the three streams
+        return self._from_x3(x3, B, H, W)
+
+    def _from_x3(self, x3: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
         tp = x3.permute(0, 3, 1, 2).contiguous()                                       # (3B, D, H, W) planes, pre-activation
         t = _dwconv_act(self.conv2d, self.act, tp) if self.with_dconv else self.act(tp)
         K, _, R = self.dt_projs_weight.shape
@@ -1024,6 +1099,18 @@ class FusionBlock_v5(nn.Module):
         self.self_attention = Cross_SS2Dv5(d_model=hidden_dim, dropout=attn_drop_rate, d_state=d_state, **kwargs)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
+    def stacked_ok(self, xt: torch.Tensor) -> bool:
+        return (xt.is_cuda and xt.dtype == torch.float32 and isinstance(self.norm, LayerNorm2d)
+                and rows_supported(self.norm.normalized_shape[0]))
+
+    def forward_stacked(self, xt: torch.Tensor) -> torch.Tensor:
+        """[view 1 | view 2] token-major (2B, H, W, C) fp32 -> (B, H, W, C): LayerNorm2d over the channels of an NCHW map is
+        the row LayerNorm of its tokens (one launch for both views), the residual sum runs on tokens."""
+        B = xt.shape[0] // 2
+        n = layernorm_rows_fn(xt, self.norm.weight, self.norm.bias, self.norm.eps, xt.dtype)
+        x = self.drop_path(self.self_attention.forward_stacked(n))
+        return xt[:B] + xt[B:] + x
+
     def forward(self, x1, x2):
         a = self.norm(x1).permute(0, 2, 3, 1)
         b = self.norm(x2).permute(0, 2, 3, 1)
@@ -1040,6 +1127,17 @@ class CSSFVSSLayer_v5(nn.Module):
                            norm_layer=norm_layer, attn_drop_rate=attn_drop_rate, d_state=d_state, **kwargs)
             for i in range(depth)])
         self.downsampling = downsampling if downsampling != 1 else None
+
+    def stacked_ok(self, xt: torch.Tensor) -> bool:
+        return all(blk.stacked_ok(xt) for blk in self.blocks)
+
+    def forward_stacked(self, xt: torch.Tensor) -> torch.Tensor:
+        """[view 1 | view 2] token-major (2B, H, W, C) -> (B, H, W, C)."""
+        B = xt.shape[0] // 2
+        x1 = None
+        for blk in self.blocks:
+            x1 = blk.forward_stacked(xt if x1 is None else torch.cat([x1, xt[B:]], dim=0))
+        return x1
 
     def forward(self, x1, x2):
         for blk in self.blocks:

@@ -6,14 +6,19 @@ kernels.  The ablation models of the reference file are out of scope (SURVEY.md 
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .fusion_vmamba import Backbone_VSSM, CSSFVSSLayer_v5, ShallowFusionBlock_v4
 
 __all__ = ["TwoViewXFMambaTop", "ModelWrapper"]
+
+# XFM_STACKED_FUSION=0: the two fusion blocks on NCHW maps, one call per view pair as the reference writes them (read once)
+STACKED_FUSION = os.environ.get("XFM_STACKED_FUSION", "1") == "1"
 
 _TRUNKS = {   # net_fusionmamba.py:151-159
     "small": dict(depths=[2, 2, 15, 2], dims=96, drop_path_rate=0.3, ssm_ratio=2.0),
@@ -58,8 +63,37 @@ class TwoViewXFMambaTop(nn.Module):
         # gives the same features as the reference's two sequential calls and halves the launches.
         self.merge_views = True
 
+    def _stacked_ok(self, x_a) -> bool:
+        tr = self.mamba_feature_extrac
+        return (STACKED_FUSION and self.merge_views and x_a.is_cuda and (len(tr.layers) - 1) in tr.out_indices
+                and tr.tokens_path_ok(x_a))
+
+    def _head(self, z, tokens: bool):
+        """``classifier(final_conv(z))``.  A 1x1 convolution commutes with the spatial mean (mean_l (W z_l + b) =
+        W mean_l z_l + b), so with the reference's avgpool -> flatten -> Linear classifier the convolution runs on the
+        pooled (B, C) rows: 49 times less work than on the map, same fp32 arithmetic up to summation order."""
+        fc, cls = self.final_conv, self.classifier
+        pooled = (isinstance(getattr(cls, "avgpool", None), nn.AdaptiveAvgPool2d) and cls.avgpool.output_size in (1, (1, 1))
+                  and isinstance(getattr(cls, "flatten", None), nn.Flatten) and len(cls) == 3
+                  and fc.kernel_size == (1, 1) and fc.stride == (1, 1) and fc.padding == (0, 0) and fc.groups == 1
+                  and fc.padding_mode == "zeros")
+        if not pooled:
+            return cls(fc(z.permute(0, 3, 1, 2) if tokens else z))
+        zp = z.mean((1, 2) if tokens else (2, 3))
+        return cls.head(F.linear(zp, fc.weight.view(fc.out_channels, fc.in_channels), fc.bias))
+
     def forward(self, x_a, x_b):
-        if self.merge_views:
+        if self._stacked_ok(x_a):
+            # the trunk's token-major stream goes on through both fusion blocks: [view 1 | view 2] (2B, H, W, C)
+            zt = self.mamba_feature_extrac(torch.cat([x_a, x_b], dim=0).expand(-1, 3, -1, -1), only_last=True,
+                                           tokens_out=True)[-1]
+            if self.shallow_mamba_fusion.stacked_ok(zt) and self.fusemamba.stacked_ok(zt):
+                z = self.fusemamba.forward_stacked(self.shallow_mamba_fusion.forward_stacked(zt))
+                with torch.autocast("cuda", enabled=False):
+                    return self._head(z.float(), tokens=True)
+            z = zt.permute(0, 3, 1, 2).contiguous()
+            z_a, z_b = z.chunk(2, dim=0)
+        elif self.merge_views:
             # (concatenate the 1-channel views first: the 3-channel broadcast stays a stride-0 view for the trunk)
             z = self.mamba_feature_extrac(torch.cat([x_a, x_b], dim=0).expand(-1, 3, -1, -1), only_last=True)[-1]
             z_a, z_b = z.chunk(2, dim=0)
@@ -73,4 +107,4 @@ class TwoViewXFMambaTop(nn.Module):
         # the 768->768->outputs head is negligible work: keep it out of autocast so the logits are not quantised
         # to the 8-bit bf16 mantissa (no effect when autocast is off, i.e. on the fp32 reference path)
         with torch.autocast("cuda", enabled=False):
-            return self.classifier(self.final_conv(z.float()))
+            return self._head(z.float(), tokens=False)
