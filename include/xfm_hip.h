@@ -223,6 +223,12 @@ int xfm_residual_settle_bwd(const void *dout, const float *scale, float *dx, voi
  */
 int xfm_partial_sums_multi(const void *jobs, const void *blocks, int nblocks, void *stream);
 
+/* (B, R, C) tokens <-> (B, C, R) planes of 2-byte elements on short maps (R <= 64 positions, C % 64 == 0, 16-byte aligned
+ * tensors): the NHWC <-> NCHW permutes around the 7 x 7 SS2D blocks (reference models/fusion_vmamba.py:594-601, 853-857) as
+ * one streaming kernel.  tokens_to_planes != 0: src (B, R, C) -> dst (B, C, R); 0: src (B, C, R) -> dst (B, R, C). */
+int xfm_transpose_short_supported(int R, int C);
+int xfm_transpose_short(const void *src, void *dst, int B, int R, int C, int tokens_to_planes, void *stream);
+
 /*
  * Skinny token-major linear layer on MFMA (csrc/tokens_gemm.hip):  y[T, out] = x[T, con] . W^T (+ bias), bf16 in / out,
  * fp32 accumulation -- `F.linear` of Mlp.fc1 / fc2 (reference models/fusion_vmamba.py:135-153) and its backward data

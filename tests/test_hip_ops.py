@@ -862,6 +862,62 @@ def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias, B, L, C)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,R,C", [(5, 49, 768), (3, 64, 128), (2, 25, 64), (96, 49, 1536), (1, 1, 64)])
+def test_transpose_short_is_the_exact_permutation_both_ways(B, R, C):
+    """xfm_transpose_short ((B, R, C) tokens <-> (B, C, R) planes, R <= 64): bit-exact against permute + contiguous, both
+    directions, and through autograd (the gradient of one move is the other)."""
+    from xfmamba_amd.proj import planes_to_tokens, tokens_to_planes, _transpose_short_ok
+    g = torch.Generator().manual_seed(B * 1000 + R)
+    t = torch.randn(B, R, C, generator=g).to(torch.bfloat16).to(DEV)
+    assert _transpose_short_ok(t, R, C)
+    p = tokens_to_planes(t)
+    assert p.shape == (B, C, R) and p.is_contiguous()
+    assert torch.equal(p, t.transpose(1, 2).contiguous())
+    assert torch.equal(planes_to_tokens(p), t)
+    tr = t.clone().requires_grad_()
+    gy = torch.randn(B, C, R, generator=g).to(torch.bfloat16).to(DEV)
+    tokens_to_planes(tr).backward(gy)
+    assert torch.equal(tr.grad, gy.transpose(1, 2).contiguous())
+    # a shape the kernel does not take goes through the framework's copy
+    u = torch.randn(2, 70, 64, generator=g).to(torch.bfloat16).to(DEV)
+    assert not _transpose_short_ok(u, 70, 64)
+    assert torch.equal(tokens_to_planes(u), u.transpose(1, 2).contiguous())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_tokens,out_tokens", [(True, False), (False, True)])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("B,L,K,M", [(64, 49, 768, 768), (32, 49, 1536, 768), (8, 25, 128, 192)])
+def test_batched_proj_short_maps_one_gemm_plus_transpose(in_tokens, out_tokens, bias, B, L, K, M):
+    """Layout-changing projections on 7 x 7 maps (trunk stage 3 in_proj / out_proj, the deep block's out_proj): one GEMM over
+    all token rows + xfm_transpose_short, against an fp32 einsum -- value, data, weight and bias gradients."""
+    from xfmamba_amd.proj import batched_proj
+    g = torch.Generator().manual_seed(L * K)
+    xp = torch.randn(B, K, L, generator=g).to(torch.bfloat16)
+    w = torch.randn(M, K, generator=g) / K ** 0.5
+    bb = torch.randn(M, generator=g) if bias else None
+    gy = torch.randn(B, M, L, generator=g).to(torch.bfloat16)
+    xr, wr = xp.float().requires_grad_(), w.to(torch.bfloat16).float().requires_grad_()
+    br = bb.clone().requires_grad_() if bias else None
+    yr = torch.einsum("mk,bkl->bml", wr, xr) + (br[None, :, None] if bias else 0)
+    yr.backward(gy.float())
+    x = (xp.transpose(1, 2).contiguous() if in_tokens else xp.clone()).to(DEV).requires_grad_()
+    wd = w.to(DEV).requires_grad_()
+    bd = bb.to(DEV).requires_grad_() if bias else None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = batched_proj(x, wd, bd, in_tokens=in_tokens, out_tokens=out_tokens)
+    assert y.shape == ((B, L, M) if out_tokens else (B, M, L)) and y.is_contiguous()
+    y.backward((gy.transpose(1, 2).contiguous() if out_tokens else gy).to(DEV))
+    yc = (y.transpose(1, 2) if out_tokens else y).float().cpu()
+    assert_close(yc, yr.detach(), 1e-2, 1e-2 * float(yr.abs().max()), "y")
+    dx = (x.grad.transpose(1, 2) if in_tokens else x.grad).float().cpu()
+    assert_close(dx, xr.grad, 1e-2, 1e-2 * float(xr.grad.abs().max()), "dx")
+    assert_close(wd.grad.float().cpu(), wr.grad, 1e-2, 1e-2 * float(wr.grad.abs().max()), "dw")
+    if bias:
+        assert_close(bd.grad.float().cpu(), br.grad, 1e-2, 1e-2 * float(br.grad.abs().max()), "db")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,L,D,XC", [(32, 196, 384, 128), (24, 196, 384, 128), (32, 132, 256, 128)])
 def test_tiled_xproj_forward_and_accumulating_backward(B, L, D, XC):
     """x_proj of a channel-lane SS2D block at 14 x 14 on the tiled form: planes -> tokens (D -> XC) through xfm_proj_gemm,

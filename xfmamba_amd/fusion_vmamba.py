@@ -38,7 +38,7 @@ from .csms6s import selective_scan_fn
 from .dwconv import dwconv3x3_silu_fn
 from .layernorm2d import layernorm2d_fn
 from .mlp_tokens import bias_gelu_fn, linear_tokens_fn, mlp_tokens_fn
-from .proj import batched_proj
+from .proj import batched_proj, planes_to_tokens, tokens_to_planes
 from .rowln import residual_settle_fn, add_layernorm_rows_fn, layernorm_rows_fn, layernorm_rows_pass_fn, rows_supported
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
 from .ss2d_chan import chan_supported, ss2d_chan_fn
@@ -923,8 +923,9 @@ class ShallowFuse_SS2Dv4(nn.Module):
         B2, H, W, _ = n.shape
         B, L = B2 // 2, H * W
         K, R, N = self.k_group, self.dt_rank, self.d_state
-        xp = _linear_rows(self.in_proj, n).permute(0, 3, 1, 2).contiguous()               # (2B, D, H, W)
-        D = xp.shape[1]
+        xp = _linear_rows(self.in_proj, n)                                                   # (2B, H, W, D)
+        D = xp.shape[-1]
+        xp = tokens_to_planes(xp.view(B2, L, D)).view(B2, D, H, W)
         xc = _dwconv_act(self.conv2d, self.act, xp) if self.with_dconv else self.act(xp)
         xs = SwappingScan_multiview.apply(xc[:B], xc[B:])                                    # (B, 2, D, L)
         x_dbl = torch.matmul(self.x_proj_weight.to(xs.dtype), xs)                            # (B, 2, R + 2N, L)
@@ -942,7 +943,7 @@ class ShallowFuse_SS2Dv4(nn.Module):
         # view 1's map is gated by view 2's squeeze and the other way round (:870-871): (sample, view) order, swapped
         gate = torch.stack([gate[B:], gate[:B]], dim=1).view(B * 2, D, 1)
         # (a transposing copy + one 3136-row GEMM: 64 per-sample products through batched_proj measured 41 vs 33 us here)
-        o = _linear_rows(self.out_proj, (yy.view(B * 2, D, L) * gate).transpose(1, 2))
+        o = _linear_rows(self.out_proj, planes_to_tokens(yy.view(B * 2, D, L) * gate))
         return self.dropout(o).view(B, 2, H, W, -1)
 
     def forward(self, x: torch.Tensor, x2: torch.Tensor):
@@ -1083,7 +1084,7 @@ class Cross_SS2Dv5(nn.Module):
         return self._from_x3(x3, B, H, W)
 
     def _from_x3(self, x3: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
-        tp = x3.permute(0, 3, 1, 2).contiguous()                                       # (3B, D, H, W) planes, pre-activation
+        tp = tokens_to_planes(x3.reshape(x3.shape[0], H * W, -1)).view(x3.shape[0], -1, H, W)   # (3B, D, H, W), pre-activation
         t = _dwconv_act(self.conv2d, self.act, tp) if self.with_dconv else self.act(tp)
         K, _, R = self.dt_projs_weight.shape
         if SS2D_MODE == "fused" and H * W > 64 and not chan_supported(t, H, W, self.A_logs.shape[1], K, t.shape[1], R):

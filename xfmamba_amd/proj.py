@@ -170,9 +170,9 @@ def wgrad_mfma(a: torch.Tensor, a_planes: bool, b: torch.Tensor, b_planes: bool,
         # Transposing such an operand to token-major first (a 5 MB copy) and contracting the samples as ONE token run
         # on the LDS-direct token x token kernel is more than twice as fast.
         if a_planes:
-            a, a_planes = a.transpose(1, 2).contiguous(), False
+            a, a_planes = (_transpose_raw(a, False) if _transpose_short_ok(a, L, M) else a.transpose(1, 2).contiguous()), False
         if b_planes:
-            b, b_planes = b.transpose(1, 2).contiguous(), False
+            b, b_planes = (_transpose_raw(b, False) if _transpose_short_ok(b, L, N) else b.transpose(1, 2).contiguous()), False
     if not a_planes and not b_planes and Bt > 1 and a.is_contiguous() and b.is_contiguous() and (Bt * L) % 64 == 0:
         a, b, L, Bt = a.view(1, Bt * L, M), b.view(1, Bt * L, N), Bt * L, 1       # one long token run
 
@@ -293,6 +293,61 @@ def mfma_planes(x, w, out, transposed=False, accumulate_into=None):
 _CAST_IN = os.environ.get("XFM_PROJ_CAST_IN", "1") == "1"
 
 
+# XFM_TRANSPOSE_SHORT=0: the framework's permute + contiguous for the 7 x 7 layout changes (A/B switch, read once)
+_TSHORT = os.environ.get("XFM_TRANSPOSE_SHORT", "1") == "1"
+
+
+def _transpose_short_ok(x: torch.Tensor, R: int, C: int) -> bool:
+    if not (_TSHORT and x.is_cuda and x.dim() == 3 and x.element_size() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0):
+        return False
+    from . import _lib
+    return bool(_lib.lib().xfm_transpose_short_supported(R, C))
+
+
+def _transpose_raw(x: torch.Tensor, to_planes: bool) -> torch.Tensor:
+    """``xfm_transpose_short`` on a contiguous 3-D tensor the caller checked with ``_transpose_short_ok`` (no autograd)."""
+    from . import _lib
+    B = x.shape[0]
+    R, Cc = (x.shape[1], x.shape[2]) if to_planes else (x.shape[2], x.shape[1])
+    y = torch.empty((B, Cc, R) if to_planes else (B, R, Cc), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device), _lib.timed("transpose_short", x.numel() * 4):
+        _lib.check(_lib.lib().xfm_transpose_short(x.data_ptr(), y.data_ptr(), B, R, Cc, 1 if to_planes else 0,
+                                                  _lib.stream_ptr()), "transpose_short")
+    return y
+
+
+class TransposeShort(torch.autograd.Function):
+    """(B, R, C) tokens -> (B, C, R) planes (``to_planes``) or back, through ``xfm_transpose_short``; the gradient is the
+    opposite move."""
+
+    @staticmethod
+    def forward(ctx, x, to_planes):
+        ctx.to_planes = to_planes
+        return _transpose_raw(x, to_planes)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        R, Cc = (dy.shape[2], dy.shape[1]) if ctx.to_planes else (dy.shape[1], dy.shape[2])
+        if _transpose_short_ok(dy, R, Cc):
+            return TransposeShort.apply(dy, not ctx.to_planes), None
+        return dy.transpose(1, 2).contiguous(), None
+
+
+def tokens_to_planes(t: torch.Tensor) -> torch.Tensor:
+    """(B, L, C) token-major -> contiguous (B, C, L) plane-major (``t.transpose(1, 2).contiguous()``)."""
+    if t.is_contiguous() and _transpose_short_ok(t, t.shape[1], t.shape[2]):
+        return TransposeShort.apply(t, True)
+    return t.transpose(1, 2).contiguous()
+
+
+def planes_to_tokens(p: torch.Tensor) -> torch.Tensor:
+    """(B, C, L) plane-major -> contiguous (B, L, C) token-major."""
+    if p.is_contiguous() and _transpose_short_ok(p, p.shape[2], p.shape[1]):
+        return TransposeShort.apply(p, False)
+    return p.transpose(1, 2).contiguous()
+
+
 class BatchedProj(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, in_tokens, out_tokens):
@@ -307,7 +362,18 @@ class BatchedProj(torch.autograd.Function):
         w = cast_weight(weight, cd)
         M, K = w.shape
         y = _mfma_proj(x, w, bias, in_tokens, out_tokens, False)
-        if y is not None:
+        L = x.shape[1] if in_tokens else x.shape[2]
+        short = (y is None and in_tokens != out_tokens and _transpose_short_ok(x, L, K)
+                 and _transpose_short_ok(x, L, M))
+        if short:
+            # short maps (7 x 7): ONE GEMM over all B * L token rows with the layout change as a streaming transpose next to it
+            # (64 per-sample products through bmm: 28 us for 64 x 49 x 768 x 768 against 8 + 3)
+            xt = x if in_tokens else _transpose_raw(x, False)                 # (B, L, K)
+            y = torch.nn.functional.linear(xt, w, None if bias is None else bias.to(cd))
+            if not out_tokens:
+                y = _transpose_raw(y, True)
+            x = xt
+        elif y is not None:
             pass
         elif out_tokens:
             xt = x if in_tokens else x.transpose(1, 2)                       # (B, L, K)
@@ -320,6 +386,7 @@ class BatchedProj(torch.autograd.Function):
             if bias is not None:
                 y = y + bias.to(cd)[:, None]
         ctx.save_for_backward(x, w)
+        ctx.short = short                                  # (x is saved token-major then, whatever layout it came in)
         ctx.meta = (in_tokens, out_tokens, weight.dtype, bias is not None and bias.dtype)
         ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None      # (identity only: the arena's slot key)
         return y
@@ -331,8 +398,25 @@ class BatchedProj(torch.autograd.Function):
         B = x.shape[0]
         M, K = w.shape
         dy = dy.contiguous() if dy.dtype == w.dtype else dy.to(w.dtype).contiguous()
-        dyp = dy.transpose(1, 2) if out_tokens else dy                        # (B, M, L)
         dx = dw = db = None
+        if ctx.short:
+            dyt = dy if out_tokens else _transpose_raw(dy, False)             # (B, L, M); x was saved as (B, L, K)
+            if ctx.needs_input_grad[0]:
+                dx = torch.matmul(dyt, w)                                     # (B, L, K)
+                if not in_tokens:
+                    dx = _transpose_raw(dx, True)
+            if ctx.needs_input_grad[1]:
+                slot = wgrad_slot(ctx.wparam, M, K) if wdtype == torch.float32 else None
+                dw = wgrad_mfma(dyt, False, x, False, out=slot, deferred=wdtype == torch.float32)
+                if dw is None and slot is not None:
+                    ctx.wparam = None
+                if dw is None:
+                    dw = _bmm_f32(dyt.reshape(1, -1, M).transpose(1, 2), x.reshape(1, -1, K))[0]
+                dw = dw.to(wdtype)
+            if bdtype is not False and ctx.needs_input_grad[2]:
+                db = dyt.sum((0, 1), dtype=torch.promote_types(dy.dtype, torch.float32)).to(bdtype)
+            return dx, dw, db, None, None
+        dyp = dy.transpose(1, 2) if out_tokens else dy                        # (B, M, L)
         if ctx.needs_input_grad[0]:
             dx = _mfma_proj(dy, w, None, out_tokens, in_tokens, True)        # dy has the output's layout, dx the input's
             if dx is not None:
