@@ -228,6 +228,8 @@ int xfm_partial_sums_multi(const void *jobs, const void *blocks, int nblocks, vo
  * one streaming kernel.  tokens_to_planes != 0: src (B, R, C) -> dst (B, C, R); 0: src (B, C, R) -> dst (B, R, C). */
 int xfm_transpose_short_supported(int R, int C);
 int xfm_transpose_short(const void *src, void *dst, int B, int R, int C, int tokens_to_planes, void *stream);
+/* dst (B, C, R) bf16 planes += transpose of src (B, R, C) bf16 tokens (fp32 add, one rounding): x_proj's data gradient at 7 x 7. */
+int xfm_transpose_short_add_bf16(const void *src, void *dst, int B, int R, int C, void *stream);
 
 /*
  * Skinny token-major linear layer on MFMA (csrc/tokens_gemm.hip):  y[T, out] = x[T, con] . W^T (+ bias), bf16 in / out,

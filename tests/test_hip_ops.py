@@ -878,6 +878,12 @@ def test_transpose_short_is_the_exact_permutation_both_ways(B, R, C):
     gy = torch.randn(B, C, R, generator=g).to(torch.bfloat16).to(DEV)
     tokens_to_planes(tr).backward(gy)
     assert torch.equal(tr.grad, gy.transpose(1, 2).contiguous())
+    # accumulating form: planes += tokens^T, fp32 add, one rounding
+    from xfmamba_amd import _lib
+    acc0 = torch.randn(B, C, R, generator=g).to(torch.bfloat16).to(DEV)
+    acc = acc0.clone()
+    _lib.check(_lib.lib().xfm_transpose_short_add_bf16(t.data_ptr(), acc.data_ptr(), B, R, C, _lib.stream_ptr()), "add")
+    assert torch.equal(acc, (acc0.float() + t.transpose(1, 2).float()).to(torch.bfloat16))
     # a shape the kernel does not take goes through the framework's copy
     u = torch.randn(2, 70, 64, generator=g).to(torch.bfloat16).to(DEV)
     assert not _transpose_short_ok(u, 70, 64)

@@ -267,7 +267,7 @@ template <typename T, int MODE> static int tok_launch(const TokArgs &a0, hipStre
 // other), so both sides move as 16-byte vectors; the tile turns in LDS (rows of 33 dwords: the 2-byte accesses of the flat run
 // walk r fastest, 33 r + c / 2 spreads them over the banks).  The framework's strided copy runs 15-30 us on these 5-14 MB
 // tensors; this is a plain HBM stream.
-template <bool TOK2PL>
+template <bool TOK2PL, bool ACC = false>
 __global__ __launch_bounds__(256) void transpose_short_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int R,
                                                               int C) {
     __shared__ uint32_t tile[64 * 33];
@@ -295,6 +295,14 @@ __global__ __launch_bounds__(256) void transpose_short_kernel(const uint16_t *__
                 const uint32_t hi = t16[r * 66 + c];
                 if (++r == R) { r = 0; ++c; }
                 w[k] = lo | (hi << 16);
+            }
+            if (ACC) {                                   // dst += (bf16 pairs widened, added in fp32, rounded once)
+                const uint4 o = *reinterpret_cast<const uint4 *>(pl_out + f);
+                const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    w[k] = pack_bf16x2(__uint_as_float(w[k] << 16) + __uint_as_float(ov[k] << 16),
+                                       __uint_as_float(w[k] & 0xffff0000u) + __uint_as_float(ov[k] & 0xffff0000u));
             }
             *reinterpret_cast<uint4 *>(pl_out + f) = make_uint4(w[0], w[1], w[2], w[3]);
         }
@@ -447,6 +455,18 @@ int xfm_transpose_short(const void *src, void *dst, int B, int R, int C, int tok
         hipLaunchKernelGGL(transpose_short_kernel<true>, grid, block, 0, (hipStream_t)stream, (const uint16_t *)src, (uint16_t *)dst, R, C);
     else
         hipLaunchKernelGGL(transpose_short_kernel<false>, grid, block, 0, (hipStream_t)stream, (const uint16_t *)src, (uint16_t *)dst, R, C);
+    return check_launch();
+}
+
+/* dst (B, C, R) bf16 planes += src (B, R, C) bf16 tokens, transposed: the accumulating half of a gradient that arrives
+ * token-major for a plane-major tensor (x_proj's data gradient at 7 x 7: dx += (d x_dbl . Wx)^T). */
+int xfm_transpose_short_add_bf16(const void *src, void *dst, int B, int R, int C, void *stream) {
+    using namespace xfm;
+    if (!src || !dst || B <= 0) return XFM_EINVAL;
+    if (!xfm_transpose_short_supported(R, C)) return XFM_ELIMIT;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return XFM_EINVAL;
+    hipLaunchKernelGGL((transpose_short_kernel<true, true>), dim3((unsigned)(C / 64), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)src, (uint16_t *)dst, R, C);
     return check_launch();
 }
 

@@ -18,7 +18,7 @@ from . import _lib
 from . import fp8 as _fp8
 from . import amp as _amp
 from .amp import cast_weight
-from .proj import zeros_f32
+from .proj import zeros_f32, _transpose_raw, _transpose_short_ok
 
 __all__ = ["ss2d_chan_fn", "chan_supported", "SS2DChanHip"]
 
@@ -87,6 +87,7 @@ class SS2DChanHip(torch.autograd.Function):
         if L != H * W or K != 4 or C2 != R + 2 * N or x.dtype != torch.bfloat16:
             raise RuntimeError("ss2d_chan: x (B,D,H*W) bf16, x_proj_weight (4,R+2N,D), dt_projs_weight (4,D,R) expected")
         x = x.contiguous()
+        xt = None
         Rp8, NBo, C2p, _ = _col_layout(R, N)
         XC = K * C2p
         rows = _row_index(K, R, N, x.device)
@@ -121,6 +122,11 @@ class SS2DChanHip(torch.autograd.Function):
             from .proj import _mfma_proj
             # (the tiled layout-changing projection where it covers the shape -- 14 x 14: 384 -> 128 -- else the library)
             xdbl = _mfma_proj(x, xw_pad, None, False, True, False) if _XPROJ_TILED else None      # (B, L, XC) token-major
+            if xdbl is None and x.dtype == torch.bfloat16 and xw_pad.dtype == torch.bfloat16 and _transpose_short_ok(x, L, Dm):
+                # short maps (7 x 7): x to token-major by the streaming transpose, then ONE GEMM over all B * L rows (the
+                # per-sample products of bmm: 28 us for the deep block against 5 + 8); the backward pass reuses xt
+                xt = _transpose_raw(x, False)                                                    # (B, L, D)
+                xdbl = torch.matmul(xt, xw_pad.t())
             if xdbl is None:
                 xdbl = torch.bmm(x.transpose(1, 2), xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC))
         A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
@@ -137,6 +143,7 @@ class SS2DChanHip(torch.autograd.Function):
         ctx.cmod = (c_mod, c_off)
         ctx.meta = (x_proj_w.dtype, tuple(x_proj_w.shape), dt_w.dtype)
         ctx.save_for_backward(x, xdbl, xw_pad, wdt, A, D, bias, chk)
+        ctx.xt = xt                                        # token-major x of the short-map path, or None
         return y
 
     @staticmethod
@@ -185,9 +192,18 @@ class SS2DChanHip(torch.autograd.Function):
             with torch.cuda.device(dev), _lib.timed("proj_gemm", Bt * L * (XC + 2 * Dm) * 2):
                 _lib.check(lib2.xfm_proj_gemm_accumulate(dxdbl.data_ptr(), xw_pad.data_ptr(), dx.data_ptr(), Bt, L, XC, Dm, 1,
                                                          _lib.stream_ptr()), "proj_gemm_accumulate")
+        elif ctx.xt is not None and dx.dtype == torch.bfloat16 and dx.is_contiguous() and dx.data_ptr() % 16 == 0:
+            t = torch.matmul(dxdbl, xw_pad)                                               # (B, L, D) token-major
+            with torch.cuda.device(dev), _lib.timed("transpose_short", t.numel() * 6):
+                _lib.check(lib2.xfm_transpose_short_add_bf16(t.data_ptr(), dx.data_ptr(), Bt, L, Dm, _lib.stream_ptr()),
+                           "transpose_short_add")                                         # dx += t^T
         else:
             dx.baddbmm_(xw_pad.t().unsqueeze(0).expand(Bt, Dm, XC), dxdbl.transpose(1, 2))   # dx += Wx^T . d x_dbl^T
-        dxw_pad = wgrad_mfma(dxdbl, False, x, True)                                       # (XC, D) fp32
+        if ctx.xt is not None:
+            dxw_pad = wgrad_mfma(dxdbl, False, ctx.xt, False)                             # (XC, D) fp32, tokens x tokens
+            ctx.xt = None
+        else:
+            dxw_pad = wgrad_mfma(dxdbl, False, x, True)                                   # (XC, D) fp32
         if dxw_pad is None:
             dxw_pad = _bmm_f32(dxdbl.transpose(1, 2), x.transpose(1, 2)).sum(0)
         if Rp8 == R:
