@@ -161,6 +161,17 @@ int xfm_layernorm2d_bwd_parts_blocks(int B, int C, int L, int x_dtype, int y_dty
 int xfm_layernorm2d_bwd_parts(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,
                               void *dx, float *parts, int B, int C, int L, int x_dtype, int y_dtype, void *stream);
 
+/* LayerNorm2d on 7 x 7 maps with wide rows (16 <= L <= 51, C % 64 == 0, C >= 512), the slab form: workgroups own a (sample,
+ * 64-channel slab) and read it as one coalesced run; two kernels with a workspace of xfm_layernorm2d_ws_floats(B, C, L) fp32
+ * values between them (0: not covered, use the entries above).  Results as xfm_layernorm2d_fwd / xfm_layernorm2d_bwd_parts;
+ * the partial rows of the backward are (B, 2, C), one row pair per sample (parts may be NULL: no weight / bias gradient). */
+int xfm_layernorm2d_ws_floats(int B, int C, int L);
+int xfm_layernorm2d_fwd_ws(const void *x, const float *weight, const float *bias, void *y, float *mean, float *rstd,
+                           float *workspace, int B, int C, int L, float eps, int x_dtype, int y_dtype, void *stream);
+int xfm_layernorm2d_bwd_parts_ws(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,
+                                 void *dx, float *parts, float *workspace, int B, int C, int L, int x_dtype, int y_dtype,
+                                 void *stream);
+
 /* Residual add + DropPath scale + LayerNorm over C of a TOKEN-MAJOR stream (rows = B*rows_per_sample tokens of C
  * channels, contiguous), one pass:   x_new = x + scale[b]*y ;  h = LayerNorm_C(x_new)*weight + bias.
  * Replaces `x = x + self.drop_path(branch(x))` followed by the next `self.norm2(x)` / `self.norm(x)` of

@@ -241,6 +241,9 @@ __global__ void __launch_bounds__(256) ln2d_bwd_dx_short_kernel(const Tx *__rest
 // (position pi, slice cs) keeps channels cs + 32 j, j < CPT = C / 32, in registers, so x (and dy) are read once and 1568
 // positions make 196 workgroups (the lanes-along-positions forms launch 25 for a 32 x 768 x 7 x 7 map: 27 us for 4.8 MB).
 // The backward kernel can leave the weight / bias gradient's partial rows ([sum dy * xhat | sum dy] over its 8 positions).
+// (Tried instead: ONE 1024-thread workgroup per sample reading its (C, L) block as a flat, fully coalesced run with the values
+//  in registers -- 46 / 77 us against 33 / 56 us here at 96 x 1536 x 7 x 7: 96 workgroups leave 160 CUs idle and a workgroup's
+//  77 loads per thread go out in register-limited batches.)
 template <typename Tx, typename Ty, int CPT>
 __global__ void __launch_bounds__(256) ln2d_fwd_short_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
                                                              const float *__restrict__ bias, Ty *__restrict__ y,
@@ -256,7 +259,8 @@ __global__ void __launch_bounds__(256) ln2d_fwd_short_kernel(const Tx *__restric
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        v[j] = ok ? ldf<Tx>(x + o + (int64_t)(cs + 32 * j) * L) : 0.f;
+        const float ld = ldf<Tx>(x + o + (int64_t)(cs + 32 * j) * L);      // (always issued: a load under a lane condition sits in
+        v[j] = ok ? ld : 0.f;                                             //  its own block and the join waits for it -- 48 serial loads)
         s += v[j];
     }
     red[cs][pi] = s;
@@ -307,8 +311,9 @@ __global__ void __launch_bounds__(256) ln2d_bwd_dx_short8_kernel(const Tx *__res
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int64_t a = o + (int64_t)(cs + 32 * j) * L;
-        g[j] = ok ? ldf<Ty>(dy + a) : 0.f;
-        xh[j] = ok ? (ldf<Tx>(x + a) - mu) * rs : 0.f;
+        const float gl = ldf<Ty>(dy + a), xl = ldf<Tx>(x + a);           // (always issued, see the forward kernel)
+        g[j] = ok ? gl : 0.f;
+        xh[j] = ok ? (xl - mu) * rs : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
@@ -351,6 +356,199 @@ __global__ void __launch_bounds__(256) ln2d_bwd_dx_short8_kernel(const Tx *__res
             }
         }
     }
+}
+
+// ---- 7 x 7 maps on the whole chip, COALESCED: the slab form (round 4).  A workgroup owns a (sample, 64-channel slab): its
+// 64 L elements are one flat run; thread t = q L + p (q < 5 channel groups, p < L <= 51 positions) reads element t + 5 L j of
+// the run in step j (channel q + 5 j of the slab, ITS position p): contiguous across the workgroup, register accumulators per
+// position, a 5-way fold through LDS.  The statistics over all C channels need the other slabs: kernel 1 leaves one partial
+// pair per (sample, slab, position) in a workspace, kernel 2 folds the C / 64 pairs of its sample (L2 reads) and applies.
+// Forward pairs: [sum (x - s) | sum (x - s)^2] with the shift s = x[b, 0, p] (no cancellation when |mean| >> std);
+// backward pairs: [sum g w | sum g w xhat].  The backward's second kernel also leaves the weight / bias gradient's partial
+// rows, one row pair per SAMPLE.  B * C / 64 workgroups (2304 at 96 x 1536) instead of 96 or position slices of 32 bytes.
+constexpr int kSlabC = 64, kSlabG = 5, kSlabJ = (kSlabC + kSlabG - 1) / kSlabG;      // 13 steps
+
+template <typename Tx>
+__global__ void __launch_bounds__(256) ln2d_slab_stats_kernel(const Tx *__restrict__ x, float *__restrict__ ws, int C, int L) {
+    __shared__ float red[2][kSlabG][52];
+    const int t = threadIdx.x, slab = blockIdx.x, b = blockIdx.y, nslab = C / kSlabC;
+    const bool act = t < kSlabG * L;
+    const int q = act ? t / L : 0, p = act ? t - q * L : 0, GL = kSlabG * L;
+    const Tx *xs = x + ((int64_t)b * C + (int64_t)slab * kSlabC) * L;
+    const float sh = ldf<Tx>(x + (int64_t)b * C * L + p);
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kSlabJ; ++j) {
+        const bool ok = act && q + kSlabG * j < kSlabC;
+        const float v = ldf<Tx>(xs + (ok ? t + GL * j : 0)) - sh;
+        s += ok ? v : 0.f;
+        s2 += ok ? v * v : 0.f;
+    }
+    if (act) {
+        red[0][q][p] = s;
+        red[1][q][p] = s2;
+    }
+    __syncthreads();
+    if (t < 2 * L) {
+        const int which = t >= L, pp = which ? t - L : t;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < kSlabG; ++k) a += red[which][k][pp];
+        ws[(((int64_t)b * nslab + slab) * 2 + which) * L + pp] = a;
+    }
+}
+
+// the nslab partial pairs of a sample, folded by all five thread groups (group q takes slabs q, q + 5, ...: the loads of a
+// group's few steps are independent; one thread per position walking all 24 slabs was 17 us of serial L2 latency)
+__device__ __forceinline__ void ln2d_slab_fold(const float *__restrict__ pw, int nslab, int L, int t,
+                                               float (&fold)[2][kSlabG][52]) {
+    if (t < kSlabG * L) {
+        const int q = t / L, p = t - q * L;
+        float a = 0.f, a2 = 0.f;
+#pragma unroll 8
+        for (int k = q; k < nslab; k += kSlabG) {
+            a += pw[(int64_t)(2 * k) * L + p];
+            a2 += pw[(int64_t)(2 * k + 1) * L + p];
+        }
+        fold[0][q][p] = a;
+        fold[1][q][p] = a2;
+    }
+    __syncthreads();
+}
+
+template <typename Tx, typename Ty>
+__global__ void __launch_bounds__(256) ln2d_slab_apply_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, Ty *__restrict__ y,
+                                                              float *__restrict__ mean, float *__restrict__ rstd,
+                                                              const float *__restrict__ ws, int C, int L, float eps) {
+    __shared__ float st[2][52];
+    __shared__ float fold[2][kSlabG][52];
+    const int t = threadIdx.x, slab = blockIdx.x, b = blockIdx.y, nslab = C / kSlabC;
+    ln2d_slab_fold(ws + (int64_t)b * nslab * 2 * L, nslab, L, t, fold);
+    if (t < L) {
+        float a = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < kSlabG; ++k) {
+            a += fold[0][k][t];
+            a2 += fold[1][k][t];
+        }
+        const float sh = ldf<Tx>(x + (int64_t)b * C * L + t);
+        const float d = a / (float)C;                       // mean - shift
+        const float var = fmaxf(a2 / (float)C - d * d, 0.f);
+        const float mu = sh + d, rs = rsqrtf(var + eps);
+        st[0][t] = mu;
+        st[1][t] = rs;
+        if (slab == 0) {
+            mean[(int64_t)b * L + t] = mu;
+            rstd[(int64_t)b * L + t] = rs;
+        }
+    }
+    __syncthreads();
+    if (t >= kSlabG * L) return;
+    const int q = t / L, p = t - q * L, GL = kSlabG * L;
+    const float mu = st[0][p], rs = st[1][p];
+    const int64_t o = ((int64_t)b * C + (int64_t)slab * kSlabC) * L + t;
+#pragma unroll
+    for (int j = 0; j < kSlabJ; ++j) {
+        const int cl = q + kSlabG * j;
+        if (cl < kSlabC) {
+            const int c = slab * kSlabC + cl;
+            stf<Ty>(y + o + GL * j, fmaf((ldf<Tx>(x + o + GL * j) - mu) * rs, w[c], bias ? bias[c] : 0.f));
+        }
+    }
+}
+
+template <typename Tx, typename Ty>
+__global__ void __launch_bounds__(256) ln2d_slab_bwd_stats_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                                  const Ty *__restrict__ dy, const float *__restrict__ mean,
+                                                                  const float *__restrict__ rstd, float *__restrict__ ws, int C,
+                                                                  int L) {
+    __shared__ float red[2][kSlabG][52];
+    const int t = threadIdx.x, slab = blockIdx.x, b = blockIdx.y, nslab = C / kSlabC;
+    const bool act = t < kSlabG * L;
+    const int q = act ? t / L : 0, p = act ? t - q * L : 0, GL = kSlabG * L;
+    const int64_t o = ((int64_t)b * C + (int64_t)slab * kSlabC) * L;
+    const float mu = mean[(int64_t)b * L + p], rs = rstd[(int64_t)b * L + p];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kSlabJ; ++j) {
+        const int cl = q + kSlabG * j;
+        const bool ok = act && cl < kSlabC;
+        const int64_t a = o + (ok ? t + GL * j : 0);
+        const float g = ldf<Ty>(dy + a) * w[slab * kSlabC + (ok ? cl : 0)];
+        const float xh = (ldf<Tx>(x + a) - mu) * rs;
+        s1 += ok ? g : 0.f;
+        s2 += ok ? g * xh : 0.f;
+    }
+    if (act) {
+        red[0][q][p] = s1;
+        red[1][q][p] = s2;
+    }
+    __syncthreads();
+    if (t < 2 * L) {
+        const int which = t >= L, pp = which ? t - L : t;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < kSlabG; ++k) a += red[which][k][pp];
+        ws[(((int64_t)b * nslab + slab) * 2 + which) * L + pp] = a;
+    }
+}
+
+template <typename Tx, typename Ty>
+__global__ void __launch_bounds__(256) ln2d_slab_bwd_apply_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                                  const Ty *__restrict__ dy, const float *__restrict__ mean,
+                                                                  const float *__restrict__ rstd, Tx *__restrict__ dx,
+                                                                  const float *__restrict__ ws, float *__restrict__ parts, int C,
+                                                                  int L) {
+    __shared__ float st[2][52];
+    __shared__ float fold[2][kSlabG][52];
+    __shared__ float col[2][kSlabC * 51];                   // [dy xhat | dy][channel of the slab][position]: odd pitch L
+    const int t = threadIdx.x, slab = blockIdx.x, b = blockIdx.y, nslab = C / kSlabC;
+    ln2d_slab_fold(ws + (int64_t)b * nslab * 2 * L, nslab, L, t, fold);
+    if (t < L) {
+        float a = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < kSlabG; ++k) {
+            a += fold[0][k][t];
+            a2 += fold[1][k][t];
+        }
+        st[0][t] = a / (float)C;
+        st[1][t] = a2 / (float)C;
+    }
+    __syncthreads();
+    const bool act = t < kSlabG * L;
+    const int q = act ? t / L : 0, p = act ? t - q * L : 0, GL = kSlabG * L;
+    const float mu = mean[(int64_t)b * L + p], rs = rstd[(int64_t)b * L + p];
+    const float m1 = st[0][p], m2 = st[1][p];
+    const int64_t o = ((int64_t)b * C + (int64_t)slab * kSlabC) * L + t;
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < kSlabJ; ++j) {
+            const int cl = q + kSlabG * j;
+            if (cl < kSlabC) {
+                const float gr = ldf<Ty>(dy + o + GL * j);
+                const float xh = (ldf<Tx>(x + o + GL * j) - mu) * rs;
+                stf<Tx>(dx + o + GL * j, rs * (gr * w[slab * kSlabC + cl] - m1 - xh * m2));
+                if (parts) {
+                    col[0][cl * L + p] = gr * xh;
+                    col[1][cl * L + p] = gr;
+                }
+            }
+        }
+    }
+    if (!parts) return;
+    __syncthreads();
+    if (t < 2 * kSlabC) {
+        const int which = t >= kSlabC, cl = which ? t - kSlabC : t;
+        const float *cp = col[which] + cl * L;
+        float a = 0.f;
+        for (int k = 0; k < L; ++k) a += cp[k];
+        parts[((int64_t)b * 2 + which) * C + slab * kSlabC + cl] = a;
+    }
+}
+
+static bool ln2d_slab_ok(int B, int C, int L) {
+    return L >= 16 && L <= 51 && C >= 512 && C % kSlabC == 0 && (int64_t)B * L <= 16 * 1024 && !getenv("XFM_LN2D_NO_SLAB");
 }
 
 static bool ln2d_short8_ok(int B, int C, int L) {
@@ -936,6 +1134,60 @@ int xfm_layernorm2d_bwd_parts(const void *x, const float *weight, const void *dy
     if (x_dtype == XFM_BF16 && y_dtype == XFM_BF16) return ln_bwd<bf16_t, bf16_t>(x, weight, dy, mean, rstd, dx, nullptr, nullptr, B, C, L, s, parts);
     if (x_dtype == XFM_BF16 && y_dtype == XFM_F32) return ln_bwd<bf16_t, float>(x, weight, dy, mean, rstd, dx, nullptr, nullptr, B, C, L, s, parts);
     return XFM_EDTYPE;
+}
+
+/* The slab form for 7 x 7 maps (two kernels, a workspace of xfm_layernorm2d_ws_floats(...) fp32 values between them; 0: the
+ * form does not cover the shape, use the entries above).  Same results as xfm_layernorm2d_fwd / _bwd_parts; the backward's
+ * partial rows are (B, 2, C): one row pair per sample. */
+int xfm_layernorm2d_ws_floats(int B, int C, int L) {
+    if (B <= 0 || C <= 0 || L <= 0 || !xfm::ln2d_slab_ok(B, C, L)) return 0;
+    return B * (C / xfm::kSlabC) * 2 * L;
+}
+
+int xfm_layernorm2d_fwd_ws(const void *x, const float *weight, const float *bias, void *y, float *mean, float *rstd,
+                           float *workspace, int B, int C, int L, float eps, int x_dtype, int y_dtype, void *stream) {
+    using namespace xfm;
+    if (!x || !weight || !y || !mean || !rstd || !workspace) return XFM_EINVAL;
+    if (!xfm_layernorm2d_ws_floats(B, C, L)) return XFM_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(C / kSlabC), (unsigned)B), block(256);
+#define XFM_LN2D_SLAB_F(TX, TY)                                                                                             \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL((ln2d_slab_stats_kernel<TX>), grid, block, 0, s, (const TX *)x, workspace, C, L);                 \
+        hipLaunchKernelGGL((ln2d_slab_apply_kernel<TX, TY>), grid, block, 0, s, (const TX *)x, weight, bias, (TY *)y, mean,  \
+                           rstd, workspace, C, L, eps);                                                                     \
+    } while (0)
+    if (x_dtype == XFM_F32 && y_dtype == XFM_F32) XFM_LN2D_SLAB_F(float, float);
+    else if (x_dtype == XFM_F32 && y_dtype == XFM_BF16) XFM_LN2D_SLAB_F(float, bf16_t);
+    else if (x_dtype == XFM_BF16 && y_dtype == XFM_BF16) XFM_LN2D_SLAB_F(bf16_t, bf16_t);
+    else if (x_dtype == XFM_BF16 && y_dtype == XFM_F32) XFM_LN2D_SLAB_F(bf16_t, float);
+    else return XFM_EDTYPE;
+#undef XFM_LN2D_SLAB_F
+    return check_launch();
+}
+
+int xfm_layernorm2d_bwd_parts_ws(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,
+                                 void *dx, float *parts, float *workspace, int B, int C, int L, int x_dtype, int y_dtype,
+                                 void *stream) {
+    using namespace xfm;
+    if (!x || !weight || !dy || !mean || !rstd || !dx || !workspace) return XFM_EINVAL;
+    if (!xfm_layernorm2d_ws_floats(B, C, L)) return XFM_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(C / kSlabC), (unsigned)B), block(256);
+#define XFM_LN2D_SLAB_B(TX, TY)                                                                                             \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL((ln2d_slab_bwd_stats_kernel<TX, TY>), grid, block, 0, s, (const TX *)x, weight, (const TY *)dy,   \
+                           mean, rstd, workspace, C, L);                                                                    \
+        hipLaunchKernelGGL((ln2d_slab_bwd_apply_kernel<TX, TY>), grid, block, 0, s, (const TX *)x, weight, (const TY *)dy,   \
+                           mean, rstd, (TX *)dx, workspace, parts, C, L);                                                   \
+    } while (0)
+    if (x_dtype == XFM_F32 && y_dtype == XFM_F32) XFM_LN2D_SLAB_B(float, float);
+    else if (x_dtype == XFM_F32 && y_dtype == XFM_BF16) XFM_LN2D_SLAB_B(float, bf16_t);
+    else if (x_dtype == XFM_BF16 && y_dtype == XFM_BF16) XFM_LN2D_SLAB_B(bf16_t, bf16_t);
+    else if (x_dtype == XFM_BF16 && y_dtype == XFM_F32) XFM_LN2D_SLAB_B(bf16_t, float);
+    else return XFM_EDTYPE;
+#undef XFM_LN2D_SLAB_B
+    return check_launch();
 }
 
 int xfm_layernorm2d_bwd(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,

@@ -33,10 +33,20 @@ class LayerNorm2dHip(torch.autograd.Function):
         mean = torch.empty((B, L), dtype=torch.float32, device=x.device)
         rstd = torch.empty((B, L), dtype=torch.float32, device=x.device)
         nbytes = x.numel() * (x.element_size() + y.element_size())
-        with torch.cuda.device(x.device), _lib.timed("layernorm2d_fwd", nbytes):
-            _lib.check(_lib.lib().xfm_layernorm2d_fwd(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), mean.data_ptr(),
-                                                      rstd.data_ptr(), B, C, L, float(eps), _lib.dtype_code(x.dtype),
-                                                      _lib.dtype_code(out_dtype), _lib.stream_ptr()), "layernorm2d_fwd")
+        nws = _lib.lib().xfm_layernorm2d_ws_floats(B, C, L)
+        if nws > 0:
+            # 7 x 7 maps with wide rows: the slab form (two kernels, partial statistics per 64-channel slab between them)
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device), _lib.timed("layernorm2d_fwd", nbytes):
+                _lib.check(_lib.lib().xfm_layernorm2d_fwd_ws(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), mean.data_ptr(),
+                                                             rstd.data_ptr(), ws.data_ptr(), B, C, L, float(eps),
+                                                             _lib.dtype_code(x.dtype), _lib.dtype_code(out_dtype),
+                                                             _lib.stream_ptr()), "layernorm2d_fwd_ws")
+        else:
+            with torch.cuda.device(x.device), _lib.timed("layernorm2d_fwd", nbytes):
+                _lib.check(_lib.lib().xfm_layernorm2d_fwd(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), mean.data_ptr(),
+                                                          rstd.data_ptr(), B, C, L, float(eps), _lib.dtype_code(x.dtype),
+                                                          _lib.dtype_code(out_dtype), _lib.stream_ptr()), "layernorm2d_fwd")
         ctx.save_for_backward(x, w, mean, rstd)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)                        # (identity only: what deferred.add_job checks)
@@ -55,6 +65,20 @@ class LayerNorm2dHip(torch.autograd.Function):
         dx = torch.empty_like(x)
         lib = _lib.lib()
         xc, yc = _lib.dtype_code(x.dtype), _lib.dtype_code(ctx.ydtype)
+        nws = lib.xfm_layernorm2d_ws_floats(B, C, L) if ctx.has_bias else 0
+        if nws > 0:
+            # the slab form (7 x 7 maps): partial rows of the weight / bias gradient per sample
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            part = torch.empty(B * 2 * C, dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device), _lib.timed("layernorm2d_bwd", x.numel() * (2 * x.element_size() + dy.element_size())):
+                _lib.check(lib.xfm_layernorm2d_bwd_parts_ws(x.data_ptr(), w.data_ptr(), dy.data_ptr(), mean.data_ptr(),
+                                                            rstd.data_ptr(), dx.data_ptr(), part.data_ptr(), ws.data_ptr(), B, C, L,
+                                                            xc, yc, _lib.stream_ptr()), "layernorm2d_bwd_parts_ws")
+            dw, db = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
+            if not _deferred.add_job(part, [dw, db], B, C, 2, params=ctx.params):
+                pr = part.view(B, 2, C).sum(0)
+                dw, db = pr[0], pr[1]
+            return dx, dw.to(ctx.wdtype), db.to(ctx.wdtype), None, None
         nblk = lib.xfm_layernorm2d_bwd_parts_blocks(B, C, L, xc, yc) if ctx.has_bias and _PARTS else 0
         if nblk > 0:
             # the dx kernel leaves the weight / bias gradient as one partial row pair per workgroup: no second kernel reading x and
