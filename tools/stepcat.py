@@ -21,7 +21,10 @@ for r in csv.DictReader(open(f)):
     elif 'ln2d' in n: fam = 'LayerNorm2d'
     elif 'wgrad_kernel' in n or 'wgrad_tt' in n: fam = 'own MFMA weight-gradient GEMM'
     elif 'tokens_gemm2' in n or 'tokens_gemm3' in n: fam = 'own MFMA GEMM with GELU epilogue (Mlp fc1 / fc2 data gradient)'
-    elif 'tokens_gemm' in n or 'planes_gemm' in n or 'proj_gemm' in n: fam = 'own MFMA GEMM'
+    elif 'tokens_gemm' in n or 'planes_gemm' in n or 'proj_gemm' in n or 'proj_tiled' in n: fam = 'own MFMA GEMM'
+    elif 'transpose_short' in n: fam = 'tokens <-> planes transposes (7x7)'
+    elif 'batch_norm' in n or 'CatArray' in n or 'elementwise_kernel' in n or 'rocclr' in n or 'layer_norm' in n or 'GammaBeta' in n or 'distribution_' in n or 'multi_tensor_apply' in n or 'softmax' in n or 'nll_loss' in n:
+        fam = 'framework elementwise / copy / fill'
     elif 'tokens_kernel' in n or 'colsum' in n: fam = 'bias+GELU / column sums'
     elif 'dwconv' in n: fam = 'depthwise conv + SiLU'
     elif 'adam' in n: fam = 'fused Adam'
