@@ -25,6 +25,7 @@ Two switches select equivalent evaluation orders (same parameters, same results;
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from functools import partial
 from typing import Any, Callable
@@ -43,6 +44,7 @@ from .rowln import residual_settle_fn, add_layernorm_rows_fn, layernorm_rows_fn,
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
 from .ss2d_chan import chan_supported, ss2d_chan_fn
 from . import fp8 as _fp8
+from .amp import cast_weight
 
 SS2D_MODE = "fused"          # "fused" | "unfused"
 # Layout of the trunk's residual stream between VSS blocks.  "tokens": (B, H, W, C) fp32 -- LayerNorm (+ residual add
@@ -580,6 +582,44 @@ def _run_blocks(blocks: nn.Sequential, x: torch.Tensor):
     return _blocks_tokens(blocks, t).permute(0, 3, 1, 2).contiguous()
 
 
+# XFM_CONV_CL=0: the strided convolutions through F.conv2d (A/B switch, read once)
+_CONV_CL = os.environ.get("XFM_CONV_CL", "1") == "1"
+
+
+class _ConvChannelsLast(torch.autograd.Function):
+    """A bias-free ``F.conv2d`` on a channels_last map with the weight's layout copies taken out.  Through ``F.conv2d`` under
+    autocast every strided convolution of the trunk pays five weight-sized copies per step (autocast's cast, the
+    channels_last copy for MIOpen's NHWC kernels in the forward pass and again in the backward pass, the weight gradient
+    back to OIHW, its cast to fp32); here the weight's compute-dtype shadow (``amp.cast_weight``) is made channels_last once,
+    kept for the backward pass, and the weight gradient goes from MIOpen's layout to the parameter's in ONE cast + permute."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding, dilation, groups):
+        cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else weight.dtype
+        ctx.x_dtype, ctx.w_dtype = x.dtype, weight.dtype
+        x = x if x.dtype == cd else x.to(cd)
+        w = cast_weight(weight, cd).contiguous(memory_format=torch.channels_last)
+        ctx.conv = (tuple(stride), tuple(padding), tuple(dilation), groups)
+        with torch.autocast("cuda", enabled=False):
+            y = torch.ops.aten.convolution(x, w, None, ctx.conv[0], ctx.conv[1], ctx.conv[2], False, [0, 0], groups)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, groups = ctx.conv
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, stride, padding, dilation, False, [0, 0], groups,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        if gw is not None:
+            gw = gw.to(dtype=ctx.w_dtype, memory_format=torch.contiguous_format)
+        if gx is not None and gx.dtype != ctx.x_dtype:
+            gx = gx.to(ctx.x_dtype)
+        return gx, gw, None, None, None, None
+
+
 def _conv_ln_tokens(conv: nn.Conv2d, norm: nn.Module, t: torch.Tensor, out_dtype=None) -> torch.Tensor:
     """``norm(conv(t))`` on a token-major (B, H, W, C) tensor -> (B, H', W', C').  The convolution is handed to
     MIOpen as a channels_last map (its implicit-GEMM kernels are NHWC-native, so no NCHW<->NHWC transposes run around
@@ -588,8 +628,11 @@ def _conv_ln_tokens(conv: nn.Conv2d, norm: nn.Module, t: torch.Tensor, out_dtype
     fused = isinstance(norm, LayerNorm2d)
     if t.dtype != conv.weight.dtype and not torch.is_autocast_enabled():
         t = t.to(conv.weight.dtype)                      # fp32 residual stream into a reduced-precision model
-    y = F.conv2d(t.permute(0, 3, 1, 2), conv.weight, None if fused else conv.bias, conv.stride, conv.padding,
-                 conv.dilation, conv.groups)
+    if _CONV_CL and fused and t.is_cuda and conv.padding_mode == "zeros" and not isinstance(conv.padding, str):
+        y = _ConvChannelsLast.apply(t.permute(0, 3, 1, 2), conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+    else:
+        y = F.conv2d(t.permute(0, 3, 1, 2), conv.weight, None if fused else conv.bias, conv.stride, conv.padding,
+                     conv.dilation, conv.groups)
     y = y.permute(0, 2, 3, 1)
     y = y if y.is_contiguous() else y.contiguous()
     if not fused:

@@ -33,7 +33,8 @@ class LayerNorm2dHip(torch.autograd.Function):
         mean = torch.empty((B, L), dtype=torch.float32, device=x.device)
         rstd = torch.empty((B, L), dtype=torch.float32, device=x.device)
         nbytes = x.numel() * (x.element_size() + y.element_size())
-        nws = _lib.lib().xfm_layernorm2d_ws_floats(B, C, L)
+        slab_dt = x.dtype in (torch.float32, torch.bfloat16) and out_dtype in (torch.float32, torch.bfloat16)
+        nws = _lib.lib().xfm_layernorm2d_ws_floats(B, C, L) if slab_dt else 0      # (the slab form is built for fp32 / bf16)
         if nws > 0:
             # 7 x 7 maps with wide rows: the slab form (two kernels, partial statistics per 64-channel slab between them)
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
@@ -65,7 +66,8 @@ class LayerNorm2dHip(torch.autograd.Function):
         dx = torch.empty_like(x)
         lib = _lib.lib()
         xc, yc = _lib.dtype_code(x.dtype), _lib.dtype_code(ctx.ydtype)
-        nws = lib.xfm_layernorm2d_ws_floats(B, C, L) if ctx.has_bias else 0
+        slab_dt = x.dtype in (torch.float32, torch.bfloat16) and ctx.ydtype in (torch.float32, torch.bfloat16)
+        nws = lib.xfm_layernorm2d_ws_floats(B, C, L) if ctx.has_bias and slab_dt else 0
         if nws > 0:
             # the slab form (7 x 7 maps): partial rows of the weight / bias gradient per sample
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
