@@ -168,6 +168,10 @@ int xfm_layernorm2d_bwd_parts(const void *x, const float *weight, const void *dy
 int xfm_layernorm2d_ws_floats(int B, int C, int L);
 int xfm_layernorm2d_fwd_ws(const void *x, const float *weight, const float *bias, void *y, float *mean, float *rstd,
                            float *workspace, int B, int C, int L, float eps, int x_dtype, int y_dtype, void *stream);
+/* Backward: workspace size and number of partial row pairs of xfm_layernorm2d_bwd_parts_ws -- the slab form above, or the split
+ * form for 14 x 14 maps with 384 channels (nothing cached, two coalesced passes; one row pair per 64 positions); 0: not covered. */
+int xfm_layernorm2d_bwd_ws_floats(int B, int C, int L);
+int xfm_layernorm2d_bwd_ws_blocks(int B, int C, int L);
 int xfm_layernorm2d_bwd_parts_ws(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,
                                  void *dx, float *parts, float *workspace, int B, int C, int L, int x_dtype, int y_dtype,
                                  void *stream);

@@ -304,7 +304,7 @@ def test_fused_ss2d_matches_oracle_chain(shape):
 
 @pytest.mark.parametrize("shape", [(2, 96, 56, 56), (3, 192, 28, 28), (2, 384, 14, 14), (5, 768, 7, 7), (1, 33, 5, 9),
                                    (2, 256, 24, 20), (1, 512, 12, 12), (2, 1024, 24, 24), (1, 2048, 12, 12),     # XFMamba-B widths
-                                   (3, 1536, 7, 7), (1, 520, 9, 5), (32, 768, 7, 7)])                                         # wide rows: 16-wave two-pass kernels
+                                   (3, 1536, 7, 7), (1, 520, 9, 5), (32, 768, 7, 7), (21, 384, 14, 14)])                                         # wide rows: 16-wave two-pass kernels
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16)])
 def test_layernorm2d_matches_torch_fp32(shape, xdt, ydt):

@@ -697,6 +697,84 @@ __global__ void __launch_bounds__(1024) ln2d_bwd_dx_cached_kernel(const Tx *__re
 
 // ---- vectorised forms of the two cached kernels for fp32 maps / bf16 outputs (the SS2D out_norm under autocast):
 // a lane owns VP consecutive positions (16- / 8-byte accesses instead of 4- / 2-byte ones), 16 waves split the channels.
+// ---- backward on 14 x 14 maps with 384 channels, split form (round 4).  The register-cached kernel above needs 16 waves per
+// workgroup to hold a position's 2 x 384 values: one workgroup per CU, every barrier idles the CU -- 40.8 us for 48 MB
+// (1.2 TB/s).  Nothing is cached here: kernel 1 (lane = position, four waves x CPW channels of a 4 CPW-channel slab) leaves
+// [sum g w | sum g w xhat] per (slab, position) in a workspace, kernel 2 folds the C / (4 CPW) slab pairs of its position, reads
+// x and dy again (just read by kernel 1: the step's 29 MB sit in the 256 MB last-level cache), writes dx and the weight /
+// bias partial rows of its 64 positions (wave sums on DPP adds).  256-thread workgroups, 4 x (B L / 64) of them.
+template <typename Tx, typename Ty, int CPW>
+__global__ void __launch_bounds__(256) ln2d_bwd_split_stats_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                                   const Ty *__restrict__ dy, const float *__restrict__ mean,
+                                                                   const float *__restrict__ rstd, float *__restrict__ ws, int C,
+                                                                   int L, int NP) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slab = blockIdx.y;
+    const int P = blockIdx.x * 64 + lane;
+    const bool ok = P < NP;
+    const int b = ok ? P / L : 0, p = ok ? P - b * L : 0;
+    const int c0 = (slab * 4 + wave) * CPW;
+    const int64_t o = ((int64_t)b * C + c0) * L + p;
+    const float mu = mean[(int64_t)b * L + p], rs = rstd[(int64_t)b * L + p];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        const float g = ldf<Ty>(dy + o + (int64_t)j * L) * w[c0 + j];
+        const float xh = (ldf<Tx>(x + o + (int64_t)j * L) - mu) * rs;
+        s1 += g;
+        s2 = fmaf(g, xh, s2);
+    }
+    red[0][wave][lane] = s1;
+    red[1][wave][lane] = s2;
+    __syncthreads();
+    if (wave < 2 && ok)
+        ws[((int64_t)slab * 2 + wave) * NP + P] = (red[wave][0][lane] + red[wave][1][lane]) + (red[wave][2][lane] + red[wave][3][lane]);
+}
+
+template <typename Tx, typename Ty, int CPW>
+__global__ void __launch_bounds__(256) ln2d_bwd_split_apply_kernel(const Tx *__restrict__ x, const float *__restrict__ w,
+                                                                   const Ty *__restrict__ dy, const float *__restrict__ mean,
+                                                                   const float *__restrict__ rstd, Tx *__restrict__ dx,
+                                                                   const float *__restrict__ ws, float *__restrict__ parts, int C,
+                                                                   int L, int NP) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slab = blockIdx.y, nslab = gridDim.y;
+    const int P = blockIdx.x * 64 + lane;
+    const bool ok = P < NP;
+    const int Pc = ok ? P : 0;
+    const int b = Pc / L, p = Pc - b * L;
+    const int c0 = (slab * 4 + wave) * CPW;
+    const int64_t o = ((int64_t)b * C + c0) * L + p;
+    const float mu = mean[(int64_t)b * L + p], rs = rstd[(int64_t)b * L + p];
+    float m1 = 0.f, m2 = 0.f;
+    for (int k = 0; k < nslab; ++k) {
+        m1 += ws[((int64_t)k * 2) * NP + Pc];
+        m2 += ws[((int64_t)k * 2 + 1) * NP + Pc];
+    }
+    m1 /= (float)C;
+    m2 /= (float)C;
+    float *pr = parts ? parts + (int64_t)blockIdx.x * 2 * C : nullptr;
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        const float gr = ldf<Ty>(dy + o + (int64_t)j * L);
+        const float xh = (ldf<Tx>(x + o + (int64_t)j * L) - mu) * rs;
+        if (ok) stf<Tx>(dx + o + (int64_t)j * L, rs * (gr * w[c0 + j] - m1 - xh * m2));
+        if (parts) {
+            const float a1 = ln2d_lane_sum<false>(ok ? gr * xh : 0.f);
+            const float a2 = ln2d_lane_sum<false>(ok ? gr : 0.f);
+            if (lane == 63) {
+                pr[c0 + j] = a1;
+                pr[C + c0 + j] = a2;
+            }
+        }
+    }
+}
+
+// channels per wave of the split form for this shape (24: slabs of 96 channels), or 0
+static int ln2d_split_cpw(int B, int C, int L) {
+    if (getenv("XFM_LN2D_NO_SPLIT")) return 0;
+    return (C == 384 && (int64_t)B * L >= 4096 && L <= 256) ? 24 : 0;
+}
+
 template <int VP> __device__ __forceinline__ void ldv_f32(const float *p, float (&v)[VP]) {
     if constexpr (VP == 4) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     else { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; }
@@ -1166,13 +1244,47 @@ int xfm_layernorm2d_fwd_ws(const void *x, const float *weight, const float *bias
     return check_launch();
 }
 
+/* Workspace (fp32 values) and partial-row count of xfm_layernorm2d_bwd_parts_ws for this shape: the slab form (7 x 7 maps:
+ * one row pair per sample) or the split form (14 x 14 maps with 384 channels: one row pair per 64 positions); 0: not covered. */
+int xfm_layernorm2d_bwd_ws_floats(int B, int C, int L) {
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (const int n = xfm_layernorm2d_ws_floats(B, C, L)) return n;
+    if (const int cpw = xfm::ln2d_split_cpw(B, C, L)) return (C / (4 * cpw)) * 2 * B * L;
+    return 0;
+}
+
+int xfm_layernorm2d_bwd_ws_blocks(int B, int C, int L) {
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (xfm_layernorm2d_ws_floats(B, C, L)) return B;
+    if (xfm::ln2d_split_cpw(B, C, L)) return (B * L + 63) / 64;
+    return 0;
+}
+
 int xfm_layernorm2d_bwd_parts_ws(const void *x, const float *weight, const void *dy, const float *mean, const float *rstd,
                                  void *dx, float *parts, float *workspace, int B, int C, int L, int x_dtype, int y_dtype,
                                  void *stream) {
     using namespace xfm;
     if (!x || !weight || !dy || !mean || !rstd || !dx || !workspace) return XFM_EINVAL;
-    if (!xfm_layernorm2d_ws_floats(B, C, L)) return XFM_ELIMIT;
+    if (!xfm_layernorm2d_bwd_ws_floats(B, C, L)) return XFM_ELIMIT;
     hipStream_t s = (hipStream_t)stream;
+    if (!xfm_layernorm2d_ws_floats(B, C, L)) {              // the split form
+        const int cpw = ln2d_split_cpw(B, C, L), NP = B * L;
+        const dim3 grid((unsigned)((NP + 63) / 64), (unsigned)(C / (4 * cpw))), block(256);
+#define XFM_LN2D_SPLIT_B(TX, TY)                                                                                            \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL((ln2d_bwd_split_stats_kernel<TX, TY, 24>), grid, block, 0, s, (const TX *)x, weight,              \
+                           (const TY *)dy, mean, rstd, workspace, C, L, NP);                                                \
+        hipLaunchKernelGGL((ln2d_bwd_split_apply_kernel<TX, TY, 24>), grid, block, 0, s, (const TX *)x, weight,              \
+                           (const TY *)dy, mean, rstd, (TX *)dx, workspace, parts, C, L, NP);                               \
+    } while (0)
+        if (x_dtype == XFM_F32 && y_dtype == XFM_F32) XFM_LN2D_SPLIT_B(float, float);
+        else if (x_dtype == XFM_F32 && y_dtype == XFM_BF16) XFM_LN2D_SPLIT_B(float, bf16_t);
+        else if (x_dtype == XFM_BF16 && y_dtype == XFM_BF16) XFM_LN2D_SPLIT_B(bf16_t, bf16_t);
+        else if (x_dtype == XFM_BF16 && y_dtype == XFM_F32) XFM_LN2D_SPLIT_B(bf16_t, float);
+        else return XFM_EDTYPE;
+#undef XFM_LN2D_SPLIT_B
+        return check_launch();
+    }
     const dim3 grid((unsigned)(C / kSlabC), (unsigned)B), block(256);
 #define XFM_LN2D_SLAB_B(TX, TY)                                                                                             \
     do {                                                                                                                    \

@@ -67,18 +67,20 @@ class LayerNorm2dHip(torch.autograd.Function):
         lib = _lib.lib()
         xc, yc = _lib.dtype_code(x.dtype), _lib.dtype_code(ctx.ydtype)
         slab_dt = x.dtype in (torch.float32, torch.bfloat16) and ctx.ydtype in (torch.float32, torch.bfloat16)
-        nws = lib.xfm_layernorm2d_ws_floats(B, C, L) if ctx.has_bias and slab_dt else 0
+        nws = lib.xfm_layernorm2d_bwd_ws_floats(B, C, L) if ctx.has_bias and slab_dt and _PARTS else 0
         if nws > 0:
-            # the slab form (7 x 7 maps): partial rows of the weight / bias gradient per sample
+            # the slab form (7 x 7 maps: partial rows of the weight / bias gradient per sample) or the split form (14 x 14 maps
+            # with 384 channels: per 64 positions); two kernels with a workspace between them
+            nrow = lib.xfm_layernorm2d_bwd_ws_blocks(B, C, L)
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-            part = torch.empty(B * 2 * C, dtype=torch.float32, device=x.device)
+            part = torch.empty(nrow * 2 * C, dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device), _lib.timed("layernorm2d_bwd", x.numel() * (2 * x.element_size() + dy.element_size())):
                 _lib.check(lib.xfm_layernorm2d_bwd_parts_ws(x.data_ptr(), w.data_ptr(), dy.data_ptr(), mean.data_ptr(),
                                                             rstd.data_ptr(), dx.data_ptr(), part.data_ptr(), ws.data_ptr(), B, C, L,
                                                             xc, yc, _lib.stream_ptr()), "layernorm2d_bwd_parts_ws")
             dw, db = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
-            if not _deferred.add_job(part, [dw, db], B, C, 2, params=ctx.params):
-                pr = part.view(B, 2, C).sum(0)
+            if not _deferred.add_job(part, [dw, db], nrow, C, 2, params=ctx.params):
+                pr = part.view(nrow, 2, C).sum(0)
                 dw, db = pr[0], pr[1]
             return dx, dw.to(ctx.wdtype), db.to(ctx.wdtype), None, None
         nblk = lib.xfm_layernorm2d_bwd_parts_blocks(B, C, L, xc, yc) if ctx.has_bias and _PARTS else 0
