@@ -157,6 +157,8 @@ def linear_tokens_fn(x, weight, bias=None):
 # direction.  XFM_MLP_FUSED=0 keeps the three-node chain (A/B switch, read once at import).
 # ---------------------------------------------------------------------------------------------------------------------------
 _FUSED = os.environ.get("XFM_MLP_FUSED", "1") == "1"
+# the Mlp's deep-k / narrow-out products (fc2 forward, fc1 data gradient) on the tiled kernel too (experiment switch, read once)
+_OWN_NARROW = os.environ.get("XFM_MLP_OWN_NARROW", "0") == "1"
 
 
 def _gemm2_ok(x, con, out):
@@ -189,7 +191,10 @@ class MlpFusedHip(torch.autograd.Function):
         H, C = w1c.shape
         x2 = x.reshape(-1, C)
         z, g = _gemm2(x2, w1c, b1, H, False, 1)
-        y = torch.nn.functional.linear(g, w2c, None if b2 is None else cast_weight(b2, cd))
+        if _OWN_NARROW and _gemm2_ok(g, H, C):
+            y, _ = _gemm2(g, w2c, b2, C, False, 0)
+        else:
+            y = torch.nn.functional.linear(g, w2c, None if b2 is None else cast_weight(b2, cd))
         ctx.save_for_backward(x2, z, g, w1c, w2c, b1)
         ctx.meta = (x.shape, w1.dtype, w2.dtype, None if b1 is None else b1.dtype, None if b2 is None else b2.dtype)
         ctx.params = (w1 if isinstance(w1, torch.nn.Parameter) else None, w2 if isinstance(w2, torch.nn.Parameter) else None,
@@ -227,7 +232,10 @@ class MlpFusedHip(torch.autograd.Function):
         else:
             dz, _ = _gemm2(dy2, w2c, b1, H, True, 2, zin=z)
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dz, w1c).view(xshape)
+            if _OWN_NARROW and _gemm2_ok(dz, H, C):
+                dx = _gemm2(dz, w1c, None, C, True, 0)[0].view(xshape)
+            else:
+                dx = torch.mm(dz, w1c).view(xshape)
         if ctx.needs_input_grad[1]:
             slot = wgrad_slot(pw1, H, C) if w1dt == torch.float32 else None
             dw1 = split_k_wgrad(dz, x2, deferred=w1dt == torch.float32, out=slot).to(w1dt)
