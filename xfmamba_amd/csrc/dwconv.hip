@@ -709,6 +709,18 @@ __global__ void __launch_bounds__(256) dwconv_strip_fwd_kernel(const T *__restri
 // lanes (one-lane DPP shifts of the whole row), the columns left and right are its own registers.  No loop, no LDS: load the
 // row, take the two neighbour rows, compute, store.  A wave holds 64 / H planes of one channel (H consecutive lanes each).
 template <int HW> __device__ __forceinline__ void dwrow_load(const uint16_t *p, bool ok, float (&v)[HW + 2]) {
+    if constexpr (HW % 2 != 0) {                       // 7 x 7: rows of 14 bytes, 2-byte aligned
+        struct __attribute__((packed, aligned(2))) Raw2 { uint16_t h[HW]; };
+        Raw2 r2;
+#pragma unroll
+        for (int i = 0; i < HW; ++i) r2.h[i] = 0;
+        if (ok) r2 = *reinterpret_cast<const Raw2 *>(p);
+        v[0] = 0.f;
+#pragma unroll
+        for (int i = 0; i < HW; ++i) v[1 + i] = __uint_as_float((uint32_t)r2.h[i] << 16);
+        v[HW + 1] = 0.f;
+        return;
+    }
     struct __attribute__((packed, aligned(4))) Raw { uint32_t w[HW / 2]; };
     Raw r;
 #pragma unroll
@@ -723,6 +735,14 @@ template <int HW> __device__ __forceinline__ void dwrow_load(const uint16_t *p, 
     v[HW + 1] = 0.f;
 }
 template <int HW> __device__ __forceinline__ void dwrow_store(uint16_t *p, const float (&v)[HW]) {
+    if constexpr (HW % 2 != 0) {
+        struct __attribute__((packed, aligned(2))) Raw2 { uint16_t h[HW]; };
+        Raw2 r2;
+#pragma unroll
+        for (int i = 0; i < HW; ++i) r2.h[i] = (uint16_t)(pack_bf16x2(v[i], 0.f) & 0xffffu);
+        *reinterpret_cast<Raw2 *>(p) = r2;
+        return;
+    }
     struct __attribute__((packed, aligned(4))) Raw { uint32_t w[HW / 2]; };
     Raw r;
 #pragma unroll
@@ -911,8 +931,10 @@ static int pick_pp(int L) { return L >= 1024 ? 1 : (L >= 256 ? 2 : 4); }
 template <typename T>
 static int launch_dw(bool bwd, const void *x, const float *w, const float *bias, const void *dy, void *out, float *dw,
                      float *dbias, int B, int D, int H, int W, int act, hipStream_t s) {
-    if (std::is_same<T, bf16_t>::value && H == W && (W == 14 || W == 12) && !getenv("XFM_DWCONV_NO_ROWLANE") && !getenv("XFM_DWCONV_GENERIC")) {
-        // 14 x 14 / 12 x 12: one lane per row
+    if (std::is_same<T, bf16_t>::value && H == W && (W == 14 || W == 12 || (W == 7 && !getenv("XFM_DWCONV_NO_ROWLANE7"))) &&
+        !getenv("XFM_DWCONV_NO_ROWLANE") && !getenv("XFM_DWCONV_GENERIC")) {
+        // 14 x 14 / 12 x 12 / 7 x 7: one lane per row (7 x 7: nine planes per wave; the wave-private plane kernel spent a whole
+        // wave's instruction stream on 49 positions -- 37 us for the deep block's 14 MB backward)
         const int ppw = 64 / W;
         const int nwaves = D * ((B + ppw - 1) / ppw);
         const dim3 grid((nwaves + 3) / 4);
@@ -927,7 +949,8 @@ static int launch_dw(bool bwd, const void *x, const float *w, const float *bias,
         return check_launch();                                                                                         \
     } while (0)
         if (W == 14) XFM_DW_ROW(14);
-        else XFM_DW_ROW(12);
+        else if (W == 12) XFM_DW_ROW(12);
+        else XFM_DW_ROW(7);
 #undef XFM_DW_ROW
     }
     // (14 x 14 maps measured no better on the strip kernels: forward 10.1 vs 11.6 us, backward 29.1 vs 24.7 us)
