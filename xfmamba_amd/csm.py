@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 __all__ = ["cross_scan_fn", "cross_merge_fn", "CrossScanHip", "CrossMergeHip",
-           "SwappingScan_multiview", "SwappingMerge_multiview"]
+           "SwappingScan_multiview", "SwappingMerge_multiview", "SwappingScanStacked"]
 
 
 def _scan(x: torch.Tensor) -> torch.Tensor:
@@ -116,6 +116,30 @@ class SwappingScan_multiview(torch.autograd.Function):
     def backward(ctx, ys: torch.Tensor):
         B, C, H, W = ctx.shape
         return ys[:, 0].reshape(B, -1, H, W), ys[:, 1].reshape(B, -1, H, W)
+
+
+class SwappingScanStacked(torch.autograd.Function):
+    """``SwappingScan_multiview`` on the two views stacked along the batch axis, ``x`` = [view 1 | view 2] (2B, C, H, W) ->
+    (B, 2, C, H*W).  Same forward kernel and the same pass-through backward (fusion_vmamba.py:217-221: route k's gradient
+    goes to view k un-swapped), returned as ONE (2B, C, H, W) tensor instead of two slice gradients."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor):
+        _lib.require_cuda(x)
+        B2, C, H, W = x.shape
+        B = B2 // 2
+        ctx.shape = (B, C, H, W)
+        x = x.contiguous()
+        out = torch.empty((B, 2, C, H * W), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().xfm_swap_scan(x.data_ptr(), x[B:].data_ptr(), out.data_ptr(), B, C, H * W,
+                                                _lib.dtype_code(x.dtype), _lib.stream_ptr()), "swap_scan")
+        return out
+
+    @staticmethod
+    def backward(ctx, ys: torch.Tensor):
+        B, C, H, W = ctx.shape
+        return ys.transpose(0, 1).reshape(2 * B, C, H, W)
 
 
 class SwappingMerge_multiview(torch.autograd.Function):

@@ -34,7 +34,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .csm import SwappingMerge_multiview, SwappingScan_multiview, cross_merge_fn, cross_scan_fn
+from .csm import SwappingMerge_multiview, SwappingScan_multiview, SwappingScanStacked, cross_merge_fn, cross_scan_fn
 from .csms6s import selective_scan_fn
 from .dwconv import dwconv3x3_silu_fn
 from .layernorm2d import layernorm2d_fn
@@ -560,6 +560,29 @@ class _PrecomputedA:
         return False
 
 
+class _PrecomputedFusionA:
+    """Context: ``A = -exp(A_logs)`` of the shallow and the deep fusion block of ``top`` from one batched evaluation
+    (``_NegExpAll``), read by their stacked forward paths."""
+
+    def __init__(self, top: nn.Module):
+        mods = top.__dict__.get("_fusion_a_mods")
+        if mods is None:
+            mods = [m for m in top.modules() if isinstance(m, (ShallowFuse_SS2Dv4, Cross_SS2Dv5))]
+            top.__dict__["_fusion_a_mods"] = mods
+        self.mods = mods
+
+    def __enter__(self):
+        if self.mods and self.mods[0].A_logs.is_cuda:
+            for m, a in zip(self.mods, _NegExpAll.apply(*[m.A_logs for m in self.mods])):
+                m.__dict__["_As_pre"] = a
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.mods:
+            m.__dict__["_As_pre"] = None
+        return False
+
+
 def _blocks_tokens_ok(blocks) -> bool:
     return len(blocks) > 0 and all(isinstance(b, VSSBlock) and b.tokens_ok() for b in blocks)
 
@@ -970,11 +993,13 @@ class ShallowFuse_SS2Dv4(nn.Module):
         D = xp.shape[-1]
         xp = tokens_to_planes(xp.view(B2, L, D)).view(B2, D, H, W)
         xc = _dwconv_act(self.conv2d, self.act, xp) if self.with_dconv else self.act(xp)
-        xs = SwappingScan_multiview.apply(xc[:B], xc[B:])                                    # (B, 2, D, L)
+        xs = SwappingScanStacked.apply(xc)                                                   # (B, 2, D, L)
         x_dbl = torch.matmul(self.x_proj_weight.to(xs.dtype), xs)                            # (B, 2, R + 2N, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         dts = torch.matmul(self.dt_projs_weight.to(xs.dtype), dts)                           # (B, 2, D, L)
-        ys = selective_scan_fn(xs.view(B, -1, L), dts.view(B, -1, L), -self.A_logs.float().exp(), Bs.contiguous(),
+        As = self.__dict__.get("_As_pre")
+        As = -self.A_logs.float().exp() if As is None else As
+        ys = selective_scan_fn(xs.view(B, -1, L), dts.view(B, -1, L), As, Bs.contiguous(),
                                Cs.contiguous(), self.Ds.float(), self.dt_projs_bias.reshape(-1).float(), True, True, None)
         # (slices of ys are what SwappingMerge_multiview returns, and their gradient is its stack)
         yy = layernorm2d_fn(ys.view(B * 2, D, H, W), self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, xp.dtype)
@@ -1098,7 +1123,9 @@ class Cross_SS2Dv5(nn.Module):
         if SS2D_MODE == "fused" and chan_supported(x3, H, W, N, K, D, R):
             # ONE kernel for the cross-fusion exchange: the three streams' four routes, dt_proj on MFMA inside, the view
             # streams reading their state through the fused stream's C rows (no cross_scan / expand / cross_merge copies)
-            y = ss2d_chan_fn(x3.reshape(B3, D, L), self.x_proj_weight, self.dt_projs_weight, -self.A_logs.float().exp(),
+            As = self.__dict__.get("_As_pre")
+            y = ss2d_chan_fn(x3.reshape(B3, D, L), self.x_proj_weight, self.dt_projs_weight,
+                             -self.A_logs.float().exp() if As is None else As,
                              self.Ds.float(), self.dt_projs_bias.reshape(-1).float(), H, W, c_mod=B, c_off=2 * B)
             if planes_out:
                 # out_norm over the channel axis of the (3B, D, H, W) planes by the LayerNorm2d kernel (same maths as the
@@ -1118,8 +1145,9 @@ class Cross_SS2Dv5(nn.Module):
     def forward_stacked(self, n: torch.Tensor) -> torch.Tensor:
         """``forward`` on the two views as one token-major batch ``n`` = [view 1 | view 2] (2B, H, W, C)."""
         B = n.shape[0] // 2
-        return self._from_x3(_linear_rows(self.in_proj_sec, torch.cat([n, (n[:B] + n[B:]) / 2], dim=0)), B, n.shape[1],
-                             n.shape[2])
+        # ((x + x2) / 2 as a mean over the view axis: slices would cost a zero fill + a copy + an add each in the backward pass)
+        avg = n.view(2, B, *n.shape[1:]).mean(0)
+        return self._from_x3(_linear_rows(self.in_proj_sec, torch.cat([n, avg], dim=0)), B, n.shape[1], n.shape[2])
 
     def forward(self, x, x2: torch.Tensor, **kwargs):
         B, H, W = x.shape[0], x.shape[1], x.shape[2]
@@ -1169,7 +1197,7 @@ class FusionBlock_v5(nn.Module):
         n = layernorm_rows_fn(xt, self.norm.weight, self.norm.bias, self.norm.eps, xt.dtype)
         x = self.drop_path(self.self_attention.forward_stacked(n))
         # (fp32 + bf16 in one mixed-type add measured 64 us for 1.2 M elements: cast first)
-        return xt[:B] + xt[B:] + x.to(xt.dtype)
+        return xt.view(2, B, *xt.shape[1:]).sum(0) + x.to(xt.dtype)
 
     def forward(self, x1, x2):
         a = self.norm(x1).permute(0, 2, 3, 1)

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fusion_vmamba import Backbone_VSSM, CSSFVSSLayer_v5, ShallowFusionBlock_v4
+from .fusion_vmamba import Backbone_VSSM, CSSFVSSLayer_v5, ShallowFusionBlock_v4, _PrecomputedFusionA as _PrecomputedA
 
 __all__ = ["TwoViewXFMambaTop", "ModelWrapper"]
 
@@ -88,7 +88,8 @@ class TwoViewXFMambaTop(nn.Module):
             zt = self.mamba_feature_extrac(torch.cat([x_a, x_b], dim=0).expand(-1, 3, -1, -1), only_last=True,
                                            tokens_out=True)[-1]
             if self.shallow_mamba_fusion.stacked_ok(zt) and self.fusemamba.stacked_ok(zt):
-                z = self.fusemamba.forward_stacked(self.shallow_mamba_fusion.forward_stacked(zt))
+                with _PrecomputedA(self):                # A = -exp(A_logs) of both fusion blocks from one batched evaluation
+                    z = self.fusemamba.forward_stacked(self.shallow_mamba_fusion.forward_stacked(zt))
                 with torch.autocast("cuda", enabled=False):
                     return self._head(z.float(), tokens=True)
             z = zt.permute(0, 3, 1, 2).contiguous()
