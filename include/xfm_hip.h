@@ -238,6 +238,20 @@ int xfm_residual_settle_bwd(const void *dout, const float *scale, float *dx, voi
  */
 int xfm_partial_sums_multi(const void *jobs, const void *blocks, int nblocks, void *stream);
 
+/* Training-mode BatchNorm2d of the shallow fusion block on the token-major stream, all views in one call: the SAME nn.BatchNorm2d
+ * applied to view 1, then to view 2 (reference models/fusion_vmamba.py:906-907).  x (V, N, C) fp32 with N = B*H*W rows per view;
+ * batch statistics per view (biased variance in y, as F.batch_norm), running statistics updated view after view with
+ * `momentum` and the unbiased variance (NULL: not tracked); y in y_dtype (fp32 / bf16: the following GEMM's dtype); mean / rstd
+ * (V, C) are kept for the backward pass.  Backward: dx (V, N, C) fp32, dgamma / dbeta (C) = totals over the views (every element
+ * written; NULL: not wanted).  workspace: xfm_bn_tokens_ws_floats(V, N, C) fp32 values.  C % 64 == 0, V <= 8. */
+int xfm_bn_tokens_supported(int V, int N, int C);
+int xfm_bn_tokens_ws_floats(int V, int N, int C);
+int xfm_bn_tokens_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                      float momentum, float eps, void *y, float *mean, float *rstd, float *workspace, int V, int N, int C,
+                      int y_dtype, void *stream);
+int xfm_bn_tokens_bwd(const float *x, const void *dy, const float *gamma, const float *mean, const float *rstd, float *dx,
+                      float *dgamma, float *dbeta, float *workspace, int V, int N, int C, int dy_dtype, void *stream);
+
 /* (B, R, C) tokens <-> (B, C, R) planes of 2-byte elements on short maps (R <= 64 positions, C % 64 == 0, 16-byte aligned
  * tensors): the NHWC <-> NCHW permutes around the 7 x 7 SS2D blocks (reference models/fusion_vmamba.py:594-601, 853-857) as
  * one streaming kernel.  tokens_to_planes != 0: src (B, R, C) -> dst (B, C, R); 0: src (B, C, R) -> dst (B, R, C). */

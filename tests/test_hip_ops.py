@@ -862,6 +862,43 @@ def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias, B, L, C)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,HW,C,odt", [(32, 7, 768, torch.bfloat16), (5, 7, 128, torch.float32), (3, 5, 64, torch.bfloat16)])
+def test_batchnorm_two_views_on_tokens_matches_batchnorm2d(B, HW, C, odt):
+    """xfm_bn_tokens_fwd/_bwd (training-mode BatchNorm2d applied to view 1, then view 2, reference fusion_vmamba.py:906-907, on
+    the token matrices) against nn.BatchNorm2d on the NCHW maps in fp32: outputs, running statistics after both views, input
+    gradient, weight / bias gradients (summed over the views)."""
+    from xfmamba_amd.fusion_vmamba import _BatchNormViews, _bn_views_ok
+    g = torch.Generator().manual_seed(C + B)
+    xt = (torch.randn(2, B, HW, HW, C, generator=g) * 1.7 + 3.0)             # |mean| > std: the shifted sums matter
+    gy = torch.randn(2, B, HW, HW, C, generator=g)
+    ref = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+        ref.bias.copy_(0.1 * torch.randn(C, generator=g))
+        ref.running_mean.copy_(torch.randn(C, generator=g))
+        ref.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    dev = torch.nn.BatchNorm2d(C).to(DEV)
+    dev.load_state_dict(ref.state_dict())
+    ref.train()
+    dev.train()
+    xr = xt.clone().requires_grad_()
+    yr = torch.stack([ref(xr[0].permute(0, 3, 1, 2)), ref(xr[1].permute(0, 3, 1, 2))]).permute(0, 1, 3, 4, 2)
+    yr.backward(gy.to(odt).float())
+    xd = xt.to(DEV).view(2, B * HW * HW, C).requires_grad_()
+    assert _bn_views_ok(dev, xd)
+    y = _BatchNormViews.apply(xd, dev.weight, dev.bias, dev.running_mean, dev.running_var, dev.momentum, dev.eps, odt)
+    assert y.dtype == odt
+    y.backward(gy.to(odt).to(DEV).view(2, B * HW * HW, C))
+    tol = 1e-2 if odt == torch.bfloat16 else 1e-4
+    assert_close(y.float().cpu().view_as(yr), yr.detach(), tol, tol * float(yr.abs().max()), "y")
+    assert_close(dev.running_mean.cpu(), ref.running_mean, 1e-5, 1e-5, "running_mean")
+    assert_close(dev.running_var.cpu(), ref.running_var, 1e-5, 1e-5, "running_var")
+    assert_close(xd.grad.cpu().view_as(xr.grad), xr.grad, 1e-4, 1e-4 * float(xr.grad.abs().max()), "dx")
+    assert_close(dev.weight.grad.cpu(), ref.weight.grad, 1e-4, 1e-4 * float(ref.weight.grad.abs().max()), "dweight")
+    assert_close(dev.bias.grad.cpu(), ref.bias.grad, 1e-4, 1e-4 * float(ref.bias.grad.abs().max()), "dbias")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,R,C", [(5, 49, 768), (3, 64, 128), (2, 25, 64), (96, 49, 1536), (1, 1, 64)])
 def test_transpose_short_is_the_exact_permutation_both_ways(B, R, C):
     """xfm_transpose_short ((B, R, C) tokens <-> (B, C, R) planes, R <= 64): bit-exact against permute + contiguous, both

@@ -23,6 +23,7 @@ for r in csv.DictReader(open(f)):
     elif 'tokens_gemm2' in n or 'tokens_gemm3' in n: fam = 'own MFMA GEMM with GELU epilogue (Mlp fc1 / fc2 data gradient)'
     elif 'tokens_gemm' in n or 'planes_gemm' in n or 'proj_gemm' in n or 'proj_tiled' in n: fam = 'own MFMA GEMM'
     elif 'transpose_short' in n: fam = 'tokens <-> planes transposes (7x7)'
+    elif 'bn_tokens' in n: fam = 'BatchNorm (two views, token-major)'
     elif 'batch_norm' in n or 'CatArray' in n or 'elementwise_kernel' in n or 'rocclr' in n or 'layer_norm' in n or 'GammaBeta' in n or 'distribution_' in n or 'multi_tensor_apply' in n or 'softmax' in n or 'nll_loss' in n:
         fam = 'framework elementwise / copy / fill'
     elif 'tokens_kernel' in n or 'colsum' in n: fam = 'bias+GELU / column sums'

@@ -912,6 +912,64 @@ def _linear_rows(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     return linear_tokens_fn(x if x.is_contiguous() else x.contiguous(), lin.weight, lin.bias)
 
 
+# XFM_BN_TOKENS=0: BatchNorm of the shallow fusion block through F.batch_norm per view (A/B switch, read once)
+_BN_TOKENS = os.environ.get("XFM_BN_TOKENS", "1") == "1"
+
+
+class _BatchNormViews(torch.autograd.Function):
+    """Training-mode ``nn.BatchNorm2d`` applied to V views one after the other (fusion_vmamba.py:906-907), on their token
+    matrices ``x`` (V, N, C) fp32, through ``xfm_bn_tokens_fwd/_bwd``: batch statistics per view, the running statistics
+    updated view after view, the output in ``out_dtype`` (the following GEMM's)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, out_dtype):
+        from . import _lib
+        V, N, C = x.shape
+        lib = _lib.lib()
+        y = torch.empty((V, N, C), dtype=out_dtype, device=x.device)
+        mean = torch.empty((V, C), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((V, C), dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.xfm_bn_tokens_ws_floats(V, N, C), dtype=torch.float32, device=x.device)
+        w = weight.float().contiguous()
+        b = bias.float().contiguous()
+        with torch.cuda.device(x.device), _lib.timed("bn_tokens_fwd", x.numel() * (8 + y.element_size())):
+            _lib.check(lib.xfm_bn_tokens_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                             float(momentum), float(eps), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             ws.data_ptr(), V, N, C, _lib.dtype_code(out_dtype), _lib.stream_ptr()), "bn_tokens_fwd")
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.dtypes = (weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        x, w, mean, rstd = ctx.saved_tensors
+        V, N, C = x.shape
+        lib = _lib.lib()
+        dy = dy.contiguous()
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        dx = torch.empty_like(x)
+        dw = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.xfm_bn_tokens_ws_floats(V, N, C), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device), _lib.timed("bn_tokens_bwd", x.numel() * (12 + 2 * dy.element_size())):
+            _lib.check(lib.xfm_bn_tokens_bwd(x.data_ptr(), dy.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                             dw.data_ptr(), db.data_ptr(), ws.data_ptr(), V, N, C, _lib.dtype_code(dy.dtype),
+                                             _lib.stream_ptr()), "bn_tokens_bwd")
+        return dx, dw.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None, None, None
+
+
+def _bn_views_ok(bn: nn.BatchNorm2d, x: torch.Tensor) -> bool:
+    """The fused two-view form covers: training mode with tracked running statistics, fp32 token matrices on the GPU."""
+    if not (_BN_TOKENS and bn.training and bn.track_running_stats and bn.momentum is not None and bn.affine and x.is_cuda
+            and x.dtype == torch.float32 and bn.weight.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0):
+        return False
+    from . import _lib
+    V, N, C = x.shape
+    return bool(_lib.lib().xfm_bn_tokens_supported(V, N, C))
+
+
 def _bn_rows(bn: nn.BatchNorm2d, rows: torch.Tensor) -> torch.Tensor:
     """``bn`` applied to the (B H W, C) token matrix of an NCHW map: what ``nn.BatchNorm2d.forward`` does (batch statistics
     in training mode, running statistics updated with ``momentum``, the step counter), on the 2-D view."""
@@ -1053,7 +1111,16 @@ class ShallowFusionBlock_v4(nn.Module):
         B2, H, W, C = xt.shape
         B = B2 // 2
         x2d = xt.reshape(2, B * H * W, C)
-        n = torch.cat([_bn_rows(self.norm, x2d[0]), _bn_rows(self.norm, x2d[1])], dim=0).view(B2, H, W, C)
+        bn = self.norm
+        if _bn_views_ok(bn, x2d):
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(2)                                               # (one step per view)
+            od = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else xt.dtype
+            od = od if od in (torch.float32, torch.bfloat16) else xt.dtype
+            n = _BatchNormViews.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, od)
+            n = n.view(B2, H, W, C)
+        else:
+            n = torch.cat([_bn_rows(bn, x2d[0]), _bn_rows(bn, x2d[1])], dim=0).view(B2, H, W, C)
         o = self.shallowfuseSS2D.forward_stacked(n)                                          # (B, 2, H, W, C)
         return (xt.view(2, B, H, W, C) + o.transpose(0, 1)).view(B2, H, W, C)            # x1 + o1 | x2 + o2 (:914)
 
