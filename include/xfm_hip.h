@@ -238,6 +238,12 @@ int xfm_residual_settle_bwd(const void *dout, const float *scale, float *dx, voi
  */
 int xfm_partial_sums_multi(const void *jobs, const void *blocks, int nblocks, void *stream);
 
+/* The deep fusion block's three streams from its two normalised views: out (3, M) = [n[0] | n[1] | (n[0] + n[1]) / 2] for
+ * n (2, M) fp32 (M % 4 == 0), in out_dtype (fp32 / bf16) -- `x_fuse = (x + x2) / 2` ahead of in_proj_sec (reference
+ * models/fusion_vmamba.py, Cross_SS2Dv5.forward) with the cat and the GEMM's cast in one kernel; _bwd: dn[k] = g[k] + g[2] / 2. */
+int xfm_views_avg_stack_fwd(const float *n, void *out, long long M, int out_dtype, void *stream);
+int xfm_views_avg_stack_bwd(const void *g, float *dn, long long M, int g_dtype, void *stream);
+
 /* Training-mode BatchNorm2d of the shallow fusion block on the token-major stream, all views in one call: the SAME nn.BatchNorm2d
  * applied to view 1, then to view 2 (reference models/fusion_vmamba.py:906-907).  x (V, N, C) fp32 with N = B*H*W rows per view;
  * batch statistics per view (biased variance in y, as F.batch_norm), running statistics updated view after view with

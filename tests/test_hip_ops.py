@@ -862,6 +862,25 @@ def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias, B, L, C)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_views_avg_stack_matches_cat_of_views_and_mean(odt):
+    """xfm_views_avg_stack_fwd/_bwd: [view 1 | view 2 | (view 1 + view 2) / 2] (Cross_SS2Dv5's three streams) in the GEMM's
+    dtype -- exactly cat + mean + cast -- and its gradient."""
+    from xfmamba_amd.fusion_vmamba import _ViewsAvgStack
+    g = torch.Generator().manual_seed(77)
+    n = torch.randn(2 * 6, 7, 7, 64, generator=g)
+    gy = torch.randn(3 * 6, 7, 7, 64, generator=g).to(odt)
+    nr = n.clone().requires_grad_()
+    ref = torch.cat([nr, (nr[:6] + nr[6:]) / 2], dim=0)
+    ref.backward(gy.float())
+    nd = n.to(DEV).requires_grad_()
+    out = _ViewsAvgStack.apply(nd, odt).view(3 * 6, 7, 7, 64)
+    assert out.dtype == odt and torch.equal(out.cpu(), ref.detach().to(odt))
+    out.backward(gy.to(DEV))
+    assert_close(nd.grad.cpu(), nr.grad, 1e-6, 1e-6, "dn")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,HW,C,odt", [(32, 7, 768, torch.bfloat16), (5, 7, 128, torch.float32), (3, 5, 64, torch.bfloat16)])
 def test_batchnorm_two_views_on_tokens_matches_batchnorm2d(B, HW, C, odt):
     """xfm_bn_tokens_fwd/_bwd (training-mode BatchNorm2d applied to view 1, then view 2, reference fusion_vmamba.py:906-907, on

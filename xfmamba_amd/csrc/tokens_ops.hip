@@ -329,6 +329,57 @@ __global__ __launch_bounds__(256) void transpose_short_kernel(const uint16_t *__
     }
 }
 
+// ---- the deep fusion block's input assembly: [view 1 | view 2 | (view 1 + view 2) / 2] (reference models/fusion_vmamba.py:
+// Cross_SS2Dv5.forward: x_fuse = (x + x2) / 2, one in_proj_sec over the three streams) written in the GEMM's dtype by one
+// kernel, and its gradient (d view k = g_k + g_fuse / 2) by another -- instead of mean + cat + cast and their backward chain.
+template <typename Ty>
+__global__ void __launch_bounds__(256) views_avg_stack_fwd_kernel(const float *__restrict__ n, Ty *__restrict__ out, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float a[4], b[4], m[4];
+        Pack<float>::ld(n + i * 4, a);
+        Pack<float>::ld(n + (nvec + i) * 4, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = (a[k] + b[k]) * 0.5f;
+        if constexpr (sizeof(Ty) == 4) {
+            float *o = reinterpret_cast<float *>(out);
+            Pack<float>::st(o + i * 4, a);
+            Pack<float>::st(o + (nvec + i) * 4, b);
+            Pack<float>::st(o + (2 * nvec + i) * 4, m);
+        } else {
+            uint16_t *o = reinterpret_cast<uint16_t *>(out);
+            *reinterpret_cast<uint2 *>(o + i * 4) = make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
+            *reinterpret_cast<uint2 *>(o + (nvec + i) * 4) = make_uint2(pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3]));
+            *reinterpret_cast<uint2 *>(o + (2 * nvec + i) * 4) = make_uint2(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]));
+        }
+    }
+}
+
+template <typename Ty>
+__global__ void __launch_bounds__(256) views_avg_stack_bwd_kernel(const Ty *__restrict__ g, float *__restrict__ dn, int64_t nvec) {
+    auto ld = [&](int64_t e, float (&v)[4]) {
+        if constexpr (sizeof(Ty) == 4) {
+            Pack<float>::ld(reinterpret_cast<const float *>(g) + e * 4, v);
+        } else {
+            const uint2 w = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(g) + e * 4);
+            v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
+            v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
+        }
+    };
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float a[4], b[4], m[4];
+        ld(i, a);
+        ld(nvec + i, b);
+        ld(2 * nvec + i, m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = fmaf(m[k], 0.5f, a[k]);
+            b[k] = fmaf(m[k], 0.5f, b[k]);
+        }
+        Pack<float>::st(dn + i * 4, a);
+        Pack<float>::st(dn + (nvec + i) * 4, b);
+    }
+}
+
 }  // namespace xfm
 
 extern "C" {
@@ -467,6 +518,37 @@ int xfm_transpose_short_add_bf16(const void *src, void *dst, int B, int R, int C
     if (((uintptr_t)src | (uintptr_t)dst) & 15) return XFM_EINVAL;
     hipLaunchKernelGGL((transpose_short_kernel<true, true>), dim3((unsigned)(C / 64), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)src, (uint16_t *)dst, R, C);
+    return check_launch();
+}
+
+/* out (3, M) = [n[0] | n[1] | (n[0] + n[1]) / 2] for n (2, M) fp32, M % 4 == 0, in out_dtype (fp32 / bf16): the three streams of
+ * Cross_SS2Dv5 (reference models/fusion_vmamba.py: x_fuse = (x + x2) / 2 ahead of in_proj_sec); _bwd: dn (2, M) fp32 from
+ * g (3, M): dn[k] = g[k] + g[2] / 2. */
+int xfm_views_avg_stack_fwd(const float *n, void *out, long long M, int out_dtype, void *stream) {
+    using namespace xfm;
+    if (!n || !out || M <= 0 || M % 4) return XFM_EINVAL;
+    if (((uintptr_t)n | (uintptr_t)out) & 15) return XFM_EINVAL;
+    const int64_t nvec = M / 4;
+    const unsigned grid = (unsigned)std::min<int64_t>((nvec + 255) / 256, 256 * 8);
+    if (out_dtype == XFM_F32)
+        hipLaunchKernelGGL((views_avg_stack_fwd_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n, (float *)out, nvec);
+    else if (out_dtype == XFM_BF16)
+        hipLaunchKernelGGL((views_avg_stack_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n, (bf16_t *)out, nvec);
+    else return XFM_EDTYPE;
+    return check_launch();
+}
+
+int xfm_views_avg_stack_bwd(const void *g, float *dn, long long M, int g_dtype, void *stream) {
+    using namespace xfm;
+    if (!g || !dn || M <= 0 || M % 4) return XFM_EINVAL;
+    if (((uintptr_t)g | (uintptr_t)dn) & 15) return XFM_EINVAL;
+    const int64_t nvec = M / 4;
+    const unsigned grid = (unsigned)std::min<int64_t>((nvec + 255) / 256, 256 * 8);
+    if (g_dtype == XFM_F32)
+        hipLaunchKernelGGL((views_avg_stack_bwd_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)g, dn, nvec);
+    else if (g_dtype == XFM_BF16)
+        hipLaunchKernelGGL((views_avg_stack_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)g, dn, nvec);
+    else return XFM_EDTYPE;
     return check_launch();
 }
 

@@ -912,6 +912,35 @@ def _linear_rows(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     return linear_tokens_fn(x if x.is_contiguous() else x.contiguous(), lin.weight, lin.bias)
 
 
+class _ViewsAvgStack(torch.autograd.Function):
+    """n (2B, ...) fp32 = [view 1 | view 2] -> (3, 2B/2 ...) flattened [view 1 | view 2 | their mean] in ``out_dtype``
+    (``xfm_views_avg_stack_fwd/_bwd``)."""
+
+    @staticmethod
+    def forward(ctx, n, out_dtype):
+        from . import _lib
+        M = n.numel() // 2
+        out = torch.empty(3 * M, dtype=out_dtype, device=n.device)
+        with torch.cuda.device(n.device), _lib.timed("views_avg_stack", M * (8 + 3 * out.element_size())):
+            _lib.check(_lib.lib().xfm_views_avg_stack_fwd(n.data_ptr(), out.data_ptr(), M, _lib.dtype_code(out_dtype),
+                                                          _lib.stream_ptr()), "views_avg_stack_fwd")
+        ctx.shape = n.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        g = g.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        M = g.numel() // 3
+        dn = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device), _lib.timed("views_avg_stack", M * (8 + 3 * g.element_size())):
+            _lib.check(_lib.lib().xfm_views_avg_stack_bwd(g.data_ptr(), dn.data_ptr(), M, _lib.dtype_code(g.dtype),
+                                                          _lib.stream_ptr()), "views_avg_stack_bwd")
+        return dn, None
+
+
 # XFM_BN_TOKENS=0: BatchNorm of the shallow fusion block through F.batch_norm per view (A/B switch, read once)
 _BN_TOKENS = os.environ.get("XFM_BN_TOKENS", "1") == "1"
 
@@ -1212,6 +1241,12 @@ class Cross_SS2Dv5(nn.Module):
     def forward_stacked(self, n: torch.Tensor) -> torch.Tensor:
         """``forward`` on the two views as one token-major batch ``n`` = [view 1 | view 2] (2B, H, W, C)."""
         B = n.shape[0] // 2
+        if n.is_cuda and n.dtype == torch.float32 and n.is_contiguous() and n.numel() % 8 == 0 and n.data_ptr() % 16 == 0:
+            od = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else n.dtype
+            if od in (torch.float32, torch.bfloat16):
+                # [view 1 | view 2 | (view 1 + view 2) / 2] in the GEMM's dtype by one kernel (mean + cat + cast otherwise)
+                x3in = _ViewsAvgStack.apply(n, od).view(3 * B, *n.shape[1:])
+                return self._from_x3(_linear_rows(self.in_proj_sec, x3in), B, n.shape[1], n.shape[2])
         # ((x + x2) / 2 as a mean over the view axis: slices would cost a zero fill + a copy + an add each in the backward pass)
         avg = n.view(2, B, *n.shape[1:]).mean(0)
         return self._from_x3(_linear_rows(self.in_proj_sec, torch.cat([n, avg], dim=0)), B, n.shape[1], n.shape[2])
