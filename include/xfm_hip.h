@@ -238,6 +238,13 @@ int xfm_residual_settle_bwd(const void *dout, const float *scale, float *dx, voi
  */
 int xfm_partial_sums_multi(const void *jobs, const void *blocks, int nblocks, void *stream);
 
+/* Squeeze gate (.) map with the layout change for out_proj: out (B, R, C) tokens = yy (B, C, R) planes * gate (B, C), bf16
+ * (`y * gate` of ShallowFuse_SS2Dv4.forward, reference models/fusion_vmamba.py:870-871); _bwd from g (B, R, C):
+ * d yy (B, C, R) = g^T * gate, d gate (B, C) = sum_r g[b, r, c] * yy[b, c, r].  8 <= R <= 64, C % 64 == 0, 16-byte aligned. */
+int xfm_gated_transpose_fwd(const void *yy, const void *gate, void *out, int B, int R, int C, void *stream);
+int xfm_gated_transpose_bwd(const void *g, const void *yy, const void *gate, void *dyy, void *dgate, int B, int R, int C,
+                            void *stream);
+
 /* The deep fusion block's three streams from its two normalised views: out (3, M) = [n[0] | n[1] | (n[0] + n[1]) / 2] for
  * n (2, M) fp32 (M % 4 == 0), in out_dtype (fp32 / bf16) -- `x_fuse = (x + x2) / 2` ahead of in_proj_sec (reference
  * models/fusion_vmamba.py, Cross_SS2Dv5.forward) with the cat and the GEMM's cast in one kernel; _bwd: dn[k] = g[k] + g[2] / 2. */

@@ -862,6 +862,27 @@ def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias, B, L, C)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,C,L", [(64, 1536, 49), (3, 128, 25), (2, 64, 64), (5, 192, 8)])
+def test_gated_planes_to_tokens_matches_multiply_then_permute(B, C, L):
+    """xfm_gated_transpose_fwd/_bwd: (y * gate).permute for out_proj (ShallowFuse_SS2Dv4, reference fusion_vmamba.py:870-871):
+    the forward bit-exact against the bf16 multiply + transposing copy, d y and d gate against fp32 autograd."""
+    from xfmamba_amd.proj import gated_planes_to_tokens, GatedPlanesToTokens
+    g = torch.Generator().manual_seed(B * L)
+    yy = torch.randn(B, C, L, generator=g).to(torch.bfloat16)
+    gate = torch.rand(B, C, generator=g).to(torch.bfloat16)
+    gy = torch.randn(B, L, C, generator=g).to(torch.bfloat16)
+    yr, gr = yy.float().requires_grad_(), gate.float().requires_grad_()
+    (yr * gr.unsqueeze(-1)).transpose(1, 2).backward(gy.float())
+    yd, gd = yy.to(DEV).requires_grad_(), gate.to(DEV).requires_grad_()
+    out = gated_planes_to_tokens(yd, gd)
+    assert isinstance(out.grad_fn, GatedPlanesToTokens._backward_cls)
+    assert torch.equal(out.cpu(), (yy * gate.unsqueeze(-1)).transpose(1, 2).contiguous())
+    out.backward(gy.to(DEV))
+    assert_close(yd.grad.float().cpu(), yr.grad, 1e-2, 1e-2 * float(yr.grad.abs().max()), "dy")
+    assert_close(gd.grad.float().cpu(), gr.grad, 1e-2, 1e-2 * float(gr.grad.abs().max()), "dgate")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
 def test_views_avg_stack_matches_cat_of_views_and_mean(odt):
     """xfm_views_avg_stack_fwd/_bwd: [view 1 | view 2 | (view 1 + view 2) / 2] (Cross_SS2Dv5's three streams) in the GEMM's

@@ -329,6 +329,91 @@ __global__ __launch_bounds__(256) void transpose_short_kernel(const uint16_t *__
     }
 }
 
+// ---- gate (.) map with the layout change: out (B, R, C) tokens = yy (B, C, R) planes * gate (B, C), bf16 (the product rounded
+// once, as the framework's bf16 multiply), and its backward: d yy = g^T * gate (planes), d gate[b, c] = sum_r g[b, r, c] yy[b, c, r]
+// (fp32 sums).  Same tiling as transpose_short_kernel: a workgroup holds all R positions of 64 channels of one sample, so the
+// per-channel sum over the positions is local (LDS float adds, at most two per thread).
+__global__ __launch_bounds__(256) void gated_transpose_fwd_kernel(const uint16_t *__restrict__ yy, const uint16_t *__restrict__ gate,
+                                                                  uint16_t *__restrict__ out, int R, int C) {
+    __shared__ uint32_t tile[64 * 33];
+    uint16_t *t16 = reinterpret_cast<uint16_t *>(tile);
+    const int b = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x, n8 = 8 * R;
+    const uint16_t *pl_in = yy + ((int64_t)b * C + c0) * R;
+    for (int i = tid; i < n8; i += 256) {
+        const int f = i * 8;
+        const uint4 v = *reinterpret_cast<const uint4 *>(pl_in + f);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        int c = f / R, r = f - c * R;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t16[r * 66 + c] = (uint16_t)(w[k] & 0xffffu);
+            if (++r == R) { r = 0; ++c; }
+            t16[r * 66 + c] = (uint16_t)(w[k] >> 16);
+            if (++r == R) { r = 0; ++c; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n8; i += 256) {
+        const int r = i >> 3, j = i & 7;
+        const uint32_t *p = tile + r * 33 + j * 4;
+        const uint4 gq = *reinterpret_cast<const uint4 *>(gate + (int64_t)b * C + c0 + j * 8);
+        const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = pack_bf16x2(__uint_as_float(p[k] << 16) * __uint_as_float(gw[k] << 16),
+                               __uint_as_float(p[k] & 0xffff0000u) * __uint_as_float(gw[k] & 0xffff0000u));
+        *reinterpret_cast<uint4 *>(out + ((int64_t)b * R + r) * C + c0 + j * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gated_transpose_bwd_kernel(const uint16_t *__restrict__ g, const uint16_t *__restrict__ yy,
+                                                                  const uint16_t *__restrict__ gate, uint16_t *__restrict__ dyy,
+                                                                  uint16_t *__restrict__ dgate, int R, int C) {
+    __shared__ uint32_t tile[64 * 33];
+    __shared__ float dg[64];
+    uint16_t *t16 = reinterpret_cast<uint16_t *>(tile);
+    const int b = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x, n8 = 8 * R;
+    if (tid < 64) dg[tid] = 0.f;
+    for (int i = tid; i < n8; i += 256) {
+        const int r = i >> 3, j = i & 7;
+        const uint4 v = *reinterpret_cast<const uint4 *>(g + ((int64_t)b * R + r) * C + c0 + j * 8);
+        uint32_t *p = tile + r * 33 + j * 4;
+        p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    }
+    __syncthreads();
+    const int64_t po = ((int64_t)b * C + c0) * R;
+    for (int i = tid; i < n8; i += 256) {
+        const int f = i * 8;
+        const uint4 yq = *reinterpret_cast<const uint4 *>(yy + po + f);
+        const uint32_t yw[4] = {yq.x, yq.y, yq.z, yq.w};
+        int c = f / R, r = f - c * R;
+        const int cfirst = c;
+        float acc0 = 0.f, acc1 = 0.f;                   // this thread's share of d gate for channel cfirst / cfirst + 1
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float e[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float gv = __uint_as_float((uint32_t)t16[r * 66 + c] << 16);
+                const float yv = h == 0 ? __uint_as_float(yw[k] << 16) : __uint_as_float(yw[k] & 0xffff0000u);
+                const float gt = __uint_as_float((uint32_t)gate[(int64_t)b * C + c0 + c] << 16);
+                e[h] = gv * gt;
+                if (c == cfirst) acc0 = fmaf(gv, yv, acc0);
+                else acc1 = fmaf(gv, yv, acc1);
+                if (++r == R) { r = 0; ++c; }
+            }
+            o[k] = pack_bf16x2(e[0], e[1]);
+        }
+        *reinterpret_cast<uint4 *>(dyy + po + f) = make_uint4(o[0], o[1], o[2], o[3]);
+        atomicAdd(&dg[cfirst], acc0);
+        if (cfirst + 1 < 64 && acc1 != 0.f) atomicAdd(&dg[cfirst + 1], acc1);
+    }
+    __syncthreads();
+    if (tid < 64) dgate[(int64_t)b * C + c0 + tid] = (uint16_t)(pack_bf16x2(dg[tid], 0.f) & 0xffffu);
+}
+
 // ---- the deep fusion block's input assembly: [view 1 | view 2 | (view 1 + view 2) / 2] (reference models/fusion_vmamba.py:
 // Cross_SS2Dv5.forward: x_fuse = (x + x2) / 2, one in_proj_sec over the three streams) written in the GEMM's dtype by one
 // kernel, and its gradient (d view k = g_k + g_fuse / 2) by another -- instead of mean + cat + cast and their backward chain.
@@ -549,6 +634,30 @@ int xfm_views_avg_stack_bwd(const void *g, float *dn, long long M, int g_dtype, 
     else if (g_dtype == XFM_BF16)
         hipLaunchKernelGGL((views_avg_stack_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)g, dn, nvec);
     else return XFM_EDTYPE;
+    return check_launch();
+}
+
+/* out (B, R, C) tokens = yy (B, C, R) planes * gate (B, C), bf16: `y * gate` of ShallowFuse_SS2Dv4.forward (reference
+ * models/fusion_vmamba.py:870-871) with the permute for out_proj folded in; _bwd: d yy (B, C, R) = g^T * gate and
+ * d gate (B, C) = sum_r g[b, r, c] * yy[b, c, r] from g (B, R, C).  Shapes of xfm_transpose_short_supported(R, C). */
+int xfm_gated_transpose_fwd(const void *yy, const void *gate, void *out, int B, int R, int C, void *stream) {
+    using namespace xfm;
+    if (!yy || !gate || !out || B <= 0) return XFM_EINVAL;
+    if (!xfm_transpose_short_supported(R, C) || R < 8) return XFM_ELIMIT;   // (R >= 8: a thread's 8 elements span <= 2 channels)
+    if (((uintptr_t)yy | (uintptr_t)gate | (uintptr_t)out) & 15) return XFM_EINVAL;
+    hipLaunchKernelGGL(gated_transpose_fwd_kernel, dim3((unsigned)(C / 64), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)yy, (const uint16_t *)gate, (uint16_t *)out, R, C);
+    return check_launch();
+}
+
+int xfm_gated_transpose_bwd(const void *g, const void *yy, const void *gate, void *dyy, void *dgate, int B, int R, int C,
+                            void *stream) {
+    using namespace xfm;
+    if (!g || !yy || !gate || !dyy || !dgate || B <= 0) return XFM_EINVAL;
+    if (!xfm_transpose_short_supported(R, C) || R < 8) return XFM_ELIMIT;
+    if (((uintptr_t)g | (uintptr_t)yy | (uintptr_t)dyy) & 15) return XFM_EINVAL;
+    hipLaunchKernelGGL(gated_transpose_bwd_kernel, dim3((unsigned)(C / 64), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)g, (const uint16_t *)yy, (const uint16_t *)gate, (uint16_t *)dyy, (uint16_t *)dgate, R, C);
     return check_launch();
 }
 

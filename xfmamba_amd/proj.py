@@ -334,6 +334,42 @@ class TransposeShort(torch.autograd.Function):
         return dy.transpose(1, 2).contiguous(), None
 
 
+class GatedPlanesToTokens(torch.autograd.Function):
+    """``(yy * gate[:, :, None]).transpose(1, 2)`` for yy (B, C, L) planes and gate (B, C), bf16 -> (B, L, C) tokens, through
+    ``xfm_gated_transpose_fwd/_bwd`` (one kernel each way; the backward also sums d gate over the positions)."""
+
+    @staticmethod
+    def forward(ctx, yy, gate):
+        from . import _lib
+        B, C, L = yy.shape
+        out = torch.empty((B, L, C), dtype=yy.dtype, device=yy.device)
+        with torch.cuda.device(yy.device), _lib.timed("gated_transpose", yy.numel() * 4):
+            _lib.check(_lib.lib().xfm_gated_transpose_fwd(yy.data_ptr(), gate.data_ptr(), out.data_ptr(), B, L, C, _lib.stream_ptr()),
+                       "gated_transpose_fwd")
+        ctx.save_for_backward(yy, gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        yy, gate = ctx.saved_tensors
+        B, C, L = yy.shape
+        g = g.contiguous() if g.dtype == yy.dtype else g.to(yy.dtype).contiguous()
+        dyy, dgate = torch.empty_like(yy), torch.empty_like(gate)
+        with torch.cuda.device(yy.device), _lib.timed("gated_transpose", yy.numel() * 6):
+            _lib.check(_lib.lib().xfm_gated_transpose_bwd(g.data_ptr(), yy.data_ptr(), gate.data_ptr(), dyy.data_ptr(),
+                                                          dgate.data_ptr(), B, L, C, _lib.stream_ptr()), "gated_transpose_bwd")
+        return dyy, dgate
+
+
+def gated_planes_to_tokens(yy: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    """``yy (B, C, L) * gate (B, C)`` as contiguous (B, L, C) tokens."""
+    if (yy.dtype == torch.bfloat16 and gate.dtype == torch.bfloat16 and yy.is_contiguous() and yy.shape[2] >= 8
+            and _transpose_short_ok(yy, yy.shape[2], yy.shape[1]) and gate.data_ptr() % 16 == 0):
+        return GatedPlanesToTokens.apply(yy, gate.contiguous())
+    return planes_to_tokens(yy * gate.unsqueeze(-1))
+
+
 def tokens_to_planes(t: torch.Tensor) -> torch.Tensor:
     """(B, L, C) token-major -> contiguous (B, C, L) plane-major (``t.transpose(1, 2).contiguous()``)."""
     if t.is_contiguous() and _transpose_short_ok(t, t.shape[1], t.shape[2]):
