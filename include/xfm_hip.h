@@ -238,6 +238,12 @@ int xfm_residual_settle_bwd(const void *dout, const float *scale, float *dx, voi
  */
 int xfm_partial_sums_multi(const void *jobs, const void *blocks, int nblocks, void *stream);
 
+/* tokens -> planes ahead of conv2d together with the squeeze pooling of ShallowFuse_SS2Dv4.forward (reference
+ * models/fusion_vmamba.py:853-871: `self.avg_pool(xp)`): planes (B, C, R) = t (B, R, C)^T, pooled (B, C) = mean_r t[b, r, c], bf16;
+ * _bwd: d t (B, R, C) = d planes^T + d pooled / R.  R <= 64, C % 64 == 0, 16-byte aligned. */
+int xfm_pooled_transpose_fwd(const void *t, void *planes, void *pooled, int B, int R, int C, void *stream);
+int xfm_pooled_transpose_bwd(const void *dplanes, const void *dpooled, void *dt, int B, int R, int C, void *stream);
+
 /* Squeeze gate (.) map with the layout change for out_proj: out (B, R, C) tokens = yy (B, C, R) planes * gate (B, C), bf16
  * (`y * gate` of ShallowFuse_SS2Dv4.forward, reference models/fusion_vmamba.py:870-871); _bwd from g (B, R, C):
  * d yy (B, C, R) = g^T * gate, d gate (B, C) = sum_r g[b, r, c] * yy[b, c, r].  8 <= R <= 64, C % 64 == 0, 16-byte aligned. */

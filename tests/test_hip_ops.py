@@ -862,6 +862,28 @@ def test_batched_proj_mfma_layout_changing(in_tokens, out_tokens, bias, B, L, C)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,L,C", [(64, 49, 1536), (3, 25, 128), (2, 64, 64), (4, 1, 64)])
+def test_tokens_to_planes_pooled_matches_permute_and_mean(B, L, C):
+    """xfm_pooled_transpose_fwd/_bwd: the tokens -> planes move with the squeeze pooling (avg_pool of ShallowFuse_SS2Dv4,
+    reference fusion_vmamba.py:866) -- planes bit-exact, pooled against the fp32 mean, d t against fp32 autograd."""
+    from xfmamba_amd.proj import tokens_to_planes_pooled, PooledTokensToPlanes
+    g = torch.Generator().manual_seed(B + L)
+    t = torch.randn(B, L, C, generator=g).to(torch.bfloat16)
+    gp = torch.randn(B, C, L, generator=g).to(torch.bfloat16)
+    gm = torch.randn(B, C, generator=g).to(torch.bfloat16)
+    tr = t.float().requires_grad_()
+    (tr.transpose(1, 2) * gp.float()).sum().backward(retain_graph=True)
+    ((tr.mean(1) * gm.float()).sum()).backward()
+    td = t.to(DEV).requires_grad_()
+    planes, pooled = tokens_to_planes_pooled(td)
+    assert isinstance(planes.grad_fn, PooledTokensToPlanes._backward_cls)
+    assert torch.equal(planes.cpu(), t.transpose(1, 2).contiguous())
+    assert_close(pooled.float().cpu(), t.float().mean(1), 1e-2, 1e-2, "pooled")
+    ((planes.float() * gp.to(DEV).float()).sum() + (pooled.float() * gm.to(DEV).float()).sum()).backward()
+    assert_close(td.grad.float().cpu(), tr.grad, 1e-2, 1e-2 * float(tr.grad.abs().max()), "dt")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,C,L", [(64, 1536, 49), (3, 128, 25), (2, 64, 64), (5, 192, 8)])
 def test_gated_planes_to_tokens_matches_multiply_then_permute(B, C, L):
     """xfm_gated_transpose_fwd/_bwd: (y * gate).permute for out_proj (ShallowFuse_SS2Dv4, reference fusion_vmamba.py:870-871):

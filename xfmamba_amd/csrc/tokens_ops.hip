@@ -329,6 +329,78 @@ __global__ __launch_bounds__(256) void transpose_short_kernel(const uint16_t *__
     }
 }
 
+// ---- tokens -> planes with the squeeze pooling: planes (B, C, R) = t^T and pooled (B, C) = mean over the R positions (bf16, fp32
+// sums) -- `self.avg_pool(xp)` of the shallow block read off the tile the transpose holds anyway; backward: d t[b, r, c] =
+// d planes[b, c, r] + d pooled[b, c] / R (one fp32 add, one rounding).
+__global__ __launch_bounds__(256) void pooled_transpose_fwd_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+                                                                   uint16_t *__restrict__ pooled, int R, int C) {
+    __shared__ uint32_t tile[64 * 33];
+    uint16_t *t16 = reinterpret_cast<uint16_t *>(tile);
+    const int b = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x, n8 = 8 * R;
+    uint16_t *pl_out = dst + ((int64_t)b * C + c0) * R;
+    for (int i = tid; i < n8; i += 256) {
+        const int r = i >> 3, j = i & 7;
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + ((int64_t)b * R + r) * C + c0 + j * 8);
+        uint32_t *p = tile + r * 33 + j * 4;
+        p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float a = 0.f;
+        for (int r = 0; r < R; ++r) a += __uint_as_float((uint32_t)t16[r * 66 + tid] << 16);
+        pooled[(int64_t)b * C + c0 + tid] = (uint16_t)(pack_bf16x2(a / (float)R, 0.f) & 0xffffu);
+    }
+    for (int i = tid; i < n8; i += 256) {
+        const int f = i * 8;
+        int c = f / R, r = f - c * R;
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = t16[r * 66 + c];
+            if (++r == R) { r = 0; ++c; }
+            const uint32_t hi = t16[r * 66 + c];
+            if (++r == R) { r = 0; ++c; }
+            w[k] = lo | (hi << 16);
+        }
+        *reinterpret_cast<uint4 *>(pl_out + f) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void pooled_transpose_bwd_kernel(const uint16_t *__restrict__ dpl, const uint16_t *__restrict__ dpool,
+                                                                   uint16_t *__restrict__ dt, int R, int C) {
+    __shared__ uint32_t tile[64 * 33];
+    uint16_t *t16 = reinterpret_cast<uint16_t *>(tile);
+    const int b = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x, n8 = 8 * R;
+    const uint16_t *pl_in = dpl + ((int64_t)b * C + c0) * R;
+    for (int i = tid; i < n8; i += 256) {
+        const int f = i * 8;
+        const uint4 v = *reinterpret_cast<const uint4 *>(pl_in + f);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        int c = f / R, r = f - c * R;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t16[r * 66 + c] = (uint16_t)(w[k] & 0xffffu);
+            if (++r == R) { r = 0; ++c; }
+            t16[r * 66 + c] = (uint16_t)(w[k] >> 16);
+            if (++r == R) { r = 0; ++c; }
+        }
+    }
+    __syncthreads();
+    const float invR = 1.f / (float)R;
+    for (int i = tid; i < n8; i += 256) {
+        const int r = i >> 3, j = i & 7;
+        const uint32_t *p = tile + r * 33 + j * 4;
+        const uint4 gq = *reinterpret_cast<const uint4 *>(dpool + (int64_t)b * C + c0 + j * 8);
+        const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = pack_bf16x2(fmaf(__uint_as_float(gw[k] << 16), invR, __uint_as_float(p[k] << 16)),
+                               fmaf(__uint_as_float(gw[k] & 0xffff0000u), invR, __uint_as_float(p[k] & 0xffff0000u)));
+        *reinterpret_cast<uint4 *>(dt + ((int64_t)b * R + r) * C + c0 + j * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ---- gate (.) map with the layout change: out (B, R, C) tokens = yy (B, C, R) planes * gate (B, C), bf16 (the product rounded
 // once, as the framework's bf16 multiply), and its backward: d yy = g^T * gate (planes), d gate[b, c] = sum_r g[b, r, c] yy[b, c, r]
 // (fp32 sums).  Same tiling as transpose_short_kernel: a workgroup holds all R positions of 64 channels of one sample, so the
@@ -658,6 +730,29 @@ int xfm_gated_transpose_bwd(const void *g, const void *yy, const void *gate, voi
     if (((uintptr_t)g | (uintptr_t)yy | (uintptr_t)dyy) & 15) return XFM_EINVAL;
     hipLaunchKernelGGL(gated_transpose_bwd_kernel, dim3((unsigned)(C / 64), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)g, (const uint16_t *)yy, (const uint16_t *)gate, (uint16_t *)dyy, (uint16_t *)dgate, R, C);
+    return check_launch();
+}
+
+/* planes (B, C, R) = t (B, R, C)^T together with pooled (B, C) = mean_r t[b, r, c], bf16: the tokens -> planes move ahead of
+ * conv2d and `self.avg_pool(xp)` of ShallowFuse_SS2Dv4.forward (reference models/fusion_vmamba.py:853-871) in one kernel;
+ * _bwd: d t (B, R, C) = d planes^T + d pooled / R.  Shapes of xfm_transpose_short_supported(R, C). */
+int xfm_pooled_transpose_fwd(const void *t, void *planes, void *pooled, int B, int R, int C, void *stream) {
+    using namespace xfm;
+    if (!t || !planes || !pooled || B <= 0) return XFM_EINVAL;
+    if (!xfm_transpose_short_supported(R, C)) return XFM_ELIMIT;
+    if (((uintptr_t)t | (uintptr_t)planes) & 15) return XFM_EINVAL;
+    hipLaunchKernelGGL(pooled_transpose_fwd_kernel, dim3((unsigned)(C / 64), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)t, (uint16_t *)planes, (uint16_t *)pooled, R, C);
+    return check_launch();
+}
+
+int xfm_pooled_transpose_bwd(const void *dplanes, const void *dpooled, void *dt, int B, int R, int C, void *stream) {
+    using namespace xfm;
+    if (!dplanes || !dpooled || !dt || B <= 0) return XFM_EINVAL;
+    if (!xfm_transpose_short_supported(R, C)) return XFM_ELIMIT;
+    if (((uintptr_t)dplanes | (uintptr_t)dpooled | (uintptr_t)dt) & 15) return XFM_EINVAL;
+    hipLaunchKernelGGL(pooled_transpose_bwd_kernel, dim3((unsigned)(C / 64), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)dplanes, (const uint16_t *)dpooled, (uint16_t *)dt, R, C);
     return check_launch();
 }
 

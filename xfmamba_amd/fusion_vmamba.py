@@ -39,7 +39,7 @@ from .csms6s import selective_scan_fn
 from .dwconv import dwconv3x3_silu_fn
 from .layernorm2d import layernorm2d_fn
 from .mlp_tokens import bias_gelu_fn, linear_tokens_fn, mlp_tokens_fn
-from .proj import batched_proj, gated_planes_to_tokens, planes_to_tokens, tokens_to_planes
+from .proj import batched_proj, gated_planes_to_tokens, planes_to_tokens, tokens_to_planes, tokens_to_planes_pooled
 from .rowln import residual_settle_fn, add_layernorm_rows_fn, layernorm_rows_fn, layernorm_rows_pass_fn, rows_supported
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
 from .ss2d_chan import chan_supported, ss2d_chan_fn
@@ -1078,7 +1078,8 @@ class ShallowFuse_SS2Dv4(nn.Module):
         K, R, N = self.k_group, self.dt_rank, self.d_state
         xp = _linear_rows(self.in_proj, n)                                                   # (2B, H, W, D)
         D = xp.shape[-1]
-        xp = tokens_to_planes(xp.view(B2, L, D)).view(B2, D, H, W)
+        xp, pooled = tokens_to_planes_pooled(xp.view(B2, L, D))                                # planes + the squeeze pooling (:866)
+        xp = xp.view(B2, D, H, W)
         xc = _dwconv_act(self.conv2d, self.act, xp) if self.with_dconv else self.act(xp)
         xs = SwappingScanStacked.apply(xc)                                                   # (B, 2, D, L)
         x_dbl = torch.matmul(self.x_proj_weight.to(xs.dtype), xs)                            # (B, 2, R + 2N, L)
@@ -1092,9 +1093,9 @@ class ShallowFuse_SS2Dv4(nn.Module):
         yy = layernorm2d_fn(ys.view(B * 2, D, H, W), self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, xp.dtype)
         f1 = self.fc1
         if len(f1) == 4 and isinstance(f1[1], nn.SiLU) and isinstance(f1[3], nn.Sigmoid):
-            gate = torch.sigmoid(_linear_rows(f1[2], F.silu(_linear_rows(f1[0], xp.mean((2, 3))))))
+            gate = torch.sigmoid(_linear_rows(f1[2], F.silu(_linear_rows(f1[0], pooled))))
         else:
-            gate = f1(self.avg_pool(xp).view(B2, D))                                         # [gate 1 | gate 2]
+            gate = f1(pooled)                                                                # [gate 1 | gate 2]
         # view 1's map is gated by view 2's squeeze and the other way round (:870-871): (sample, view) order, swapped
         gate = torch.stack([gate[B:], gate[:B]], dim=1).view(B * 2, D)
         # (a transposing copy + one 3136-row GEMM: 64 per-sample products through batched_proj measured 41 vs 33 us here)

@@ -334,6 +334,42 @@ class TransposeShort(torch.autograd.Function):
         return dy.transpose(1, 2).contiguous(), None
 
 
+class PooledTokensToPlanes(torch.autograd.Function):
+    """t (B, L, C) tokens -> (planes (B, C, L), pooled (B, C) = mean over the positions), bf16, through
+    ``xfm_pooled_transpose_fwd/_bwd``: the squeeze pooling read off the tile the transpose holds anyway."""
+
+    @staticmethod
+    def forward(ctx, t):
+        from . import _lib
+        B, L, C = t.shape
+        planes = torch.empty((B, C, L), dtype=t.dtype, device=t.device)
+        pooled = torch.empty((B, C), dtype=t.dtype, device=t.device)
+        with torch.cuda.device(t.device), _lib.timed("transpose_short", t.numel() * 4):
+            _lib.check(_lib.lib().xfm_pooled_transpose_fwd(t.data_ptr(), planes.data_ptr(), pooled.data_ptr(), B, L, C,
+                                                           _lib.stream_ptr()), "pooled_transpose_fwd")
+        ctx.shape = (B, L, C)
+        return planes, pooled
+
+    @staticmethod
+    def backward(ctx, dplanes, dpooled):
+        from . import _lib
+        B, L, C = ctx.shape
+        dplanes = torch.zeros((B, C, L), dtype=dpooled.dtype, device=dpooled.device) if dplanes is None else dplanes.contiguous()
+        dpooled = torch.zeros((B, C), dtype=dplanes.dtype, device=dplanes.device) if dpooled is None else dpooled.contiguous()
+        dt = torch.empty((B, L, C), dtype=dplanes.dtype, device=dplanes.device)
+        with torch.cuda.device(dplanes.device), _lib.timed("transpose_short", dt.numel() * 4):
+            _lib.check(_lib.lib().xfm_pooled_transpose_bwd(dplanes.data_ptr(), dpooled.data_ptr(), dt.data_ptr(), B, L, C,
+                                                           _lib.stream_ptr()), "pooled_transpose_bwd")
+        return dt
+
+
+def tokens_to_planes_pooled(t: torch.Tensor):
+    """``(t.transpose(1, 2).contiguous(), t.mean(1))`` for (B, L, C) tokens."""
+    if t.dtype == torch.bfloat16 and t.is_contiguous() and _transpose_short_ok(t, t.shape[1], t.shape[2]):
+        return PooledTokensToPlanes.apply(t)
+    return t.transpose(1, 2).contiguous(), t.mean(1)
+
+
 class GatedPlanesToTokens(torch.autograd.Function):
     """``(yy * gate[:, :, None]).transpose(1, 2)`` for yy (B, C, L) planes and gate (B, C), bf16 -> (B, L, C) tokens, through
     ``xfm_gated_transpose_fwd/_bwd`` (one kernel each way; the backward also sums d gate over the positions)."""
