@@ -560,29 +560,6 @@ class _PrecomputedA:
         return False
 
 
-class _PrecomputedFusionA:
-    """Context: ``A = -exp(A_logs)`` of the shallow and the deep fusion block of ``top`` from one batched evaluation
-    (``_NegExpAll``), read by their stacked forward paths."""
-
-    def __init__(self, top: nn.Module):
-        mods = top.__dict__.get("_fusion_a_mods")
-        if mods is None:
-            mods = [m for m in top.modules() if isinstance(m, (ShallowFuse_SS2Dv4, Cross_SS2Dv5))]
-            top.__dict__["_fusion_a_mods"] = mods
-        self.mods = mods
-
-    def __enter__(self):
-        if self.mods and self.mods[0].A_logs.is_cuda:
-            for m, a in zip(self.mods, _NegExpAll.apply(*[m.A_logs for m in self.mods])):
-                m.__dict__["_As_pre"] = a
-        return self
-
-    def __exit__(self, *exc):
-        for m in self.mods:
-            m.__dict__["_As_pre"] = None
-        return False
-
-
 def _blocks_tokens_ok(blocks) -> bool:
     return len(blocks) > 0 and all(isinstance(b, VSSBlock) and b.tokens_ok() for b in blocks)
 
@@ -1085,9 +1062,7 @@ class ShallowFuse_SS2Dv4(nn.Module):
         x_dbl = torch.matmul(self.x_proj_weight.to(xs.dtype), xs)                            # (B, 2, R + 2N, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         dts = torch.matmul(self.dt_projs_weight.to(xs.dtype), dts)                           # (B, 2, D, L)
-        As = self.__dict__.get("_As_pre")
-        As = -self.A_logs.float().exp() if As is None else As
-        ys = selective_scan_fn(xs.view(B, -1, L), dts.view(B, -1, L), As, Bs.contiguous(),
+        ys = selective_scan_fn(xs.view(B, -1, L), dts.view(B, -1, L), -self.A_logs.float().exp(), Bs.contiguous(),
                                Cs.contiguous(), self.Ds.float(), self.dt_projs_bias.reshape(-1).float(), True, True, None)
         # (slices of ys are what SwappingMerge_multiview returns, and their gradient is its stack)
         yy = layernorm2d_fn(ys.view(B * 2, D, H, W), self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, xp.dtype)
@@ -1220,9 +1195,7 @@ class Cross_SS2Dv5(nn.Module):
         if SS2D_MODE == "fused" and chan_supported(x3, H, W, N, K, D, R):
             # ONE kernel for the cross-fusion exchange: the three streams' four routes, dt_proj on MFMA inside, the view
             # streams reading their state through the fused stream's C rows (no cross_scan / expand / cross_merge copies)
-            As = self.__dict__.get("_As_pre")
-            y = ss2d_chan_fn(x3.reshape(B3, D, L), self.x_proj_weight, self.dt_projs_weight,
-                             -self.A_logs.float().exp() if As is None else As,
+            y = ss2d_chan_fn(x3.reshape(B3, D, L), self.x_proj_weight, self.dt_projs_weight, -self.A_logs.float().exp(),
                              self.Ds.float(), self.dt_projs_bias.reshape(-1).float(), H, W, c_mod=B, c_off=2 * B)
             if planes_out:
                 # out_norm over the channel axis of the (3B, D, H, W) planes by the LayerNorm2d kernel (same maths as the

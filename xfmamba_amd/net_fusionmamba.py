@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fusion_vmamba import Backbone_VSSM, CSSFVSSLayer_v5, ShallowFusionBlock_v4, _PrecomputedFusionA as _PrecomputedA
+from .fusion_vmamba import Backbone_VSSM, CSSFVSSLayer_v5, ShallowFusionBlock_v4
 
 __all__ = ["TwoViewXFMambaTop", "ModelWrapper"]
 
@@ -88,8 +88,9 @@ class TwoViewXFMambaTop(nn.Module):
             zt = self.mamba_feature_extrac(torch.cat([x_a, x_b], dim=0).expand(-1, 3, -1, -1), only_last=True,
                                            tokens_out=True)[-1]
             if self.shallow_mamba_fusion.stacked_ok(zt) and self.fusemamba.stacked_ok(zt):
-                with _PrecomputedA(self):                # A = -exp(A_logs) of both fusion blocks from one batched evaluation
-                    z = self.fusemamba.forward_stacked(self.shallow_mamba_fusion.forward_stacked(zt))
+                # (A = -exp(A_logs) of the two blocks stays two tiny kernels each: batched through _NegExpAll the multi-tensor
+                #  launches of two tensors measured 21 + 10 + 17 us against 4 x 2.6 + 4 x 4.8)
+                z = self.fusemamba.forward_stacked(self.shallow_mamba_fusion.forward_stacked(zt))
                 with torch.autocast("cuda", enabled=False):
                     return self._head(z.float(), tokens=True)
             z = zt.permute(0, 3, 1, 2).contiguous()
