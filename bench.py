@@ -101,6 +101,25 @@ def cpu_baseline(batch=2, size=224):
                        f"oracle = restatement of the reference CPU selective-scan path; {dt:.1f} s/step")
 
 
+def _library_conv_kernels(step):
+    """The convolution kernels the library (MIOpen / composable_kernel) launches in one eager step -- the solvers its find pass
+    chose for the four strided 3x3 convolutions and the stem on this machine -- as {kernel name: launches}; None on failure."""
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        out = {}
+        for e in prof.key_averages():
+            n = e.key
+            if any(k in n for k in ("igemm_", "_ZN2ck", "ck::", "miopen", "MIOpen", "naive_conv", "gemm_conv", "Conv")):
+                short = n.split("(")[0][:96]
+                out[short] = out.get(short, 0) + e.count
+        return out
+    except Exception:                                       # noqa: BLE001
+        return None
+
+
 def _aten_profile(step):
     """Which framework operators still launch kernels in one eager step (development aid for the element-wise tail)."""
     from torch.profiler import profile, ProfilerActivity
@@ -379,6 +398,9 @@ def main():
         _lib.set_timer(None)
     else:
         ksteps = a.steps
+    conv_kernels = None
+    if rank == 0 and not a.no_kernel_timer:
+        conv_kernels = _library_conv_kernels(step)   # (after the timed region: which MIOpen / CK solvers the find pass chose)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -474,6 +496,7 @@ def main():
                             "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1),
                             "ms_per_step": round(v["total_ms"] / ksteps, 3)} for k, v in kernels.items()},
             "launch_mode": (f"hipGraph({scope})" if graph is not None else "eager"),
+            "library_conv_kernels": conv_kernels,
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
