@@ -399,7 +399,7 @@ def main():
     else:
         ksteps = a.steps
     conv_kernels = None
-    if rank == 0 and not a.no_kernel_timer:
+    if world == 1 and not a.no_kernel_timer:         # (one process only: an extra step on rank 0 alone would hang the collectives)
         conv_kernels = _library_conv_kernels(step)   # (after the timed region: which MIOpen / CK solvers the find pass chose)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
