@@ -373,7 +373,7 @@ def main():
 
     for _ in range(a.warmup):
         run_step()
-    if a.aten_profile and rank == 0:
+    if a.aten_profile and world == 1:
         _aten_profile(step)
     timer = None
     if not a.no_kernel_timer and graph is None:
