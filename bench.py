@@ -68,6 +68,9 @@ def parse():
                     "torch.profiler; prints the framework (aten) operators that still launch kernels, by input shapes and "
                     "innermost package frame, to stderr")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
+    ap.add_argument("--report-conv-kernels", action="store_true", help="development: after the JSON line's measurements, one extra "
+                    "eager step under torch.profiler to list the MIOpen / CK convolution solvers the find pass chose (off by "
+                    "default: it nests a profiler inside rocprofv3 runs and adds an eager step to their kernel statistics)")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave MIOpen's default solver heuristics (default: "
                     "torch.backends.cudnn.benchmark = True, i.e. MIOpen's own find pass during warm-up; +5 %% measured)")
     return ap.parse_args()
@@ -141,26 +144,52 @@ def _aten_profile(step):
         print(f"[aten-profile] {t:8.1f} us {n:4d}  {k:30s} {shp}  {where}", file=sys.stderr)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a):
+    """``python bench.py --gpus N`` typed without a launcher: start the N ranks as a fresh child process
+    (``python -m torch.distributed.run``; never an exec -- nothing in THIS process has touched the GPU yet and nothing will),
+    forward its output and exit with its return code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:           # before ANY torch.cuda call
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     # (development hook: XFM_BENCH_BACKEND=gloo runs the N > 1 flow -- captured forward/backward/packing, eager
     #  all-reduce + Adam -- with every rank on GPU 0 of a one-GPU box; never used for a reported number)
     backend = os.environ.get("XFM_BENCH_BACKEND", "nccl")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run, or without a launcher)"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend != "nccl":                                    # host-side rendezvous: needs no GPU
+            dist.init_process_group(backend)
+            if rank == 0:
+                print(f"[bench] ranks: {dist.get_world_size()} ({backend})", file=sys.stderr, flush=True)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     if backend != "nccl":
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(backend)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world > 1 and backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+        if rank == 0:
+            print(f"[bench] RCCL ranks: {dist.get_world_size()}", file=sys.stderr, flush=True)
 
     from xfmamba_amd import _lib, fusion_vmamba
     from xfmamba_amd.amp import WeightCache
@@ -338,6 +367,8 @@ def main():
             graph, graph_b, loss_static = capture()
         except Exception as e:                       # noqa: BLE001
             torch.cuda.synchronize()
+            from xfmamba_amd import deferred as _deferred
+            _deferred.release_capture_tables(dev)    # the abandoned capture's job tables go back to the pool
             if phased is not None:
                 # the two-graph data-parallel step did not come up (every rank runs the same code and fails alike): fall
                 # back to ONE graph for forward + backward + packing and the all-reduce after it
@@ -399,7 +430,7 @@ def main():
     else:
         ksteps = a.steps
     conv_kernels = None
-    if world == 1 and not a.no_kernel_timer:         # (one process only: an extra step on rank 0 alone would hang the collectives)
+    if world == 1 and a.report_conv_kernels:         # (one process only: an extra step on rank 0 alone would hang the collectives)
         conv_kernels = _library_conv_kernels(step)   # (after the timed region: which MIOpen / CK solvers the find pass chose)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -482,7 +513,8 @@ def main():
                                    f"fwd+bwd+Adam, train mode" + cfg_label,
                        "note": "outnorm0-2 of the trunk are skipped: the reference computes them and discards the "
                                "results (net_fusionmamba.py:200-201); they carry no gradient",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_allreduce": ("bf16" if comm is not None else "fp32") if world > 1 else None,
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "ranks": (dist.get_world_size() if world > 1 else 1), "collective_backend": ("RCCL" if backend == "nccl" else backend) if world > 1 else None, "grad_allreduce": ("bf16" if comm is not None else "fp32") if world > 1 else None,
                        "dp_step": (f"two hipGraphs cut after trunk stage {a.dp_cut}: the late layers' all-reduce runs under the early "
                                    f"layers' backward; Adam reads the summed wire bucket in place" if graph_b is not None else
                                    (None if world == 1 else (dp_fallback or ("one graph (forward + backward + packing), all-reduce after it"

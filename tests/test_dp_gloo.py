@@ -378,3 +378,21 @@ def test_real_model_two_graph_step_averages_like_one_process_over_three_replays(
         p.join(timeout=120)
         assert p.exitcode == 0
     assert all(r[1] for r in res), res
+
+
+def test_bench_self_launches_its_ranks_when_typed_without_a_launcher():
+    """``python bench.py --gpus 2`` with no WORLD_SIZE in the environment (how the driver types it) starts its own two ranks through
+    torch.distributed.run as a child process and gets through the rendezvous; on this GPU-less machine the ranks then stop at
+    the 'needs MI355X GPUs' check -- not at the WORLD_SIZE assertion of round 4."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["XFM_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    err = r.stderr
+    assert "[bench] ranks: 2 (gloo)" in err, err[-2000:]
+    assert "but WORLD_SIZE=" not in err, err[-2000:]
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs MI355X GPUs" in err, err[-2000:]

@@ -306,7 +306,8 @@ def test_fused_ss2d_matches_oracle_chain(shape):
                                    (2, 256, 24, 20), (1, 512, 12, 12), (2, 1024, 24, 24), (1, 2048, 12, 12),     # XFMamba-B widths
                                    (3, 1536, 7, 7), (1, 520, 9, 5), (32, 768, 7, 7), (21, 384, 14, 14)])                                         # wide rows: 16-wave two-pass kernels
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
-                                     (torch.bfloat16, torch.bfloat16)])
+                                     (torch.bfloat16, torch.bfloat16), (torch.float16, torch.float16),
+                                     (torch.float32, torch.float16)])      # fp16: a .half() model / default autocast
 def test_layernorm2d_matches_torch_fp32(shape, xdt, ydt):
     """LayerNorm2d (reference fusion_vmamba.py:52-57: permute -> F.layer_norm -> permute) vs plain PyTorch fp32."""
     from xfmamba_amd.layernorm2d import layernorm2d_fn

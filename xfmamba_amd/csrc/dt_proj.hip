@@ -505,10 +505,9 @@ template <int DB> static int dt_proj_bwd_merged_launch(const DtProjBwdArgs &a, i
     constexpr int D = 32 * DB;
     const size_t lds = (size_t)(DB <= 4 ? 3 : 2) * (D * 256 + 32 * 256) + (size_t)32 * (D + 8) * 2;
     auto fn = dt_proj_bwd_merged_kernel<DB>;
-    static bool opted = false;
-    if (lds > 64 * 1024 && !opted) {
-        if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
-        opted = true;
+    static xfm::LdsOptIn opted;
+    if (lds > 64 * 1024) {
+        if (!xfm::lds_opt_in(opted, (const void *)fn, lds)) return XFM_ELAUNCH;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)(B * 4)), dim3(256), lds, s, a);
     return check_launch();
@@ -555,13 +554,8 @@ int xfm_ss2d_dt_proj_bwd_mfma(const void *ddts, const void *xr, const void *weig
     a.ltiles = ((L + 31) / 32 + 3) / 4;
     const size_t lds = (size_t)32 * (D + 8) * sizeof(uint16_t);
     if (lds > 64 * 1024) {                                        // D = 1024 (XFMamba-B stage 2): 66 048 B, opt in
-        static bool once = false;
-        if (!once) {
-            if (hipFuncSetAttribute((const void *)dt_proj_bwd_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
-                return XFM_ELAUNCH;
-            once = true;
-        }
+        static xfm::LdsOptIn once;
+        if (!xfm::lds_opt_in(once, (const void *)dt_proj_bwd_dx_kernel, 160 * 1024)) return XFM_ELAUNCH;
     }
     hipLaunchKernelGGL(dt_proj_bwd_dx_kernel, dim3((unsigned)((int64_t)B * 4 * a.ltiles)), dim3(256), lds, s, a);
     int rc = check_launch();

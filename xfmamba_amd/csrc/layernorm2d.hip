@@ -1264,7 +1264,7 @@ int xfm_layernorm2d_bwd_parts_ws(const void *x, const float *weight, const void 
                                  void *dx, float *parts, float *workspace, int B, int C, int L, int x_dtype, int y_dtype,
                                  void *stream) {
     using namespace xfm;
-    if (!x || !weight || !dy || !mean || !rstd || !dx || !workspace) return XFM_EINVAL;
+    if (!x || !weight || !dy || !mean || !rstd || !dx || !parts || !workspace) return XFM_EINVAL;
     if (!xfm_layernorm2d_bwd_ws_floats(B, C, L)) return XFM_ELIMIT;
     hipStream_t s = (hipStream_t)stream;
     if (!xfm_layernorm2d_ws_floats(B, C, L)) {              // the split form

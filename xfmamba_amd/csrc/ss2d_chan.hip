@@ -902,11 +902,8 @@ template <int KS> static int deep_launch(const DeepArgs &da, hipStream_t s) {
     constexpr bool bwd = true;
     const size_t lds = DeepBwdLds::total;
     const void *fn = (const void *)deep_bwd_kernel<KS>;
-    static bool opted = false;
-    if (lds > 64 * 1024 && !opted) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
-        opted = true;
-    }
+    static LdsOptIn opted;
+    if (lds > 64 * 1024 && !lds_opt_in(opted, fn, lds)) return XFM_ELAUNCH;
     DeepArgs args = da;
     void *kargs[] = {&args};
     // (a kernel, not a memset node: under stream capture the memset of this workspace slice replayed with stale contents)
@@ -934,11 +931,8 @@ template <int HW, int N, int KS> static int chan_launch(const ChanArgs &a, bool 
     const size_t lds = bwd ? ChanBwdLds<HW, N, YT>::total : lds_f;
     const void *fn = bwd ? (const void *)ss2dc_bwd_kernel<HW, N, KS, YT> : (const void *)ss2dc_fwd_kernel<HW, N, KS, YT>;
     if (lds > 160 * 1024) return XFM_ELIMIT;
-    static bool opted[2] = {false, false};                        // (per template instantiation: once per kernel)
-    if (lds > 64 * 1024 && !opted[bwd]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
-        opted[bwd] = true;
-    }
+    static LdsOptIn opted[2];                                     // (per template instantiation: once per kernel and device)
+    if (lds > 64 * 1024 && !lds_opt_in(opted[bwd], fn, lds)) return XFM_ELAUNCH;
     ChanArgs args = a;
     // one 32-channel tile per workgroup measured fastest also for d_state 16 (deep block, 96 x 48 tiles: 999 us against
     // 1256 / 1648 / 2111 us with 2 / 4 / 8 tiles per workgroup: parallelism beats the smaller dB / dC flush)

@@ -440,11 +440,8 @@ template <int HW, int KS> static int launch_bwd(const ChanArgs &a, hipStream_t s
     static const int pad = [] { const char *e = getenv("XFM_CHAN1_LDSPAD"); return e ? atoi(e) : 0; }();   // occupancy experiments
     const size_t lds = Lds<HW>::total + pad;
     const void *fn = (const void *)bwd_kernel<HW, KS>;
-    static bool opted = false;                                      // (per template instantiation: once per kernel)
-    if (lds > 64 * 1024 && !opted) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
-        opted = true;
-    }
+    static LdsOptIn opted;                                          // (per template instantiation: once per kernel and device)
+    if (lds > 64 * 1024 && !lds_opt_in(opted, fn, lds)) return XFM_ELAUNCH;
     ChanArgs args = a;
     static const int dbg = [] { const char *e = getenv("XFM_CHAN1_DBG"); return e ? atoi(e) : 0; }();
     args.ct = dbg & ~1;
@@ -657,11 +654,8 @@ template <int HW, int KS> static int launch_fwd(const ChanArgs &a, hipStream_t s
     using YT = typename std::conditional<(HW > 12), uint16_t, float>::type;
     const size_t lds = FwdLds<HW, YT>::total;
     const void *fn = (const void *)fwd_kernel<HW, KS, YT>;
-    static bool opted = false;
-    if (lds > 64 * 1024 && !opted) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XFM_ELAUNCH;
-        opted = true;
-    }
+    static LdsOptIn opted;
+    if (lds > 64 * 1024 && !lds_opt_in(opted, fn, lds)) return XFM_ELAUNCH;
     ChanArgs args = a;
     args.ct = 0;
     void *kargs[] = {&args};

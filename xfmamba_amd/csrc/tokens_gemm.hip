@@ -593,12 +593,8 @@ static int tokens_gemm2_launch_nt(TokGemm2Args a, hipStream_t s) {
     const size_t lds = (size_t)OCH * (CON + 8) * sizeof(uint16_t) + (size_t)OCH * sizeof(float) +
                        (size_t)(NT / 64) * 32 * (OCH + 8) * sizeof(uint16_t);
     auto fn = tokens_gemm2_kernel<CON, OCH, EPI, NT>;
-    static bool opted = false;
-    if (lds > 64 * 1024 && !opted) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return XFM_ELAUNCH;
-        opted = true;
-    }
+    static LdsOptIn opted;
+    if (lds > 64 * 1024 && !lds_opt_in(opted, reinterpret_cast<const void *>(fn), lds)) return XFM_ELAUNCH;
     const int chunks = a.OUT / OCH;
     const int64_t ntiles = (a.T + 31) / 32;
     // one workgroup per CU (the weight chunk takes ~100 KB of LDS): the CUs are split evenly over the chunks
@@ -903,12 +899,8 @@ template <int EPI, bool WT>
 static int tokens_gemm3_launch(const TokGemm2Args &a, int con, hipStream_t s) {
     const size_t lds = 2 * kG3Stage + 512;
     auto fn = tokens_gemm3_kernel<EPI, WT>;
-    static bool opted = false;
-    if (!opted) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return XFM_ELAUNCH;
-        opted = true;
-    }
+    static LdsOptIn opted;
+    if (!lds_opt_in(opted, reinterpret_cast<const void *>(fn), lds)) return XFM_ELAUNCH;
     const int ntn = a.OUT / 128;
     const int64_t ntm = (a.T + 127) / 128;
     const int64_t ntiles = ntm * ntn;
@@ -1155,12 +1147,8 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
 template <bool PIN, bool WT> static int proj_tiled_launch(ProjTiledArgs a, hipStream_t s) {
     const size_t lds = 2 * kG3Stage + 512;
     auto fn = proj_tiled_kernel<PIN, WT>;
-    static bool opted = false;
-    if (!opted) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return XFM_ELAUNCH;
-        opted = true;
-    }
+    static LdsOptIn opted;
+    if (!lds_opt_in(opted, reinterpret_cast<const void *>(fn), lds)) return XFM_ELAUNCH;
     a.ltiles = (a.L + 127) / 128;
     a.ntn = a.OUT / 128;
     a.ntiles = a.B * a.ltiles * a.ntn;
@@ -1250,8 +1238,12 @@ int xfm_tokens_gemm2(const void *x, const void *weight_bf16, const float *bias, 
     a.T = T;
     a.OUT = out;
     a.wt = weight_transposed ? 1 : 0;
+#ifdef XFM_GEMM2_TIMING
     static const int dbg = [] { const char *e = getenv("XFM_GEMM2_DBG"); return e ? atoi(e) : 0; }();   // timing switches: 2, 4
     a.wt |= dbg & 62;
+#else
+    constexpr int dbg = 0;                                        // (the timing switches exist in -DXFM_GEMM2_TIMING builds only)
+#endif
     a.wgs_per_chunk = 1;
     hipStream_t s = (hipStream_t)stream;
     const int form = tokens_gemm2_form();

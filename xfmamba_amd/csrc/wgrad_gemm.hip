@@ -760,11 +760,8 @@ static int wgrad_launch(WgradArgs a, int nslices, hipStream_t s) {
     const size_t lds = 2 * (ABYTES + BBYTES);
     const int nbm = (a.M + kWgTile - 1) / kWgTile, nbn = (a.N + kWgTile - 1) / kWgTile;
     if (lds > 64 * 1024) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)wgrad_kernel<APL, BPL, BK, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        static LdsOptIn attr;
+        if (!lds_opt_in(attr, (const void *)wgrad_kernel<APL, BPL, BK, RAG>, lds)) return XFM_ELAUNCH;
     }
     a.wgs = nbm * nbn * nslices;
     a.xcd_map = wg_xcd_map() ? 1 : 0;
@@ -855,12 +852,10 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     hipStream_t s = (hipStream_t)stream;
     if (glds) {
         const size_t lds = (size_t)kGlStages * 2 * kGlTile;
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)wgrad_tt_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void *)wgrad_tt_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        static xfm::LdsOptIn attr[2];
+        if (!xfm::lds_opt_in(attr[0], (const void *)wgrad_tt_glds_kernel<false>, lds) ||
+            !xfm::lds_opt_in(attr[1], (const void *)wgrad_tt_glds_kernel<true>, lds))
+            return XFM_ELAUNCH;
         w.wgs = tiles * nsl;
         w.xcd_map = wg_xcd_map() ? 1 : 0;
         const int grid = w.xcd_map ? (w.wgs + 7) / 8 * 8 : w.wgs;

@@ -10,6 +10,20 @@
 #include "../../include/xfm_hip.h"
 
 namespace xfm {
+// ---- host side: opt a kernel in to more than 64 KB of dynamic LDS, once per DEVICE -------------------------------------
+// (hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: a process-wide "done" flag would leave the second
+//  GPU of a multi-device process with the 64 KB default.  `done` is a bit per device ordinal, updated atomically.)
+struct LdsOptIn { unsigned long long done = 0; };
+static inline bool lds_opt_in(LdsOptIn &st, const void *fn, size_t lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&st.done, __ATOMIC_ACQUIRE) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    __atomic_fetch_or(&st.done, bit, __ATOMIC_RELEASE);
+    return true;
+}
+
 
 constexpr float kLog2e = 1.4426950408889634f;
 

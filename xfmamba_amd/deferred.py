@@ -62,9 +62,23 @@ def reserve_capture_tables(device, n: int = _CAP_POOL_MIN) -> None:
         free.append(_new_tables(device))
 
 
-def _tables(device, capturing):
+def release_capture_tables(device=None) -> None:
+    """Hand the table pairs of captured flushes back to the pool.  Call it when the graphs that recorded them are gone -- a
+    capture that failed, a graph that was destroyed or is about to be re-captured -- and never while such a graph can still be
+    replayed (its memcpy nodes read the pinned tables at every replay)."""
+    for dev, used in _S["cap_used"].items():
+        if device is None or dev == str(device):
+            for sl in used:
+                sl["key"] = None
+            _S["cap_free"].setdefault(dev, []).extend(used)
+            used.clear()
+
+
+def _tables(device, capturing, key=None):
     """Eager flushes share one table pair per device (rewritten when the job set changes, behind an event).  A flush under
-    capture takes a pair from the pool and keeps it for the life of the process: the graph's memcpy nodes read it at replay."""
+    capture takes a pair from the pool; the pair stays with the graph (its memcpy nodes read it at replay) until
+    ``release_capture_tables``.  A captured flush of a job set that an earlier capture already recorded (the same step captured
+    again) reuses that pair -- same contents, read-only at replay -- instead of taking another one."""
     dev = str(device)
     if not capturing:
         sl = _S["eager"].get(dev)
@@ -72,6 +86,9 @@ def _tables(device, capturing):
             sl = _S["eager"][dev] = _new_tables(device)
         reserve_capture_tables(device)
         return sl
+    for sl in _S["cap_used"].get(dev, ()):
+        if key is not None and sl["key"] == key:
+            return sl
     free = _S["cap_free"].get(dev)
     if not free:
         raise RuntimeError("xfmamba_amd.deferred: no job table left for a flush under capture -- run a warm-up step with "
@@ -126,8 +143,8 @@ def flush(_end_of_pass: bool = True) -> None:
     _S["jobs"] = []
     dev = jobs[0][0].device
     capturing = torch.cuda.is_current_stream_capturing()
-    sl = _tables(dev, capturing)
     key = tuple((p.data_ptr(), tuple(outs), nblk, C, nparts) for p, outs, nblk, C, nparts in jobs)
+    sl = _tables(dev, capturing, key)
     if key != sl["key"]:
         if sl["evt"] is not None:
             sl["evt"].synchronize()                  # the previous upload of this pinned table may still be in flight

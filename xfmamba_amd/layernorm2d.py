@@ -83,7 +83,8 @@ class LayerNorm2dHip(torch.autograd.Function):
                 pr = part.view(nrow, 2, C).sum(0)
                 dw, db = pr[0], pr[1]
             return dx, dw.to(ctx.wdtype), db.to(ctx.wdtype), None, None
-        nblk = lib.xfm_layernorm2d_bwd_parts_blocks(B, C, L, xc, yc) if ctx.has_bias and _PARTS else 0
+        # (the partial-row kernels exist for fp32 / bf16 only: fp16 maps keep xfm_layernorm2d_bwd below)
+        nblk = lib.xfm_layernorm2d_bwd_parts_blocks(B, C, L, xc, yc) if ctx.has_bias and slab_dt and _PARTS else 0
         if nblk > 0:
             # the dx kernel leaves the weight / bias gradient as one partial row pair per workgroup: no second kernel reading x and
             # dy again; folded with all the other column sums of the step (deferred.py) or summed here

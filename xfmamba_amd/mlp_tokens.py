@@ -171,6 +171,14 @@ def _gemm2_ok(x, con, out):
 def _gemm2(x2, w, bias, out, transposed, epi, zin=None):
     """xfm_tokens_gemm2 on (T, con) rows: epi 1 -> (z, g), epi 2 -> (dz, None), epi 0 -> (y, None)."""
     T, con = x2.shape
+    # (the kernel's 16-byte vector loads: a gradient or weight VIEW at an odd offset is copied to a fresh -- 256-byte aligned --
+    #  allocation instead of failing the step; never taken on the model's own tensors)
+    if x2.data_ptr() % 16 or not x2.is_contiguous():
+        x2 = x2.clone(memory_format=torch.contiguous_format)
+    if w.data_ptr() % 16:
+        w = w.clone()
+    if zin is not None and zin.data_ptr() % 16:
+        zin = zin.clone()
     y = torch.empty((T, out), dtype=x2.dtype, device=x2.device)
     y2 = torch.empty_like(y) if epi == 1 else None
     b = None if bias is None else bias.float().contiguous()
