@@ -351,7 +351,11 @@ typedef struct {
     int batch, d_inner, H, W, dstate;
     int delta_softplus;    /* 0: step = dts + bias; 1: step = softplus(dts + bias) (models/csms6s.py:49-50); 2: dts already
                             * holds softplus(raw + bias) (xfm_ss2d_dt_proj_fwd epilogue): delta_bias is not read, and
-                            * ddts / ddelta_bias are still the gradients of the RAW pre-activation / of the bias */
+                            * ddts / ddelta_bias are still the gradients of the RAW pre-activation / of the bias;
+                            * 3: dt_proj INSIDE the kernel (models/fusion_vmamba.py:1147-1150):
+                            * step = softplus(dt_w . xrt + bias) formed per position, dts is NOT read (may be NULL) and the
+                            * (batch, 4, d_inner, L) step sizes never reach HBM; ddts is still written (gradient of the raw
+                            * pre-activation, the operand of xfm_ss2d_dt_proj_bwd_mfma).  Shapes: xfm_ss2d_dtfused_rank() */
     int in_dtype;          /* of x, dts, Bs, Cs, dx, ddts */
     int out_dtype;         /* of y / dy (fp32 = "oflex") */
     const void *x;         /* (batch, d_inner, H*W) */
@@ -369,7 +373,23 @@ typedef struct {
     float *dBs, *dCs;      /* (batch, 4, dstate, H*W) fp32 ZEROED, per-route order */
     float *dA;             /* (4*d_inner, dstate) fp32 ZEROED */
     float *dD, *ddelta_bias; /* (4*d_inner) fp32 ZEROED */
+    /* delta_softplus == 3 only (ignored otherwise) */
+    const void *xrt;       /* the dt_proj input rows of x_proj's output in the blocked form xfm_ss2d_xr_rows writes:
+                              (batch, 4, ceil(H*W / 512), dt_rank_p, 64, 8) in_dtype, per-route order */
+    const void *dt_w;      /* (4, d_inner, dt_rank_p) in_dtype: dt_projs_weight rows, zero-padded to dt_rank_p */
+    int dt_rank_p;         /* xfm_ss2d_dtfused_rank(...) */
 } xfm_ss2d_params_t;
+
+/* dt_proj inside the fused SS2D core (delta_softplus == 3): the padded rank to lay xrt / dt_w out with (dt_rank rounded up
+ * to even), or 0 when this shape / dtype has no such kernel (bf16 I/O, d_state 1, the wide square maps of csrc/ss2d_l3.hip,
+ * dt_rank <= 16) -- the caller then materialises dts (xfm_ss2d_dt_proj_fwd*) and uses mode 2. */
+int xfm_ss2d_dtfused_rank(int batch, int d_inner, int H, int W, int dstate, int dt_rank, int in_dtype);
+/* xr (B4, R, L) -> xrt (B4, ceil(L / 512), Rp, 64, 8): the copy of the (small) dt_proj input rows that the mode-3 kernels read,
+ * blocked by their chunk geometry: a chunk row is 512 route positions = 64 chunks of 8; piece j (8 values = 16 bytes) of chunk
+ * c holds values 8 j .. 8 j + 7 of the chunk's 8 positions x Rp ranks, position-major (value p * Rp + r), so that every load
+ * instruction of a wave (lane = chunk) is one contiguous KB.  Positions past L and ranks R .. Rp - 1 are zero.  B4 = batch * 4
+ * routes, rows already in per-route order (xfm_ss2d_route_split); 16-bit dtypes, L % 8 == 0, Rp 6 or 12. */
+int xfm_ss2d_xr_rows(const void *xr, void *xrt, long long B4, int R, int Rp, int L, int dtype, void *stream);
 
 /* The chunking (and so the size of chk) depends on the I/O dtype: 16-byte vectors per lane where rows allow. */
 int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, int in_dtype, xfm_scan_plan_t *plan);

@@ -632,6 +632,66 @@ def test_ss2d_xproj_core_matches_operator_chain(shape, dt):
         assert_close(a.float().cpu(), b.float().cpu(), tol, tol * float(b.float().abs().max()) + 1e-7, name)
 
 
+DTFUSED_SHAPES = [
+    # (B, D, H, R): dt_proj INSIDE the wide-map scan kernels (delta_softplus 3, csrc/ss2d_l3.hip) -- built for dt_rank 6 at
+    # 56 x 56 and dt_rank 12 at 28 x 28 (XFMamba-T / -S stages 0 / 1); odd ranks exercise the zero padding to Rp
+    (2, 96, 56, 6),         # stage 0 of XFMamba-T: 7 chunk rows with an 8-lane tail row, row 5 of the dB / dC sums in LDS
+    (16, 8, 56, 6),         # batch % 8 == 0: XCD-local sample placement, several planes per workgroup
+    (1, 5, 56, 5),          # rank 5 padded to 6, odd channel count
+    (3, 192, 28, 12),       # stage 1: four planes per tile, 2 chunk rows, 34-lane tail
+    (8, 24, 28, 12),
+    (2, 8, 28, 11),         # rank 11 padded to 12
+]
+
+
+@pytest.mark.parametrize("shape", DTFUSED_SHAPES, ids=[f"B{s[0]}D{s[1]}H{s[2]}R{s[3]}" for s in DTFUSED_SHAPES])
+def test_ss2d_with_dt_proj_inside_matches_oracle(shape, monkeypatch):
+    """x_proj -> split -> dt_proj -> softplus -> 4-route scan -> merge with the step sizes formed INSIDE the scan kernels
+    (reference models/fusion_vmamba.py:1145-1174) against the fp32 CPU oracle chain (cross_scan_ref,
+    _proj_dt_B_C, the C scan, cross_merge_ref): y and every gradient; no dt_proj forward kernel may run, no (B,4,D,L) step-size
+    tensor may be allocated.  Also against the materialised-step-size path (XFM_SS2D_DT_FUSED=0) of the same node."""
+    from xfmamba_amd import _lib, ss2d
+    B, D, H, R = shape
+    W, N, K = H, 1, 4
+    L, C2 = H * W, R + 2
+    g = torch.Generator().manual_seed(B * D + R)
+    x = torch.randn(B, D, H, W, generator=g).bfloat16()
+    xw = (torch.randn(K, C2, D, generator=g) * D ** -0.5).bfloat16().float()        # (the values the bf16 GEMM sees)
+    dtw = (torch.randn(K, D, R, generator=g) * R ** -0.5).bfloat16().float()
+    A = -torch.rand(K * D, N, generator=g) - 0.1
+    Dp = torch.randn(K * D, generator=g)
+    bias = torch.rand(K * D, generator=g) * 4 - 4.5               # softplus argument around -2.5: step sizes 0.01 .. 0.5
+    gy = torch.randn(B, D, L, generator=g)
+    ref = [t.float().clone().requires_grad_() for t in (x, xw, dtw, A, Dp, bias)]
+    xs = O.cross_scan_ref(ref[0])
+    dts, Bs, Cs = O._proj_dt_B_C(xs, ref[1], ref[2], R, N)
+    ys = c_scan.selective_scan_c(xs.reshape(B, -1, L), dts.reshape(B, -1, L), ref[3], Bs.contiguous(), Cs.contiguous(),
+                                 ref[4], ref[5], True, True)
+    y_ref = O.cross_merge_ref(ys.view(B, K, D, H, W))
+    y_ref.backward(gy)
+    assert _lib.lib().xfm_ss2d_dtfused_rank(B, D, H, W, N, R, _lib.dtype_code(torch.bfloat16)) == (R + 1) // 2 * 2
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ss2d, "_DT_FUSED", fused)
+        timer = _lib.KernelTimer()
+        _lib.set_timer(timer)
+        t = [v.to(DEV).requires_grad_() for v in (x.view(B, D, L), xw, dtw, A, Dp, bias)]
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ss2d.ss2d_xproj_core_fn(t[0], t[1], t[2], t[3], t[4], t[5], H, W)
+        y.backward(gy.to(DEV))
+        _lib.set_timer(None)
+        ran = set(timer.summary())
+        assert ("dt_proj_fwd" in ran) == (not fused) and ("xr_rows" in ran) == fused, sorted(ran)
+        outs[fused] = [y.detach()] + [v.grad for v in t]
+    names = ("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias")
+    refs = [y_ref.detach().view(B, D, L)] + [r.grad for r in ref]
+    for name, a, r in zip(names, outs[True], refs):
+        r = r.reshape(a.shape)
+        assert_close(a.float().cpu(), r, 1e-2, 1e-2 * (float(r.abs().max()) + 1e-6), name)      # BASELINE: 1e-2 for bf16 I/O
+    for name, a, b in zip(names, outs[True], outs[False]):
+        assert_close(a.float().cpu(), b.float().cpu(), 1e-2, 1e-2 * float(b.float().abs().max()) + 1e-7, name + " vs mode 2")
+
+
 @pytest.mark.parametrize("shape", [(8, 24, 56, 56), (8, 48, 28, 28), (2, 16, 48, 48), (8, 32, 24, 24)])
 def test_ss2d_backward_workspace_entry_equals_the_atomics_entry(shape, monkeypatch):
     """xfm_ss2d_bwd_ws (per-workgroup dB / dC partial rows in a caller workspace + one summing kernel, the default from

@@ -241,13 +241,23 @@ int ss2d_launch_lean(const void *fn, const SS2DArgs &a, const Plan2 &pl, bool bw
 int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, size_t ws_bytes);   // ss2d_l3.hip: wide maps
 size_t ss2d_l3_ws_bytes(const xfm_ss2d_params_t *p);
 int ss2d_l3_nseg(int batch, int D, int H, int W, int N, int in_dtype);
+int ss2d_l3_dtfused_rank(int batch, int D, int H, int W, int N, int R, int in_dtype);
 static bool ss2d_forced() {
     static const bool f = getenv("XFM_SS2D_FORCE") != nullptr;      // tuning hook, read once per process
     return f;
 }
 
 static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream, float *ws = nullptr, size_t ws_bytes = 0) {
-    if (!p || !p->x || !p->dts || !p->Bs || !p->Cs || !p->A || !p->D || !p->delta_bias) return XFM_EINVAL;
+    if (!p || !p->x || !p->Bs || !p->Cs || !p->A || !p->D || !p->delta_bias) return XFM_EINVAL;
+    if (p->delta_softplus == 3) {
+        // dt_proj inside the kernel: only the wide-map kernels of ss2d_l3.hip have it (xfm_ss2d_dtfused_rank)
+        if (!p->xrt || !p->dt_w || p->dt_rank_p <= 0) return XFM_EINVAL;
+        if (!bwd && !p->y) return XFM_EINVAL;
+        if (bwd && (!p->dy || !p->dx || !p->ddts || !p->dBs || !p->dCs || !p->dA || !p->dD || !p->ddelta_bias)) return XFM_EINVAL;
+        if (p->out_dtype != XFM_F32) return XFM_EDTYPE;
+        return ss2d_l3_run(p, bwd, (hipStream_t)stream, ws, ws_bytes);
+    }
+    if (!p->dts) return XFM_EINVAL;
     if (!bwd && !p->y) return XFM_EINVAL;
     if (bwd && (!p->dy || !p->dx || !p->ddts || !p->dBs || !p->dCs || !p->dA || !p->dD || !p->ddelta_bias))
         return XFM_EINVAL;
@@ -303,6 +313,10 @@ int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, int in_dtype
     if (!xfm::ss2d_forced())                       // the wide-map kernels (ss2d_l3.hip) index chk by their own geometry
         plan->n_chunks = std::max(plan->n_chunks, xfm::ss2d_l3_nseg(batch, d_inner, H, W, dstate, in_dtype));
     return XFM_OK;
+}
+int xfm_ss2d_dtfused_rank(int batch, int d_inner, int H, int W, int dstate, int dt_rank, int in_dtype) {
+    if (xfm::ss2d_forced()) return 0;
+    return xfm::ss2d_l3_dtfused_rank(batch, d_inner, H, W, dstate, dt_rank, in_dtype);
 }
 int xfm_ss2d_fwd(const xfm_ss2d_params_t *p, void *stream) { return xfm::run2(p, false, stream); }
 int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream) { return xfm::run2(p, true, stream); }

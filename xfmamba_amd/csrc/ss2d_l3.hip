@@ -12,7 +12,12 @@
 //     cross-row steps run under EXEC row masks with the row totals in SGPRs (v_readlane);
 //   * the carries enter through one FMA and a one-lane wave shift instead of exclusive-prefix shifts of both halves
 //     of the map;
-//   * softplus handling is a template parameter (1: in-kernel with bias, 2: the step sizes arrive activated).
+//   * softplus handling is a template parameter (1: in-kernel with bias, 2: the step sizes arrive activated,
+//     3: dt_proj INSIDE the kernel -- SURVEY 8(f) rank 1, reference models/fusion_vmamba.py:1147-1150: the step size
+//     softplus(W_dt . xr + bias) is formed per position from the dt_proj input rows `xrt` (batch, 4, L, Rp) -- position-major,
+//     route order, the same for all channels of a route, so they come out of L2 -- with v_dot2_f32_bf16 against the channel's
+//     Rp weights held as bf16 pairs in scalar registers: Rp / 2 instructions per position, no unpack.  The (B, 4, D, L) step
+//     sizes are never stored: 8 of the 14 (forward) / 24 (backward) bytes per element at the "dts" boundary are gone).
 // Roofline: HBM (24 B per (b,d,p) element backward, 14 B forward at this boundary: ss2d_kernels.hpp).
 #include <cstdlib>
 
@@ -31,7 +36,10 @@ namespace xfm {
 #endif
 typedef float l3f2 __attribute__((ext_vector_type(2)));
 
-template <int HW> struct L3Geom {
+// RP2: dt_rank pairs of the mode-3 kernels (0 otherwise); they hold 2 RP2 operand vectors per chunk row in flight, so the
+// 56 x 56 backward keeps one chunk row less of the dB / dC sums in registers (row 5 joins the tail row in the LDS strip:
+// 68.6 KB per workgroup, still two per CU)
+template <int HW, int RP2 = 0> struct L3Geom {
     static constexpr int L = HW * HW;
     static constexpr int ROW = 512;                             // positions per chunk row: 64 lanes x 8
     static constexpr int NSEG = (L + ROW - 1) / ROW;
@@ -40,7 +48,8 @@ template <int HW> struct L3Geom {
     // dB / dC sums of a route over the planes of a workgroup: the first NREG chunk rows in registers (16 per row), the
     // rest in a wave-private LDS strip (56 x 56: row 5 and the 8-lane tail row -- 256 registers hold five rows next to
     // the working set, and 4.6 KB per wave still leave two workgroups per CU)
-    static constexpr int NREG = NSEG < L3_NREG ? NSEG : L3_NREG;
+    static constexpr int NREG_MAX = L3_NREG - ((RP2 > 0 && NSEG > 5) ? 1 : 0);
+    static constexpr int NREG = NSEG < NREG_MAX ? NSEG : NREG_MAX;
     static constexpr int NACC = NREG;
     static constexpr int LSZ = NSEG > NREG ? L - NREG * ROW : 0;   // positions whose sums live in LDS
 };
@@ -135,8 +144,78 @@ template <bool REV> __device__ __forceinline__ uint4 l3_pack(const l3f2 (&v)[4])
 
 __device__ __forceinline__ l3f2 l3_exp2(const l3f2 t) { return l3f2{exp2_fast(t.x), exp2_fast(t.y)}; }
 
-// operands of one chunk row, requested one row ahead
-struct L3Ops { uint4 d, b, c; float h; };
+// operands of one chunk row, requested one row ahead.  d: the step-size vector (NX = 1), or in mode 3 the lane's piece of
+// the dt_proj input rows: 8 positions x Rp bf16 = NX = Rp / 4 vectors, contiguous
+template <int NX> struct L3Ops { uint4 d[NX]; uint4 b, c; float h; };
+// Mode 3 (NX > 1): the rows are stored BLOCKED by this file's chunk geometry -- (chunk row, piece j, chunk c, 8 values) with
+// piece j of chunk c = values 8 j .. 8 j + 7 of the chunk's 8 positions x Rp ranks (position-major) -- so that load
+// instruction j of a wave is one contiguous KB (lane = chunk).  Position-major rows read directly put a lane's 16-byte pieces
+// 16 Rp bytes apart: 48 different 128-byte lines per instruction, each fetched by 6 instructions -- measured 126 vs 88 us for the
+// 56 x 56 forward, the texture-address path being the bound.
+template <int NX> __device__ __forceinline__ void l3_ops_load(L3Ops<NX> &op, const bf16_t *drow, const bf16_t *Brow,
+                                                              const bf16_t *Crow, const int tp) {
+    if constexpr (NX == 1) {
+        op.d[0] = *reinterpret_cast<const uint4 *>(drow + tp);
+    } else {
+        const bf16_t *blk = drow + (int64_t)(tp >> 9) * (512 * NX) + ((tp >> 3) & 63) * 8;   // chunk row, chunk
+#pragma unroll
+        for (int j = 0; j < NX; ++j) op.d[j] = *reinterpret_cast<const uint4 *>(blk + j * 512);
+    }
+    op.b = *reinterpret_cast<const uint4 *>(Brow + tp);
+    op.c = *reinterpret_cast<const uint4 *>(Crow + tp);
+}
+template <int NX> __device__ __forceinline__ void l3_ops_zero(L3Ops<NX> &op) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) op.d[j] = make_uint4(0, 0, 0, 0);
+    op.b = op.c = make_uint4(0, 0, 0, 0);
+}
+
+// mode 3: raw step size of the lane's 8 positions in TRAVERSAL order = bias + sum_j <xr pair j of the position, weight pair j>
+typedef __bf16 l3bf2 __attribute__((ext_vector_type(2)));
+template <int RP2, bool REV>
+__device__ __forceinline__ void l3_delta_raw(const uint4 (&d)[2 * RP2], const uint32_t (&wp)[RP2], const float bias, l3f2 (&v)[4]) {
+    uint32_t w[8 * RP2];
+#pragma unroll
+    for (int j = 0; j < 2 * RP2; ++j) {
+        w[4 * j] = d[j].x; w[4 * j + 1] = d[j].y; w[4 * j + 2] = d[j].z; w[4 * j + 3] = d[j].w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int p = REV ? 7 - e : e;
+        float s = bias;
+#pragma unroll
+        for (int j = 0; j < RP2; ++j)
+            s = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const l3bf2 *>(&w[p * RP2 + j]),
+                                                *reinterpret_cast<const l3bf2 *>(&wp[j]), s, false);
+        if (e & 1) v[e >> 1].y = s; else v[e >> 1].x = s;
+    }
+}
+// softplus (threshold 20, reference models/csms6s.py:49-50) of a step size that was formed from bf16 operands: log2(1 + z)
+// straight from v_log_f32 (relative error ~6e-8 / z: far inside the bf16 bound for every step size above 1e-4), no series
+// Without selects: with r = x log2(e), log2(1 + 2^r) >= r and equals r in fp32 from r = 25 on, so max(log2(1 + 2^min(r, 64)), r)
+// IS the thresholded softplus to the last bit that matters (log1p(e^x) - x < 2.1e-9 for x > 20) and never overflows.
+__device__ __forceinline__ float l3_softplus(const float x) {
+    const float r = x * kLog2e;
+    const float t = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(r, 64.f)));
+    return fmaxf(t, r) * 0.6931471805599453f;
+}
+// ... and d softplus / d x = 1 - 1 / (1 + 2^r)  (1 for large r: rcp of 2^64 is 5e-20)
+__device__ __forceinline__ float l3_softplus_sig(const float x, float &sig) {
+    const float r = x * kLog2e;
+    const float zp1 = 1.0f + __builtin_amdgcn_exp2f(fminf(r, 64.f));
+    sig = 1.0f - __builtin_amdgcn_rcpf(zp1);
+    return fmaxf(__builtin_amdgcn_logf(zp1), r) * 0.6931471805599453f;
+}
+// the RP2 weight pairs of channel row `row` (wave-uniform: scalar loads, scalar registers)
+template <int RP2> __device__ __forceinline__ void l3_weight_pairs(const void *dtw, const int row, uint32_t (&wp)[RP2 ? RP2 : 1]) {
+    if constexpr (RP2 > 0) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(dtw) + (int64_t)__builtin_amdgcn_readfirstlane(row) * RP2;
+#pragma unroll
+        for (int j = 0; j < RP2; ++j) wp[j] = __builtin_amdgcn_readfirstlane(src[j]);
+    } else {
+        wp[0] = 0;
+    }
+}
 struct L3Lds { uint4 x, g; };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -258,13 +337,14 @@ __device__ __forceinline__ void l3_merge_store(bf16_t *out, const bf16_t *P0, co
 // ---------------------------------------------------------------------------------------------------------------------
 // forward, one route over one plane
 // ---------------------------------------------------------------------------------------------------------------------
-template <int HW, bool REV, int MODE>
+template <int HW, bool REV, int MODE, int RP2>
 __device__ __forceinline__ void l3_fwd_plane(const bf16_t *__restrict__ dts_row, const bf16_t *__restrict__ Brow,
                                              const bf16_t *__restrict__ Crow, float *__restrict__ chk_row,
                                              const bool more_planes, const float A2, const float Dr, const float bias,
-                                             const bf16_t *xq, bf16_t *yq, const int lane, L3Ops &op) {
+                                             const uint32_t (&wp)[RP2 ? RP2 : 1], const bf16_t *xq, bf16_t *yq, const int lane,
+                                             L3Ops<(MODE == 3 ? 2 * RP2 : 1)> &op) {
     using G = L3Geom<HW>;
-    constexpr int L = G::L, NSEG = G::NSEG;
+    constexpr int L = G::L, NSEG = G::NSEG, NX = MODE == 3 ? 2 * RP2 : 1;
     const int ci = REV ? 63 - lane : lane;
     const bool tail_live = !G::HAS_TAIL || ci < G::TAILV;
     float hc = 0.f;                                   // state entering the chunk row
@@ -279,36 +359,41 @@ __device__ __forceinline__ void l3_fwd_plane(const bf16_t *__restrict__ dts_row,
         const int sp = REV ? NSEG - 1 - i : i;
         const int tp0 = sp * G::ROW + ci * 8;
         const bool is_tail = G::HAS_TAIL && sp == NSEG - 1;
-        const uint4 dv = op.d, bv = op.b, cv = op.c, xv = xn;
+        l3f2 v[4];
+        if constexpr (MODE == 3) l3_delta_raw<RP2, REV>(op.d, wp, bias, v);       // (dt_proj: consumed before the registers are re-requested)
+        else l3_unpack<REV>(op.d[0], v);
+        const uint4 bv = op.b, cv = op.c, xv = xn;
         {   // request the next row (this plane's row i + 1, or the first row of the next plane)
             const int in_ = i + 1 < NSEG ? i + 1 : 0;
             const int spn = REV ? NSEG - 1 - in_ : in_;
             const int tpn = spn * G::ROW + ci * 8;
-            const bf16_t *drow = i + 1 < NSEG ? dts_row : dts_row + L;
+            const bf16_t *drow = (i + 1 < NSEG || MODE == 3) ? dts_row : dts_row + L;   // (mode 3: the route's rows serve every plane)
             const bool dead = G::HAS_TAIL && spn == NSEG - 1 && !tail_live;
             if (i + 1 < NSEG || more_planes) {
-                if (!dead) {
-                    op.d = *reinterpret_cast<const uint4 *>(drow + tpn);
-                    op.b = *reinterpret_cast<const uint4 *>(Brow + tpn);
-                    op.c = *reinterpret_cast<const uint4 *>(Crow + tpn);
-                } else {
-                    op.d = op.b = op.c = make_uint4(0, 0, 0, 0);
-                }
+                if (!dead) l3_ops_load<NX>(op, drow, Brow, Crow, tpn);
+                else l3_ops_zero<NX>(op);
             }
             if (i + 1 < NSEG) xn = dead ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(xq + tpn);
         }
-        l3f2 v[4], u[4], Bq[4], Cq[4];
-        l3_unpack<REV>(dv, v);
+        l3f2 u[4], Bq[4], Cq[4];
         l3_unpack<REV>(xv, u);
         l3_unpack<REV>(bv, Bq);
         l3_unpack<REV>(cv, Cq);
         if constexpr (MODE != 2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float v0 = v[q].x + bias, v1 = v[q].y + bias;
+                float v0 = v[q].x, v1 = v[q].y;
+                if constexpr (MODE != 3) {
+                    v0 += bias;
+                    v1 += bias;
+                }
                 if constexpr (MODE == 1) {
                     v0 = softplus20(v0);
                     v1 = softplus20(v1);
+                }
+                if constexpr (MODE == 3) {
+                    v0 = l3_softplus(v0);
+                    v1 = l3_softplus(v1);
                 }
                 v[q] = l3f2{v0, v1};
             }
@@ -394,10 +479,10 @@ __device__ __forceinline__ void l3_block_map(const LeanArgs &a, const int groups
     }
 }
 
-template <int HW, int PPT, int MODE, bool REV>
+template <int HW, int PPT, int MODE, int RP2, bool REV>
 __device__ __forceinline__ void l3_fwd_body(const LeanArgs &a, float *smem, const int wave, const int lane) {
     using G = L3Geom<HW>;
-    constexpr int L = G::L, PL = PPT * L, NSEG = G::NSEG;
+    constexpr int L = G::L, PL = PPT * L, NSEG = G::NSEG, NX = MODE == 3 ? 2 * RP2 : 1;
     const int D = a.D_;
     const int tiles_pb = D / PPT;
     const int groups_pb = tiles_pb / a.pli;
@@ -414,18 +499,15 @@ __device__ __forceinline__ void l3_fwd_body(const LeanArgs &a, float *smem, cons
     const bf16_t *Brow = (const bf16_t *)a.Bs + route * L, *Crow = (const bf16_t *)a.Cs + route * L;
     const int n_planes = a.pli * PPT;
     const int ci = REV ? 63 - lane : lane;
-    L3Ops op;
+    // mode 3: the route's dt_proj input rows (L, Rp) serve every plane; otherwise the step sizes of the first plane
+    const bf16_t *drow0 = MODE == 3 ? (const bf16_t *)a.xrt + route * (NSEG * 512 * (2 * RP2))
+                                    : (const bf16_t *)a.dts + (route * D + (int64_t)tg * a.pli * PPT) * L;
+    L3Ops<NX> op;
     {   // operands of the first chunk row of the first plane
-        const int64_t r0 = route * D + (int64_t)tg * a.pli * PPT;
         const int sp = REV ? NSEG - 1 : 0;
         const int tp = sp * G::ROW + ci * 8;
-        if (!(G::HAS_TAIL && sp == NSEG - 1) || ci < G::TAILV) {
-            op.d = *reinterpret_cast<const uint4 *>((const bf16_t *)a.dts + r0 * L + tp);
-            op.b = *reinterpret_cast<const uint4 *>(Brow + tp);
-            op.c = *reinterpret_cast<const uint4 *>(Crow + tp);
-        } else {
-            op.d = op.b = op.c = make_uint4(0, 0, 0, 0);
-        }
+        if (!(G::HAS_TAIL && sp == NSEG - 1) || ci < G::TAILV) l3_ops_load<NX>(op, drow0, Brow, Crow, tp);
+        else l3_ops_zero<NX>(op);
         op.h = 0.f;
     }
     constexpr int NVX = 2;
@@ -461,8 +543,11 @@ __device__ __forceinline__ void l3_fwd_body(const LeanArgs &a, float *smem, cons
             const int d = d0 + pl, row = k * D + d;
             const float A2 = a.A[row] * kLog2e, Dr = a.D[row], bias = MODE == 2 ? 0.f : a.bias[row];
             const bool more = it * PPT + pl + 1 < n_planes;
-            l3_fwd_plane<HW, REV, MODE>((const bf16_t *)a.dts + (route * D + d) * L, Brow, Crow,
-                                        a.chk + (route * D + d) * NSEG, more, A2, Dr, bias, xq + pl * L, yq + pl * L, lane, op);
+            uint32_t wp[RP2 ? RP2 : 1];
+            l3_weight_pairs<RP2>(a.dtw, row, wp);
+            l3_fwd_plane<HW, REV, MODE, RP2>(MODE == 3 ? drow0 : (const bf16_t *)a.dts + (route * D + d) * L, Brow, Crow,
+                                             a.chk + (route * D + d) * NSEG, more, A2, Dr, bias, wp, xq + pl * L, yq + pl * L,
+                                             lane, op);
         }
         __syncthreads();
         int tz2;
@@ -480,27 +565,30 @@ __device__ __forceinline__ void l3_fwd_body(const LeanArgs &a, float *smem, cons
     }
 }
 
-template <int HW, int PPT, int MODE>
-__global__ void __launch_bounds__(256, L3_WPE_FWD) ss2d_l3_fwd_kernel(const LeanArgs a) {
+// (forward: four waves per SIMD at 128 registers; with 12 operand vectors per chunk row in flight -- dt_rank 12 -- three at 168)
+template <int HW, int PPT, int MODE, int RP2 = 0>
+__global__ void __launch_bounds__(256, (RP2 > 4 ? 3 : L3_WPE_FWD)) ss2d_l3_fwd_kernel(const LeanArgs a) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave & 1) l3_fwd_body<HW, PPT, MODE, true>(a, smem, wave, lane);
-    else l3_fwd_body<HW, PPT, MODE, false>(a, smem, wave, lane);
+    if (wave & 1) l3_fwd_body<HW, PPT, MODE, RP2, true>(a, smem, wave, lane);
+    else l3_fwd_body<HW, PPT, MODE, RP2, false>(a, smem, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward, one route over one plane
 // ---------------------------------------------------------------------------------------------------------------------
-template <int HW, bool REV, int MODE>
+template <int HW, bool REV, int MODE, int RP2>
 __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row, bf16_t *__restrict__ ddts_row,
                                              const bf16_t *__restrict__ Brow, const bf16_t *__restrict__ Crow,
                                              const float *__restrict__ chk_row, const bool more_planes, const float An,
-                                             const float Dr, const float bias, const bf16_t *xq, const bf16_t *gq,
-                                             bf16_t *dxq, float *ldsacc, l3f2 (&rB)[L3Geom<HW>::NACC][4],
-                                             l3f2 (&rC)[L3Geom<HW>::NACC][4], float &dA_acc, float &dD_acc,
-                                             float &dbias_acc, const int lane, L3Ops &op, const int dbg) {
-    using G = L3Geom<HW>;
-    constexpr int L = G::L, NSEG = G::NSEG;
+                                             const float Dr, const float bias, const uint32_t (&wp)[RP2 ? RP2 : 1],
+                                             const bf16_t *xq, const bf16_t *gq,
+                                             bf16_t *dxq, float *ldsacc, l3f2 (&rB)[L3Geom<HW, RP2>::NACC][4],
+                                             l3f2 (&rC)[L3Geom<HW, RP2>::NACC][4], float &dA_acc, float &dD_acc,
+                                             float &dbias_acc, const int lane, L3Ops<(MODE == 3 ? 2 * RP2 : 1)> &op,
+                                             const int dbg) {
+    using G = L3Geom<HW, RP2>;
+    constexpr int L = G::L, NSEG = G::NSEG, NX = MODE == 3 ? 2 * RP2 : 1;
     const float A2 = An * kLog2e;
     const int ci = REV ? 63 - lane : lane;
     const bool tail_live = !G::HAS_TAIL || ci < G::TAILV;
@@ -508,8 +596,10 @@ __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row,
     l3f2 dA2 = {0.f, 0.f}, dD2 = dA2, db2 = dA2;
     // x / dy of the chunk row to process, read from LDS one row ahead (a wave has one partner on its SIMD: an exposed LDS
     // round trip at the head of every row is not covered by anything)
+    // (mode 3 reads them at the head of their own row instead: the dt_proj dot products run under the round trip, and the 8
+    //  registers of the look-ahead are what the 56 x 56 kernel needs for the dt_proj operand vectors)
     L3Lds ln;
-    {
+    if constexpr (MODE != 3) {
         const int sp0 = REV ? 0 : NSEG - 1;
         if (G::HAS_TAIL && sp0 == NSEG - 1 && !tail_live) {
             ln.x = ln.g = make_uint4(0, 0, 0, 0);
@@ -523,29 +613,35 @@ __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row,
         const int sp = REV ? NSEG - 1 - i : i;        // physical chunk row
         const int tp0 = sp * G::ROW + ci * 8;
         const bool is_tail = G::HAS_TAIL && sp == NSEG - 1;
-        const uint4 dv = op.d, bv = op.b, cv = op.c;
+        if constexpr (MODE == 3) {
+            if (is_tail && !tail_live) {
+                ln.x = ln.g = make_uint4(0, 0, 0, 0);
+            } else {
+                ln.x = *reinterpret_cast<const uint4 *>(xq + tp0);
+                ln.g = *reinterpret_cast<const uint4 *>(gq + tp0);
+            }
+        }
+        l3f2 v[4];
+        if constexpr (MODE == 3) l3_delta_raw<RP2, REV>(op.d, wp, bias, v);       // (dt_proj: consumed before the registers are re-requested)
+        else l3_unpack<REV>(op.d[0], v);
+        const uint4 bv = op.b, cv = op.c;
         const float hin = op.h;
         // ---- request the next row to process (this plane's row i - 1, or the last row of the next plane)
         {
             const int in_ = i > 0 ? i - 1 : NSEG - 1;
             const int spn = REV ? NSEG - 1 - in_ : in_;
             const int tpn = spn * G::ROW + ci * 8;
-            const bf16_t *drow = i > 0 ? dts_row : dts_row + L;
+            const bf16_t *drow = (i > 0 || MODE == 3) ? dts_row : dts_row + L;     // (mode 3: the route's rows serve every plane)
             const float *crow = i > 0 ? chk_row : chk_row + NSEG;
             if ((i > 0 || more_planes) && !(dbg & 16)) {
                 const bool ok = !(G::HAS_TAIL && spn == NSEG - 1) || tail_live;
-                if (ok) {
-                    op.d = *reinterpret_cast<const uint4 *>(drow + tpn);
-                    op.b = *reinterpret_cast<const uint4 *>(Brow + tpn);
-                    op.c = *reinterpret_cast<const uint4 *>(Crow + tpn);
-                } else {
-                    op.d = op.b = op.c = make_uint4(0, 0, 0, 0);
-                }
+                if (ok) l3_ops_load<NX>(op, drow, Brow, Crow, tpn);
+                else l3_ops_zero<NX>(op);
                 op.h = in_ > 0 ? crow[in_ - 1] : 0.f;
             }
         }
         const uint4 xv = ln.x, gv = ln.g;
-        if (i > 0) {
+        if (MODE != 3 && i > 0) {
             const int spn = REV ? NSEG - i : i - 1;
             if (G::HAS_TAIL && spn == NSEG - 1 && !tail_live) {
                 ln.x = ln.g = make_uint4(0, 0, 0, 0);
@@ -554,8 +650,7 @@ __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row,
                 ln.g = *reinterpret_cast<const uint4 *>(gq + spn * G::ROW + ci * 8);
             }
         }
-        l3f2 v[4], u[4], g[4], Bq[4], Cq[4], sg[4];
-        l3_unpack<REV>(dv, v);
+        l3f2 u[4], g[4], Bq[4], Cq[4], sg[4];
         l3_unpack<REV>(xv, u);
         l3_unpack<REV>(gv, g);
         l3_unpack<REV>(bv, Bq);
@@ -567,10 +662,18 @@ __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row,
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float s0 = 1.f, s1 = 1.f;
-                float v0 = v[q].x + bias, v1 = v[q].y + bias;
+                float v0 = v[q].x, v1 = v[q].y;
+                if constexpr (MODE != 3) {
+                    v0 += bias;
+                    v1 += bias;
+                }
                 if constexpr (MODE == 1) {
                     v0 = softplus20_sig(v0, s0);
                     v1 = softplus20_sig(v1, s1);
+                }
+                if constexpr (MODE == 3) {
+                    v0 = l3_softplus_sig(v0, s0);
+                    v1 = l3_softplus_sig(v1, s1);
                 }
                 v[q] = l3f2{v0, v1};
                 sg[q] = l3f2{s0, s1};
@@ -699,10 +802,10 @@ __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row,
 
 // the whole walk of a workgroup for one direction (a template parameter from the top: the ascending and the descending
 // waves share no code path below this point, so the accumulators never meet at a join)
-template <int HW, int PPT, int MODE, bool REV>
+template <int HW, int PPT, int MODE, int RP2, bool REV>
 __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, const int wave, const int lane) {
-    using G = L3Geom<HW>;
-    constexpr int L = G::L, PL = PPT * L, NSEG = G::NSEG;
+    using G = L3Geom<HW, RP2>;
+    constexpr int L = G::L, PL = PPT * L, NSEG = G::NSEG, NX = MODE == 3 ? 2 * RP2 : 1;
     const int D = a.D_;
     const int tiles_pb = D / PPT;
     const int groups_pb = tiles_pb / a.pli;
@@ -725,18 +828,15 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
     const int n_planes = a.pli * PPT;
     const int ci = REV ? 63 - lane : lane;
     // operands of the first chunk row to process (the last one, in route order, of the first plane)
-    L3Ops op;
+    const bf16_t *drow0 = MODE == 3 ? (const bf16_t *)a.xrt + route * (NSEG * 512 * (2 * RP2))
+                                    : (const bf16_t *)a.dts + (route * D + (int64_t)tg * a.pli * PPT) * L;
+    L3Ops<NX> op;
     {
         const int64_t r0 = route * D + (int64_t)tg * a.pli * PPT;
         const int sp = REV ? 0 : NSEG - 1;
         const int tp = sp * G::ROW + ci * 8;
-        if (!(G::HAS_TAIL && sp == NSEG - 1) || ci < G::TAILV) {
-            op.d = *reinterpret_cast<const uint4 *>((const bf16_t *)a.dts + r0 * L + tp);
-            op.b = *reinterpret_cast<const uint4 *>(Brow + tp);
-            op.c = *reinterpret_cast<const uint4 *>(Crow + tp);
-        } else {
-            op.d = op.b = op.c = make_uint4(0, 0, 0, 0);
-        }
+        if (!(G::HAS_TAIL && sp == NSEG - 1) || ci < G::TAILV) l3_ops_load<NX>(op, drow0, Brow, Crow, tp);
+        else l3_ops_zero<NX>(op);
         op.h = NSEG > 1 ? a.chk[r0 * NSEG + NSEG - 2] : 0.f;
     }
     constexpr int NVX = 2, NVG = 4;                    // PL <= 4096 elements: 512 / 1024 vectors over 256 threads
@@ -796,9 +896,11 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
             const float An = a.A[row], Dr = a.D[row], bias = MODE == 2 ? 0.f : a.bias[row];
             const bool more = it * PPT + pl + 1 < n_planes;
             float dA_acc, dD_acc, dbias_acc;
-            l3_bwd_plane<HW, REV, MODE>((const bf16_t *)a.dts + ro, (bf16_t *)a.ddts + ro, Brow, Crow, chk_row, more, An, Dr,
-                                        bias, xq + pl * L, gq + pl * L, dxq + pl * L, ldsacc, rB, rC, dA_acc, dD_acc,
-                                        dbias_acc, lane, op, a.dbg);
+            uint32_t wp[RP2 ? RP2 : 1];
+            l3_weight_pairs<RP2>(a.dtw, row, wp);
+            l3_bwd_plane<HW, REV, MODE, RP2>(MODE == 3 ? drow0 : (const bf16_t *)a.dts + ro, (bf16_t *)a.ddts + ro, Brow, Crow,
+                                             chk_row, more, An, Dr, bias, wp, xq + pl * L, gq + pl * L, dxq + pl * L, ldsacc, rB,
+                                             rC, dA_acc, dD_acc, dbias_acc, lane, op, a.dbg);
             for (int o = 32; o > 0; o >>= 1) {
                 dA_acc += __shfl_xor(dA_acc, o, 64);
                 dD_acc += __shfl_xor(dD_acc, o, 64);
@@ -879,22 +981,22 @@ __global__ void __launch_bounds__(256) ss2d_l3_parts_kernel(const float *__restr
 
 // kernel: wave w owns route {0,2,1,3}[w];
 // LDS: xN | xT | gN | gT (bf16, PPT planes) | 4 private dx planes (bf16) | 4 x [dB | dC] strips (LSZ fp32 each)
-template <int HW, int PPT, int MODE>
+template <int HW, int PPT, int MODE, int RP2 = 0>
 __global__ void __launch_bounds__(256, L3_WPE) ss2d_l3_bwd_kernel(const LeanArgs a) {
     static_assert(L3Geom<HW>::L % 8 == 0 && L3Geom<HW>::NSEG <= 8, "map size not covered");
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave & 1) l3_bwd_body<HW, PPT, MODE, true>(a, smem, wave, lane);
-    else l3_bwd_body<HW, PPT, MODE, false>(a, smem, wave, lane);
+    if (wave & 1) l3_bwd_body<HW, PPT, MODE, RP2, true>(a, smem, wave, lane);
+    else l3_bwd_body<HW, PPT, MODE, RP2, false>(a, smem, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-static int l3_pli(int batch, int tiles_pb, bool bwd) {
+static int l3_pli(int batch, int tiles_pb, bool bwd, int fwd_wpe = L3_WPE_FWD) {
     // tiles per workgroup: ONE round of the resident workgroups (2 per CU backward, 4 forward).  The dB / dC flush of a
     // workgroup is 8 L floats; as float atomics (~1.3 TB/s chip-wide) 1024 workgroups spend 79 us of a 56 x 56 launch there.
-    const int resident = bwd ? 512 : 256 * L3_WPE_FWD;
+    const int resident = bwd ? 512 : 256 * fwd_wpe;
     int pli = (int)(((int64_t)batch * tiles_pb + resident - 1) / resident);
     if (pli < 1) pli = 1;
     if (pli > tiles_pb) pli = tiles_pb;
@@ -902,6 +1004,18 @@ static int l3_pli(int batch, int tiles_pb, bool bwd) {
     if (env_pli > 0) pli = std::max(1, std::min(tiles_pb, env_pli));
     while (tiles_pb % pli) --pli;
     return pli;
+}
+
+// the dt_rank pairs (Rp / 2) the mode-3 kernels are built for, per map size (0: none)
+static int l3_rp2(const int H, const int rank_p) {
+    if (rank_p <= 0 || (rank_p & 1)) return 0;
+    const int rp2 = rank_p / 2;
+    if ((H == 56 && rp2 == 3) || (H == 28 && rp2 == 6)) return rp2;       // XFMamba-T / -S stages 0 / 1: dt_rank 6 / 12
+    return 0;
+}
+
+template <int HW, int PPT, int RP2> static const void *l3_fn3(const bool bwd) {
+    return bwd ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 3, RP2> : (const void *)ss2d_l3_fwd_kernel<HW, PPT, 3, RP2>;
 }
 
 template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool bwd, hipStream_t s, float *ws, size_t ws_bytes) {
@@ -923,16 +1037,27 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
     static const int env_dbg = [] { const char *e = getenv("XFM_L3_DBG"); return e ? atoi(e) : 0; }();
     la.dbg = env_dbg;                                  // 16 no operand prefetch, 32 no ddts / dx stores
     const int tiles_pb = D / PPT;
-    const int pli = l3_pli(p.batch, tiles_pb, bwd);
+    const int rp2 = p.delta_softplus == 3 ? l3_rp2(HW, p.dt_rank_p) : 0;
+    const int pli = l3_pli(p.batch, tiles_pb, bwd, rp2 > 4 ? 3 : L3_WPE_FWD);
     la.pli = pli;
     static const bool env_no_xmap = getenv("XFM_L3_NO_XMAP") != nullptr;
     la.xmap = (p.batch % 8 == 0 && !env_no_xmap) ? 1 : 0;
     const int groups = tiles_pb / pli;
     const size_t need = (size_t)p.batch * groups * 4 * 2 * L * sizeof(float);
     la.parts = (bwd && ws && ws_bytes >= need && groups > 1 && L % 4 == 0) ? ws : nullptr;
-    const size_t lds = bwd ? (size_t)8 * PL * 2 + (size_t)4 * 2 * G::LSZ * sizeof(float) : (size_t)6 * PL * 2;
+    size_t lds = bwd ? (size_t)8 * PL * 2 + (size_t)4 * 2 * G::LSZ * sizeof(float) : (size_t)6 * PL * 2;
     const void *fn;
-    if (bwd)
+    if (p.delta_softplus == 3) {
+        la.xrt = p.xrt; la.dtw = p.dt_w;
+        constexpr int RP2 = HW == 56 ? 3 : (HW == 28 ? 6 : 0);           // the (map, dt_rank) pairs built: l3_rp2
+        if constexpr (RP2 > 0) {
+            if (rp2 != RP2) return XFM_ELIMIT;
+            fn = l3_fn3<HW, PPT, RP2>(bwd);
+            if (bwd) lds = (size_t)8 * PL * 2 + (size_t)4 * 2 * L3Geom<HW, RP2>::LSZ * sizeof(float);
+        } else {
+            return XFM_ELIMIT;
+        }
+    } else if (bwd)
         fn = p.delta_softplus == 2 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 2>
                                    : (p.delta_softplus == 1 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 1>
                                                             : (const void *)ss2d_l3_bwd_kernel<HW, PPT, 0>);
@@ -970,7 +1095,8 @@ int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, 
     }();
     if (!bwd && !fwd_enabled) return XFM_ELIMIT;
     if (p->in_dtype != XFM_BF16 || p->out_dtype != XFM_F32 || p->dstate != 1 || p->H != p->W) return XFM_ELIMIT;
-    if (p->delta_softplus < 0 || p->delta_softplus > 2) return XFM_ELIMIT;
+    if (p->delta_softplus < 0 || p->delta_softplus > 3) return XFM_ELIMIT;
+    if (p->delta_softplus == 3 && !l3_rp2(p->H, p->dt_rank_p)) return XFM_ELIMIT;
     const int ppt = l3_ppt(p->H);
     if (!ppt || p->d_inner % ppt) return XFM_ELIMIT;
     if (!p->chk) return XFM_ELIMIT;            // no checkpoint buffer: the generic path decides (EINVAL if it needs one too)
@@ -995,6 +1121,44 @@ int ss2d_l3_nseg(int batch, int D, int H, int W, int N, int in_dtype) {
     return (H * W + 511) / 512;
 }
 
+// padded dt_rank for dt_proj inside the kernels of this file (0: no such kernel)
+int ss2d_l3_dtfused_rank(int batch, int D, int H, int W, int N, int R, int in_dtype) {
+    static const bool off = [] { const char *e = getenv("XFM_L3_DTFUSED"); return e && e[0] == '0'; }();   // A/B switch, read once
+    if (off || !ss2d_l3_nseg(batch, D, H, W, N, in_dtype) || R <= 0) return 0;
+    const int rp = (R + 1) & ~1;
+    return l3_rp2(H, rp) ? rp : 0;
+}
+
+// xr (B4, R, L) -> xrt (B4, nrow, Rp, 64, 8), nrow = ceil(L / 512): the blocked rows the mode-3 kernels read (l3_ops_load).
+// A thread owns one chunk (8 positions): R 16-byte reads (contiguous across the wave), Rp 16-byte writes (contiguous
+// across the wave per piece); positions past L and ranks past R are zero.
+template <int RP> __global__ void __launch_bounds__(64) l3_xr_rows_kernel(const uint16_t *__restrict__ xr, uint16_t *__restrict__ xrt,
+                                                                          const int R, const int L) {
+    const int64_t bk = blockIdx.y;
+    const int sp = blockIdx.x, c = threadIdx.x, nrow = gridDim.x;
+    const int t0 = sp * 512 + c * 8;
+    uint16_t v[8 * RP];
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (r < R && t0 < L) q = *reinterpret_cast<const uint4 *>(xr + (bk * R + r) * L + t0);      // (L % 8 == 0: whole chunks)
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[(2 * i) * RP + r] = (uint16_t)(w[i] & 0xffffu);
+            v[(2 * i + 1) * RP + r] = (uint16_t)(w[i] >> 16);
+        }
+    }
+    uint16_t *dst = xrt + ((bk * nrow + sp) * RP * 64 + c) * 8;
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)v[8 * j + 2 * i] | ((uint32_t)v[8 * j + 2 * i + 1] << 16);
+        *reinterpret_cast<uint4 *>(dst + j * 512) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // bytes of the partial-sum workspace the backward can use (0: shape not covered here)
 size_t ss2d_l3_ws_bytes(const xfm_ss2d_params_t *p) {
     if (p->in_dtype != XFM_BF16 || p->dstate != 1 || p->H != p->W) return 0;
@@ -1006,3 +1170,17 @@ size_t ss2d_l3_ws_bytes(const xfm_ss2d_params_t *p) {
 }
 
 }  // namespace xfm
+
+extern "C" {
+int xfm_ss2d_xr_rows(const void *xr, void *xrt, long long B4, int R, int Rp, int L, int dtype, void *stream) {
+    using namespace xfm;
+    if (!xr || !xrt || B4 <= 0 || B4 > 65535 || R <= 0 || Rp < R || L <= 0) return XFM_EINVAL;
+    if (dtype != XFM_BF16 && dtype != XFM_F16) return XFM_EDTYPE;                 // (16-bit values are moved, not converted)
+    if (L % 8 != 0 || (Rp != 6 && Rp != 12)) return XFM_ELIMIT;                   // the ranks l3_rp2 builds kernels for
+    const dim3 grid((unsigned)((L + 511) / 512), (unsigned)B4);
+    hipStream_t s = (hipStream_t)stream;
+    if (Rp == 6) hipLaunchKernelGGL(l3_xr_rows_kernel<6>, grid, dim3(64), 0, s, (const uint16_t *)xr, (uint16_t *)xrt, R, L);
+    else hipLaunchKernelGGL(l3_xr_rows_kernel<12>, grid, dim3(64), 0, s, (const uint16_t *)xr, (uint16_t *)xrt, R, L);
+    return check_launch();
+}
+}

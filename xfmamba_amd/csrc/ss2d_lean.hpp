@@ -35,6 +35,8 @@ struct LeanArgs {
     uint32_t magicH;   // ceil(2^32 / H)
     float *parts;      // ss2d_l3.hip: (batch, groups, 4, 2, L) fp32 partial dB / dC sums of the workgroups (null: atomics)
     int xmap;          // ss2d_l3.hip: 1 = XCD-local sample placement (batch % 8 == 0), see l3_block_map
+    const void *xrt;   // ss2d_l3.hip, softplus mode 3: dt_proj input rows (batch, 4, L, Rp) bf16, position-major, route order
+    const void *dtw;   //                               dt_proj weight (4, D, Rp) bf16
 };
 
 // ---- DPP helpers -------------------------------------------------------------------------------

@@ -11,6 +11,7 @@ the (B,4,D,L) fp32 scan outputs of the reference ever reach HBM.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -18,6 +19,17 @@ from . import _lib
 from . import fp8 as _fp8
 from .amp import cast_weight
 from .proj import mfma_planes, zeros_f32
+
+# dt_proj inside the wide-map scan kernels (delta_softplus 3, csrc/ss2d_l3.hip): built, parity-tested against the oracle
+# (tests/test_hip_ops.py::test_ss2d_with_dt_proj_inside_matches_oracle) and MEASURED SLOWER than the materialised step sizes
+# (mode 2) on MI355X -- batch 64, rocprofv3-free event timing, us per launch, mode 2 incl. its dt_proj_fwd launch:
+#   56 x 56 (D 96, R 6):   forward 128 + 11 (xr_rows) vs 87 + 55;  backward 260 vs 202
+#   28 x 28 (D 192, R 12): forward 111 + 14           vs 54 + 39;  backward 188 vs 132
+# i.e. +0.28 ms on the 14.2 ms step.  Why: the dt_proj input rows are the same for all D channels of a route, so every channel
+# plane re-reads them through the CU's vector-memory path (R + 2 KB per 512-position chunk row instead of 3 KB: 925 MB per
+# 56 x 56 forward launch against 270 MB), and the softplus / sigmoid transcendentals are evaluated in the forward AND again in
+# the backward sweep of kernels that are issue-bound already.  Opt in with XFM_SS2D_DT_FUSED=1.
+_DT_FUSED = os.environ.get("XFM_SS2D_DT_FUSED", "0") == "1"
 
 __all__ = ["ss2d_core_fn", "ss2d_proj_core_fn", "ss2d_xproj_core_fn", "SS2DCoreHip", "SS2DProjCoreHip", "to_route_order"]
 
@@ -36,12 +48,14 @@ def _plan(Bt, Dm, H, W, N, dtype):
     return plan
 
 
-def _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, out_dtype, chk, softplus_mode=1):
+def _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, out_dtype, chk, softplus_mode=1, xrt=None, dt_w=None):
     Bt, Dm, L = x.shape
     p.batch, p.d_inner, p.H, p.W, p.dstate = Bt, Dm, H, W, A.shape[1]
     p.delta_softplus = softplus_mode
     p.in_dtype, p.out_dtype = _lib.dtype_code(x.dtype), _lib.dtype_code(out_dtype)
-    p.x, p.dts, p.Bs, p.Cs = x.data_ptr(), dts.data_ptr(), Bs.data_ptr(), Cs.data_ptr()
+    p.x, p.dts, p.Bs, p.Cs = x.data_ptr(), _lib.ptr(dts), Bs.data_ptr(), Cs.data_ptr()
+    if softplus_mode == 3:                      # dt_proj inside the scan kernel: its input rows and weight instead of dts
+        p.xrt, p.dt_w, p.dt_rank_p = xrt.data_ptr(), dt_w.data_ptr(), xrt.shape[3]
     p.A, p.D, p.delta_bias = A.data_ptr(), D.data_ptr(), bias.data_ptr()
     p.chk = _lib.ptr(chk)
 
@@ -155,7 +169,19 @@ class SS2DProjCoreHip(torch.autograd.Function):
         w = cast_weight(dt_w, x.dtype)
         lib = _lib.lib()
         mode = 1
-        if x.dtype in (torch.float32, torch.bfloat16) and lib.xfm_ss2d_dt_proj_supported(Dm, R, L):
+        xrt = wp = None
+        Rp = lib.xfm_ss2d_dtfused_rank(Bt, Dm, H, W, N, R, _lib.dtype_code(x.dtype)) if _DT_FUSED else 0
+        if Rp > 0:
+            # SURVEY 8(f) rank 1 on the wide maps: dt_proj INSIDE the scan kernels (models/fusion_vmamba.py:1147-1150): they read
+            # the position-major copy of the (small) dt_proj input rows; the (B, 4, D, L) step sizes never reach HBM
+            mode = 3
+            dts = None
+            xrt = torch.empty((Bt, 4, (L + 511) // 512, Rp, 64, 8), dtype=x.dtype, device=x.device)     # blocked: include/xfm_hip.h
+            with torch.cuda.device(x.device), _lib.timed("xr_rows", 2 * xr.numel() * xr.element_size()):
+                _lib.check(lib.xfm_ss2d_xr_rows(xr.data_ptr(), xrt.data_ptr(), Bt * 4, R, Rp, L, _lib.dtype_code(x.dtype),
+                                                _lib.stream_ptr()), "xr_rows")
+            wp = w.contiguous() if Rp == R else torch.nn.functional.pad(w, (0, Rp - R)).contiguous()
+        elif x.dtype in (torch.float32, torch.bfloat16) and lib.xfm_ss2d_dt_proj_supported(Dm, R, L):
             # dt_proj kernel with the bias + softplus epilogue: the scan kernels then read the activated step size
             # (mode 2) instead of re-evaluating softplus per route element in the forward AND the backward pass
             mode = 2
@@ -177,26 +203,27 @@ class SS2DProjCoreHip(torch.autograd.Function):
                if plan.n_chunks > 1 else None)
         y = torch.empty((Bt, Dm, L), dtype=torch.float32, device=x.device)
         p = _lib.SS2DParams()
-        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, mode)
+        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, mode, xrt, wp)
         p.y = y.data_ptr()
         isz = x.element_size()
-        nbytes = Bt * Dm * L * (5 * isz + 4) + 2 * Bt * 4 * N * L * isz
         # SURVEY 8(d), "dt_proj also fused" boundary: x, y and the x_proj rows (2 B D L + 4 B (R + 2N) L elements)
         nbytes_f = Bt * Dm * L * (isz + 4) + Bt * 4 * (R + 2 * N) * L * isz
+        # the kernel's own boundary: with dts (modes 0-2) 6 B D L + 8 B N L elements; mode 3 IS the fused boundary
+        nbytes = nbytes_f if mode == 3 else Bt * Dm * L * (5 * isz + 4) + 2 * Bt * 4 * N * L * isz
         with torch.cuda.device(x.device), _lib.timed("ss2d_fwd", nbytes, nbytes_f):
             _lib.check(_lib.lib().xfm_ss2d_fwd(ctypes.byref(p), _lib.stream_ptr()), "ss2d_fwd")
         ctx.hw = (H, W)
         ctx.mode = mode
         ctx.wdtype = dt_w.dtype
         ctx.xw_meta = None if x_proj_w is None else (x_proj_w.dtype, tuple(x_proj_w.shape))
-        ctx.save_for_backward(x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw)
+        ctx.save_for_backward(x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw, xrt, wp)
         return y
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         from .proj import _bmm_f32, wgrad_mfma
-        x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw = ctx.saved_tensors
+        x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw, xrt, wp = ctx.saved_tensors
         H, W = ctx.hw
         dev = x.device
         Bt, Dm, L = x.shape
@@ -204,7 +231,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
         N = A.shape[1]
         dy = dy.contiguous().float()
         dx = torch.empty_like(x)
-        ddts = torch.empty_like(dts)
+        ddts = torch.empty((Bt, 4, Dm, L), dtype=x.dtype, device=dev)
         nbc, na, nd = Bt * 4 * N * L, A.numel(), D.numel()
         lib = _lib.lib()
         mfma_bwd = (x.dtype == torch.bfloat16 and L % 4 == 0 and Dm <= 1024 and lib.xfm_ss2d_dt_proj_mfma_rp(Dm, R, L) > 0)
@@ -214,13 +241,14 @@ class SS2DProjCoreHip(torch.autograd.Function):
         dA = acc[2 * nbc:2 * nbc + na].view(A.shape)
         dD, dbias = acc[2 * nbc + na:2 * nbc + na + nd], acc[2 * nbc + na + nd:2 * nbc + na + 2 * nd]
         p = _lib.SS2DParams()
-        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, ctx.mode)
+        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, ctx.mode, xrt, wp)
         p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
         p.dBs, p.dCs, p.dA, p.dD, p.ddelta_bias = (dBs.data_ptr(), dCs.data_ptr(), dA.data_ptr(), dD.data_ptr(),
                                                    dbias.data_ptr())
         isz = x.element_size()
-        nbytes = Bt * Dm * L * (10 * isz + 4) + 2 * Bt * 4 * N * L * (isz + 4)
-        # the same boundary for the backward: x, dy, dx and the x_proj rows with their gradient (8 B per element + small)
+        # the kernel's own boundary: x, dy, dx, ddts written and -- modes 0-2 only -- dts read, + the B / C rows and their sums
+        nbytes = Bt * Dm * L * ((6 if ctx.mode == 3 else 10) * isz + 4) + 2 * Bt * 4 * N * L * (isz + 4)
+        # the "dt_proj also fused" boundary for the backward: x, dy, dx and the x_proj rows with their gradient (8 B per element + small)
         nbytes_f = Bt * Dm * L * (2 * isz + 4) + 2 * Bt * 4 * (R + 2 * N) * L * isz
         # scratch for the workgroups' partial dB / dC sums (wide-map kernels: stores + one summing pass instead of atomics)
         wsb = lib.xfm_ss2d_bwd_ws_bytes(ctypes.byref(p))
