@@ -517,7 +517,12 @@ __global__ void __launch_bounds__(128) ss2dc_bwd_kernel(const ChanArgs a) {
 namespace deep {
 
 constexpr int HW = 7, L = 49, P = 7, NSTEP = 7, N = 16, LP = 50;   // LP: bf16 plane pitch (LP / 2 odd: conflict-free lanes)
-constexpr int TBL = 2 * N * NSTEP * 8;                           // floats of a wave's B / C table: [B | C][state][step][8]
+constexpr int TBL = 2 * N * NSTEP * 8;                           // floats of a wave's B / C table: [state pair][step][8][B0 B1 C0 C1]
+typedef float df2 __attribute__((ext_vector_type(2)));           // a state PAIR: the pair's arithmetic is packed fp32 (v_pk_*_f32)
+// slot of (B: w = 0 / C: w = 1, state n, sequence position s) in the table
+__device__ __forceinline__ int deep_slot(const int w, const int n, const int s) {
+    return ((((n >> 1) * NSTEP + s / P) * 8 + s % P) << 2) + 2 * w + (n & 1);
+}
 
 struct DeepArgs {
     ChanArgs a;
@@ -553,25 +558,19 @@ __device__ __forceinline__ void deep_fill_bc(const ChanArgs &a, const int sb, co
         slot[q] = -1;
         if (s < L) {
             r[q] = *reinterpret_cast<const cu32x4_t *>(src + ((int64_t)(w ? sbC : sb) * L + deep_nat(k, s)) * a.XC + w * N + nb);
-            slot[q] = ((w * N + nb) * NSTEP + s / P) * 8 + s % P;
+            slot[q] = deep_slot(w, nb, s);                                  // states nb, nb + 1: adjacent floats; + 2 j: pair j on
         }
     }
-    for (int e = lane; e < 2 * N * NSTEP; e += 64) T[e * 8 + 7] = 0.f;      // the pad slot of every row
+    for (int e = lane; e < (N / 2) * NSTEP; e += 64)                        // the pad slot of every (pair, step)
+        *reinterpret_cast<float4 *>(T + (e * 8 + 7) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (slot[q] >= 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                T[slot[q] + (2 * j) * NSTEP * 8] = deep_lo(r[q][j]);
-                T[slot[q] + (2 * j + 1) * NSTEP * 8] = deep_hi(r[q][j]);
-            }
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float2 *>(T + slot[q] + j * (NSTEP * 8 * 4)) = make_float2(deep_lo(r[q][j]), deep_hi(r[q][j]));
         }
     }
-}
-__device__ __forceinline__ void deep_row(const float *T, const int w, const int n, const int st, float (&r)[8]) {
-    const float4 *q = reinterpret_cast<const float4 *>(T + ((w * N + n) * NSTEP + st) * 8);
-    const float4 lo = q[0], hi = q[1];
-    r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = lo.w; r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = hi.w;
 }
 
 // dt_proj of one step for the 64 channels of the tile: acc[i] = raw step size of position i of the step (i < 7).
@@ -717,7 +716,8 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
         }
         const cf32x16_t acc = deep_dt_step<KS>(a, c0, k, lane, bv, xf);
         if (st > 0) deep_load_x<KS>(a, sb, k, st - 1, lane, xf);
-        float dl[P], sg[P], u[P], g[P], dlu[P], sB[P], sA[P];
+        float dl[P], sg[P], u[P], g[P], dlu[P];
+        df2 sB2[P], sA2[P];                                          // per-position sums over the states, even | odd states apart
         int nat[P];
 #pragma unroll
         for (int i = 0; i < P; ++i) {
@@ -726,61 +726,68 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
             u[i] = bf16_bits_to_float(xs[lane * LP + nat[i]]);
             g[i] = bf16_bits_to_float(gs[lane * LP + nat[i]]);
             dlu[i] = dl[i] * u[i];
-            sB[i] = sA[i] = 0.f;
+            sB2[i] = sA2[i] = df2{0.f, 0.f};
         }
 #pragma unroll 1
         for (int np = 0; np < N / 2; ++np) {
-            const float2 An = {As[(2 * np) * 64 + lane], As[(2 * np + 1) * 64 + lane]};
-            const float A20 = An.x * kLog2e, A21 = An.y * kLog2e;
+            // The two states of a pair run as the two halves of packed fp32 instructions (left to the compiler the pair's
+            // scalars were packed in 17 of 166 places): 11 packed + 2 transcendental instructions per position and pair.
+            const df2 An = {As[(2 * np) * 64 + lane], As[(2 * np + 1) * 64 + lane]};
+            const df2 A2 = An * kLog2e;
             const uint32_t hp = hb[np * 64 + lane];
-            float b0[8], b1[8], c0r[8], c1r[8];
-            deep_row(T, 0, 2 * np, st, b0);
-            deep_row(T, 0, 2 * np + 1, st, b1);
-            deep_row(T, 1, 2 * np, st, c0r);
-            deep_row(T, 1, 2 * np + 1, st, c1r);
-            float E0 = Es[(2 * np) * 64 + lane], E1 = Es[(2 * np + 1) * 64 + lane];
-            float dA0 = dAs[(2 * np) * 64 + lane], dA1 = dAs[(2 * np + 1) * 64 + lane];
-            float av0[P], av1[P], hv0[P], hv1[P];
-            const float hin0 = deep_lo(hp), hin1 = deep_hi(hp);
-            float h0 = hin0, h1 = hin1;
+            const float4 *Tq = reinterpret_cast<const float4 *>(T) + (np * NSTEP + st) * 8;
+            df2 bq[P], cq[P];
 #pragma unroll
             for (int i = 0; i < P; ++i) {
-                av0[i] = exp2_fast(dl[i] * A20);
-                av1[i] = exp2_fast(dl[i] * A21);
-                h0 = fmaf(av0[i], h0, dlu[i] * b0[i]);
-                h1 = fmaf(av1[i], h1, dlu[i] * b1[i]);
-                hv0[i] = h0;
-                hv1[i] = h1;
+                const float4 q = Tq[i];                              // (B, C) of both states at position i: one broadcast read
+                bq[i] = df2{q.x, q.y};
+                cq[i] = df2{q.z, q.w};
             }
+            df2 E = {Es[(2 * np) * 64 + lane], Es[(2 * np + 1) * 64 + lane]};
+            df2 dA = {dAs[(2 * np) * 64 + lane], dAs[(2 * np + 1) * 64 + lane]};
+            const df2 hin = {deep_lo(hp), deep_hi(hp)};
+            df2 h = hin, av[P], hv[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const df2 t = A2 * dl[i];
+                av[i] = df2{exp2_fast(t.x), exp2_fast(t.y)};
+                h = __builtin_elementwise_fma(av[i], h, bq[i] * dlu[i]);
+                hv[i] = h;
+            }
+            df2 dBp[P], dCp[P];
+#pragma unroll
+            for (int i = P - 1; i >= 0; --i) {
+                const df2 dh = __builtin_elementwise_fma(cq[i], df2{g[i], g[i]}, E);
+                E = av[i] * dh;
+                const df2 dha = E * (i > 0 ? hv[i - 1] : hin);      // dh * a_t h_{t-1} = (a_t dh) h_{t-1}
+                sB2[i] = __builtin_elementwise_fma(dh, bq[i], sB2[i]);
+                sA2[i] = __builtin_elementwise_fma(dha, An, sA2[i]);
+                dA = __builtin_elementwise_fma(dha, df2{dl[i], dl[i]}, dA);
+                dBp[i] = dh * dlu[i];
+                dCp[i] = hv[i] * g[i];
+            }
+            Es[(2 * np) * 64 + lane] = E.x;
+            Es[(2 * np + 1) * 64 + lane] = E.y;
+            dAs[(2 * np) * 64 + lane] = dA.x;
+            dAs[(2 * np + 1) * 64 + lane] = dA.y;
             float dB0[8], dC0[8], dB1[8], dC1[8];
             dB0[7] = dC0[7] = dB1[7] = dC1[7] = 0.f;
 #pragma unroll
-            for (int i = P - 1; i >= 0; --i) {
-                const float dh0 = fmaf(c0r[i], g[i], E0), dh1 = fmaf(c1r[i], g[i], E1);
-                E0 = av0[i] * dh0;
-                E1 = av1[i] * dh1;
-                const float dha0 = E0 * (i > 0 ? hv0[i - 1] : hin0);        // dh * a_t h_{t-1} = (a_t dh) h_{t-1}
-                const float dha1 = E1 * (i > 0 ? hv1[i - 1] : hin1);
-                sB[i] = fmaf(dh0, b0[i], sB[i]);
-                sB[i] = fmaf(dh1, b1[i], sB[i]);
-                sA[i] = fmaf(dha0, An.x, sA[i]);
-                sA[i] = fmaf(dha1, An.y, sA[i]);
-                dA0 = fmaf(dha0, dl[i], dA0);
-                dA1 = fmaf(dha1, dl[i], dA1);
-                dB0[i] = dh0 * dlu[i];
-                dB1[i] = dh1 * dlu[i];
-                dC0[i] = g[i] * hv0[i];
-                dC1[i] = g[i] * hv1[i];
+            for (int i = 0; i < P; ++i) {
+                dB0[i] = dBp[i].x; dB1[i] = dBp[i].y;
+                dC0[i] = dCp[i].x; dC1[i] = dCp[i].y;
             }
-            Es[(2 * np) * 64 + lane] = E0;
-            Es[(2 * np + 1) * 64 + lane] = E1;
-            dAs[(2 * np) * 64 + lane] = dA0;
-            dAs[(2 * np + 1) * 64 + lane] = dA1;
             // dB / dC of the two states: sums over the 64 channel lanes, into the table slots just read
             // sets: 0 = dB of state 2 np, 1 = dC of it, 2 = dB of state 2 np + 1, 3 = dC of it
             const float tot = deep_colsum4(dB0, dC0, dB1, dC1, lane);
             if (lane < 32 && (lane & 7) < P)
-                T[(((lane >> 3) & 1) * N + 2 * np + (lane >> 4)) * NSTEP * 8 + st * 8 + (lane & 7)] = tot;
+                T[(((np * NSTEP + st) * 8 + (lane & 7)) << 2) + 2 * ((lane >> 3) & 1) + (lane >> 4)] = tot;
+        }
+        float sB[P], sA[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            sB[i] = sB2[i].x + sB2[i].y;
+            sA[i] = sA2[i].x + sA2[i].y;
         }
         // ---- per-position results: du of this route into the wave's planes, d raw step size to the staging rows
 #pragma unroll
@@ -810,7 +817,7 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
             const int n = e / L, pnat = e - n * L;
             int t = (k & 1) ? (pnat % HW) * HW + pnat / HW : pnat;           // sequence index of the position on route k
             t = (k & 2) ? L - 1 - t : t;
-            atomicAdd(dst + e, T[((op * N + n) * NSTEP + t / P) * 8 + t % P]);
+            atomicAdd(dst + e, T[deep_slot(op, n, t)]);
         }
     }
     wave_sync();
