@@ -530,7 +530,14 @@ struct DeepArgs {
     float *dAt;              // (4, N, D) fp32 scratch, zeroed per backward call: dA with the CHANNEL fastest, so that a wave's
                              // atomic instruction covers 256 contiguous bytes (in the (4 D, N) layout of dA its 64 lanes hit
                              // 64 different lines: ~17x slower per instruction, MI355X_MICROARCH.md "Global float atomics")
+    int dbg;                 // timing-only switches (builds with -DXFM_DEEP_TIMING, XFM_DEEP_DBG=<bits>): 1 no pair arithmetic,
+                             // 2 no final atomics, 4 no dt_proj step, 8 no B / C table fill, 16 no ddts / du stores, 32 no column sums
 };
+#ifdef XFM_DEEP_TIMING
+#define DEEP_DBG(da, bit) (((da).dbg & (bit)) != 0)
+#else
+#define DEEP_DBG(da, bit) false
+#endif
 
 // natural position of sequence index s (0..48) of route k
 __host__ __device__ __forceinline__ int deep_nat(const int k, const int s) {
@@ -592,18 +599,23 @@ __device__ __forceinline__ void deep_load_x(const ChanArgs &a, const int sb, con
     }
 }
 
+// the dt_proj weight fragments of the tile's two 32-channel blocks for route k: the same for every step of a pass, so the
+// backward holds them in registers for the whole pass (requested per step they exposed an L2 round trip in front of the MFMAs)
+template <int KS> struct DeepW { cbf16x8_t f[2 * KS]; };
 template <int KS>
-__device__ __forceinline__ cf32x16_t deep_dt_step(const ChanArgs &a, const int c0, const int k, const int lane,
-                                                  const float bv, const DeepX<KS> &x) {
+__device__ __forceinline__ void deep_load_w(const ChanArgs &a, const int c0, const int k, const int lane, DeepW<KS> &w) {
     const int row32 = lane & 31, kb = lane >> 5;
     const uint16_t *w0 = a.wdt + ((int64_t)k * a.D + c0 + row32) * a.Rp8 + 8 * kb;
     const uint16_t *w1 = w0 + (int64_t)32 * a.Rp8;
-    cbf16x8_t fb[2 * KS];
 #pragma unroll
     for (int m = 0; m < 2 * KS; ++m) {
         const int ks = m % KS, blk = m / KS;
-        fb[m] = chan_ld8(16 * ks + 8 * kb < a.Rp8 ? (blk ? w1 : w0) + 16 * ks : a.zeros);
+        w.f[m] = chan_ld8(16 * ks + 8 * kb < a.Rp8 ? (blk ? w1 : w0) + 16 * ks : a.zeros);
     }
+}
+template <int KS>
+__device__ __forceinline__ cf32x16_t deep_dt_step(const float bv, const DeepX<KS> &x, const DeepW<KS> &w) {
+    const cbf16x8_t(&fb)[2 * KS] = w.f;
     cf32x16_t acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = bv;
@@ -632,8 +644,8 @@ __device__ __forceinline__ float deep_colsum8(const float (&v)[8], const cbf16x8
 // the four value sets of a state pair (dB, dC of both states: 4 x 7 per-lane values) in ONE accumulator: set s lands in
 // columns 8 s .. 8 s + 7 through its own selector, so the in-lane sum of the 16 accumulator rows and the cross-half add are
 // paid once instead of four times.  Lane j < 32 returns the total of value (j & 7) of set (j >> 3).
-__device__ __forceinline__ float deep_colsum4(const float (&v0)[8], const float (&v1)[8], const float (&v2)[8], const float (&v3)[8],
-                                              const int lane) {
+__device__ __forceinline__ cf32x16_t deep_colsum4_issue(const float (&v0)[8], const float (&v1)[8], const float (&v2)[8],
+                                                        const float (&v3)[8], const int lane) {
     const float *vs[4] = {v0, v1, v2, v3};
     const cf32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     cf32x16_t t = zero16;
@@ -646,6 +658,10 @@ __device__ __forceinline__ float deep_colsum4(const float (&v0)[8], const float 
         const cbf16x8_t sel = chan_indicator(((lane >> 3) & 3) == q ? 0 : 1, lane & 7);
         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf16x8_t *>(&pk), sel, t, 0, 0, 0);
     }
+    return t;
+}
+// ... and the fold of its accumulator (the caller puts a state pair's worth of other work between the two)
+__device__ __forceinline__ float deep_colsum4_fold(const cf32x16_t &t) {
     float s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     s += ((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]));
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -685,13 +701,20 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
     const int sbC = a.c_mod > 0 ? a.c_off + sb % a.c_mod : sb;
     const uint32_t *chk = da.chkp + (((int64_t)sb * 4 + k) * NSTEP) * (N / 2) * a.D + c0 + lane;
     DeepX<KS> xf;
+    DeepW<KS> wf;
     deep_load_x<KS>(a, sb, k, NSTEP - 1, lane, xf);
+    deep_load_w<KS>(a, c0, k, lane, wf);
     // states entering a step: requested one step ahead (eight loads in flight under a whole step of work: inside the
     // state loop each would expose an HBM round trip), handed over through LDS
-    uint32_t hn[N / 2];
+    // (TWO steps ahead: these 132 MB are the largest stream of the kernel and a wave is alone on its SIMD -- with one step
+    //  of look-ahead the bytes in flight per CU capped the launch at ~1.4 TB/s, 95 us of it with everything else switched off)
+    uint32_t hn[N / 2], hn2[N / 2];
 #pragma unroll
-    for (int np = 0; np < N / 2; ++np) hn[np] = chk[((int64_t)(NSTEP - 2) * (N / 2) + np) * a.D];
-    deep_fill_bc(a, sb, sbC, k, T, lane);
+    for (int np = 0; np < N / 2; ++np) {
+        hn[np] = chk[((int64_t)(NSTEP - 2) * (N / 2) + np) * a.D];
+        hn2[np] = chk[((int64_t)(NSTEP - 3) * (N / 2) + np) * a.D];
+    }
+    if (!DEEP_DBG(da, 8)) deep_fill_bc(a, sb, sbC, k, T, lane);
     {
         float av[N];
 #pragma unroll
@@ -712,10 +735,17 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
 #pragma unroll
         for (int np = 0; np < N / 2; ++np) {
             hb[np * 64 + lane] = st > 0 ? hn[np] : 0u;
-            if (st > 1) hn[np] = chk[((int64_t)(st - 2) * (N / 2) + np) * a.D];
+            hn[np] = hn2[np];
+            if (st > 2) hn2[np] = chk[((int64_t)(st - 3) * (N / 2) + np) * a.D];
         }
-        const cf32x16_t acc = deep_dt_step<KS>(a, c0, k, lane, bv, xf);
-        if (st > 0) deep_load_x<KS>(a, sb, k, st - 1, lane, xf);
+        cf32x16_t acc;
+        if (!DEEP_DBG(da, 4)) {
+            acc = deep_dt_step<KS>(bv, xf, wf);
+            if (st > 0) deep_load_x<KS>(a, sb, k, st - 1, lane, xf);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = bv;
+        }
         float dl[P], sg[P], u[P], g[P], dlu[P];
         df2 sB2[P], sA2[P];                                          // per-position sums over the states, even | odd states apart
         int nat[P];
@@ -728,39 +758,51 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
             dlu[i] = dl[i] * u[i];
             sB2[i] = sA2[i] = df2{0.f, 0.f};
         }
-#pragma unroll 1
-        for (int np = 0; np < N / 2; ++np) {
+        // A wave is alone on its SIMD here: every LDS round trip and every MFMA result it waits for is dead time (measured:
+        // ~2400 cycles per state pair and step for ~215 instructions).  So the pair loop is software-pipelined by hand: the
+        // operands of pair np + 1 (decay rates, entering states, carries, the 7 table rows: 14 LDS reads) are requested
+        // before pair np computes, and the column sums of pair np (four dependent MFMAs) are folded and stored only after
+        // the arithmetic of pair np + 1.  Two register sets, the loop written out twice (no moves).
+        struct PairOps { df2 An, E, dA; uint32_t hp; float4 q[P]; };
+        auto load_pair = [&](const int np, PairOps &o) {
+            o.An = df2{As[(2 * np) * 64 + lane], As[(2 * np + 1) * 64 + lane]};
+            o.hp = hb[np * 64 + lane];
+            const float4 *Tq = reinterpret_cast<const float4 *>(T) + (np * NSTEP + st) * 8;
+#pragma unroll
+            for (int i = 0; i < P; ++i) o.q[i] = Tq[i];              // (B, C) of both states at position i: one broadcast read
+            o.E = df2{Es[(2 * np) * 64 + lane], Es[(2 * np + 1) * 64 + lane]};
+            o.dA = df2{dAs[(2 * np) * 64 + lane], dAs[(2 * np + 1) * 64 + lane]};
+        };
+        cf32x16_t pend;                                              // column-sum accumulator of the previous pair
+        int pend_np = -1;
+        auto fold_pending = [&]() {
+            if (pend_np < 0) return;
+            const float tot = deep_colsum4_fold(pend);
+            if (lane < 32 && (lane & 7) < P)
+                T[(((pend_np * NSTEP + st) * 8 + (lane & 7)) << 2) + 2 * ((lane >> 3) & 1) + (lane >> 4)] = tot;
+        };
+        auto run_pair = [&](const int np, const PairOps &o) {
             // The two states of a pair run as the two halves of packed fp32 instructions (left to the compiler the pair's
             // scalars were packed in 17 of 166 places): 11 packed + 2 transcendental instructions per position and pair.
-            const df2 An = {As[(2 * np) * 64 + lane], As[(2 * np + 1) * 64 + lane]};
-            const df2 A2 = An * kLog2e;
-            const uint32_t hp = hb[np * 64 + lane];
-            const float4 *Tq = reinterpret_cast<const float4 *>(T) + (np * NSTEP + st) * 8;
-            df2 bq[P], cq[P];
-#pragma unroll
-            for (int i = 0; i < P; ++i) {
-                const float4 q = Tq[i];                              // (B, C) of both states at position i: one broadcast read
-                bq[i] = df2{q.x, q.y};
-                cq[i] = df2{q.z, q.w};
-            }
-            df2 E = {Es[(2 * np) * 64 + lane], Es[(2 * np + 1) * 64 + lane]};
-            df2 dA = {dAs[(2 * np) * 64 + lane], dAs[(2 * np + 1) * 64 + lane]};
-            const df2 hin = {deep_lo(hp), deep_hi(hp)};
+            const df2 An = o.An, A2 = An * kLog2e;
+            df2 E = o.E, dA = o.dA;
+            const df2 hin = {deep_lo(o.hp), deep_hi(o.hp)};
             df2 h = hin, av[P], hv[P];
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 const df2 t = A2 * dl[i];
                 av[i] = df2{exp2_fast(t.x), exp2_fast(t.y)};
-                h = __builtin_elementwise_fma(av[i], h, bq[i] * dlu[i]);
+                h = __builtin_elementwise_fma(av[i], h, df2{o.q[i].x, o.q[i].y} * dlu[i]);
                 hv[i] = h;
             }
             df2 dBp[P], dCp[P];
 #pragma unroll
             for (int i = P - 1; i >= 0; --i) {
-                const df2 dh = __builtin_elementwise_fma(cq[i], df2{g[i], g[i]}, E);
+                const df2 bq = {o.q[i].x, o.q[i].y}, cq = {o.q[i].z, o.q[i].w};
+                const df2 dh = __builtin_elementwise_fma(cq, df2{g[i], g[i]}, E);
                 E = av[i] * dh;
                 const df2 dha = E * (i > 0 ? hv[i - 1] : hin);      // dh * a_t h_{t-1} = (a_t dh) h_{t-1}
-                sB2[i] = __builtin_elementwise_fma(dh, bq[i], sB2[i]);
+                sB2[i] = __builtin_elementwise_fma(dh, bq, sB2[i]);
                 sA2[i] = __builtin_elementwise_fma(dha, An, sA2[i]);
                 dA = __builtin_elementwise_fma(dha, df2{dl[i], dl[i]}, dA);
                 dBp[i] = dh * dlu[i];
@@ -779,10 +821,24 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
             }
             // dB / dC of the two states: sums over the 64 channel lanes, into the table slots just read
             // sets: 0 = dB of state 2 np, 1 = dC of it, 2 = dB of state 2 np + 1, 3 = dC of it
-            const float tot = deep_colsum4(dB0, dC0, dB1, dC1, lane);
-            if (lane < 32 && (lane & 7) < P)
-                T[(((np * NSTEP + st) * 8 + (lane & 7)) << 2) + 2 * ((lane >> 3) & 1) + (lane >> 4)] = tot;
+            if (DEEP_DBG(da, 32)) {
+                sB2[0] += df2{dB0[0] + dC0[1], dB1[2] + dC1[3]};
+                return;
+            }
+            fold_pending();                                          // (the previous pair's MFMAs finished long ago)
+            pend = deep_colsum4_issue(dB0, dC0, dB1, dC1, lane);
+            pend_np = np;
+        };
+        PairOps oa, ob;
+        load_pair(0, oa);
+#pragma unroll 1
+        for (int np = 0; np < (DEEP_DBG(da, 1) ? 0 : N / 2); np += 2) {
+            load_pair(np + 1, ob);
+            run_pair(np, oa);
+            if (np + 2 < N / 2) load_pair(np + 2, oa);
+            run_pair(np + 1, ob);
         }
+        fold_pending();
         float sB[P], sA[P];
 #pragma unroll
         for (int i = 0; i < P; ++i) {
@@ -800,13 +856,18 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
             *q = deep_bf16(FIRST ? du : bf16_bits_to_float(*q) + du);
         }
         wave_sync();
-        if (lane < P * 8) {                                          // ddts rows: [position][64 channels] bf16, 16-byte stores
+        if (lane < P * 8 && !DEEP_DBG(da, 16)) {                                          // ddts rows: [position][64 channels] bf16, 16-byte stores
             const int i = lane >> 3, part = lane & 7;
             const int nf = deep_nat(k, st * P + i);
             const cu32x4_t v = *reinterpret_cast<const cu32x4_t *>(stg + i * 64 + 8 * part);
             *reinterpret_cast<cu32x4_t *>(a.ddts + ((((int64_t)sb * 4 + k) * L + nf) * a.D + c0 + 8 * part)) = v;
         }
         wave_sync();
+    }
+    if (DEEP_DBG(da, 2)) {
+        if (dbacc == 12345.678f) atomicAdd(a.dbias + wrow, dbacc + dAs[lane] + T[lane]);
+        wave_sync();
+        return;
     }
     for (int n = 0; n < N; ++n) atomicAdd(da.dAt + ((int64_t)k * N + n) * a.D + c0 + lane, dAs[n * 64 + lane]);
     atomicAdd(a.dbias + wrow, dbacc);
@@ -838,18 +899,48 @@ __global__ void __launch_bounds__(128) deep_bwd_kernel(const DeepArgs da) {
     chan_block_map(a.xmap, tiles, sb, c0);
     c0 *= 64;
     {
+        // the tile's x (bf16) and dy (fp32) planes are one contiguous run each: ALL of a thread's vectors are requested before
+        // the first LDS write (a load / convert / scatter loop exposed one HBM round trip per iteration, 13 per workgroup:
+        // most of the ~140 us this launch took with every other phase switched off)
         const uint16_t *src = a.x + ((int64_t)sb * a.D + c0) * L;
         const float *gsrc = a.dy + ((int64_t)sb * a.D + c0) * L;
-        for (int v = threadIdx.x; v < 64 * L / 2; v += 128) {
-            const uint32_t r = *reinterpret_cast<const uint32_t *>(src + 2 * v);
-            const float2 gr = *reinterpret_cast<const float2 *>(gsrc + 2 * v);
-            const uint32_t gp = pack_bf16x2(gr.x, gr.y);
-            const int e = 2 * v, c = e / L, l = e - c * L;
-            const int e1 = e + 1, c1 = e1 / L, l1 = e1 - c1 * L;
-            xs[c * LP + l] = (uint16_t)(r & 0xffffu);
-            xs[c1 * LP + l1] = (uint16_t)(r >> 16);
-            gs[c * LP + l] = (uint16_t)(gp & 0xffffu);
-            gs[c1 * LP + l1] = (uint16_t)(gp >> 16);
+        constexpr int NVX = 64 * L / 8, NVG = 64 * L / 4, PX = (NVX + 127) / 128, PG = (NVG + 127) / 128;
+        cu32x4_t rx[PX];
+        float4 rg[PG];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int v = threadIdx.x + 128 * j;
+            rx[j] = *reinterpret_cast<const cu32x4_t *>(src + 8 * (v < NVX ? v : 0));
+        }
+#pragma unroll
+        for (int j = 0; j < PG; ++j) {
+            const int v = threadIdx.x + 128 * j;
+            rg[j] = *reinterpret_cast<const float4 *>(gsrc + 4 * (v < NVG ? v : 0));
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int v = threadIdx.x + 128 * j;
+            if (v < NVX) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = 8 * v + 2 * q, c = e / L, l = e - c * L;
+                    const int e1 = e + 1, c1 = e1 / L, l1 = e1 - c1 * L;
+                    xs[c * LP + l] = (uint16_t)(rx[j][q] & 0xffffu);
+                    xs[c1 * LP + l1] = (uint16_t)(rx[j][q] >> 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PG; ++j) {
+            const int v = threadIdx.x + 128 * j;
+            if (v < NVG) {
+                const float f[4] = {rg[j].x, rg[j].y, rg[j].z, rg[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = 4 * v + q, c = e / L, l = e - c * L;
+                    gs[c * LP + l] = deep_bf16(f[q]);
+                }
+            }
         }
         if (threadIdx.x < 64) {
             const int q = threadIdx.x;
@@ -912,6 +1003,11 @@ template <int KS> static int deep_launch(const DeepArgs &da, hipStream_t s) {
     static LdsOptIn opted;
     if (lds > 64 * 1024 && !lds_opt_in(opted, fn, lds)) return XFM_ELAUNCH;
     DeepArgs args = da;
+    args.dbg = 0;
+#ifdef XFM_DEEP_TIMING
+    static const int env_dbg = [] { const char *e = getenv("XFM_DEEP_DBG"); return e ? atoi(e) : 0; }();
+    args.dbg = env_dbg;
+#endif
     void *kargs[] = {&args};
     // (a kernel, not a memset node: under stream capture the memset of this workspace slice replayed with stale contents)
     if (bwd) hipLaunchKernelGGL(deep_zero_kernel, dim3((4 * N * da.a.D + 255) / 256), dim3(256), 0, s, da.dAt, 4 * N * da.a.D);
