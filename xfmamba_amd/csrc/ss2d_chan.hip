@@ -114,6 +114,9 @@ __device__ __forceinline__ void chan_fwd_pass(const ChanArgs &a, const int sb, c
                 }
                 hst[0] = hh;
             } else {
+                // (packed fp32 over position pairs for the two products outside the recurrence -- step size x decay rate,
+                //  B x step size x input -- was built and LOST: 240 -> 320 us; v_pk_mul_f32 beside the broadcast MFMAs of the next
+                //  state costs more than the scalar pair, MI355X_MICROARCH.md "price of one filler beside MFMAs")
                 float dl[NV], du[NV];
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
