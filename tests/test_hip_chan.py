@@ -71,7 +71,11 @@ def test_ss2d_chan_matches_oracle_chain(B, D, HW, R):
     assert y.dtype == torch.float32
     y.backward(gy.to(DEV))
     got = [y.detach()] + [v.grad for v in t]
-    tols = (1e-2 if HW > 12 else 2e-3, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2)
+    # y: the operator's input is bf16, BASELINE's bound for 16-bit I/O is 1e-2.  Up to 12 x 12 the two passes keep their partial
+    # sums in fp32 planes and y holds 2e-3; at 14 x 14 the planes are bf16 words (two workgroups more per CU), i.e. each pass's
+    # partial sum is rounded to bf16 once before the fp32 merge: half a bf16 ulp of a partial sum = 2e-3 of ITS magnitude, so
+    # the bound there is 5e-3 of the output scale (measured 2.0e-3 ... 3.1e-3 over these cases), not the 1e-2 of round 4.
+    tols = (5e-3 if HW > 12 else 2e-3, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2)
     for name, a, b, tol in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), got, ref, tols):
         assert_close(a.float().cpu(), b.float(), tol, tol * float(b.abs().max()) + 1e-7, name)
 

@@ -429,6 +429,80 @@ def test_model_bf16_autocast_gradients_track_the_oracle(cfg):
                 assert cos > 0.97, (k, cos)
 
 
+def test_model_tiny_bf16_batch32_training_gradients_match_the_oracle_on_four_samples():
+    """BASELINE configs[1] at its REAL batch in TRAINING form: XFMamba-T, bf16 autocast, 32 two-view
+    samples, forward + backward through the launch shapes the bench uses (batch 64 after the view merge: XCD-local sample
+    maps, the wide-map tile plans, the deep block's 96 samples).  The loss is the cross entropy of FOUR of the 32 samples
+    (its logit gradient taken at the fp32 oracle's logits and fed to all three backward passes as the same cotangent);
+    with DropPath 0 and BatchNorm reading its running statistics the samples do not interact, so the parameter gradients
+    equal those of the same four samples run as a batch of 4 -- which is what the CPU oracle computes (fp32 = truth, under
+    bf16 autocast = yardstick).  Every parameter-gradient norm of the HIP path must sit within 1.5x the yardstick's own error
+    (+ 5e-2, the floor of the batch-2 test), ten sampled tensors also in direction, and the global norm within 1.5x + 1e-2."""
+    from oracle import c_scan
+    m = _tiny_with_synth_weights().train()
+    for mod in m.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()
+    g = torch.Generator().manual_seed(4321)
+    xa, xb = torch.randn(32, 1, 224, 224, generator=g), torch.randn(32, 1, 224, 224, generator=g)
+    lab = torch.randint(0, 2, (32,), generator=g)
+    pick = torch.tensor([1, 9, 18, 30])
+    sd = O.synth_state_dict(load_json("g5_state_shapes.json")["tiny"], seed=0)
+    cot = {}
+
+    def oracle_grads(autocast):
+        leaves = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in sd.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            o = O.xfmamba_top_ref(leaves, xa[pick], xb[pick], False, c_scan.selective_scan_c)     # (BatchNorm: running statistics)
+        if "g" not in cot:
+            # d CE / d logits at the fp32 oracle's logits: ONE cotangent for all three backward passes.  (With each run's own
+            # softmax the synthetic weights' saturated logits turn a 2e-2 logit difference into a 20 % difference of
+            # (p - onehot), i.e. of EVERY gradient: a property of the loss at these logits, not of any backward kernel.)
+            lg = o.detach().float().requires_grad_()
+            torch.nn.functional.cross_entropy(lg, lab[pick]).backward()
+            cot["g"] = lg.grad.clone()
+        o.float().backward(cot["g"])
+        return {k: v.grad.float() for k, v in leaves.items() if v.requires_grad and v.grad is not None}, o.detach().float()
+
+    ref, lo_ref = oracle_grads(False)
+    orc, _ = oracle_grads(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m(xa.to(DEV), xb.to(DEV))
+    out.float()[pick.to(DEV)].backward(cot["g"].to(DEV))
+    hip = {k: p.grad.float().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    assert torch.isfinite(out).all()
+    d_log = float((out.float().cpu()[pick] - lo_ref).abs().max()) / float(lo_ref.abs().max())
+    assert d_log < 3e-2, d_log
+    assert set(ref) == set(hip), set(ref) ^ set(hip)
+    sampled = [k for pat in ("patch_embed.0.weight", "layers.0.blocks.0.op.x_proj_weight", "layers.0.blocks.1.op.dt_projs_weight",
+                             "layers.1.blocks.0.op.A_logs", "layers.1.downsample", "layers.2.blocks.3.mlp.fc1.weight",
+                             "layers.2.blocks.7.op.out_proj.weight", "layers.3.blocks.1.op.in_proj.weight",
+                             "shallowfuseSS2D.x_proj_weight", "dt_projs_weight", "final_conv")
+               for k in sorted(ref) if pat in k][:14]
+    assert len(sampled) >= 8, sampled
+    tot_h = tot_o = tot_r = 0.0
+    for k, gr in ref.items():
+        rn = float(gr.double().norm())
+        eh = abs(float(hip[k].double().norm()) - rn) / (rn + 1e-12)
+        eo = abs(float(orc[k].double().norm()) - rn) / (rn + 1e-12)
+        if gr.numel() < 16:
+            # (the classifier's 2-element bias gradient is mean(softmax - onehot) over four samples: a cancelling sum of O(1)
+            #  terms, so its NORM amplifies the logits' bf16 error; held element-wise on the scale of its terms instead)
+            da, do = float((hip[k] - gr).abs().max()), float((orc[k] - gr).abs().max())
+            assert da <= 1.5 * do + 2e-2, (k, da, do)
+        else:
+            assert eh <= 1.5 * eo + 5e-2, (k, eh, eo)
+        tot_h += float(hip[k].double().pow(2).sum()); tot_o += float(orc[k].double().pow(2).sum()); tot_r += rn * rn
+        if k in sampled and rn > 0:
+            cos = float(torch.nn.functional.cosine_similarity(hip[k].flatten().double(), gr.flatten().double(), dim=0))
+            cos_o = float(torch.nn.functional.cosine_similarity(orc[k].flatten().double(), gr.flatten().double(), dim=0))
+            assert cos > min(0.97, cos_o - 0.02), (k, cos, cos_o)
+    eh, eo = abs(tot_h ** 0.5 - tot_r ** 0.5) / tot_r ** 0.5, abs(tot_o ** 0.5 - tot_r ** 0.5) / tot_r ** 0.5
+    assert eh <= 1.5 * eo + 1e-2, (eh, eo)
+
+
 def test_model_tiny_fp32_every_gradient_tensor_matches_the_oracle():
     """the reference record holds ~10 full gradient tensors and the norm of every other one; here EVERY
     parameter gradient of the fp32 HIP path is compared element-wise with the CPU oracle (itself pinned to the record by

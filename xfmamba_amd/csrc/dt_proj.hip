@@ -169,7 +169,7 @@ template <int KS> __global__ __launch_bounds__(256) void dt_proj_mfma_kernel(DtP
             for (int g = 0; g < 4; ++g) {
                 float y[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = act ? softplus20(acc[4 * g + i] + bv) : acc[4 * g + i];
+                for (int i = 0; i < 4; ++i) y[i] = act ? softplus20_16bit(acc[4 * g + i] + bv) : acc[4 * g + i];
                 pk[g][0] = pack_bf16x2(y[0], y[1]);
                 pk[g][1] = pack_bf16x2(y[2], y[3]);
             }
@@ -205,8 +205,8 @@ template <int KS> __global__ __launch_bounds__(256) void dt_proj_mfma_kernel(DtP
             const int row0 = (v & 3) + 8 * (v >> 2) + 4 * h;        // rows of regs v and v + 1 are adjacent channels
             float y0 = acc[v], y1 = acc[v + 1];
             if (a.bias) {
-                y0 = softplus20(y0 + a.bias[k * a.D + d0 + row0]);
-                y1 = softplus20(y1 + a.bias[k * a.D + d0 + row0 + 1]);
+                y0 = softplus20_16bit(y0 + a.bias[k * a.D + d0 + row0]);
+                y1 = softplus20_16bit(y1 + a.bias[k * a.D + d0 + row0 + 1]);
             }
             if (valid) {
                 const uint32_t pk = pack_bf16x2(y0, y1);
