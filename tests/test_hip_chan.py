@@ -123,3 +123,59 @@ def test_ss2d_chan_dstate16_matches_oracle_chain(B, D, HW, R, streams):
     tols = (2e-3, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2)
     for name, a, b, tol in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), got, ref, tols):
         assert_close(a.float().cpu(), b.float(), tol, tol * float(b.abs().max()) + 1e-7, name)
+
+
+CASES_SWAP = [  # B (per view), D, R   -- the shallow swap block: 2 forward-only routes over the channel-swapped views, d_state 16, 7 x 7
+    (2, 64, 4), (3, 128, 48), (1, 192, 33), (8, 64, 4),
+    (32, 1536, 48),         # the shallow block of XFMamba-T / S at the bench batch: the real launch shape
+]
+
+
+@pytest.mark.parametrize("B,D,R", CASES_SWAP)
+def test_ss2d_chan_swap_matches_oracle_chain(B, D, R):
+    """The shallow block's exchange as ONE kernel each way (xfm_ss2dc_fwd/_bwd with n_routes == 1, wdiv == B; reference
+    models/fusion_vmamba.py:189-241, 808-845): swap -> x_proj -> dt_proj -> softplus -> two forward row-major scans, against the
+    CPU oracle chain (swap_scan_ref, einsums, the C scan) with the kernel's bf16 rounding point on x_dbl.  The node takes the
+    swapped planes [route 0 | route 1]; the swap itself (and its pass-through backward, the reference's quirk) is checked
+    against swap_scan_ref and against the identity."""
+    from xfmamba_amd.ss2d_chan import chan_supported, ss2d_chan_swap_fn, swap_views_stacked
+    HW, N, K = 7, 16, 2
+    L, C2 = HW * HW, R + 2 * N
+    g = torch.Generator().manual_seed(B * D + R)
+    x1, x2 = _bf(torch.randn(B, D, HW, HW, generator=g)), _bf(torch.randn(B, D, HW, HW, generator=g))
+    xw = _bf(torch.randn(K, C2, D, generator=g) * D ** -0.5)
+    dtw = _bf(torch.randn(K, D, R, generator=g) * R ** -0.5)
+    A = -(torch.arange(1, N + 1, dtype=torch.float32).repeat(K * D, 1)) * (1 + 0.05 * torch.randn(K * D, N, generator=g))
+    Dp = torch.randn(K * D, generator=g)
+    dt0 = torch.exp(torch.rand(K * D, generator=g) * 4.6 - 6.9)
+    bias = dt0 + torch.log(-torch.expm1(-dt0))
+    bias[::97] = 21.0
+    gy = _bf(torch.randn(2 * B, D, L, generator=g))                                   # route-major: [route 0 | route 1]
+    # ---- oracle
+    xs_ref = O.swap_scan_ref(x1, x2)                                                   # (B, 2, D, L)
+    t = [v.clone().requires_grad_() for v in (xs_ref, xw, dtw, A, Dp, bias)]
+    x_dbl = torch.einsum("bkdl,kcd->bkcl", t[0], t[1])
+    x_dbl = x_dbl + (_bf(x_dbl) - x_dbl).detach()                                      # the kernel's bf16 rounding point
+    dts = torch.einsum("bkrl,kdr->bkdl", x_dbl[:, :, :R], t[2])
+    Bs, Cs = x_dbl[:, :, R:R + N].contiguous(), x_dbl[:, :, R + N:].contiguous()
+    ys = c_scan.selective_scan_c(t[0].reshape(B, -1, L), dts.reshape(B, -1, L), t[3], Bs, Cs, t[4], t[5], True, True)
+    ys = ys.view(B, K, D, L)
+    ys.backward(gy.view(K, B, D, L).transpose(0, 1))
+    ref = [ys.detach().transpose(0, 1).reshape(2 * B, D, L), t[0].grad.transpose(0, 1).reshape(2 * B, D, L)] + [v.grad for v in t[1:]]
+    # ---- the swap: forward = swap_scan_ref in route-major order, backward = identity (pass-through, fusion_vmamba.py:217-221)
+    xc = torch.cat([x1, x2], dim=0).view(2 * B, D, L).bfloat16().to(DEV).requires_grad_()
+    xs = swap_views_stacked(xc)
+    assert torch.equal(xs.float().cpu(), xs_ref.transpose(0, 1).reshape(2 * B, D, L))
+    gsw = torch.randn(2 * B, D, L, generator=g).bfloat16()
+    xs.backward(gsw.to(DEV))
+    assert torch.equal(xc.grad.cpu(), gsw)
+    # ---- the node
+    h = [v.to(DEV).requires_grad_() for v in (xs.detach(), xw, dtw, A, Dp, bias)]
+    assert chan_supported(h[0], HW, HW, N, 1, D, R)
+    y = ss2d_chan_swap_fn(h[0], h[1], h[2], h[3], h[4], h[5], HW, HW)
+    assert y.dtype == torch.float32 and y.shape == (2 * B, D, L)
+    y.backward(gy.to(DEV))
+    got = [y.detach()] + [v.grad for v in h]
+    tols = (2e-3, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2)
+    for name, a, b, tol in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), got, ref, tols):
+        assert_close(a.float().cpu(), b.float(), tol, tol * float(b.abs().max()) + 1e-7, name)

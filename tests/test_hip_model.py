@@ -468,9 +468,17 @@ def test_model_tiny_bf16_batch32_training_gradients_match_the_oracle_on_four_sam
 
     ref, lo_ref = oracle_grads(False)
     orc, _ = oracle_grads(True)
+    from xfmamba_amd import _lib
+    timer = _lib.KernelTimer()
+    _lib.set_timer(timer)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = m(xa.to(DEV), xb.to(DEV))
     out.float()[pick.to(DEV)].backward(cot["g"].to(DEV))
+    _lib.set_timer(None)
+    ran = set(timer.summary())
+    # the shallow block's exchange ran as ONE kernel each way (xfm_ss2dc_fwd/_bwd, n_routes 1), not as the operator chain
+    assert {"ss2dc16s_fwd", "ss2dc16s_bwd", "ss2dc16_fwd", "ss2dc16_bwd"} <= ran, sorted(ran)
+    assert not ({"selective_scan_fwd", "selective_scan_bwd", "dt_proj_fwd" if False else "cross_scan"} & ran), sorted(ran)
     hip = {k: p.grad.float().cpu() for k, p in m.named_parameters() if p.grad is not None}
     assert torch.isfinite(out).all()
     d_log = float((out.float().cpu()[pick] - lo_ref).abs().max()) / float(lo_ref.abs().max())

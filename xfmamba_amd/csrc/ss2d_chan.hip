@@ -687,9 +687,11 @@ struct DeepBwdLds {
     static constexpr size_t total = wave0 + 2 * wave_sz;
 };
 
+// k: the route (its geometry, its columns of the x_proj rows, its slice of ddts / dBC / the checkpoints); nr: routes per
+// sample; ws: the weight set (rows of wdt / A / bias / dA) -- route k itself with four routes, sample sb / wdiv with one
 template <int KS, bool FIRST>
-__device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, const int c0, const int k,
-                                              const uint16_t *xs, const uint16_t *gs, char *wl) {
+__device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, const int c0, const int k, const int nr,
+                                              const int ws, const uint16_t *xs, const uint16_t *gs, char *wl) {
     const ChanArgs &a = da.a;
     const int lane = threadIdx.x & 63;
     uint16_t *dup = reinterpret_cast<uint16_t *>(wl + DeepBwdLds::dup);
@@ -698,15 +700,15 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
     float *Es = reinterpret_cast<float *>(wl + DeepBwdLds::Es), *dAs = reinterpret_cast<float *>(wl + DeepBwdLds::dAs);
     float *As = reinterpret_cast<float *>(wl + DeepBwdLds::As);
     uint32_t *hb = reinterpret_cast<uint32_t *>(wl + DeepBwdLds::hb);
-    const int64_t wrow = (int64_t)k * a.D + c0 + lane;
+    const int64_t wrow = (int64_t)ws * a.D + c0 + lane;
     const float bv = a.bias[wrow];
     const float *Arow = a.A + wrow * N;
     const int sbC = a.c_mod > 0 ? a.c_off + sb % a.c_mod : sb;
-    const uint32_t *chk = da.chkp + (((int64_t)sb * 4 + k) * NSTEP) * (N / 2) * a.D + c0 + lane;
+    const uint32_t *chk = da.chkp + (((int64_t)sb * nr + k) * NSTEP) * (N / 2) * a.D + c0 + lane;
     DeepX<KS> xf;
     DeepW<KS> wf;
     deep_load_x<KS>(a, sb, k, NSTEP - 1, lane, xf);
-    deep_load_w<KS>(a, c0, k, lane, wf);
+    deep_load_w<KS>(a, c0, ws, lane, wf);
     // states entering a step: requested one step ahead (eight loads in flight under a whole step of work: inside the
     // state loop each would expose an HBM round trip), handed over through LDS
     // (TWO steps ahead: these 132 MB are the largest stream of the kernel and a wave is alone on its SIMD -- with one step
@@ -863,7 +865,7 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
             const int i = lane >> 3, part = lane & 7;
             const int nf = deep_nat(k, st * P + i);
             const cu32x4_t v = *reinterpret_cast<const cu32x4_t *>(stg + i * 64 + 8 * part);
-            *reinterpret_cast<cu32x4_t *>(a.ddts + ((((int64_t)sb * 4 + k) * L + nf) * a.D + c0 + 8 * part)) = v;
+            *reinterpret_cast<cu32x4_t *>(a.ddts + ((((int64_t)sb * nr + k) * L + nf) * a.D + c0 + 8 * part)) = v;
         }
         wave_sync();
     }
@@ -872,11 +874,11 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
         wave_sync();
         return;
     }
-    for (int n = 0; n < N; ++n) atomicAdd(da.dAt + ((int64_t)k * N + n) * a.D + c0 + lane, dAs[n * 64 + lane]);
+    for (int n = 0; n < N; ++n) atomicAdd(da.dAt + ((int64_t)ws * N + n) * a.D + c0 + lane, dAs[n * 64 + lane]);
     atomicAdd(a.dbias + wrow, dbacc);
     // dB / dC of this route over the tile: contiguous fp32 atomics in natural position order (the table is in route order)
     for (int op = 0; op < 2; ++op) {
-        float *dst = a.dBC + ((((int64_t)(op ? sbC : sb) * 4 + k) * 2 + op) * N) * L;
+        float *dst = a.dBC + ((((int64_t)(op ? sbC : sb) * nr + k) * 2 + op) * N) * L;
         for (int e = lane; e < N * L; e += 64) {
             const int n = e / L, pnat = e - n * L;
             int t = (k & 1) ? (pnat % HW) * HW + pnat / HW : pnat;           // sequence index of the position on route k
@@ -887,8 +889,12 @@ __device__ __forceinline__ void deep_bwd_pass(const DeepArgs &da, const int sb, 
     wave_sync();
 }
 
-template <int KS>
-__global__ void __launch_bounds__(128) deep_bwd_kernel(const DeepArgs da) {
+// NR = 4: the deep block (two waves: rows, columns; routes k and k + 2 one after the other).  NR = 1: ONE forward row-major
+// route per sample and no merge across routes -- the shallow swap block (reference models/fusion_vmamba.py:808-845) with its
+// two channel-swapped views as 2B samples, weight set sb / wdiv; a workgroup is one wave.
+template <int KS, int NR>
+__global__ void __launch_bounds__(NR == 4 ? 128 : 64) deep_bwd_kernel(const DeepArgs da) {
+    constexpr int NT = NR == 4 ? 128 : 64;
     const ChanArgs &a = da.a;
     using LD = DeepBwdLds;
     extern __shared__ float smem[];
@@ -901,28 +907,29 @@ __global__ void __launch_bounds__(128) deep_bwd_kernel(const DeepArgs da) {
     int sb, c0;
     chan_block_map(a.xmap, tiles, sb, c0);
     c0 *= 64;
+    const int ws1 = NR == 1 ? sb / a.wdiv : 0;                       // weight set of a single-route sample
     {
         // the tile's x (bf16) and dy (fp32) planes are one contiguous run each: ALL of a thread's vectors are requested before
         // the first LDS write (a load / convert / scatter loop exposed one HBM round trip per iteration, 13 per workgroup:
         // most of the ~140 us this launch took with every other phase switched off)
         const uint16_t *src = a.x + ((int64_t)sb * a.D + c0) * L;
         const float *gsrc = a.dy + ((int64_t)sb * a.D + c0) * L;
-        constexpr int NVX = 64 * L / 8, NVG = 64 * L / 4, PX = (NVX + 127) / 128, PG = (NVG + 127) / 128;
+        constexpr int NVX = 64 * L / 8, NVG = 64 * L / 4, PX = (NVX + NT - 1) / NT, PG = (NVG + NT - 1) / NT;
         cu32x4_t rx[PX];
         float4 rg[PG];
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
-            const int v = threadIdx.x + 128 * j;
+            const int v = threadIdx.x + NT * j;
             rx[j] = *reinterpret_cast<const cu32x4_t *>(src + 8 * (v < NVX ? v : 0));
         }
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
-            const int v = threadIdx.x + 128 * j;
+            const int v = threadIdx.x + NT * j;
             rg[j] = *reinterpret_cast<const float4 *>(gsrc + 4 * (v < NVG ? v : 0));
         }
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
-            const int v = threadIdx.x + 128 * j;
+            const int v = threadIdx.x + NT * j;
             if (v < NVX) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -935,7 +942,7 @@ __global__ void __launch_bounds__(128) deep_bwd_kernel(const DeepArgs da) {
         }
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
-            const int v = threadIdx.x + 128 * j;
+            const int v = threadIdx.x + NT * j;
             if (v < NVG) {
                 const float f[4] = {rg[j].x, rg[j].y, rg[j].z, rg[j].w};
 #pragma unroll
@@ -947,38 +954,47 @@ __global__ void __launch_bounds__(128) deep_bwd_kernel(const DeepArgs da) {
         }
         if (threadIdx.x < 64) {
             const int q = threadIdx.x;
-            dsum[q] = (a.Dp[c0 + q] + a.Dp[a.D + c0 + q]) + (a.Dp[2 * a.D + c0 + q] + a.Dp[3 * a.D + c0 + q]);
+            if constexpr (NR == 4) dsum[q] = (a.Dp[c0 + q] + a.Dp[a.D + c0 + q]) + (a.Dp[2 * a.D + c0 + q] + a.Dp[3 * a.D + c0 + q]);
+            else dsum[q] = a.Dp[(int64_t)ws1 * a.D + c0 + q];
         }
     }
     __syncthreads();
-    if (wave == 0) {
-        deep_bwd_pass<KS, true>(da, sb, c0, 0, xs, gs, wl);
-        deep_bwd_pass<KS, false>(da, sb, c0, 2, xs, gs, wl);
+    if constexpr (NR == 1) {
+        deep_bwd_pass<KS, true>(da, sb, c0, 0, 1, ws1, xs, gs, wl);
+    } else if (wave == 0) {
+        deep_bwd_pass<KS, true>(da, sb, c0, 0, 4, 0, xs, gs, wl);
+        deep_bwd_pass<KS, false>(da, sb, c0, 2, 4, 2, xs, gs, wl);
     } else {
-        deep_bwd_pass<KS, true>(da, sb, c0, 1, xs, gs, wl);
-        deep_bwd_pass<KS, false>(da, sb, c0, 3, xs, gs, wl);
+        deep_bwd_pass<KS, true>(da, sb, c0, 1, 4, 1, xs, gs, wl);
+        deep_bwd_pass<KS, false>(da, sb, c0, 3, 4, 3, xs, gs, wl);
     }
     __syncthreads();
     // ---- dx = rows + columns + (sum_k D_k) g ; dD_k[c] += sum_l g u (the same for every route k)
     const uint16_t *d0 = reinterpret_cast<const uint16_t *>(sm + LD::wave0 + LD::dup);
-    const uint16_t *d1 = reinterpret_cast<const uint16_t *>(sm + LD::wave0 + LD::wave_sz + LD::dup);
+    const uint16_t *d1 = NR == 4 ? reinterpret_cast<const uint16_t *>(sm + LD::wave0 + LD::wave_sz + LD::dup) : d0;
     uint16_t *dst = a.dx + ((int64_t)sb * a.D + c0) * L;
-    for (int v = threadIdx.x; v < 64 * L / 2; v += 128) {
+    for (int v = threadIdx.x; v < 64 * L / 2; v += NT) {
         float o[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = 2 * v + q, c = e / L, l = e - c * L, off = c * LP + l;
-            o[q] = fmaf(dsum[c], bf16_bits_to_float(gs[off]), bf16_bits_to_float(d0[off]) + bf16_bits_to_float(d1[off]));
+            const float du = NR == 4 ? bf16_bits_to_float(d0[off]) + bf16_bits_to_float(d1[off]) : bf16_bits_to_float(d0[off]);
+            o[q] = fmaf(dsum[c], bf16_bits_to_float(gs[off]), du);
         }
         *reinterpret_cast<uint32_t *>(dst + 2 * v) = pack_bf16x2(o[0], o[1]);
     }
-    {
+    if constexpr (NR == 4) {
         const int c = threadIdx.x >> 1, part = threadIdx.x & 1;      // two lanes per channel split the plane
         float s = 0.f;
         for (int l = part; l < L; l += 2) s = fmaf(bf16_bits_to_float(gs[c * LP + l]), bf16_bits_to_float(xs[c * LP + l]), s);
         s += __shfl_xor(s, 1, 64);
         if (part == 0)
             for (int kk = 0; kk < 4; ++kk) atomicAdd(a.dD + kk * a.D + c0 + c, s);
+    } else {
+        const int c = threadIdx.x;
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s = fmaf(bf16_bits_to_float(gs[c * LP + l]), bf16_bits_to_float(xs[c * LP + l]), s);
+        atomicAdd(a.dD + (int64_t)ws1 * a.D + c0 + c, s);
     }
 }
 
@@ -987,22 +1003,21 @@ __global__ void __launch_bounds__(256) deep_zero_kernel(float *p, const int n) {
     if (e < n) p[e] = 0.f;
 }
 
-// dA (4 D, N) += dAt (4, N, D)
-__global__ void __launch_bounds__(256) deep_dA_finish_kernel(const float *dAt, float *dA, const int D) {
+// dA (sets D, N) += dAt (sets, N, D)
+__global__ void __launch_bounds__(256) deep_dA_finish_kernel(const float *dAt, float *dA, const int D, const int sets) {
     const int e = blockIdx.x * 256 + threadIdx.x;                   // index into dA: (k D + c) N + n
-    if (e >= 4 * D * N) return;
+    if (e >= sets * D * N) return;
     const int n = e % N, r = e / N, k = r / D, c = r - k * D;
     dA[e] += dAt[((int64_t)k * N + n) * D + c];
 }
 
 static int deep_supported(int H, int W, int N_, int NR, int D, int R) {
-    return H == 7 && W == 7 && N_ == 16 && NR == 4 && D % 64 == 0 && R >= 1 && R <= 48;
+    return H == 7 && W == 7 && N_ == 16 && (NR == 4 || NR == 1) && D % 64 == 0 && R >= 1 && R <= 48;
 }
 
-template <int KS> static int deep_launch(const DeepArgs &da, hipStream_t s) {
-    constexpr bool bwd = true;
-    const size_t lds = DeepBwdLds::total;
-    const void *fn = (const void *)deep_bwd_kernel<KS>;
+template <int KS, int NR> static int deep_launch(const DeepArgs &da, hipStream_t s) {
+    const size_t lds = NR == 4 ? DeepBwdLds::total : DeepBwdLds::wave0 + DeepBwdLds::wave_sz;
+    const void *fn = (const void *)deep_bwd_kernel<KS, NR>;
     static LdsOptIn opted;
     if (lds > 64 * 1024 && !lds_opt_in(opted, fn, lds)) return XFM_ELAUNCH;
     DeepArgs args = da;
@@ -1012,14 +1027,137 @@ template <int KS> static int deep_launch(const DeepArgs &da, hipStream_t s) {
     args.dbg = env_dbg;
 #endif
     void *kargs[] = {&args};
+    const int sets = NR == 4 ? 4 : (da.a.Bt + da.a.wdiv - 1) / da.a.wdiv;
     // (a kernel, not a memset node: under stream capture the memset of this workspace slice replayed with stale contents)
-    if (bwd) hipLaunchKernelGGL(deep_zero_kernel, dim3((4 * N * da.a.D + 255) / 256), dim3(256), 0, s, da.dAt, 4 * N * da.a.D);
-    const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(da.a.Bt * (da.a.D / 64))), dim3(128), kargs, lds, s);
+    hipLaunchKernelGGL(deep_zero_kernel, dim3((sets * N * da.a.D + 255) / 256), dim3(256), 0, s, da.dAt, sets * N * da.a.D);
+    const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(da.a.Bt * (da.a.D / 64))), dim3(NR == 4 ? 128 : 64), kargs, lds, s);
     if (e != hipSuccess) {
         set_last_hip_error(e);
         return XFM_ELAUNCH;
     }
-    if (bwd) hipLaunchKernelGGL(deep_dA_finish_kernel, dim3((4 * da.a.D * N + 255) / 256), dim3(256), 0, s, da.dAt, da.a.dA, da.a.D);
+    hipLaunchKernelGGL(deep_dA_finish_kernel, dim3((sets * da.a.D * N + 255) / 256), dim3(256), 0, s, da.dAt, da.a.dA, da.a.D, sets);
+    return check_launch();
+}
+
+// ---- forward with ONE route per sample (n_routes == 1: the shallow swap block) ------------------------------------------
+// The first-design forward above puts a route and its reverse into the two halves of a wave; a sample with a single forward
+// route would idle half of it.  Here a workgroup is one wave = 64 channels of the sample's route, the second design's B / C
+// table in LDS (pair-interleaved: one 16-byte broadcast read per position and state pair), and -- nothing but the dt_proj
+// MFMAs of a step's head runs beside them -- the two states of a pair as packed fp32, all eight pairs unrolled with their
+// decay rates and states in registers.  Writes the packed row checkpoints deep_bwd_kernel<KS, 1> reads.
+struct DeepFwd1Lds {
+    static constexpr size_t xs = 0, ys = xs + 64 * LP * 2, T = ys + 64 * LP * 4, total = T + (size_t)TBL * 4;
+};
+
+template <int KS>
+__global__ void __launch_bounds__(64) deep_fwd1_kernel(const DeepArgs da) {
+    const ChanArgs &a = da.a;
+    extern __shared__ float smem[];
+    char *sm = reinterpret_cast<char *>(smem);
+    uint16_t *xs = reinterpret_cast<uint16_t *>(sm + DeepFwd1Lds::xs);
+    float *ys = reinterpret_cast<float *>(sm + DeepFwd1Lds::ys);
+    float *T = reinterpret_cast<float *>(sm + DeepFwd1Lds::T);
+    const int lane = threadIdx.x;
+    const int tiles = a.D / 64;
+    int sb, c0;
+    chan_block_map(a.xmap, tiles, sb, c0);
+    c0 *= 64;
+    const int ws = sb / a.wdiv;
+    {
+        const uint16_t *src = a.x + ((int64_t)sb * a.D + c0) * L;
+        constexpr int NVX = 64 * L / 8, PX = (NVX + 63) / 64;
+        cu32x4_t rx[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int v = lane + 64 * j;
+            rx[j] = *reinterpret_cast<const cu32x4_t *>(src + 8 * (v < NVX ? v : 0));
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int v = lane + 64 * j;
+            if (v < NVX) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = 8 * v + 2 * q, c = e / L, l = e - c * L;
+                    const int e1 = e + 1, c1 = e1 / L, l1 = e1 - c1 * L;
+                    xs[c * LP + l] = (uint16_t)(rx[j][q] & 0xffffu);
+                    xs[c1 * LP + l1] = (uint16_t)(rx[j][q] >> 16);
+                }
+            }
+        }
+    }
+    deep_fill_bc(a, sb, sb, 0, T, lane);
+    const int64_t wrow = (int64_t)ws * a.D + c0 + lane;
+    const float bv = a.bias[wrow], Dv = a.Dp[wrow];
+    df2 A2p[N / 2], h2[N / 2];
+    {
+        const float *Arow = a.A + wrow * N;
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4 *>(Arow + 4 * q);
+            A2p[2 * q] = df2{t.x, t.y} * kLog2e;
+            A2p[2 * q + 1] = df2{t.z, t.w} * kLog2e;
+        }
+#pragma unroll
+        for (int np = 0; np < N / 2; ++np) h2[np] = df2{0.f, 0.f};
+    }
+    DeepX<KS> xf;
+    DeepW<KS> wf;
+    deep_load_x<KS>(a, sb, 0, 0, lane, xf);
+    deep_load_w<KS>(a, c0, ws, lane, wf);
+    uint32_t *chk = da.chkp + ((int64_t)sb * NSTEP) * (N / 2) * a.D + c0 + lane;
+    wave_sync();
+#pragma unroll 1
+    for (int st = 0; st < NSTEP; ++st) {
+        const cf32x16_t acc = deep_dt_step<KS>(bv, xf, wf);
+        if (st + 1 < NSTEP) deep_load_x<KS>(a, sb, 0, st + 1, lane, xf);
+        float dl[P], u[P], dlu[P];
+        df2 y2[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            dl[i] = chan_softplus(acc[i]);
+            u[i] = bf16_bits_to_float(xs[lane * LP + st * P + i]);
+            dlu[i] = dl[i] * u[i];
+            y2[i] = df2{0.f, 0.f};
+        }
+        const float4 *Tst = reinterpret_cast<const float4 *>(T) + st * 8;
+#pragma unroll
+        for (int np = 0; np < N / 2; ++np) {
+            df2 h = h2[np];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const float4 q = Tst[np * NSTEP * 8 + i];            // (B, C) of both states at position i: one broadcast read
+                const df2 t = A2p[np] * dl[i];
+                const df2 av = {exp2_fast(t.x), exp2_fast(t.y)};
+                h = __builtin_elementwise_fma(av, h, df2{q.x, q.y} * dlu[i]);
+                y2[i] = __builtin_elementwise_fma(df2{q.z, q.w}, h, y2[i]);
+            }
+            h2[np] = h;
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) ys[lane * LP + st * P + i] = fmaf(Dv, u[i], y2[i].x + y2[i].y);
+        if (st + 1 < NSTEP) {
+#pragma unroll
+            for (int np = 0; np < N / 2; ++np) chk[((int64_t)st * (N / 2) + np) * a.D] = pack_bf16x2(h2[np].x, h2[np].y);
+        }
+    }
+    wave_sync();
+    float *dst = a.y + ((int64_t)sb * a.D + c0) * L;
+    for (int v = lane; v < 64 * L / 4; v += 64) {
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = 4 * v + q, c = e / L, l = e - c * L;
+            o[q] = ys[c * LP + l];
+        }
+        *reinterpret_cast<float4 *>(dst + 4 * v) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int KS> static int deep_fwd1_launch(const DeepArgs &da, hipStream_t s) {
+    DeepArgs args = da;
+    args.dbg = 0;
+    hipLaunchKernelGGL(deep_fwd1_kernel<KS>, dim3((unsigned)(da.a.Bt * (da.a.D / 64))), dim3(64), DeepFwd1Lds::total, s, args);
     return check_launch();
 }
 
@@ -1072,6 +1210,7 @@ static int chan_supported(int HW_h, int HW_w, int N, int NR, int D, int R) {
     if (N == 1 && NR == 4 && (HW_h == 7 || HW_h == 12 || HW_h == 14)) return 1;
 #ifdef XFM_CHAN_N16
     if (N == 16 && NR == 4 && (HW_h == 5 || HW_h == 7 || HW_h == 12)) return 1;
+    if (N == 16 && NR == 1 && HW_h == 7 && D % 64 == 0 && R <= 48) return 1;      // the shallow swap block: namespace deep
 #endif
     return 0;
 }
@@ -1093,6 +1232,7 @@ static int chan_run(const xfm_ss2dc_params_t *p, bool bwd, void *stream) {
     a.XC = p->n_routes * a.C2p;
     a.Kp = (p->dt_rank + 15) / 16 * 16;
     a.c_mod = p->c_mod; a.c_off = p->c_off;
+    a.wdiv = p->wdiv > 0 ? p->wdiv : 1;
     a.zeros = (const uint16_t *)p->zeros;
     a.xmap = (p->batch % 8 == 0 && !getenv("XFM_CHAN_NO_XMAP")) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
@@ -1105,17 +1245,27 @@ static int chan_run(const xfm_ss2dc_params_t *p, bool bwd, void *stream) {
         // workspace (xfm_ss2dc_nsteps = 7 steps): packed bf16 checkpoints in the first half, the dA scratch behind.
         // Forward: the first-design kernel (two directions per wave; 222 us against 307 us for a 64-lane forward of the
         // second design) writing one packed checkpoint per row / column; backward: namespace deep.
+        deep::DeepArgs da;
+        da.a = a;
+        da.chkp = reinterpret_cast<uint32_t *>(p->chk);
+        da.dAt = p->chk + (size_t)p->batch * p->n_routes * deep::NSTEP * (deep::N / 2) * p->d_inner;   // (sets * 16 D floats of the second half)
+        if (p->n_routes == 1) {
+            // one forward route per sample (the shallow swap block): the single-route kernels of namespace deep, both ways
+            if (p->wdiv < 1 || p->c_mod != 0 || (p->batch + p->wdiv - 1) / p->wdiv > p->batch * deep::NSTEP / 4) return XFM_EINVAL;
+            switch (a.Kp / 16) {
+                case 1: return bwd ? deep::deep_launch<1, 1>(da, s) : deep::deep_fwd1_launch<1>(da, s);
+                case 2: return bwd ? deep::deep_launch<2, 1>(da, s) : deep::deep_fwd1_launch<2>(da, s);
+                case 3: return bwd ? deep::deep_launch<3, 1>(da, s) : deep::deep_fwd1_launch<3>(da, s);
+            }
+            return XFM_ELIMIT;
+        }
         if (!bwd) {
             a.chk16 = reinterpret_cast<uint16_t *>(p->chk);
         } else {
-            deep::DeepArgs da;
-            da.a = a;
-            da.chkp = reinterpret_cast<uint32_t *>(p->chk);
-            da.dAt = p->chk + (size_t)p->batch * 4 * deep::NSTEP * (deep::N / 2) * p->d_inner;   // (64 D floats of the second half)
             switch (a.Kp / 16) {
-                case 1: return deep::deep_launch<1>(da, s);
-                case 2: return deep::deep_launch<2>(da, s);
-                case 3: return deep::deep_launch<3>(da, s);
+                case 1: return deep::deep_launch<1, 4>(da, s);
+                case 2: return deep::deep_launch<2, 4>(da, s);
+                case 3: return deep::deep_launch<3, 4>(da, s);
             }
         }
     }

@@ -33,6 +33,7 @@ struct ChanArgs {
     const uint16_t *zeros;   // >= 2 * Kp zero bf16 (16-byte aligned): k-slots of the other route of a pair
     int ct;                  // consecutive 32-channel tiles walked by one workgroup (amortises the dB / dC flush)
     int xmap;                // 1: samples are dealt to the XCDs (Bt % 8 == 0), see chan_block_map
+    int wdiv;                // n_routes == 1: sample sb uses weight set sb / wdiv (include/xfm_hip.h)
 };
 
 // Workgroup -> (sample, first index inside the sample).  Every workgroup of a sample re-reads that sample's x_proj rows

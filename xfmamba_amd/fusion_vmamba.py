@@ -52,6 +52,9 @@ SS2D_MODE = "fused"          # "fused" | "unfused"
 # planes from in_proj's GEMM epilogue layout.  "planes": NCHW as the reference's channel_first blocks
 # (1x1 convs through MIOpen).  Same parameters, same results.
 STREAM_LAYOUT = "tokens"
+# the shallow block's swap scan as one kernel each way (xfm_ss2dc_fwd/_bwd, n_routes 1); XFM_SHALLOW_KERNEL=0: the
+# swap_scan -> matmul -> matmul -> selective_scan_fn operator chain (the A/B switch of the tests)
+SHALLOW_KERNEL = os.environ.get("XFM_SHALLOW_KERNEL", "1") == "1"
 
 
 def trunc_normal_(t, std=0.02):
@@ -1058,6 +1061,23 @@ class ShallowFuse_SS2Dv4(nn.Module):
         xp, pooled = tokens_to_planes_pooled(xp.view(B2, L, D))                                # planes + the squeeze pooling (:866)
         xp = xp.view(B2, D, H, W)
         xc = _dwconv_act(self.conv2d, self.act, xp) if self.with_dconv else self.act(xp)
+        from .ss2d_chan import chan_supported, ss2d_chan_swap_fn, swap_views_stacked
+        f1 = self.fc1
+        if len(f1) == 4 and isinstance(f1[1], nn.SiLU) and isinstance(f1[3], nn.Sigmoid):
+            gate = torch.sigmoid(_linear_rows(f1[2], F.silu(_linear_rows(f1[0], pooled))))
+        else:
+            gate = f1(pooled)                                                                # [gate 1 | gate 2]
+        if SHALLOW_KERNEL and xc.dtype == torch.bfloat16 and D % 2 == 0 and chan_supported(xc, H, W, N, 1, D, R):
+            # the exchange as ONE kernel each way: the two swap routes are 2B single-route samples in
+            # [view 1 | view 2] order, x_proj / dt_proj inside the node, the reference's pass-through swap gradient kept
+            xs = swap_views_stacked(xc.view(B2, D, L))                                       # (2B, D, L) = [route 0 | route 1]
+            ys = ss2d_chan_swap_fn(xs, self.x_proj_weight, self.dt_projs_weight, -self.A_logs.float().exp(), self.Ds.float(),
+                                   self.dt_projs_bias.reshape(-1).float(), H, W)             # (2B, D, L) fp32, view order
+            yy = layernorm2d_fn(ys.view(B2, D, H, W), self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, xp.dtype)
+            # view 1's map is gated by view 2's squeeze and the other way round (:870-871)
+            gate = torch.cat([gate[B:], gate[:B]], dim=0)
+            o = _linear_rows(self.out_proj, gated_planes_to_tokens(yy.view(B2, D, L), gate))
+            return self.dropout(o).view(2, B, H, W, -1).transpose(0, 1)                      # (B, 2, H, W, C) as a view
         xs = SwappingScanStacked.apply(xc)                                                   # (B, 2, D, L)
         x_dbl = torch.matmul(self.x_proj_weight.to(xs.dtype), xs)                            # (B, 2, R + 2N, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
@@ -1066,11 +1086,6 @@ class ShallowFuse_SS2Dv4(nn.Module):
                                Cs.contiguous(), self.Ds.float(), self.dt_projs_bias.reshape(-1).float(), True, True, None)
         # (slices of ys are what SwappingMerge_multiview returns, and their gradient is its stack)
         yy = layernorm2d_fn(ys.view(B * 2, D, H, W), self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, xp.dtype)
-        f1 = self.fc1
-        if len(f1) == 4 and isinstance(f1[1], nn.SiLU) and isinstance(f1[3], nn.Sigmoid):
-            gate = torch.sigmoid(_linear_rows(f1[2], F.silu(_linear_rows(f1[0], pooled))))
-        else:
-            gate = f1(pooled)                                                                # [gate 1 | gate 2]
         # view 1's map is gated by view 2's squeeze and the other way round (:870-871): (sample, view) order, swapped
         gate = torch.stack([gate[B:], gate[:B]], dim=1).view(B * 2, D)
         # (a transposing copy + one 3136-row GEMM: 64 per-sample products through batched_proj measured 41 vs 33 us here)

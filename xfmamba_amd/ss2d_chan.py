@@ -20,7 +20,7 @@ from . import amp as _amp
 from .amp import cast_weight
 from .proj import zeros_f32, _transpose_raw, _transpose_short_ok
 
-__all__ = ["ss2d_chan_fn", "chan_supported", "SS2DChanHip"]
+__all__ = ["ss2d_chan_fn", "ss2d_chan_swap_fn", "swap_views_stacked", "chan_supported", "SS2DChanHip", "SS2DChanSwapHip"]
 
 ENABLED = os.environ.get("XFM_SS2D_CHAN", "1") == "1"       # read once at import (A/B switch of the benches)
 
@@ -219,3 +219,136 @@ def ss2d_chan_fn(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod=0, c
     as one batch [view 1 | view 2 | fused]: the view streams read through the fused stream's C, reference
     models/fusion_vmamba.py:536-538, 567-569)."""
     return SS2DChanHip.apply(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod, c_off)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the shallow swap block (reference models/fusion_vmamba.py:189-241, 808-845): K = 2 FORWARD-ONLY row-major routes over the
+# two channel-swapped views.  With the views stacked [view 1 | view 2] along the batch axis the two routes ARE 2B samples
+# with one route each (route k = rows k B .. (k + 1) B - 1, weight set k): xfm_ss2dc_fwd/_bwd with n_routes == 1, wdiv == B --
+# the single-route kernels of csrc/ss2d_chan.hip (namespace deep), dt_proj inside, no (B, 2, D, L) step-size tensor, no
+# swap_scan -> matmul -> matmul -> contiguous -> rowscan operator chain.
+# ---------------------------------------------------------------------------------------------------------------------
+class SwapViewsStacked(torch.autograd.Function):
+    """x = [view 1 | view 2] (2B, C, L) -> [route 0 | route 1] (2B, C, L): even channels exchanged between the views
+    (``SwappingScan_multiview``, reference fusion_vmamba.py:189-221).  ``xfm_swap_scan`` with the batch folded into the channel
+    axis (C even, so channel parity survives) writes the two routes one after the other.  The backward is the reference's
+    un-swapped pass-through (:217-221): route k's gradient goes to view k -- in this ordering the identity."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_cuda(x)
+        B2, C, L = x.shape
+        if B2 % 2 or C % 2:
+            raise RuntimeError("swap_views_stacked: an even batch [view 1 | view 2] and an even channel count expected")
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        half = x.numel() // 2
+        with torch.cuda.device(x.device), _lib.timed("swap_scan", 2 * x.numel() * x.element_size()):
+            _lib.check(_lib.lib().xfm_swap_scan(x.data_ptr(), x.data_ptr() + half * x.element_size(), out.data_ptr(), 1,
+                                                (B2 // 2) * C, L, _lib.dtype_code(x.dtype), _lib.stream_ptr()), "swap_scan")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy
+
+
+def swap_views_stacked(x):
+    return SwapViewsStacked.apply(x)
+
+
+class SS2DChanSwapHip(torch.autograd.Function):
+    """x_proj -> split -> dt_proj -> softplus -> scan of the two swap routes (fusion_vmamba.py:813-833) as one node.
+    x (2B, D, L) bf16 = [route 0 | route 1] planes; x_proj_weight (2, R + 2N, D); dt_projs_weight (2, D, R); A (2D, N);
+    D / bias (2D,) -> ys (2B, D, L) fp32 = [route 0 | route 1]."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, x_proj_w, dt_w, A, D, bias, H, W):
+        _lib.require_cuda(x, x_proj_w, dt_w, A, D, bias)
+        Bt, Dm, L = x.shape
+        K, C2, _ = x_proj_w.shape
+        R, N = dt_w.shape[2], A.shape[1]
+        if L != H * W or K != 2 or Bt % 2 or C2 != R + 2 * N or x.dtype != torch.bfloat16:
+            raise RuntimeError("ss2d_chan_swap: x (2B,D,H*W) bf16, x_proj_weight (2,R+2N,D), dt_projs_weight (2,D,R) expected")
+        x = x.contiguous()
+        B = Bt // 2
+        Rp8, NBo, C2p, idx = _col_layout(R, N)
+        wdt = cast_weight(dt_w, x.dtype)
+        wdt = (torch.nn.functional.pad(wdt, (0, Rp8 - R)) if Rp8 != R else wdt).contiguous()    # (2, D, Rp8)
+        xw = cast_weight(x_proj_w, x.dtype)
+        if Rp8 == R:
+            xw_pad = (torch.nn.functional.pad(xw, (0, 0, 0, C2p - C2)) if C2p != C2 else xw).contiguous()
+        else:
+            xw_pad = torch.zeros((K, C2p, Dm), dtype=x.dtype, device=x.device)
+            xw_pad[:, torch.tensor(idx, device=x.device)] = xw
+        xt = _transpose_raw(x, False)                                                        # (2B, L, D) token-major
+        xdbl = torch.bmm(xt.view(K, B * L, Dm), xw_pad.transpose(1, 2)).view(Bt, L, C2p)     # one product per weight set
+        A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
+        lib = _lib.lib()
+        nst = lib.xfm_ss2dc_nsteps(H, W, N)
+        chk = torch.empty((Bt, 1, nst, N, Dm), dtype=torch.float32, device=x.device)
+        y = torch.empty((Bt, Dm, L), dtype=torch.float32, device=x.device)
+        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 1, 0, 0, B, chk)
+        p.y = y.data_ptr()
+        with torch.cuda.device(x.device), _lib.timed("ss2dc16s_fwd", Bt * Dm * L * (2 + 4) + xdbl.numel() * 2):
+            _lib.check(lib.xfm_ss2dc_fwd(ctypes.byref(p), _lib.stream_ptr()), "ss2dc_fwd (n_routes 1)")
+        ctx.hw = (H, W)
+        ctx.meta = (x_proj_w.dtype, tuple(x_proj_w.shape), dt_w.dtype)
+        ctx.save_for_backward(x, xt, xdbl, xw_pad, wdt, A, D, bias, chk)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        from .proj import _bmm_f32
+        x, xt, xdbl, xw_pad, wdt, A, D, bias, chk = ctx.saved_tensors
+        H, W = ctx.hw
+        xw_dtype, xw_shape, dtw_dtype = ctx.meta
+        dev = x.device
+        Bt, Dm, L = x.shape
+        K, C2 = xw_shape[0], xw_shape[1]
+        B = Bt // 2
+        N = A.shape[1]
+        R = C2 - 2 * N
+        Rp8, NBo, C2p, idx = _col_layout(R, N)
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        ddts = torch.empty((Bt, 1, L, Dm), dtype=x.dtype, device=dev)
+        nbc, na, nd = Bt * 2 * N * L, A.numel(), D.numel()
+        acc = zeros_f32(nbc + na + 2 * nd, dev)                # ONE fill for all accumulators
+        dBC = acc[:nbc].view(Bt, 1, 2, N, L)
+        dA = acc[nbc:nbc + na].view(A.shape)
+        dD, dbias = acc[nbc + na:nbc + na + nd], acc[nbc + na + nd:]
+        lib = _lib.lib()
+        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 1, 0, 0, B, chk)
+        p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
+        p.dBC, p.dA, p.dD, p.ddelta_bias = dBC.data_ptr(), dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
+        with torch.cuda.device(dev), _lib.timed("ss2dc16s_bwd", Bt * Dm * L * (2 + 4 + 2 + 2) + xdbl.numel() * 2):
+            _lib.check(lib.xfm_ss2dc_bwd(ctypes.byref(p), _lib.stream_ptr()), "ss2dc_bwd (n_routes 1)")
+        # d x_dbl: the dt_proj columns from ddts (one small product per weight set), the B / C columns from the scan kernel
+        g2 = ddts.view(K, B * L, Dm)
+        dxr = torch.bmm(g2, wdt)                                                             # (2, B L, Rp8), zero beyond R
+        dbc = dBC.view(Bt, 2 * N, L).transpose(1, 2).to(x.dtype)                             # (2B, L, 2N): [dB | dC]
+        dxdbl = torch.cat([dxr.view(Bt, L, Rp8), dbc], dim=2)                                # (2B, L, C2p)
+        dwdt = _bmm_f32(g2.transpose(1, 2), xdbl.view(K, B * L, C2p)[:, :, :R])              # (2, D, R) fp32
+        # x_proj backward: dx += (d x_dbl . Wx)^T through the streaming transpose, dWx = d x_dbl^T . x (token-major x)
+        d2 = dxdbl.view(K, B * L, C2p)
+        t = torch.bmm(d2, xw_pad).view(Bt, L, Dm)
+        if dx.data_ptr() % 16 == 0 and t.is_contiguous() and _transpose_short_ok(t, L, Dm):
+            with torch.cuda.device(dev), _lib.timed("transpose_short", t.numel() * 6):
+                _lib.check(lib.xfm_transpose_short_add_bf16(t.data_ptr(), dx.data_ptr(), Bt, L, Dm, _lib.stream_ptr()),
+                           "transpose_short_add")                                            # dx += t^T
+        else:
+            dx += t.transpose(1, 2)
+        dxw_pad = _bmm_f32(d2.transpose(1, 2), xt.view(K, B * L, Dm))                        # (2, C2p, D) fp32
+        if Rp8 == R:
+            dxw = dxw_pad[:, :C2].to(xw_dtype)
+        else:
+            dxw = dxw_pad[:, torch.tensor(idx, device=dev)].to(xw_dtype)
+        return dx, dxw, dwdt.to(dtw_dtype), dA, dD, dbias, None, None
+
+
+def ss2d_chan_swap_fn(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W):
+    """x (2B, D, L) bf16 = [route 0 | route 1] (``swap_views_stacked``); weights of the two routes stacked -> (2B, D, L) fp32."""
+    return SS2DChanSwapHip.apply(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W)
