@@ -430,6 +430,9 @@ int xfm_ss2d_bwd_ws(const xfm_ss2d_params_t *p, void *workspace, size_t workspac
 typedef struct {
     int batch, d_inner, H, W, dstate, dt_rank, n_routes;
     int c_mod, c_off, wdiv;
+    int y_tokens;          /* != 0: y and dy are TOKEN-MAJOR (batch, L, d_inner) fp32 -- what a row LayerNorm / token GEMM behind the
+                              scan reads and hands back (out_norm + out_proj, models/fusion_vmamba.py:1186-1205), so that neither is a
+                              layout-changing operator; only where xfm_ss2dc_ytokens_supported() says so, XFM_ELIMIT otherwise */
     const void *x, *xdbl, *wdt;
     const void *zeros;     /* >= 256 bytes of zeros, 16-byte aligned (k-slots of the sibling route in the stacked product) */
     const float *A, *D, *delta_bias;
@@ -440,6 +443,7 @@ typedef struct {
     float *dBC, *dA, *dD, *ddelta_bias;
 } xfm_ss2dc_params_t;
 int xfm_ss2dc_supported(int H, int W, int dstate, int n_routes, int d_inner, int dt_rank);
+int xfm_ss2dc_ytokens_supported(int H, int W, int dstate, int n_routes);
 int xfm_ss2dc_nsteps(int H, int W, int dstate);
 int xfm_ss2dc_fwd(const xfm_ss2dc_params_t *p, void *stream);
 int xfm_ss2dc_bwd(const xfm_ss2dc_params_t *p, void *stream);

@@ -80,6 +80,34 @@ def test_ss2d_chan_matches_oracle_chain(B, D, HW, R):
         assert_close(a.float().cpu(), b.float(), tol, tol * float(b.abs().max()) + 1e-7, name)
 
 
+@pytest.mark.parametrize("B,D,HW,R", [(2, 384, 14, 24), (3, 768, 7, 48), (1, 96, 14, 6), (5, 32, 7, 2), (64, 384, 14, 24), (16, 768, 7, 48)])
+def test_ss2d_chan_token_major_output_matches_oracle_chain(B, D, HW, R):
+    """The same operator with y written and dy read TOKEN-MAJOR (B, L, D) (``y_tokens``: what the row LayerNorm and the token
+    GEMM of out_norm / out_proj behind the scan take, models/fusion_vmamba.py:1186-1205): output and every gradient against the
+    oracle chain, and bit-identical to the plane-major run of the same kernels (only the epilogue / prologue addressing differs)."""
+    from xfmamba_amd.ss2d_chan import chan_supported, ss2d_chan_fn, ytokens_supported
+    N = 1
+    assert ytokens_supported(HW, HW, N)
+    x, xw, dtw, A, Dp, bias, gy = _inputs(B, D, HW, R, N, B * D + HW + R)
+    ref = _oracle(x, xw, dtw, A, Dp, bias, gy, HW, N)
+    outs = []
+    for tok in (True, False):
+        t = [v.to(DEV).requires_grad_() for v in (x.bfloat16(), xw, dtw, A, Dp, bias)]
+        assert chan_supported(t[0], HW, HW, N, 4, D, R)
+        y = ss2d_chan_fn(t[0], t[1], t[2], t[3], t[4], t[5], HW, HW, y_tokens=tok)
+        assert y.shape == ((B, HW * HW, D) if tok else (B, D, HW * HW)) and y.dtype == torch.float32
+        g = gy.to(DEV)
+        y.backward(g.transpose(1, 2).contiguous() if tok else g)
+        outs.append([(y.detach().transpose(1, 2) if tok else y.detach())] + [v.grad for v in t])
+    tols = (5e-3 if HW > 12 else 2e-3, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2)
+    for name, a, b, tol in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), outs[0], ref, tols):
+        assert_close(a.float().cpu(), b.float(), tol, tol * float(b.abs().max()) + 1e-7, name)
+    # y: the same arithmetic, bit for bit.  dx also takes the x_proj gradient of the dB / dC columns, which both runs sum over
+    # the channel tiles with fp32 atomics in launch order: equal up to that order's rounding (one bf16 ulp here and there)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert_close(outs[0][1].float().cpu(), outs[1][1].float().cpu(), 8e-3, 8e-3 * float(outs[1][1].float().abs().max()), "dx tokens vs planes")
+
+
 def test_ss2d_chan_equals_lean_fused_path_at_bench_shape():
     """Stage-2 shape of the bench (two views of 32 samples, 384 channels, 14 x 14): the channel-lane kernel and the
     lean chunk-scan kernel chain (dt_proj kernel + xfm_ss2d_fwd/_bwd) are two implementations of the same operator."""

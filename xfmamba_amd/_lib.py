@@ -26,7 +26,7 @@ SYMBOLS = (
     "xfm_add_layernorm_rows_supported", "xfm_add_layernorm_rows_bwd_blocks", "xfm_add_layernorm_rows_fwd",
     "xfm_add_layernorm_rows_bwd", "xfm_colsum_blocks", "xfm_bias_gelu_fwd", "xfm_bias_gelu_bwd", "xfm_colsum", "xfm_partial_sums_multi", "xfm_pooled_transpose_fwd", "xfm_pooled_transpose_bwd", "xfm_gated_transpose_fwd", "xfm_gated_transpose_bwd", "xfm_views_avg_stack_fwd", "xfm_views_avg_stack_bwd", "xfm_bn_tokens_supported", "xfm_bn_tokens_ws_floats", "xfm_bn_tokens_fwd", "xfm_bn_tokens_bwd", "xfm_transpose_short_supported", "xfm_transpose_short", "xfm_transpose_short_add_bf16", "xfm_residual_settle_fwd", "xfm_residual_settle_bwd", "xfm_tokens_gemm_supported", "xfm_tokens_gemm", "xfm_tokens_gemm2_supported", "xfm_tokens_gemm2", "xfm_tokens_gemm2_parts_blocks", "xfm_tokens_gemm2_parts", "xfm_proj_gemm_supported", "xfm_proj_gemm", "xfm_proj_gemm_accumulate", "xfm_planes_gemm_supported", "xfm_planes_gemm",
     "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd", "xfm_ss2d_bwd_ws_bytes", "xfm_ss2d_bwd_ws", "xfm_ss2d_dtfused_rank", "xfm_ss2d_xr_rows",
-    "xfm_ss2dc_supported", "xfm_ss2dc_nsteps", "xfm_ss2dc_fwd", "xfm_ss2dc_bwd", "xfm_ss2dc_post",
+    "xfm_ss2dc_supported", "xfm_ss2dc_ytokens_supported", "xfm_ss2dc_nsteps", "xfm_ss2dc_fwd", "xfm_ss2dc_bwd", "xfm_ss2dc_post",
     "xfm_fp8_planes_gemm_supported", "xfm_fp8_planes_gemm", "xfm_adam_multi", "xfm_adam_multi_scaled",
     "xfm_wgrad_supported", "xfm_wgrad",
 )
@@ -72,6 +72,7 @@ class SS2DCParams(C.Structure):
     _fields_ = [
         ("batch", C.c_int), ("d_inner", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dstate", C.c_int),
         ("dt_rank", C.c_int), ("n_routes", C.c_int), ("c_mod", C.c_int), ("c_off", C.c_int), ("wdiv", C.c_int),
+        ("y_tokens", C.c_int),
         ("x", C.c_void_p), ("xdbl", C.c_void_p), ("wdt", C.c_void_p), ("zeros", C.c_void_p),
         ("A", C.c_void_p), ("D", C.c_void_p), ("delta_bias", C.c_void_p),
         ("y", C.c_void_p), ("chk", C.c_void_p), ("dy", C.c_void_p), ("dx", C.c_void_p), ("ddts", C.c_void_p),
@@ -116,6 +117,7 @@ def lib() -> C.CDLL:
             fn.restype = C.c_int
         l.xfm_ss2dc_supported.argtypes = [C.c_int] * 6
         l.xfm_ss2dc_nsteps.argtypes = [C.c_int] * 3
+        l.xfm_ss2dc_ytokens_supported.argtypes = [C.c_int] * 4
         l.xfm_fp8_planes_gemm_supported.argtypes = [C.c_int] * 2
         l.xfm_fp8_planes_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
         l.xfm_partial_sums_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

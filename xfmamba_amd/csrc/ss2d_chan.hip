@@ -1204,6 +1204,7 @@ template <int HW, int N> static int chan_dispatch_ks(const ChanArgs &a, bool bwd
 
 int chan1_run(const ChanArgs &a, int HW, bool bwd, hipStream_t s);      // ss2d_chan1.hip: d_state 1, second generation
 int chan1_covers(int H, int W, int N, int n_routes);
+int chan1_ytok(int H, int W, int N, int n_routes);
 
 static int chan_supported(int HW_h, int HW_w, int N, int NR, int D, int R) {
     if (HW_h != HW_w || D % 32 || R < 1 || R > 64) return 0;
@@ -1233,6 +1234,8 @@ static int chan_run(const xfm_ss2dc_params_t *p, bool bwd, void *stream) {
     a.Kp = (p->dt_rank + 15) / 16 * 16;
     a.c_mod = p->c_mod; a.c_off = p->c_off;
     a.wdiv = p->wdiv > 0 ? p->wdiv : 1;
+    a.ytok = p->y_tokens ? 1 : 0;
+    if (a.ytok && (p->c_mod != 0 || !chan1_ytok(p->H, p->W, p->dstate, p->n_routes))) return XFM_ELIMIT;
     a.zeros = (const uint16_t *)p->zeros;
     a.xmap = (p->batch % 8 == 0 && !getenv("XFM_CHAN_NO_XMAP")) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
@@ -1296,6 +1299,7 @@ extern "C" {
 int xfm_ss2dc_supported(int H, int W, int dstate, int n_routes, int d_inner, int dt_rank) {
     return xfm::chan_supported(H, W, dstate, n_routes, d_inner, dt_rank);
 }
+int xfm_ss2dc_ytokens_supported(int H, int W, int dstate, int n_routes) { return xfm::chan1_ytok(H, W, dstate, n_routes); }
 int xfm_ss2dc_nsteps(int H, int W, int dstate) {
     if (H == 7 && W == 7 && dstate == 16) return 7;      // one row / column per step (second design, namespace deep)
     if (xfm::chan1_covers(H, W, dstate, 4)) return H;    // ss2d_chan1.hip: one row / column per step at every size

@@ -189,6 +189,52 @@ __device__ __forceinline__ void stage_tile(uint32_t *xg, const uint16_t *xsrc, c
     }
 }
 
+// The same staging with dy TOKEN-MAJOR (a.ytok: dy (Bt, L, D) fp32, the layout a row LayerNorm / token GEMM hands back): a
+// position's 32 channels of this tile are 128 contiguous bytes.  x (plane-major run) fills the low halves of the words, dy the
+// high halves, as 2-byte LDS writes; all of a thread's loads are in flight before the first write.
+template <int HW>
+__device__ __forceinline__ void stage_tile_tok(uint32_t *xg, const uint16_t *xsrc, const float *gtok, const int D, const int tid) {
+    constexpr int L = HW * HW, Lq = Lds<HW>::Lq;
+    constexpr int NX = 32 * L / 8, KX = (NX + 127) / 128;          // x: groups of 8 positions of a channel
+    constexpr int NG = L * 8, KG = (NG + 127) / 128;               // dy: groups of 4 channels of a position
+    cu32x4_t xr[KX];
+    float4 g[KG];
+#pragma unroll
+    for (int k = 0; k < KX; ++k)
+        if (tid + 128 * k < NX) xr[k] = *reinterpret_cast<const cu32x4_t *>(xsrc + 8 * (tid + 128 * k));
+#pragma unroll
+    for (int k = 0; k < KG; ++k) {
+        const int v = tid + 128 * k;
+        if (v < NG) g[k] = *reinterpret_cast<const float4 *>(gtok + (int64_t)(v >> 3) * D + 4 * (v & 7));
+    }
+    uint16_t *x16 = reinterpret_cast<uint16_t *>(xg);
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        const int v = tid + 128 * k;
+        if (v < NX) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = 8 * v + 2 * q, c = e / L, l = e - c * L;
+                const int e1 = e + 1, c1 = e1 / L, l1 = e1 - c1 * L;
+                x16[2 * (c * Lq + l)] = (uint16_t)(xr[k][q] & 0xffffu);
+                x16[2 * (c1 * Lq + l1)] = (uint16_t)(xr[k][q] >> 16);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KG; ++k) {
+        const int v = tid + 128 * k;
+        if (v < NG) {
+            const int l = v >> 3, c4 = 4 * (v & 7);
+            const uint32_t p0 = pack_bf16x2(g[k].x, g[k].y), p1 = pack_bf16x2(g[k].z, g[k].w);
+            x16[2 * ((c4 + 0) * Lq + l) + 1] = (uint16_t)(p0 & 0xffffu);
+            x16[2 * ((c4 + 1) * Lq + l) + 1] = (uint16_t)(p0 >> 16);
+            x16[2 * ((c4 + 2) * Lq + l) + 1] = (uint16_t)(p1 & 0xffffu);
+            x16[2 * ((c4 + 3) * Lq + l) + 1] = (uint16_t)(p1 >> 16);
+        }
+    }
+}
+
 template <int HW, int KS, bool COL>
 __device__ __forceinline__ void bwd_pass(const ChanArgs &a, const int sb, const int c0, char *sm) {
     using G = Geom1<HW>;
@@ -379,7 +425,8 @@ __global__ void __launch_bounds__(128, 2) bwd_kernel(const ChanArgs a) {
     int sb, t;
     chan_block_map(a.xmap, a.D / 32, sb, t);
     const int c0 = 32 * t;
-    stage_tile<HW>(xg, a.x + ((int64_t)sb * a.D + c0) * L, a.dy + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
+    if (a.ytok) stage_tile_tok<HW>(xg, a.x + ((int64_t)sb * a.D + c0) * L, a.dy + (int64_t)sb * L * a.D + c0, a.D, threadIdx.x);
+    else stage_tile<HW>(xg, a.x + ((int64_t)sb * a.D + c0) * L, a.dy + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
     if (threadIdx.x < 32) {
         const int q = threadIdx.x;
         dsum[q] = (a.Dp[c0 + q] + a.Dp[a.D + c0 + q]) + (a.Dp[2 * a.D + c0 + q] + a.Dp[3 * a.D + c0 + q]);
@@ -636,7 +683,15 @@ __global__ void __launch_bounds__(128, 2) fwd_kernel(const ChanArgs a) {
         const int o = (c * Lq + l) * 4;
         return fmaf(dsum[c], bf16_bits_to_float(xs[c * Lp + l]), y_ld<YT>(yr + o) + y_ld<YT>(yc + o));
     };
-    if constexpr (L % 4 == 0) {
+    if (a.ytok) {
+        // y TOKEN-MAJOR (Bt, L, D): a position's 32 channels of this tile as eight 16-byte stores (128 contiguous bytes)
+        float *tok = a.y + (int64_t)sb * L * a.D + c0;
+        for (int v = threadIdx.x; v < L * 8; v += 128) {
+            const int l = v >> 3, c4 = 4 * (v & 7);
+            *reinterpret_cast<float4 *>(tok + (int64_t)l * a.D + c4) =
+                make_float4(yval(c4, l), yval(c4 + 1, l), yval(c4 + 2, l), yval(c4 + 3, l));
+        }
+    } else if constexpr (L % 4 == 0) {
         for (int v = threadIdx.x; v < 32 * L / 4; v += 128) {
             const int e = 4 * v, c = e / L, l = e - c * L;
             *reinterpret_cast<float4 *>(dst + e) = make_float4(yval(c, l), yval(c, l + 1), yval(c, l + 2), yval(c, l + 3));
@@ -692,8 +747,13 @@ static bool chan1_on() {
 int chan1_covers(int H, int W, int N, int n_routes) {
     return chan1_on() && N == 1 && n_routes == 4 && H == W && (H == 14 || H == 12 || H == 7);
 }
+// maps whose second-generation kernels run BOTH ways (so y / dy can be token-major: ChanArgs::ytok)
+int chan1_ytok(int H, int W, int N, int n_routes) {
+    return chan1_covers(H, W, N, n_routes) && (H == 14 || H == 7);
+}
 int chan1_run(const ChanArgs &a, int HW, bool bwd, hipStream_t s) {
     if (!chan1_on() || a.c_mod > 0) return XFM_ELIMIT;
+    if (a.ytok && HW != 14 && HW != 7) return XFM_ELIMIT;
     if ((int64_t)a.Bt * 4 * HW * HW * a.D * 2 >= ((int64_t)1 << 32)) return XFM_ELIMIT;     // 32-bit ddts offsets
     if (HW == 14) return bwd ? chan1::dispatch_bwd<14>(a, s) : chan1::dispatch_fwd<14>(a, s);
     // (12 x 12: the first-generation forward is faster -- 38.8 vs 42.9 us at XFMamba-B's stage 3 -- and writes the same

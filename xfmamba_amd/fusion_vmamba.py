@@ -42,7 +42,7 @@ from .mlp_tokens import bias_gelu_fn, linear_tokens_fn, mlp_tokens_fn
 from .proj import batched_proj, gated_planes_to_tokens, planes_to_tokens, tokens_to_planes, tokens_to_planes_pooled
 from .rowln import residual_settle_fn, add_layernorm_rows_fn, layernorm_rows_fn, layernorm_rows_pass_fn, rows_supported
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
-from .ss2d_chan import chan_supported, ss2d_chan_fn
+from .ss2d_chan import chan_supported, ss2d_chan_fn, ytokens_supported
 from . import fp8 as _fp8
 from .amp import cast_weight
 
@@ -370,6 +370,18 @@ class SS2Dv2(nn.Module):
                 z = self.act(z)
         x = x.reshape(B, -1, H, W)
         x = _dwconv_act(self.conv2d, self.act, x) if self.with_dconv else self.act(x)
+        D, N, R = x.shape[1], self.d_state, self.dt_rank
+        if (z is None and SS2D_MODE == "fused" and isinstance(self.out_act, nn.Identity) and isinstance(self.out_norm, LayerNorm2d)
+                and x.dtype == torch.bfloat16 and not _fp8.ENABLED and rows_supported(D) and chan_supported(x, H, W, N, 4, D, R)
+                and ytokens_supported(H, W, N)):
+            # short maps (14 x 14, 7 x 7): the scan writes y TOKEN-MAJOR, so out_norm (the reference's channel-last nn.LayerNorm,
+            # models/fusion_vmamba.py:1186-1188) is the row LayerNorm and out_proj (:1205) a plain token GEMM -- no LayerNorm2d
+            # pass over planes, no layout-changing projection, token x token weight gradients (round 5)
+            As = self._As_pre if self._As_pre is not None else -self.A_logs.float().exp()
+            yt = ss2d_chan_fn(x.reshape(B, D, L), self.x_proj_weight, self.dt_projs_weight, As, self.Ds.float(),
+                              self.dt_projs_bias.reshape(-1).float(), H, W, y_tokens=True)                   # (B, L, D) fp32
+            yn = layernorm_rows_fn(yt.view(B, H, W, D), self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, x.dtype)
+            return self.dropout(linear_tokens_fn(yn, self.out_proj.weight, self.out_proj.bias))
         y = self.out_act(self.forward_core(x)).view(B, -1, L)
         if z is not None:
             y = y * z

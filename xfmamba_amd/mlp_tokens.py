@@ -110,6 +110,10 @@ def _skinny(x, w, bias, out, transposed):
     return y
 
 
+# square token GEMMs on the tiled kernel of xfm_tokens_gemm2 (epilogue 0); XFM_TILED_LINEAR=0: the library
+_TILED_LINEAR = os.environ.get("XFM_TILED_LINEAR", "1") == "1"
+
+
 class LinearTokens(torch.autograd.Function):
     """``F.linear`` on (..., K) tokens whose bias gradient comes from the column-sum kernel."""
 
@@ -119,6 +123,10 @@ class LinearTokens(torch.autograd.Function):
         w = cast_weight(weight, cd)
         if _skinny_ok(x, w):
             y = _skinny(x, w, bias, w.shape[0], False)
+        elif _TILED_LINEAR and w.shape[0] == w.shape[1] and _gemm2_ok(x, w.shape[1], w.shape[0]) and w.is_contiguous():
+            # square products of the 14 x 14 / 7 x 7 stages (384 -> 384, 768 -> 768) on the tiled LDS-direct kernel
+            # (tools/gemm3probe.py: 9.8 vs 12.9 us for the library at 12544 x 384 -> 384)
+            y = _gemm2(x.reshape(-1, x.shape[-1]), w, bias, w.shape[0], False, 0)[0].view(*x.shape[:-1], w.shape[0])
         else:
             y = torch.nn.functional.linear(x, w, None if bias is None else cast_weight(bias, cd))
         ctx.save_for_backward(x, w)
@@ -137,6 +145,8 @@ class LinearTokens(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if _skinny_ok(dy2, w, transposed=True):
                 dx = _skinny(dy2, w, None, w.shape[1], True).view(x.shape)
+            elif _TILED_LINEAR and w.shape[0] == w.shape[1] and _gemm2_ok(dy2, w.shape[0], w.shape[1]) and w.is_contiguous():
+                dx = _gemm2(dy2, w, None, w.shape[1], True, 0)[0].view(x.shape)
             else:
                 dx = torch.mm(dy2, w).view(x.shape)
         if ctx.needs_input_grad[1]:

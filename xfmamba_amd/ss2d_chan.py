@@ -20,7 +20,7 @@ from . import amp as _amp
 from .amp import cast_weight
 from .proj import zeros_f32, _transpose_raw, _transpose_short_ok
 
-__all__ = ["ss2d_chan_fn", "ss2d_chan_swap_fn", "swap_views_stacked", "chan_supported", "SS2DChanHip", "SS2DChanSwapHip"]
+__all__ = ["ytokens_supported", "ss2d_chan_fn", "ss2d_chan_swap_fn", "swap_views_stacked", "chan_supported", "SS2DChanHip", "SS2DChanSwapHip"]
 
 ENABLED = os.environ.get("XFM_SS2D_CHAN", "1") == "1"       # read once at import (A/B switch of the benches)
 
@@ -65,8 +65,20 @@ def _zeros(device):
     return z
 
 
-def _params(x, xdbl, wdt, A, D, bias, H, W, N, R, n_routes, c_mod, c_off, wdiv, chk):
+def ytokens_supported(H: int, W: int, N: int, n_routes: int = 4) -> bool:
+    """The kernels of this shape can write y / read dy TOKEN-MAJOR (B, L, D) (second-generation d_state-1 kernels)."""
+    return bool(ENABLED and _YTOK and _lib.lib().xfm_ss2dc_ytokens_supported(H, W, N, n_routes))
+
+
+# y / dy of the channel-lane core token-major where the kernels can (14 x 14, 7 x 7; d_state 1): out_norm is then the row
+# LayerNorm and out_proj a plain token GEMM -- no LayerNorm2d, no layout-changing projection, no plane-major weight-gradient
+# operand behind the scan.  XFM_SS2D_YTOK=0: planes (the A/B switch).
+_YTOK = os.environ.get("XFM_SS2D_YTOK", "1") == "1"
+
+
+def _params(x, xdbl, wdt, A, D, bias, H, W, N, R, n_routes, c_mod, c_off, wdiv, chk, y_tokens=False):
     p = _lib.SS2DCParams()
+    p.y_tokens = 1 if y_tokens else 0
     p.zeros = _zeros(x.device).data_ptr()
     p.batch, p.d_inner, p.H, p.W, p.dstate, p.dt_rank, p.n_routes = x.shape[0], x.shape[1], H, W, N, R, n_routes
     p.c_mod, p.c_off, p.wdiv = c_mod, c_off, wdiv
@@ -79,10 +91,11 @@ def _params(x, xdbl, wdt, A, D, bias, H, W, N, R, n_routes, c_mod, c_off, wdiv, 
 class SS2DChanHip(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, x_proj_w, dt_w, A, D, bias, H, W, c_mod=0, c_off=0):
+    def forward(ctx, x, x_proj_w, dt_w, A, D, bias, H, W, c_mod=0, c_off=0, y_tokens=False):
         _lib.require_cuda(x, x_proj_w, dt_w, A, D, bias)
         Bt, Dm, L = x.shape
         K, C2, _ = x_proj_w.shape
+        ctx.ytok = bool(y_tokens)
         R, N = dt_w.shape[2], A.shape[1]
         if L != H * W or K != 4 or C2 != R + 2 * N or x.dtype != torch.bfloat16:
             raise RuntimeError("ss2d_chan: x (B,D,H*W) bf16, x_proj_weight (4,R+2N,D), dt_projs_weight (4,D,R) expected")
@@ -133,8 +146,8 @@ class SS2DChanHip(torch.autograd.Function):
         lib = _lib.lib()
         nst = lib.xfm_ss2dc_nsteps(H, W, N)
         chk = torch.empty((Bt, K, nst, N, Dm), dtype=torch.float32, device=x.device)
-        y = torch.empty((Bt, Dm, L), dtype=torch.float32, device=x.device)
-        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, c_mod, c_off, 1, chk)
+        y = torch.empty((Bt, L, Dm) if y_tokens else (Bt, Dm, L), dtype=torch.float32, device=x.device)
+        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, c_mod, c_off, 1, chk, y_tokens)
         p.y = y.data_ptr()
         nbytes = Bt * Dm * L * (2 + 4) + xdbl.numel() * 2
         with torch.cuda.device(x.device), _lib.timed("ss2dc_fwd" if N == 1 else "ss2dc16_fwd", nbytes):
@@ -170,7 +183,7 @@ class SS2DChanHip(torch.autograd.Function):
         dD, dbias = acc[nbc + na:nbc + na + nd], acc[nbc + na + nd:nbc + na + 2 * nd]
         dwdt = acc[nbc + na + 2 * nd:].view(K, Dm, R)
         lib = _lib.lib()
-        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, ctx.cmod[0], ctx.cmod[1], 1, chk)
+        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, ctx.cmod[0], ctx.cmod[1], 1, chk, ctx.ytok)
         p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
         p.dBC, p.dA, p.dD, p.ddelta_bias = dBC.data_ptr(), dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
         nbytes = Bt * Dm * L * (2 + 4 + 2 + 2 * K) + xdbl.numel() * 2
@@ -210,15 +223,16 @@ class SS2DChanHip(torch.autograd.Function):
             dxw = dxw_pad.view(K, C2p, Dm)[:, :C2].to(xw_dtype)
         else:
             dxw = dxw_pad.index_select(0, _row_index(K, R, N, dev)).view(xw_shape).to(xw_dtype)
-        return dx, dxw, dwdt.to(dtw_dtype), dA, dD, dbias, None, None, None, None
+        return dx, dxw, dwdt.to(dtw_dtype), dA, dD, dbias, None, None, None, None, None
 
 
-def ss2d_chan_fn(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod=0, c_off=0):
+def ss2d_chan_fn(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod=0, c_off=0, y_tokens=False):
     """x (B,D,L) bf16 natural; x_proj_weight (4,R+2N,D); dt_projs_weight (4,D,R); A (4D,N); D/bias (4D,) -> y (B,D,L) fp32.
     ``c_mod > 0``: sample sb reads its C operand from sample ``c_off + sb % c_mod`` (the deep fusion block's three streams
     as one batch [view 1 | view 2 | fused]: the view streams read through the fused stream's C, reference
-    models/fusion_vmamba.py:536-538, 567-569)."""
-    return SS2DChanHip.apply(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod, c_off)
+    models/fusion_vmamba.py:536-538, 567-569).  ``y_tokens``: y comes out (and its gradient goes in) TOKEN-MAJOR (B, L, D)
+    (``ytokens_supported``)."""
+    return SS2DChanHip.apply(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod, c_off, y_tokens)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
