@@ -433,6 +433,8 @@ typedef struct {
     int y_tokens;          /* != 0: y and dy are TOKEN-MAJOR (batch, L, d_inner) fp32 -- what a row LayerNorm / token GEMM behind the
                               scan reads and hands back (out_norm + out_proj, models/fusion_vmamba.py:1186-1205), so that neither is a
                               layout-changing operator; only where xfm_ss2dc_ytokens_supported() says so, XFM_ELIMIT otherwise */
+    int x_tokens;          /* != 0: x and dx are TOKEN-MAJOR (batch, L, d_inner) bf16 as well (a token-major depthwise convolution in
+                              front of the scan: in_proj / x_proj and their gradients are plain token GEMMs then); same condition */
     const void *x, *xdbl, *wdt;
     const void *zeros;     /* >= 256 bytes of zeros, 16-byte aligned (k-slots of the sibling route in the stacked product) */
     const float *A, *D, *delta_bias;

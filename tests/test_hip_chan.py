@@ -91,21 +91,27 @@ def test_ss2d_chan_token_major_output_matches_oracle_chain(B, D, HW, R):
     x, xw, dtw, A, Dp, bias, gy = _inputs(B, D, HW, R, N, B * D + HW + R)
     ref = _oracle(x, xw, dtw, A, Dp, bias, gy, HW, N)
     outs = []
-    for tok in (True, False):
-        t = [v.to(DEV).requires_grad_() for v in (x.bfloat16(), xw, dtw, A, Dp, bias)]
-        assert chan_supported(t[0], HW, HW, N, 4, D, R)
-        y = ss2d_chan_fn(t[0], t[1], t[2], t[3], t[4], t[5], HW, HW, y_tokens=tok)
+    for tok, xtok in ((True, False), (False, False), (True, True)):
+        t = [v.to(DEV).requires_grad_() for v in ((x.transpose(1, 2).contiguous() if xtok else x).bfloat16(), xw, dtw, A, Dp, bias)]
+        assert chan_supported(x.bfloat16().to(DEV), HW, HW, N, 4, D, R)
+        y = ss2d_chan_fn(t[0], t[1], t[2], t[3], t[4], t[5], HW, HW, y_tokens=tok, x_tokens=xtok)
         assert y.shape == ((B, HW * HW, D) if tok else (B, D, HW * HW)) and y.dtype == torch.float32
         g = gy.to(DEV)
         y.backward(g.transpose(1, 2).contiguous() if tok else g)
-        outs.append([(y.detach().transpose(1, 2) if tok else y.detach())] + [v.grad for v in t])
+        grads = [v.grad for v in t]
+        if xtok:                                       # x and dx token-major (a token-major depthwise convolution in front)
+            assert grads[0].shape == (B, HW * HW, D)
+            grads[0] = grads[0].transpose(1, 2)
+        outs.append([(y.detach().transpose(1, 2) if tok else y.detach())] + grads)
     tols = (5e-3 if HW > 12 else 2e-3, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2)
     for name, a, b, tol in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), outs[0], ref, tols):
         assert_close(a.float().cpu(), b.float(), tol, tol * float(b.abs().max()) + 1e-7, name)
     # y: the same arithmetic, bit for bit.  dx also takes the x_proj gradient of the dB / dC columns, which both runs sum over
     # the channel tiles with fp32 atomics in launch order: equal up to that order's rounding (one bf16 ulp here and there)
-    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[2][0], outs[1][0])
     assert_close(outs[0][1].float().cpu(), outs[1][1].float().cpu(), 8e-3, 8e-3 * float(outs[1][1].float().abs().max()), "dx tokens vs planes")
+    for name, a, b, tol in zip(("y", "dx", "dx_proj_w", "ddt_w", "dA", "dD", "dbias"), outs[2], ref, tols):
+        assert_close(a.float().cpu(), b.float(), tol, tol * float(b.abs().max()) + 1e-7, name + " (x, y token-major)")
 
 
 def test_ss2d_chan_equals_lean_fused_path_at_bench_shape():

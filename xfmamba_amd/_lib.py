@@ -72,7 +72,7 @@ class SS2DCParams(C.Structure):
     _fields_ = [
         ("batch", C.c_int), ("d_inner", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dstate", C.c_int),
         ("dt_rank", C.c_int), ("n_routes", C.c_int), ("c_mod", C.c_int), ("c_off", C.c_int), ("wdiv", C.c_int),
-        ("y_tokens", C.c_int),
+        ("y_tokens", C.c_int), ("x_tokens", C.c_int),
         ("x", C.c_void_p), ("xdbl", C.c_void_p), ("wdt", C.c_void_p), ("zeros", C.c_void_p),
         ("A", C.c_void_p), ("D", C.c_void_p), ("delta_bias", C.c_void_p),
         ("y", C.c_void_p), ("chk", C.c_void_p), ("dy", C.c_void_p), ("dx", C.c_void_p), ("ddts", C.c_void_p),

@@ -1235,7 +1235,8 @@ static int chan_run(const xfm_ss2dc_params_t *p, bool bwd, void *stream) {
     a.c_mod = p->c_mod; a.c_off = p->c_off;
     a.wdiv = p->wdiv > 0 ? p->wdiv : 1;
     a.ytok = p->y_tokens ? 1 : 0;
-    if (a.ytok && (p->c_mod != 0 || !chan1_ytok(p->H, p->W, p->dstate, p->n_routes))) return XFM_ELIMIT;
+    a.xtok = p->x_tokens ? 1 : 0;
+    if ((a.ytok || a.xtok) && (p->c_mod != 0 || !chan1_ytok(p->H, p->W, p->dstate, p->n_routes))) return XFM_ELIMIT;
     a.zeros = (const uint16_t *)p->zeros;
     a.xmap = (p->batch % 8 == 0 && !getenv("XFM_CHAN_NO_XMAP")) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;

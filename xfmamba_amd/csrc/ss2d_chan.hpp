@@ -34,6 +34,7 @@ struct ChanArgs {
     int ct;                  // consecutive 32-channel tiles walked by one workgroup (amortises the dB / dC flush)
     int xmap;                // 1: samples are dealt to the XCDs (Bt % 8 == 0), see chan_block_map
     int wdiv;                // n_routes == 1: sample sb uses weight set sb / wdiv (include/xfm_hip.h)
+    int xtok;                // 1: x and dx are TOKEN-MAJOR (Bt, L, D) bf16 (same kernels as ytok)
     int ytok;                // 1: y and dy are TOKEN-MAJOR (Bt, L, D) fp32 (second-generation d_state-1 kernels at 14 x 14 / 7 x 7)
 };
 

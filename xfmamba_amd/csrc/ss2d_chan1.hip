@@ -193,19 +193,22 @@ __device__ __forceinline__ void stage_tile(uint32_t *xg, const uint16_t *xsrc, c
 // position's 32 channels of this tile are 128 contiguous bytes.  x (plane-major run) fills the low halves of the words, dy the
 // high halves, as 2-byte LDS writes; all of a thread's loads are in flight before the first write.
 template <int HW>
-__device__ __forceinline__ void stage_tile_tok(uint32_t *xg, const uint16_t *xsrc, const float *gtok, const int D, const int tid) {
+__device__ __forceinline__ void stage_tile_tok(uint32_t *xg, const uint16_t *xsrc, const float *gsrc, const int D, const bool xtok,
+                                               const bool gtok, const int tid) {
     constexpr int L = HW * HW, Lq = Lds<HW>::Lq;
-    constexpr int NX = 32 * L / 8, KX = (NX + 127) / 128;          // x: groups of 8 positions of a channel
-    constexpr int NG = L * 8, KG = (NG + 127) / 128;               // dy: groups of 4 channels of a position
+    constexpr int NX = 32 * L / 8, KX = (NX + 127) / 128;          // x: 16-byte pieces (8 positions of a channel, or 8 channels of a position)
+    constexpr int NG = L * 8, KG = (NG + 127) / 128;               // dy: 16-byte pieces (4 positions of a channel, or 4 channels of a position)
     cu32x4_t xr[KX];
     float4 g[KG];
 #pragma unroll
-    for (int k = 0; k < KX; ++k)
-        if (tid + 128 * k < NX) xr[k] = *reinterpret_cast<const cu32x4_t *>(xsrc + 8 * (tid + 128 * k));
+    for (int k = 0; k < KX; ++k) {
+        const int v = tid + 128 * k;
+        if (v < NX) xr[k] = *reinterpret_cast<const cu32x4_t *>(xtok ? xsrc + (int64_t)(v >> 2) * D + 8 * (v & 3) : xsrc + 8 * v);
+    }
 #pragma unroll
     for (int k = 0; k < KG; ++k) {
         const int v = tid + 128 * k;
-        if (v < NG) g[k] = *reinterpret_cast<const float4 *>(gtok + (int64_t)(v >> 3) * D + 4 * (v & 7));
+        if (v < NG) g[k] = *reinterpret_cast<const float4 *>(gtok ? gsrc + (int64_t)(v >> 3) * D + 4 * (v & 7) : gsrc + 4 * v);
     }
     uint16_t *x16 = reinterpret_cast<uint16_t *>(xg);
 #pragma unroll
@@ -214,10 +217,19 @@ __device__ __forceinline__ void stage_tile_tok(uint32_t *xg, const uint16_t *xsr
         if (v < NX) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int e = 8 * v + 2 * q, c = e / L, l = e - c * L;
-                const int e1 = e + 1, c1 = e1 / L, l1 = e1 - c1 * L;
-                x16[2 * (c * Lq + l)] = (uint16_t)(xr[k][q] & 0xffffu);
-                x16[2 * (c1 * Lq + l1)] = (uint16_t)(xr[k][q] >> 16);
+                int i0, i1;                                          // word index (c * Lq + l) of the two elements of dword q
+                if (xtok) {
+                    const int l = v >> 2, c = 8 * (v & 3) + 2 * q;
+                    i0 = c * Lq + l;
+                    i1 = i0 + Lq;
+                } else {
+                    const int e = 8 * v + 2 * q, c = e / L, l = e - c * L;
+                    const int e1 = e + 1, c1 = e1 / L, l1 = e1 - c1 * L;
+                    i0 = c * Lq + l;
+                    i1 = c1 * Lq + l1;
+                }
+                x16[2 * i0] = (uint16_t)(xr[k][q] & 0xffffu);
+                x16[2 * i1] = (uint16_t)(xr[k][q] >> 16);
             }
         }
     }
@@ -225,12 +237,19 @@ __device__ __forceinline__ void stage_tile_tok(uint32_t *xg, const uint16_t *xsr
     for (int k = 0; k < KG; ++k) {
         const int v = tid + 128 * k;
         if (v < NG) {
-            const int l = v >> 3, c4 = 4 * (v & 7);
             const uint32_t p0 = pack_bf16x2(g[k].x, g[k].y), p1 = pack_bf16x2(g[k].z, g[k].w);
-            x16[2 * ((c4 + 0) * Lq + l) + 1] = (uint16_t)(p0 & 0xffffu);
-            x16[2 * ((c4 + 1) * Lq + l) + 1] = (uint16_t)(p0 >> 16);
-            x16[2 * ((c4 + 2) * Lq + l) + 1] = (uint16_t)(p1 & 0xffffu);
-            x16[2 * ((c4 + 3) * Lq + l) + 1] = (uint16_t)(p1 >> 16);
+            const uint16_t h[4] = {(uint16_t)(p0 & 0xffffu), (uint16_t)(p0 >> 16), (uint16_t)(p1 & 0xffffu), (uint16_t)(p1 >> 16)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int i;
+                if (gtok) {
+                    i = (4 * (v & 7) + j) * Lq + (v >> 3);
+                } else {
+                    const int e = 4 * v + j, c = e / L;
+                    i = c * Lq + (e - c * L);
+                }
+                x16[2 * i + 1] = h[j];
+            }
         }
     }
 }
@@ -425,7 +444,10 @@ __global__ void __launch_bounds__(128, 2) bwd_kernel(const ChanArgs a) {
     int sb, t;
     chan_block_map(a.xmap, a.D / 32, sb, t);
     const int c0 = 32 * t;
-    if (a.ytok) stage_tile_tok<HW>(xg, a.x + ((int64_t)sb * a.D + c0) * L, a.dy + (int64_t)sb * L * a.D + c0, a.D, threadIdx.x);
+    if (a.ytok || a.xtok)
+        stage_tile_tok<HW>(xg, a.xtok ? a.x + (int64_t)sb * L * a.D + c0 : a.x + ((int64_t)sb * a.D + c0) * L,
+                           a.ytok ? a.dy + (int64_t)sb * L * a.D + c0 : a.dy + ((int64_t)sb * a.D + c0) * L, a.D, a.xtok != 0,
+                           a.ytok != 0, threadIdx.x);
     else stage_tile<HW>(xg, a.x + ((int64_t)sb * a.D + c0) * L, a.dy + ((int64_t)sb * a.D + c0) * L, threadIdx.x);
     if (threadIdx.x < 32) {
         const int q = threadIdx.x;
@@ -442,7 +464,23 @@ __global__ void __launch_bounds__(128, 2) bwd_kernel(const ChanArgs a) {
     uint16_t *dst = a.dx + ((int64_t)sb * a.D + c0) * L;
     auto lo = [](const uint32_t w) { return __uint_as_float(w << 16); };
     auto hi = [](const uint32_t w) { return __uint_as_float(w & 0xffff0000u); };
-    if constexpr (L % 4 == 0) {
+    if (a.xtok) {
+        // dx TOKEN-MAJOR (Bt, L, D) bf16: four channels of a position per thread and trip, one 8-byte store (64 contiguous bytes
+        // per position and tile)
+        uint16_t *tok = a.dx + (int64_t)sb * L * a.D + c0;
+        for (int v = threadIdx.x; v < L * 8; v += 128) {
+            const int l = v >> 3, c4 = 4 * (v & 7);
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int off = (c4 + j) * Lq + l;
+                o[j] = fmaf(dsum[c4 + j], hi(xg[off]), lo(dd[off]) + hi(dd[off]));
+            }
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            *reinterpret_cast<u32x2_t *>(tok + (int64_t)l * a.D + c4) = pk;
+        }
+    } else if constexpr (L % 4 == 0) {
         // four positions of one channel per thread and trip, one 8-byte store
         for (int v = threadIdx.x; v < 32 * L / 4; v += 128) {
             const int e = 4 * v, c = e / L, l = e - c * L, off = c * Lq + l;
@@ -643,7 +681,29 @@ __global__ void __launch_bounds__(128, 2) fwd_kernel(const ChanArgs a) {
     int sb, t;
     chan_block_map(a.xmap, a.D / 32, sb, t);
     const int c0 = 32 * t;
-    {   // stage x: all loads of a thread first
+    if (a.xtok) {
+        // x TOKEN-MAJOR (Bt, L, D) bf16: a position's 32 channels of this tile are 64 contiguous bytes = four 16-byte pieces
+        constexpr int NV = L * 4, KV = (NV + 127) / 128;
+        const uint16_t *xsrc = a.x + (int64_t)sb * L * a.D + c0;
+        cu32x4_t xr[KV];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int v = threadIdx.x + 128 * k;
+            if (v < NV) xr[k] = *reinterpret_cast<const cu32x4_t *>(xsrc + (int64_t)(v >> 2) * a.D + 8 * (v & 3));
+        }
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int v = threadIdx.x + 128 * k;
+            if (v < NV) {
+                const int l = v >> 2, c8 = 8 * (v & 3);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xs[(c8 + 2 * q) * Lp + l] = (uint16_t)(xr[k][q] & 0xffffu);
+                    xs[(c8 + 2 * q + 1) * Lp + l] = (uint16_t)(xr[k][q] >> 16);
+                }
+            }
+        }
+    } else {   // stage x: all loads of a thread first
         constexpr int NX = 32 * L / 8, KX = (NX + 127) / 128;
         const uint16_t *xsrc = a.x + ((int64_t)sb * a.D + c0) * L;
         cu32x4_t xr[KX];
@@ -753,7 +813,7 @@ int chan1_ytok(int H, int W, int N, int n_routes) {
 }
 int chan1_run(const ChanArgs &a, int HW, bool bwd, hipStream_t s) {
     if (!chan1_on() || a.c_mod > 0) return XFM_ELIMIT;
-    if (a.ytok && HW != 14 && HW != 7) return XFM_ELIMIT;
+    if ((a.ytok || a.xtok) && HW != 14 && HW != 7) return XFM_ELIMIT;
     if ((int64_t)a.Bt * 4 * HW * HW * a.D * 2 >= ((int64_t)1 << 32)) return XFM_ELIMIT;     // 32-bit ddts offsets
     if (HW == 14) return bwd ? chan1::dispatch_bwd<14>(a, s) : chan1::dispatch_fwd<14>(a, s);
     // (12 x 12: the first-generation forward is faster -- 38.8 vs 42.9 us at XFMamba-B's stage 3 -- and writes the same

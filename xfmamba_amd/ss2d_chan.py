@@ -76,11 +76,12 @@ def ytokens_supported(H: int, W: int, N: int, n_routes: int = 4) -> bool:
 _YTOK = os.environ.get("XFM_SS2D_YTOK", "1") == "1"
 
 
-def _params(x, xdbl, wdt, A, D, bias, H, W, N, R, n_routes, c_mod, c_off, wdiv, chk, y_tokens=False):
+def _params(x, xdbl, wdt, A, D, bias, H, W, N, R, n_routes, c_mod, c_off, wdiv, chk, y_tokens=False, x_tokens=False):
     p = _lib.SS2DCParams()
     p.y_tokens = 1 if y_tokens else 0
+    p.x_tokens = 1 if x_tokens else 0
     p.zeros = _zeros(x.device).data_ptr()
-    p.batch, p.d_inner, p.H, p.W, p.dstate, p.dt_rank, p.n_routes = x.shape[0], x.shape[1], H, W, N, R, n_routes
+    p.batch, p.d_inner, p.H, p.W, p.dstate, p.dt_rank, p.n_routes = x.shape[0], (x.shape[2] if x_tokens else x.shape[1]), H, W, N, R, n_routes
     p.c_mod, p.c_off, p.wdiv = c_mod, c_off, wdiv
     p.x, p.xdbl, p.wdt = x.data_ptr(), xdbl.data_ptr(), wdt.data_ptr()
     p.A, p.D, p.delta_bias = A.data_ptr(), D.data_ptr(), bias.data_ptr()
@@ -91,11 +92,14 @@ def _params(x, xdbl, wdt, A, D, bias, H, W, N, R, n_routes, c_mod, c_off, wdiv, 
 class SS2DChanHip(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, x_proj_w, dt_w, A, D, bias, H, W, c_mod=0, c_off=0, y_tokens=False):
+    def forward(ctx, x, x_proj_w, dt_w, A, D, bias, H, W, c_mod=0, c_off=0, y_tokens=False, x_tokens=False):
         _lib.require_cuda(x, x_proj_w, dt_w, A, D, bias)
-        Bt, Dm, L = x.shape
+        if x_tokens:
+            Bt, L, Dm = x.shape                  # x (B, L, D) TOKEN-MAJOR (a token-major depthwise convolution in front)
+        else:
+            Bt, Dm, L = x.shape
         K, C2, _ = x_proj_w.shape
-        ctx.ytok = bool(y_tokens)
+        ctx.ytok, ctx.xtok = bool(y_tokens), bool(x_tokens)
         R, N = dt_w.shape[2], A.shape[1]
         if L != H * W or K != 4 or C2 != R + 2 * N or x.dtype != torch.bfloat16:
             raise RuntimeError("ss2d_chan: x (B,D,H*W) bf16, x_proj_weight (4,R+2N,D), dt_projs_weight (4,D,R) expected")
@@ -114,7 +118,23 @@ class SS2DChanHip(torch.autograd.Function):
             out = torch.zeros((XC, Dm), dtype=w3.dtype, device=w3.device)
             return out.index_copy_(0, rows, w3.reshape(K * C2, Dm))
 
-        if _fp8.usable(x, Dm, XC):
+        if x_tokens:
+            # x_proj on the token-major x: one plain token GEMM (the tiled kernel where it covers the widths)
+            from .mlp_tokens import _gemm2, _gemm2_ok
+            xw3 = _amp.padded_shadow(x_proj_w, C2p, x.dtype) if plain else None
+            if xw3 is not None:
+                xw_pad = xw3.view(XC, Dm)
+            else:
+                xw_pad = padded(cast_weight(x_proj_w, x.dtype)).contiguous()
+                if plain and isinstance(x_proj_w, torch.nn.Parameter):
+                    _amp.adopt_padded(x_proj_w, xw_pad.view(K, C2p, Dm))
+            x2 = x.view(Bt * L, Dm)
+            if _gemm2_ok(x2, Dm, XC) and xw_pad.is_contiguous():
+                xdbl = _gemm2(x2, xw_pad, None, XC, False, 0)[0].view(Bt, L, XC)
+            else:
+                xdbl = torch.matmul(x, xw_pad.t())
+            xt = x
+        elif _fp8.usable(x, Dm, XC):
             # BASELINE configs[4]: x_proj with fp8 weights on the fp8 matrix cores (straight-through backward with the
             # de-quantised weight)
             wq, scale, xw_pad = _fp8.quantize_weight(padded(x_proj_w.detach().float()))
@@ -147,7 +167,7 @@ class SS2DChanHip(torch.autograd.Function):
         nst = lib.xfm_ss2dc_nsteps(H, W, N)
         chk = torch.empty((Bt, K, nst, N, Dm), dtype=torch.float32, device=x.device)
         y = torch.empty((Bt, L, Dm) if y_tokens else (Bt, Dm, L), dtype=torch.float32, device=x.device)
-        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, c_mod, c_off, 1, chk, y_tokens)
+        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, c_mod, c_off, 1, chk, y_tokens, x_tokens)
         p.y = y.data_ptr()
         nbytes = Bt * Dm * L * (2 + 4) + xdbl.numel() * 2
         with torch.cuda.device(x.device), _lib.timed("ss2dc_fwd" if N == 1 else "ss2dc16_fwd", nbytes):
@@ -167,7 +187,10 @@ class SS2DChanHip(torch.autograd.Function):
         H, W = ctx.hw
         xw_dtype, xw_shape, dtw_dtype = ctx.meta
         dev = x.device
-        Bt, Dm, L = x.shape
+        if ctx.xtok:
+            Bt, L, Dm = x.shape
+        else:
+            Bt, Dm, L = x.shape
         K, C2 = xw_shape[0], xw_shape[1]
         N = A.shape[1]
         R = C2 - 2 * N
@@ -183,7 +206,7 @@ class SS2DChanHip(torch.autograd.Function):
         dD, dbias = acc[nbc + na:nbc + na + nd], acc[nbc + na + nd:nbc + na + 2 * nd]
         dwdt = acc[nbc + na + 2 * nd:].view(K, Dm, R)
         lib = _lib.lib()
-        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, ctx.cmod[0], ctx.cmod[1], 1, chk, ctx.ytok)
+        p = _params(x, xdbl, wdt, A, D, bias, H, W, N, R, 4, ctx.cmod[0], ctx.cmod[1], 1, chk, ctx.ytok, ctx.xtok)
         p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
         p.dBC, p.dA, p.dD, p.ddelta_bias = dBC.data_ptr(), dA.data_ptr(), dD.data_ptr(), dbias.data_ptr()
         nbytes = Bt * Dm * L * (2 + 4 + 2 + 2 * K) + xdbl.numel() * 2
@@ -197,7 +220,10 @@ class SS2DChanHip(torch.autograd.Function):
                                           dwdt.data_ptr(), Bt, Dm, L, R, N, _lib.stream_ptr()), "ss2dc_post")
         # x_proj backward on the natural map
         lib2 = _lib.lib()
-        if (_XPROJ_TILED and XC % 64 == 0 and Dm % 128 == 0 and Bt * L >= 4096 and lib2.xfm_proj_gemm_supported(XC, Dm, L)
+        if ctx.xtok:
+            # token-major x: dx (B, L, D) += d x_dbl . Wx as one token GEMM with beta = 1; dWx = d x_dbl^T . x, tokens x tokens
+            dx.view(Bt * L, Dm).addmm_(dxdbl.view(Bt * L, XC), xw_pad)
+        elif (_XPROJ_TILED and XC % 64 == 0 and Dm % 128 == 0 and Bt * L >= 4096 and lib2.xfm_proj_gemm_supported(XC, Dm, L)
                 and xw_pad.dtype == torch.bfloat16 and dxdbl.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16
                 and dx.is_contiguous()
                 and dxdbl.data_ptr() % 16 == 0 and xw_pad.data_ptr() % 16 == 0 and xw_pad.is_contiguous()):
@@ -223,16 +249,16 @@ class SS2DChanHip(torch.autograd.Function):
             dxw = dxw_pad.view(K, C2p, Dm)[:, :C2].to(xw_dtype)
         else:
             dxw = dxw_pad.index_select(0, _row_index(K, R, N, dev)).view(xw_shape).to(xw_dtype)
-        return dx, dxw, dwdt.to(dtw_dtype), dA, dD, dbias, None, None, None, None, None
+        return dx, dxw, dwdt.to(dtw_dtype), dA, dD, dbias, None, None, None, None, None, None
 
 
-def ss2d_chan_fn(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod=0, c_off=0, y_tokens=False):
+def ss2d_chan_fn(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod=0, c_off=0, y_tokens=False, x_tokens=False):
     """x (B,D,L) bf16 natural; x_proj_weight (4,R+2N,D); dt_projs_weight (4,D,R); A (4D,N); D/bias (4D,) -> y (B,D,L) fp32.
     ``c_mod > 0``: sample sb reads its C operand from sample ``c_off + sb % c_mod`` (the deep fusion block's three streams
     as one batch [view 1 | view 2 | fused]: the view streams read through the fused stream's C, reference
     models/fusion_vmamba.py:536-538, 567-569).  ``y_tokens``: y comes out (and its gradient goes in) TOKEN-MAJOR (B, L, D)
     (``ytokens_supported``)."""
-    return SS2DChanHip.apply(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod, c_off, y_tokens)
+    return SS2DChanHip.apply(x, x_proj_weight, dt_projs_weight, A, D, bias, H, W, c_mod, c_off, y_tokens, x_tokens)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
