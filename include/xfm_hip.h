@@ -145,6 +145,19 @@ int xfm_dwconv3x3_fwd(const void *x, const float *weight, const float *bias, voi
 int xfm_dwconv3x3_bwd(const void *x, const float *weight, const float *bias, const void *dy, void *dx, float *dweight,
                       float *dbias, int B, int D, int H, int W, int dtype, int silu, void *stream);
 
+/*
+ * The same operator on TOKEN-MAJOR maps x (B, H, W, C) bf16 (csrc/dwconv_tok.hip; 14 x 14 and 7 x 7 maps, C % 8 == 0): with the
+ * depthwise stage token-major the SS2D block of the short-map stages never leaves the token layout (xfm_ss2dc_fwd/_bwd with
+ * x_tokens / y_tokens).  weight (C, 1, 3, 3) = (C, 9) fp32, bias (C) fp32 or NULL; y = silu(conv(x) + bias) bf16.
+ * Backward: dz_ws (B, H, W, C) bf16 and part_ws (B * H, 10, C) fp32 are caller workspaces (the gradient of the pre-activation
+ * and one partial row of the weight / bias sums per map row, folded by a small second kernel); dweight (C, 9) and dbias (C, or
+ * NULL) fp32 ZEROED by the caller (the fold adds), dx (B, H, W, C) bf16.  All pointers 16-byte aligned.
+ */
+int xfm_dwconv3x3_tokens_supported(int H, int W, int C);
+int xfm_dwconv3x3_tokens_fwd(const void *x, const float *weight, const float *bias, void *y, int B, int H, int W, int C, void *stream);
+int xfm_dwconv3x3_tokens_bwd(const void *x, const float *weight, const float *bias, const void *dy, void *dz_ws, void *dx,
+                             float *part_ws, float *dweight, float *dbias, int B, int H, int W, int C, void *stream);
+
 /* LayerNorm over C of x (B, C, L) [NCHW with L = H*W], eps inside the rsqrt, affine weight/bias (C) fp32 (bias may
  * be NULL).  y may be a narrower dtype than x (the consumer GEMM's).  mean / rstd: (B, L) fp32, written by fwd and
  * read by bwd.  bwd: dx in x_dtype; dweight / dbias fp32, ZEROED by the caller (dbias may be NULL). */

@@ -334,6 +334,42 @@ def test_layernorm2d_matches_torch_fp32(shape, xdt, ydt):
     assert_close(bd.grad.cpu(), br.grad, tol, tol * float(br.grad.abs().max()), "db")
 
 
+@pytest.mark.parametrize("shape", [(2, 14, 384), (3, 7, 768), (1, 14, 8), (5, 7, 40), (64, 14, 384), (64, 7, 768)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_dwconv3x3_silu_on_token_major_maps_matches_torch_fp32(shape, with_bias):
+    """Depthwise 3 x 3 convolution + SiLU (reference fusion_vmamba.py:1198-1201) on TOKEN-MAJOR maps (B, H, W, C) bf16
+    (xfm_dwconv3x3_tokens_fwd/_bwd, csrc/dwconv_tok.hip) vs F.conv2d + F.silu in fp32 on the NCHW view: output, dx, dweight,
+    dbias; and against the plane-major kernel on the transposed map."""
+    import torch.nn.functional as F
+    from xfmamba_amd.dwconv import dwconv3x3_silu_fn, dwconv3x3_silu_tokens_fn, dwconv_tokens_supported
+    B, HW, C = shape
+    g = torch.Generator().manual_seed(B + HW + C)
+    x = torch.randn(B, HW, HW, C, generator=g).bfloat16()
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    b = 0.2 * torch.randn(C, generator=g) if with_bias else None
+    gy = torch.randn(B, HW, HW, C, generator=g).bfloat16()
+    xr, wr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if with_bias else None
+    yr = F.silu(F.conv2d(xr, wr, br, padding=1, groups=C))
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    bd = b.to(DEV).requires_grad_() if with_bias else None
+    assert dwconv_tokens_supported(xd)
+    y = dwconv3x3_silu_tokens_fn(xd, wd, bd)
+    y.backward(gy.to(DEV))
+    assert y.dtype == torch.bfloat16 and y.shape == x.shape
+    tol = 1e-2
+    assert_close(y.float().cpu(), yr.detach().permute(0, 2, 3, 1), tol, tol * float(yr.abs().max()), "y")
+    assert_close(xd.grad.float().cpu(), xr.grad.permute(0, 2, 3, 1), tol, tol * float(xr.grad.abs().max()), "dx")
+    assert_close(wd.grad.cpu(), wr.grad, tol, tol * float(wr.grad.abs().max()), "dw")
+    if with_bias:
+        assert_close(bd.grad.cpu(), br.grad, tol, tol * float(br.grad.abs().max()), "db")
+    # the plane-major kernel on the transposed map: the same operator
+    xp = x.permute(0, 3, 1, 2).contiguous().to(DEV).requires_grad_()
+    yp = dwconv3x3_silu_fn(xp, w.to(DEV), None if b is None else b.to(DEV), True)
+    assert_close(y.float().cpu(), yp.detach().float().cpu().permute(0, 2, 3, 1), 1e-2, 1e-2 * float(yr.abs().max()), "y vs planes")
+
+
 @pytest.mark.parametrize("C", [48, 96, 192, 384, 768, 64, 1024])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["plain", "add", "add_scale"])

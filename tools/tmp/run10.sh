@@ -1,0 +1,1 @@
+for v in 1 0; do XFM_TOKEN_SS2D=$v python bench.py --steps 20 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_tok$v.json; done

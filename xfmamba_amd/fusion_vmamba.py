@@ -36,7 +36,7 @@ import torch.nn.functional as F
 
 from .csm import SwappingMerge_multiview, SwappingScan_multiview, SwappingScanStacked, cross_merge_fn, cross_scan_fn
 from .csms6s import selective_scan_fn
-from .dwconv import dwconv3x3_silu_fn
+from .dwconv import dwconv3x3_silu_fn, dwconv3x3_silu_tokens_fn, dwconv_tokens_supported
 from .layernorm2d import layernorm2d_fn
 from .mlp_tokens import bias_gelu_fn, linear_tokens_fn, mlp_tokens_fn
 from .proj import batched_proj, gated_planes_to_tokens, planes_to_tokens, tokens_to_planes, tokens_to_planes_pooled
@@ -55,6 +55,12 @@ STREAM_LAYOUT = "tokens"
 # the shallow block's swap scan as one kernel each way (xfm_ss2dc_fwd/_bwd, n_routes 1); XFM_SHALLOW_KERNEL=0: the
 # swap_scan -> matmul -> matmul -> selective_scan_fn operator chain (the A/B switch of the tests)
 SHALLOW_KERNEL = os.environ.get("XFM_SHALLOW_KERNEL", "1") == "1"
+# SS2D blocks of the short-map stages (14 x 14, 7 x 7) ENTIRELY token-major: in_proj / x_proj as token GEMMs, the token-major
+# depthwise convolution (csrc/dwconv_tok.hip), the scan reading x token-major.  Built, parity-tested and measured at break-even
+# with the default (planes between in_proj and the scan, token-major only BEHIND the scan): 13.60 vs 13.62 ms per step -- the
+# layout-changing projections it removes (-0.69 ms) come back as plain token GEMMs (+0.59 ms) and the token-major depthwise
+# kernels are 5 / 11 us per block slower than the plane-major ones (14.3 / 31.5 vs 9.1 / 20.6 us).  Opt in: XFM_TOKEN_SS2D=1.
+TOKEN_SS2D = os.environ.get("XFM_TOKEN_SS2D", "0") == "1"
 
 
 def trunc_normal_(t, std=0.02):
@@ -362,6 +368,22 @@ class SS2Dv2(nn.Module):
         GEMMs' operand flags."""
         B, H, W, C = h.shape
         L = H * W
+        D, N, R = self.d_inner, self.d_state, self.dt_rank
+        if (TOKEN_SS2D and self.disable_z and SS2D_MODE == "fused" and self.with_dconv and isinstance(self.act, nn.SiLU)
+                and isinstance(self.out_act, nn.Identity) and isinstance(self.out_norm, LayerNorm2d) and h.dtype == torch.bfloat16
+                and not _fp8.ENABLED and self.conv2d.kernel_size == (3, 3) and self.conv2d.padding == (1, 1)
+                and self.conv2d.groups == D and rows_supported(D) and chan_supported(h, H, W, N, 4, D, R)
+                and ytokens_supported(H, W, N) and dwconv_tokens_supported(h.new_empty((1, H, W, D)))):
+            # short maps (14 x 14, 7 x 7): the whole block stays TOKEN-MAJOR (round 5) -- in_proj, x_proj, out_proj and their data
+            # gradients are plain token GEMMs, every weight gradient is tokens x tokens, the depthwise convolution walks
+            # (B, H, W, D) maps (csrc/dwconv_tok.hip), the scan reads x / writes y token-major, out_norm is the row LayerNorm
+            xt = linear_tokens_fn(h.view(B, L, C), self.in_proj.weight, self.in_proj.bias)               # (B, L, D)
+            xt = dwconv3x3_silu_tokens_fn(xt.view(B, H, W, D), self.conv2d.weight, self.conv2d.bias)
+            As = self._As_pre if self._As_pre is not None else -self.A_logs.float().exp()
+            yt = ss2d_chan_fn(xt.view(B, L, D), self.x_proj_weight, self.dt_projs_weight, As, self.Ds.float(),
+                              self.dt_projs_bias.reshape(-1).float(), H, W, y_tokens=True, x_tokens=True)  # (B, L, D) fp32
+            yn = layernorm_rows_fn(yt.view(B, H, W, D), self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, h.dtype)
+            return self.dropout(linear_tokens_fn(yn, self.out_proj.weight, self.out_proj.bias))
         x = batched_proj(h.view(B, L, C), self.in_proj.weight, self.in_proj.bias, in_tokens=True, out_tokens=False)
         z = None
         if not self.disable_z:
