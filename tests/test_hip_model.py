@@ -107,6 +107,19 @@ def test_deep_fusion_block_golden_through_channel_lane_kernel():
             assert_close(params[k[len(pre):]].grad.float().cpu(), ref, 5e-2, 5e-2 * float(ref.abs().max()) + 1e-7, k)
 
 
+def _lib_timer():
+    from xfmamba_amd import _lib
+    t = _lib.KernelTimer()
+    _lib.set_timer(t)
+    return t
+
+
+def _lib_timer_stop(t):
+    from xfmamba_amd import _lib
+    _lib.set_timer(None)
+    return set(t.summary())
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,H", [(96, 56), (192, 28), (384, 14), (768, 7)])
 def test_vss_stage_tokens_stream_matches_planes_and_oracle(C, H, dt):
@@ -121,19 +134,27 @@ def test_vss_stage_tokens_stream_matches_planes_and_oracle(C, H, dt):
     x = torch.randn(2, C, H, H, device=DEV)
     gy = torch.randn(2, C, H, H, device=DEV)
     res = {}
-    old = fv.STREAM_LAYOUT
+    old, old_full = fv.STREAM_LAYOUT, fv.TOKEN_SS2D
+    # "tokens_full": the SS2D block of the short-map stages entirely token-major (fv.TOKEN_SS2D: token-major depthwise
+    # convolution, the scan reading x token-major; opt-in) -- the same stream layout, one more kernel path to hold to the oracle
+    layouts = ("planes", "tokens") + (("tokens_full",) if (dt == torch.bfloat16 and H <= 14) else ())
     try:
-        for layout in ("planes", "tokens"):
-            fv.STREAM_LAYOUT = layout
+        for layout in layouts:
+            fv.STREAM_LAYOUT = "tokens" if layout == "tokens_full" else layout
+            fv.TOKEN_SS2D = layout == "tokens_full"
             blocks.zero_grad(set_to_none=True)
             xi = x.clone().requires_grad_()
+            timer = _lib_timer()
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
                 y = fv._run_blocks(blocks, xi)
             y.float().backward(gy)
+            ran = _lib_timer_stop(timer)
+            if layout == "tokens_full":
+                assert "proj_gemm" not in ran and "layernorm2d_fwd" not in ran, sorted(ran)      # no layout-changing product left
             res[layout] = (y.detach().float().cpu(), xi.grad.cpu(),
                            {k: p.grad.detach().cpu().clone() for k, p in blocks.named_parameters()})
     finally:
-        fv.STREAM_LAYOUT = old
+        fv.STREAM_LAYOUT, fv.TOKEN_SS2D = old, old_full
     sd = {f"b.{k}": v.detach().cpu() for k, v in blocks.state_dict().items()}
     xr = x.cpu().clone().requires_grad_()
     pr = {k: v.clone().requires_grad_() for k, v in sd.items()}
@@ -142,7 +163,7 @@ def test_vss_stage_tokens_stream_matches_planes_and_oracle(C, H, dt):
         yr = O.vss_block_ref(pr, f"b.{i}.", yr)
     yr.backward(gy.cpu())
     tol = 1e-3 if dt == torch.float32 else 2e-2
-    for layout in ("planes", "tokens"):
+    for layout in layouts:
         y, dx, grads = res[layout]
         assert_close(y, yr.detach(), tol, tol * float(yr.abs().max()), f"{layout} y")
         assert_close(dx, xr.grad, tol, tol * float(xr.grad.abs().max()), f"{layout} dx")
