@@ -465,8 +465,9 @@ def main():
                 # timer name -> kernel key of tools/pmc_traffic.py (HBM bytes per launch from the PMC counters of this very
                 # command: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc passes; MI355X_MICROARCH.md "HBM")
                 pmc_key = {"ss2d_bwd": "ss2d_l3_bwd_kernel", "ss2d_fwd": "ss2d_l3_fwd_kernel",
-                           "ss2dc_bwd": "chan1::bwd_kernel", "ss2dc_fwd": "ss2dc_fwd_kernel_n1",
-                           "ss2dc16_bwd": "deep_bwd_kernel", "ss2dc16_fwd": "ss2dc_fwd_kernel_n16"}
+                           "ss2dc_bwd": "chan1::bwd_kernel", "ss2dc_fwd": "chan1::fwd_kernel",
+                           "ss2dc16_bwd": "deep_bwd_kernel<3, 4>", "ss2dc16_fwd": "ss2dc_fwd_kernel_n16",
+                           "ss2dc16s_bwd": "deep_bwd_kernel<3, 1>", "ss2dc16s_fwd": "deep_fwd1_kernel"}
 
                 def roof_of(name):
                     k = kernels[name]
