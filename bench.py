@@ -175,21 +175,29 @@ def main():
     #  all-reduce + Adam -- with every rank on GPU 0 of a one-GPU box; never used for a reported number)
     backend = os.environ.get("XFM_BENCH_BACKEND", "nccl")
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run, or without a launcher)"
+    cuda_ok = torch.cuda.is_available()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend != "nccl":                                    # host-side rendezvous: needs no GPU
+        if backend != "nccl" and not cuda_ok:
+            # a machine without GPUs (the CPU test of the launcher): the host-side rendezvous still proves that the ranks came
+            # up; the assert below then stops them.  (With a GPU the group is created AFTER the device is set, as for RCCL:
+            # a gloo group created before the process touched the GPU returned NaN sums for device tensors.)
             dist.init_process_group(backend)
             if rank == 0:
                 print(f"[bench] ranks: {dist.get_world_size()} ({backend})", file=sys.stderr, flush=True)
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    assert cuda_ok, "bench.py needs MI355X GPUs"
     if backend != "nccl":
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 and backend == "nccl":
-        dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
         if rank == 0:
-            print(f"[bench] RCCL ranks: {dist.get_world_size()}", file=sys.stderr, flush=True)
+            print(f"[bench] {'RCCL ' if backend == 'nccl' else ''}ranks: {dist.get_world_size()}"
+                  f"{'' if backend == 'nccl' else ' (' + backend + ')'}", file=sys.stderr, flush=True)
 
     from xfmamba_amd import _lib, fusion_vmamba
     from xfmamba_amd.amp import WeightCache

@@ -25,6 +25,8 @@ two graphs of one step (``dp.PhasedGrads``) or several flushes inside one graph 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
