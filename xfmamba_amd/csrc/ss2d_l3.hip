@@ -34,6 +34,9 @@ namespace xfm {
 #ifndef L3_WPE
 #define L3_WPE 2
 #endif
+#ifndef L3_PREFETCH
+#define L3_PREFETCH 1                                  // backward: the next tile's planes by LDS-direct loads (l3_dma_tile)
+#endif
 typedef float l3f2 __attribute__((ext_vector_type(2)));
 
 // RP2: dt_rank pairs of the mode-3 kernels (0 otherwise); they hold 2 RP2 operand vectors per chunk row in flight, so the
@@ -132,12 +135,19 @@ template <bool REV> __device__ __forceinline__ void l3_unpack(const uint4 &r, l3
         o[q] = REV ? l3f2{hi, lo} : l3f2{lo, hi};
     }
 }
+// (the conversion names its two sources itself: through a two-element vector conversion the descending routes, whose pairs sit
+//  in registers high element first, paid a v_pk_mov_b32 half swap in front of every v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t l3_cvt_pk(const float lo, const float hi) {
+    uint32_t w;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi));
+    return w;
+}
 template <bool REV> __device__ __forceinline__ uint4 l3_pack(const l3f2 (&v)[4]) {
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const l3f2 p = v[REV ? 3 - i : i];
-        w[i] = REV ? pack_bf16x2(p.y, p.x) : pack_bf16x2(p.x, p.y);
+        w[i] = REV ? l3_cvt_pk(p.y, p.x) : l3_cvt_pk(p.x, p.y);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
@@ -331,6 +341,78 @@ __device__ __forceinline__ void l3_merge_store(bf16_t *out, const bf16_t *P0, co
             }
         }
         *reinterpret_cast<uint4 *>(out + e0) = VecIO<bf16_t, 8>::pack(o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The NEXT tile's planes by LDS-direct loads (backward; modes 0-2).  A tile's x (bf16) and dy (fp32) are PL contiguous
+// elements each: x lands in the other natural x image as it is, dy in a raw fp32 strip; no register is held and the issuing
+// wave waits for nothing -- the round trip runs under the current tile's sweeps (register staging of the next tile before the
+// sweeps was tried twice: 24 live registers put the kernel past 256).  The loads are inline asm on purpose: for the builtin
+// the compiler orders every later LDS read behind the load (vmcnt(0) in front of the sweeps' first ds_read).  As asm they are
+// invisible to its vmcnt bookkeeping, which can only make a later counted wait stricter (in-order return), never unsafe; the
+// issue point is chosen so that it does not: right after the wave's operands of the tile's first chunk row have arrived.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void l3_dma16(const void *src, const uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_base) : "memory");
+}
+
+template <int PL>
+__device__ __forceinline__ void l3_dma_tile(const bf16_t *xs, const float *gs, const uint32_t xdst, const uint32_t gdst,
+                                            const int wave, const int lane) {
+    constexpr int NVX = PL * 2 / 16, NVG = PL * 4 / 16;              // 16-byte vectors
+    constexpr int NXP = (NVX + 63) / 64, NGP = (NVG + 63) / 64;      // pieces of one wave instruction (1 KB)
+#pragma unroll
+    for (int q = 0; q < (NXP + NGP + 3) / 4; ++q) {
+        const int p = 4 * q + wave;                                  // (uniform)
+        if (p < NXP) {
+            const int v = 64 * p + lane;
+            if (v < NVX) l3_dma16(reinterpret_cast<const uint4 *>(xs) + v, xdst + 1024u * p);
+        } else if (p < NXP + NGP) {
+            const int pg = p - NXP, v = 64 * pg + lane;
+            if (v < NVG) l3_dma16(reinterpret_cast<const uint4 *>(gs) + v, gdst + 1024u * pg);
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t l3_lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+// tile start with the planes already in LDS (x natural, dy raw fp32): dy -> bf16 natural image, both transposed images.
+// Consecutive lanes take the same column block of consecutive rows (l3_vec_pos): 2-byte scatters on consecutive addresses.
+template <int HW, int PPT>
+__device__ __forceinline__ void l3_stage_lds(const bf16_t *xN, bf16_t *xT, const float *graw, bf16_t *gN, bf16_t *gT,
+                                             const int tid) {
+    constexpr int L = HW * HW, VS = HW % 8 == 0 ? 8 : 4, nvec = PPT * L / VS;
+    static_assert(HW % VS == 0, "rows must be whole vectors");
+    for (int v = tid; v < nvec; v += 256) {
+        int e0, pl, h, w;
+        l3_vec_pos<HW, VS>(v, e0, pl, h, w);
+        uint16_t *tx = reinterpret_cast<uint16_t *>(xT) + pl * L + w * HW + h;
+        uint16_t *tg = reinterpret_cast<uint16_t *>(gT) + pl * L + w * HW + h;
+        uint32_t xw[VS / 2], gw[VS / 2];
+        if constexpr (VS == 8) {
+            const uint4 r = *reinterpret_cast<const uint4 *>(xN + e0);
+            const float4 g0 = *reinterpret_cast<const float4 *>(graw + e0), g1 = *reinterpret_cast<const float4 *>(graw + e0 + 4);
+            xw[0] = r.x; xw[1] = r.y; xw[2] = r.z; xw[3] = r.w;
+            gw[0] = pack_bf16x2(g0.x, g0.y); gw[1] = pack_bf16x2(g0.z, g0.w);
+            gw[2] = pack_bf16x2(g1.x, g1.y); gw[3] = pack_bf16x2(g1.z, g1.w);
+            *reinterpret_cast<uint4 *>(gN + e0) = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+        } else {
+            const uint2 r = *reinterpret_cast<const uint2 *>(xN + e0);
+            const float4 g0 = *reinterpret_cast<const float4 *>(graw + e0);
+            xw[0] = r.x; xw[1] = r.y;
+            gw[0] = pack_bf16x2(g0.x, g0.y); gw[1] = pack_bf16x2(g0.z, g0.w);
+            *reinterpret_cast<uint2 *>(gN + e0) = make_uint2(gw[0], gw[1]);
+        }
+#pragma unroll
+        for (int q = 0; q < VS / 2; ++q) {
+            tx[(2 * q) * HW] = (uint16_t)(xw[q] & 0xffffu);
+            tx[(2 * q + 1) * HW] = (uint16_t)(xw[q] >> 16);
+            tg[(2 * q) * HW] = (uint16_t)(gw[q] & 0xffffu);
+            tg[(2 * q + 1) * HW] = (uint16_t)(gw[q] >> 16);
+        }
     }
 }
 
@@ -577,7 +659,16 @@ __global__ void __launch_bounds__(256, (RP2 > 4 ? 3 : L3_WPE_FWD)) ss2d_l3_fwd_k
 // ---------------------------------------------------------------------------------------------------------------------
 // backward, one route over one plane
 // ---------------------------------------------------------------------------------------------------------------------
-template <int HW, bool REV, int MODE, int RP2>
+// what the first chunk row of a tile's first plane sends for: the next tile's planes (l3_dma_tile)
+struct L3Next {
+    const bf16_t *x;
+    const float *g;
+    uint32_t xdst, gdst;
+    int wave;
+    bool go;
+};
+
+template <int HW, bool REV, int MODE, int RP2, int PFPL = 0>
 __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row, bf16_t *__restrict__ ddts_row,
                                              const bf16_t *__restrict__ Brow, const bf16_t *__restrict__ Crow,
                                              const float *__restrict__ chk_row, const bool more_planes, const float An,
@@ -586,7 +677,7 @@ __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row,
                                              bf16_t *dxq, float *ldsacc, l3f2 (&rB)[L3Geom<HW, RP2>::NACC][4],
                                              l3f2 (&rC)[L3Geom<HW, RP2>::NACC][4], float &dA_acc, float &dD_acc,
                                              float &dbias_acc, const int lane, L3Ops<(MODE == 3 ? 2 * RP2 : 1)> &op,
-                                             const int dbg) {
+                                             const int dbg, const L3Next &nx) {
     using G = L3Geom<HW, RP2>;
     constexpr int L = G::L, NSEG = G::NSEG, NX = MODE == 3 ? 2 * RP2 : 1;
     const float A2 = An * kLog2e;
@@ -626,6 +717,15 @@ __device__ __forceinline__ void l3_bwd_plane(const bf16_t *__restrict__ dts_row,
         else l3_unpack<REV>(op.d[0], v);
         const uint4 bv = op.b, cv = op.c;
         const float hin = op.h;
+        if constexpr (PFPL > 0) {
+            // the next tile's planes: sent for once this row's operands are here (nothing of this wave is in flight behind the
+            // explicit wait, so the asm loads cannot make a compiler-counted wait stricter than it is)
+            if (nx.go && i == NSEG - 1) {
+                int lz;                               // (opaque: the piece addresses are formed here, not held through the loop)
+                asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0" : "=v"(lz)::"memory");
+                l3_dma_tile<PFPL>(nx.x, nx.g, nx.xdst, nx.gdst, nx.wave, lane + lz);
+            }
+        }
         // ---- request the next row to process (this plane's row i - 1, or the last row of the next plane)
         {
             const int in_ = i > 0 ? i - 1 : NSEG - 1;
@@ -813,6 +913,10 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
     l3_block_map(a, groups_pb, b, tg);
     bf16_t *xN = reinterpret_cast<bf16_t *>(smem), *xT = xN + PL, *gN = xT + PL, *gT = gN + PL, *DX = gT + PL;
     float *ldsacc = smem + (8 * (size_t)PL * 2) / 4 + wave * 2 * G::LSZ;
+    // (modes 0-2) behind the strips: the second natural x image and the raw dy of the tile being fetched (l3_dma_tile)
+    constexpr bool PF = MODE != 3 && L3_PREFETCH;
+    bf16_t *xN1 = reinterpret_cast<bf16_t *>(smem + (8 * (size_t)PL * 2) / 4 + 4 * 2 * G::LSZ);
+    float *graw = reinterpret_cast<float *>(xN1 + PL);
     for (int e = lane; e < 2 * G::LSZ; e += 64) ldsacc[e] = 0.f;
     l3f2 rB[G::NACC][4], rC[G::NACC][4];
 #pragma unroll
@@ -821,7 +925,7 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
         for (int q = 0; q < 4; ++q) rB[s][q] = rC[s][q] = l3f2{0.f, 0.f};
     const bool col = wave >> 1;
     const int k = (REV ? 2 : 0) + (wave >> 1);
-    const bf16_t *xq = col ? xT : xN, *gq = col ? gT : gN;
+    const bf16_t *gq = col ? gT : gN;
     bf16_t *dxq = DX + (size_t)wave * PL;
     const int64_t route = (int64_t)b * 4 + k;
     const bf16_t *Brow = (const bf16_t *)a.Bs + route * L, *Crow = (const bf16_t *)a.Cs + route * L;
@@ -841,6 +945,11 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
     }
     constexpr int NVX = 2, NVG = 4;                    // PL <= 4096 elements: 512 / 1024 vectors over 256 threads
     static_assert(PL <= 4096, "tile beyond the staging registers");
+    if constexpr (PF) {
+        const int64_t po0 = ((int64_t)b * D + (int64_t)tg * a.pli * PPT) * L;
+        if (!(a.dbg & 2))
+            l3_dma_tile<PL>((const bf16_t *)a.x + po0, (const float *)a.dy + po0, l3_lds_addr(xN), l3_lds_addr(graw), wave, lane);
+    }
 #pragma unroll 1
     for (int it = 0; it < a.pli; ++it) {
         const int d0 = (tg * a.pli + it) * PPT;
@@ -848,7 +957,21 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
         int tz;
         asm volatile("v_mov_b32 %0, 0" : "=v"(tz));    // opaque zero: keeps the per-thread tile positions out of registers
         const int tid = threadIdx.x + tz;
-        if constexpr (HW % 8 == 0) {
+        bf16_t *xNc = (PF && (it & 1)) ? xN1 : xN;    // this tile's natural x image
+        const bf16_t *xq = col ? xT : xNc;
+        L3Next nx{};
+        if constexpr (PF) {
+            // tile `it` was sent for during tile it - 1 (or above): wait for this wave's pieces, then for everybody's
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // (also: the previous tile's merge has read the private planes)
+            if (!(a.dbg & 8)) l3_stage_lds<HW, PPT>(xNc, xT, graw, gN, gT, tid);
+            nx.x = (const bf16_t *)a.x + po + PL;
+            nx.g = (const float *)a.dy + po + PL;
+            nx.xdst = l3_lds_addr((it & 1) ? xN : xN1);
+            nx.gdst = l3_lds_addr(graw);
+            nx.wave = wave;
+            nx.go = it + 1 < a.pli && !(a.dbg & 2);
+        } else if constexpr (HW % 8 == 0) {
             // Register staging in memory order.  (Named scalars, not arrays: hipcc left a uint4 / float4 array as an alloca --
             // 48 bytes of scratch per lane and plane, the vectors stored and re-read around the barrier: 1.9x the algorithmic
             // HBM bytes in the PMC counters.  Requesting the NEXT tile's vectors before the sweeps was tried: the 24 live
@@ -898,9 +1021,11 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
             float dA_acc, dD_acc, dbias_acc;
             uint32_t wp[RP2 ? RP2 : 1];
             l3_weight_pairs<RP2>(a.dtw, row, wp);
-            l3_bwd_plane<HW, REV, MODE, RP2>(MODE == 3 ? drow0 : (const bf16_t *)a.dts + ro, (bf16_t *)a.ddts + ro, Brow, Crow,
-                                             chk_row, more, An, Dr, bias, wp, xq + pl * L, gq + pl * L, dxq + pl * L, ldsacc, rB,
-                                             rC, dA_acc, dD_acc, dbias_acc, lane, op, a.dbg);
+            l3_bwd_plane<HW, REV, MODE, RP2, (PF ? PL : 0)>(MODE == 3 ? drow0 : (const bf16_t *)a.dts + ro, (bf16_t *)a.ddts + ro,
+                                                            Brow, Crow, chk_row, more, An, Dr, bias, wp, xq + pl * L, gq + pl * L,
+                                                            dxq + pl * L, ldsacc, rB, rC, dA_acc, dD_acc, dbias_acc, lane, op,
+                                                            a.dbg, nx);
+            nx.go = false;
             for (int o = 32; o > 0; o >>= 1) {
                 dA_acc += __shfl_xor(dA_acc, o, 64);
                 dD_acc += __shfl_xor(dD_acc, o, 64);
@@ -918,10 +1043,10 @@ __device__ __forceinline__ void l3_bwd_body(const LeanArgs &a, float *smem, cons
             asm volatile("v_mov_b32 %0, 0" : "=v"(tz2));
             if constexpr (HW % 8 == 0) {
                 // the sums into the (now free) natural x image in the conflict-free order, then out in memory order
-                l3_merge_store<HW, PPT>(xN, DX, DX + PL, DX + 2 * PL, DX + 3 * PL, threadIdx.x + tz2);
+                l3_merge_store<HW, PPT>(xNc, DX, DX + PL, DX + 2 * PL, DX + 3 * PL, threadIdx.x + tz2);
                 __syncthreads();
                 for (int v = threadIdx.x + tz2; v < PL / 8; v += 256)
-                    *reinterpret_cast<uint4 *>((bf16_t *)a.dx + po + v * 8) = *reinterpret_cast<const uint4 *>(xN + v * 8);
+                    *reinterpret_cast<uint4 *>((bf16_t *)a.dx + po + v * 8) = *reinterpret_cast<const uint4 *>(xNc + v * 8);
             } else {
                 l3_merge_store<HW, PPT>((bf16_t *)a.dx + po, DX, DX + PL, DX + 2 * PL, DX + 3 * PL, threadIdx.x + tz2);
             }
@@ -1046,6 +1171,7 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
     const size_t need = (size_t)p.batch * groups * 4 * 2 * L * sizeof(float);
     la.parts = (bwd && ws && ws_bytes >= need && groups > 1 && L % 4 == 0) ? ws : nullptr;
     size_t lds = bwd ? (size_t)8 * PL * 2 + (size_t)4 * 2 * G::LSZ * sizeof(float) : (size_t)6 * PL * 2;
+    if (bwd && p.delta_softplus != 3 && L3_PREFETCH) lds += (size_t)PL * 2 + (size_t)PL * 4;   // second x image | raw dy
     const void *fn;
     if (p.delta_softplus == 3) {
         la.xrt = p.xrt; la.dtw = p.dt_w;
