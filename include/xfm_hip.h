@@ -158,6 +158,22 @@ int xfm_dwconv3x3_tokens_fwd(const void *x, const float *weight, const float *bi
 int xfm_dwconv3x3_tokens_bwd(const void *x, const float *weight, const float *bias, const void *dy, void *dz_ws, void *dx,
                              float *part_ws, float *dweight, float *dbias, int B, int H, int W, int C, void *stream);
 
+/*
+ * 3 x 3, stride-2, padding-1 convolution on TOKEN-MAJOR maps (csrc/conv_tok.hip): the second convolution of the patch embedding
+ * and the three downsample layers of the trunk (reference models/fusion_vmamba.py:1504-1518 `_make_patch_embed_v2`, :1531-1538
+ * `_make_downsample_v3`; there `nn.Conv2d(dim, out_dim, 3, 2, 1)` on (B, C, H, W)), without bias (the caller folds it into the
+ * LayerNorm that follows).  x (B, H, W, C), y (B, H/2, W/2, O), weight (O, 3, 3, C) -- the channels_last memory of the
+ * (O, C, 3, 3) parameter --, all bf16; H, W even, C % 8 == 0, O % 8 == 0, pointers 16-byte aligned.
+ *   _fwd         fills col (B H/2 W/2, 9 C) bf16 (the 3 x 3 neighbourhoods as rows: keep it for _bwd_weight) and y = col . W^T
+ *   _bwd_data    dcol (B H/2 W/2, 9 C) bf16 is a workspace; dx (B, H, W, C) bf16
+ *   _bwd_weight  dweight (O, 3, 3, C) fp32 ZEROED by the caller (fp32 atomics add into it)
+ */
+int xfm_conv3x3s2_tokens_supported(int C, int O, int H, int W);
+int xfm_conv3x3s2_tokens_fwd(const void *x, const void *weight, void *col, void *y, int B, int H, int W, int C, int O, void *stream);
+int xfm_conv3x3s2_tokens_bwd_data(const void *dy, const void *weight, void *dcol, void *dx, int B, int H, int W, int C, int O,
+                                  void *stream);
+int xfm_conv3x3s2_tokens_bwd_weight(const void *dy, const void *col, float *dweight, int B, int H, int W, int C, int O, void *stream);
+
 /* LayerNorm over C of x (B, C, L) [NCHW with L = H*W], eps inside the rsqrt, affine weight/bias (C) fp32 (bias may
  * be NULL).  y may be a narrower dtype than x (the consumer GEMM's).  mean / rstd: (B, L) fp32, written by fwd and
  * read by bwd.  bwd: dx in x_dtype; dweight / dbias fp32, ZEROED by the caller (dbias may be NULL). */

@@ -370,6 +370,40 @@ def test_dwconv3x3_silu_on_token_major_maps_matches_torch_fp32(shape, with_bias)
     assert_close(y.float().cpu(), yp.detach().float().cpu().permute(0, 2, 3, 1), 1e-2, 1e-2 * float(yr.abs().max()), "y vs planes")
 
 
+# (B, H, W, C, O): the four layers of XFMamba-T at reduced batch, odd sizes (O and 9 C not whole 128-wide tiles, a token count
+# that is not a whole 128-token tile or 64-token weight-gradient stage), the smallest map
+CONV_S2_SHAPES = [(2, 112, 112, 48, 96), (2, 56, 56, 96, 192), (4, 28, 28, 192, 384), (8, 14, 14, 384, 768),
+                  (3, 6, 10, 8, 8), (1, 2, 2, 16, 24), (5, 12, 8, 40, 136), (64, 14, 14, 384, 768)]
+
+
+@pytest.mark.parametrize("shape", CONV_S2_SHAPES)
+def test_conv3x3_stride2_on_token_major_maps_matches_torch_fp32(shape):
+    """The trunk's 3 x 3 stride-2 padding-1 convolutions (reference fusion_vmamba.py:1504-1518, 1531-1538) on TOKEN-MAJOR maps
+    through xfm_conv3x3s2_tokens_fwd/_bwd_data/_bwd_weight (csrc/conv_tok.hip: neighbourhood rows + the library's MFMA GEMMs)
+    vs F.conv2d in fp32 on the NCHW view of the same bf16 operands: output, dx, dweight at 1e-2 of the largest value."""
+    import torch.nn.functional as F
+    from xfmamba_amd import _lib
+    from xfmamba_amd.conv_tokens import conv3x3s2_tokens_fn
+    B, H, W, C, O = shape
+    g = torch.Generator().manual_seed(B + H + C + O)
+    x = torch.randn(B, H, W, C, generator=g).bfloat16()
+    w = (torch.randn(O, C, 3, 3, generator=g) * (9 * C) ** -0.5).bfloat16().float()     # (bf16-exact: the kernel reads a bf16 shadow)
+    gy = torch.randn(B, H // 2, W // 2, O, generator=g).bfloat16()
+    xr, wr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(), w.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, None, stride=2, padding=1)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    assert _lib.lib().xfm_conv3x3s2_tokens_supported(C, O, H, W)
+    y = conv3x3s2_tokens_fn(xd, wd)
+    y.backward(gy.to(DEV))
+    assert y.dtype == torch.bfloat16 and y.shape == (B, H // 2, W // 2, O)
+    tol = 1e-2
+    assert_close(y.float().cpu(), yr.detach().permute(0, 2, 3, 1), tol, tol * float(yr.abs().max()), "y")
+    assert_close(xd.grad.float().cpu(), xr.grad.permute(0, 2, 3, 1), tol, tol * float(xr.grad.abs().max()), "dx")
+    assert wd.grad.shape == w.shape
+    assert_close(wd.grad.cpu(), wr.grad, tol, tol * float(wr.grad.abs().max()), "dw")
+
+
 @pytest.mark.parametrize("C", [48, 96, 192, 384, 768, 64, 1024])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["plain", "add", "add_scale"])

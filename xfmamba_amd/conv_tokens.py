@@ -1,0 +1,98 @@
+"""3 x 3, stride-2, padding-1 convolution on token-major maps -- the second convolution of the patch embedding and the three
+downsample layers of the trunk (reference ``models/fusion_vmamba.py:1504-1518``, ``:1531-1538``: ``nn.Conv2d(dim, out_dim, 3,
+2, 1)``) -- through ``xfm_conv3x3s2_tokens_fwd/_bwd_data/_bwd_weight`` (csrc/conv_tok.hip): the 3 x 3 neighbourhoods as rows,
+then the library's own MFMA GEMM kernels.  No convolution library, no solver search.  The parameter stays where the reference
+keeps it (``weight`` (O, C, 3, 3)); the bias is NOT applied here (the caller folds it into the LayerNorm that follows).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _lib
+from .amp import cast_weight
+from .proj import wgrad_slot, zeros_f32
+
+__all__ = ["conv3x3s2_tokens_fn", "conv3x3s2_tokens_supported", "Conv3x3S2TokensHip"]
+
+# XFM_CONV_OWN=0: the strided convolutions stay on the convolution library (A/B switch, read once).
+# XFM_CONV_OWN_MIN_C: the fewest input channels the own path takes.  Measured per pass at batch 64 (tools/convprobe.py, us, own /
+# library): 112 x 112 x 48 -> 96: 104 / 48 forward, 124 / 88 data gradient, 38 / 66 weight gradient; 56 x 56 x 96 -> 192: 62 / 36,
+# 60 / 60, 33 / 65; 28 x 28 x 192 -> 384: 48 / 43, 44 / 54, 29 / 60; 14 x 14 x 384 -> 768: 58 / 53, 40 / 68, 34 / 59.  The
+# neighbourhood rows cost 9/4 of the input in HBM traffic each way: at the two large maps that is more than the library's implicit
+# GEMM spends in total, so those two layers stay on it.
+_OWN = os.environ.get("XFM_CONV_OWN", "1") == "1"
+_OWN_MIN_C = int(os.environ.get("XFM_CONV_OWN_MIN_C", "192"))
+
+
+def conv3x3s2_tokens_supported(t: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
+    """Token-major t (B, H, W, C) bf16 (or fp32 under bf16 autocast) and a convolution ``xfm_conv3x3s2_tokens_*`` covers."""
+    if not (_OWN and t.is_cuda and t.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"):
+        return False
+    cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else conv.weight.dtype
+    if cd != torch.bfloat16:
+        return False
+    B, H, W, C = t.shape
+    return C >= _OWN_MIN_C and bool(_lib.lib().xfm_conv3x3s2_tokens_supported(C, conv.out_channels, H, W))
+
+
+class Conv3x3S2TokensHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, weight):
+        _lib.require_cuda(t, weight)
+        B, H, W, C = t.shape
+        O = weight.shape[0]
+        if weight.shape != (O, C, 3, 3):
+            raise RuntimeError("conv3x3s2_tokens: weight must be (O, C, 3, 3)")
+        ctx.t_dtype, ctx.w_dtype = t.dtype, weight.dtype
+        x = t.contiguous() if t.dtype == torch.bfloat16 else t.to(torch.bfloat16).contiguous()
+        # (O, 3, 3, C): the channels_last memory of the parameter's bf16 shadow
+        w = cast_weight(weight, torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+        OH, OW = H // 2, W // 2
+        T = B * OH * OW
+        col = torch.empty(T, 9 * C, dtype=torch.bfloat16, device=t.device)
+        y = torch.empty(B, OH, OW, O, dtype=torch.bfloat16, device=t.device)
+        nbytes = x.numel() * 2 + 2 * col.numel() * 2 + y.numel() * 2
+        with torch.cuda.device(t.device), _lib.timed("conv3x3s2_fwd", nbytes):
+            _lib.check(_lib.lib().xfm_conv3x3s2_tokens_fwd(x.data_ptr(), w.data_ptr(), col.data_ptr(), y.data_ptr(), B, H, W, C, O,
+                                                           _lib.stream_ptr()), "conv3x3s2_tokens_fwd")
+        ctx.shape = (B, H, W, C, O)
+        ctx.weight = weight
+        ctx.save_for_backward(col, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, w = ctx.saved_tensors
+        B, H, W, C, O = ctx.shape
+        dy = dy.contiguous() if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16).contiguous()
+        lib = _lib.lib()
+        dx = dw = None
+        with torch.cuda.device(dy.device):
+            if ctx.needs_input_grad[1]:
+                slot = wgrad_slot(ctx.weight, O, 9 * C)
+                acc = slot if slot is not None else zeros_f32(O * 9 * C, dy.device).view(O, 9 * C)
+                with _lib.timed("conv3x3s2_wgrad", (dy.numel() + col.numel()) * 2):
+                    _lib.check(lib.xfm_conv3x3s2_tokens_bwd_weight(dy.data_ptr(), col.data_ptr(), acc.data_ptr(), B, H, W, C, O,
+                                                                   _lib.stream_ptr()), "conv3x3s2_tokens_bwd_weight")
+                # (O, 3, 3, C) sums seen as the parameter's (O, C, 3, 3): a channels_last gradient (optim.py brings it to the
+                # parameter's layout, as it did for the convolution library's)
+                dw = acc.view(O, 3, 3, C).permute(0, 3, 1, 2)
+                if dw.dtype != ctx.w_dtype:
+                    dw = dw.to(ctx.w_dtype)
+            if ctx.needs_input_grad[0]:
+                dcol = torch.empty_like(col)
+                dx = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=dy.device)
+                with _lib.timed("conv3x3s2_dgrad", (dy.numel() + 2 * dcol.numel() + dx.numel()) * 2):
+                    _lib.check(lib.xfm_conv3x3s2_tokens_bwd_data(dy.data_ptr(), w.data_ptr(), dcol.data_ptr(), dx.data_ptr(), B, H, W,
+                                                                 C, O, _lib.stream_ptr()), "conv3x3s2_tokens_bwd_data")
+                if dx.dtype != ctx.t_dtype:
+                    dx = dx.to(ctx.t_dtype)
+        return dx, dw
+
+
+def conv3x3s2_tokens_fn(t: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """t (B, H, W, C), weight (O, C, 3, 3) -> conv2d(t, weight, stride 2, padding 1) as (B, H/2, W/2, O) bf16 (no bias)."""
+    return Conv3x3S2TokensHip.apply(t, weight)

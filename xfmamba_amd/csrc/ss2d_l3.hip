@@ -1191,6 +1191,8 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
         fn = p.delta_softplus == 2 ? (const void *)ss2d_l3_fwd_kernel<HW, PPT, 2>
                                    : (p.delta_softplus == 1 ? (const void *)ss2d_l3_fwd_kernel<HW, PPT, 1>
                                                             : (const void *)ss2d_l3_fwd_kernel<HW, PPT, 0>);
+    static const int env_pad = [] { const char *e = getenv("XFM_L3_LDS_PAD"); return e ? atoi(e) : 0; }();   // occupancy experiments
+    lds += (size_t)env_pad;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const unsigned grid = (unsigned)((int64_t)p.batch * (tiles_pb / pli));
     void *kargs[] = {&la};

@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
     const int tn = vid % ntn, tm = vid / ntn;
     const int64_t t0 = (int64_t)tm * 128;
     const int n0 = tn * 128;
-    if (tid < 128) bl[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+    if (tid < 128) bl[tid] = (a.bias && n0 + tid < a.OUT) ? a.bias[n0 + tid] : 0.f;
     const int wm = wave >> 1, wn = wave & 1;               // wave -> outputs 64 wm .., tokens 64 wn ..
     // ---- global side of the LDS-direct loads (lane constants; k0 is added per stage through the scalar base)
     const uint16_t *gx[4], *gw[4];
@@ -674,12 +674,13 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
         int64_t tr = t0 + row;
         if (tr >= a.T) tr = a.T - 1;
         gx[i] = a.x + tr * CON + 8 * ch;
+        // (OUT need not be whole tiles: rows / column chunks past it read clamped addresses, and are never stored)
         if constexpr (!WT) {
-            gw[i] = a.w + (int64_t)(n0 + row) * CON + 8 * ch;
+            gw[i] = a.w + (int64_t)min(n0 + row, a.OUT - 1) * CON + 8 * ch;
         } else {                                           // (CON, OUT): rows 4 (4 wave + i) .. + 3 of the k-major image
             const int kr = 4 * (4 * wave + i) + (lane >> 4);
             const int cw = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
-            gw[i] = a.w + (int64_t)kr * a.OUT + n0 + 8 * cw;
+            gw[i] = a.w + (int64_t)kr * a.OUT + min(n0 + 8 * cw, a.OUT - 8);
         }
     }
     const int NST = (CON + 63) / 64;
@@ -825,12 +826,13 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
         for (int e = 0; e < 8; ++e) bbv[e] = bl[8 * ck + e];
     }
     tg_u32x4_t zi[EPI == 2 ? 8 : 1];
+    const bool col_ok = n0 + 8 * ck < a.OUT;               // (OUT % 8 == 0)
     if constexpr (EPI == 2) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int64_t row = t0 + 16 * i + rl;
             if (row >= a.T) row = a.T - 1;
-            zi[i] = *reinterpret_cast<const tg_u32x4_t *>(a.zin + row * a.OUT + n0 + 8 * ck);
+            zi[i] = *reinterpret_cast<const tg_u32x4_t *>(a.zin + row * a.OUT + min(n0 + 8 * ck, a.OUT - 8));
         }
     }
     float csum[8];                                         // EPI 2: column sums of this thread's rows (dz as stored: bf16)
@@ -841,7 +843,7 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
         const int r = 16 * i + rl;
         const int64_t row = t0 + r;
         const tg_u32x4_t v = *reinterpret_cast<const tg_u32x4_t *>(img + r * SP + 8 * ck);
-        if (row >= a.T) continue;
+        if (row >= a.T || !col_ok) continue;
         const int64_t off = row * a.OUT + n0 + 8 * ck;
         if constexpr (EPI == 0) {
             *reinterpret_cast<tg_u32x4_t *>(a.y + off) = v;
@@ -885,7 +887,7 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
             *reinterpret_cast<float4 *>(red + rl * 128 + 8 * ck) = make_float4(csum[0], csum[1], csum[2], csum[3]);
             *reinterpret_cast<float4 *>(red + rl * 128 + 8 * ck + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
             __syncthreads();
-            if (tid < 128) {
+            if (tid < 128 && n0 + tid < a.OUT) {
                 float s = 0.f;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) s += red[q * 128 + tid];
@@ -901,7 +903,7 @@ static int tokens_gemm3_launch(const TokGemm2Args &a, int con, hipStream_t s) {
     auto fn = tokens_gemm3_kernel<EPI, WT>;
     static LdsOptIn opted;
     if (!lds_opt_in(opted, reinterpret_cast<const void *>(fn), lds)) return XFM_ELAUNCH;
-    const int ntn = a.OUT / 128;
+    const int ntn = (a.OUT + 127) / 128;
     const int64_t ntm = (a.T + 127) / 128;
     const int64_t ntiles = ntm * ntn;
     if (ntiles > (1 << 30)) return XFM_ELIMIT;
@@ -1166,6 +1168,22 @@ static int tokens_gemm3(const TokGemm2Args &a, int con, int epi, hipStream_t s) 
     if (epi == 0) return wt ? tokens_gemm3_launch<0, true>(a, con, s) : tokens_gemm3_launch<0, false>(a, con, s);
     if (epi == 1) return wt ? tokens_gemm3_launch<1, true>(a, con, s) : tokens_gemm3_launch<1, false>(a, con, s);
     return wt ? tokens_gemm3_launch<2, true>(a, con, s) : tokens_gemm3_launch<2, false>(a, con, s);
+}
+
+// y (T, out) = x (T, con) . W^T through the tiled form, no bias: W as (out, con), or -- wt -- as (con, out).  con, out % 8 == 0,
+// 16-byte aligned operands.  (xfm namespace, not part of the C ABI: csrc/conv_tok.hip)
+int tokens_gemm3_plain(const void *x, const void *w, void *y, long long T, int con, int out, bool wt, hipStream_t s) {
+    if (con % 8 || out % 8 || con < 8 || out < 8 || T <= 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15))
+        return XFM_ELIMIT;
+    TokGemm2Args a{};
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w);
+    a.y = static_cast<uint16_t *>(y);
+    a.T = T;
+    a.OUT = out;
+    a.wt = wt ? 1 : 0;
+    a.wgs_per_chunk = 1;
+    return tokens_gemm3(a, con, 0, s);
 }
 
 template <int CON, int OCH>

@@ -35,6 +35,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .csm import SwappingMerge_multiview, SwappingScan_multiview, SwappingScanStacked, cross_merge_fn, cross_scan_fn
+from .conv_tokens import conv3x3s2_tokens_fn, conv3x3s2_tokens_supported
 from .csms6s import selective_scan_fn
 from .dwconv import dwconv3x3_silu_fn, dwconv3x3_silu_tokens_fn, dwconv_tokens_supported
 from .layernorm2d import layernorm2d_fn
@@ -665,13 +666,17 @@ def _conv_ln_tokens(conv: nn.Conv2d, norm: nn.Module, t: torch.Tensor, out_dtype
     fused = isinstance(norm, LayerNorm2d)
     if t.dtype != conv.weight.dtype and not torch.is_autocast_enabled():
         t = t.to(conv.weight.dtype)                      # fp32 residual stream into a reduced-precision model
-    if _CONV_CL and fused and t.is_cuda and conv.padding_mode == "zeros" and not isinstance(conv.padding, str):
-        y = _ConvChannelsLast.apply(t.permute(0, 3, 1, 2), conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if fused and conv3x3s2_tokens_supported(t, conv):
+        # the library's own MFMA path (csrc/conv_tok.hip): every 3 x 3 stride-2 convolution with at least 8 input channels
+        y = conv3x3s2_tokens_fn(t, conv.weight)
     else:
-        y = F.conv2d(t.permute(0, 3, 1, 2), conv.weight, None if fused else conv.bias, conv.stride, conv.padding,
-                     conv.dilation, conv.groups)
-    y = y.permute(0, 2, 3, 1)
-    y = y if y.is_contiguous() else y.contiguous()
+        if _CONV_CL and fused and t.is_cuda and conv.padding_mode == "zeros" and not isinstance(conv.padding, str):
+            y = _ConvChannelsLast.apply(t.permute(0, 3, 1, 2), conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+        else:
+            y = F.conv2d(t.permute(0, 3, 1, 2), conv.weight, None if fused else conv.bias, conv.stride, conv.padding,
+                         conv.dilation, conv.groups)
+        y = y.permute(0, 2, 3, 1)
+        y = y if y.is_contiguous() else y.contiguous()
     if not fused:
         return y if out_dtype is None else y.to(out_dtype)
     if y.dtype not in (torch.float32, torch.bfloat16):
