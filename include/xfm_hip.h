@@ -173,6 +173,12 @@ int xfm_conv3x3s2_tokens_fwd(const void *x, const void *weight, void *col, void 
 int xfm_conv3x3s2_tokens_bwd_data(const void *dy, const void *weight, void *dcol, void *dx, int B, int H, int W, int C, int O,
                                   void *stream);
 int xfm_conv3x3s2_tokens_bwd_weight(const void *dy, const void *col, float *dweight, int B, int H, int W, int C, int O, void *stream);
+/* The same weight gradient straight from the input map x (B, H, W, C) -- no `col` rows -- for layers whose forward pass ran
+ * elsewhere (csrc/wgrad_gemm.hip: the token x token kernel gathers the window taps itself).  _supported: B H/2 W/2 a multiple of 64
+ * and at least 2048, H/2 >= 64 / (W/2) + 2. */
+int xfm_conv3x3s2_tokens_bwd_weight_x_supported(int B, int H, int W, int C, int O);
+int xfm_conv3x3s2_tokens_bwd_weight_x(const void *dy, const void *x, float *dweight, int B, int H, int W, int C, int O,
+                                      void *stream);
 
 /* LayerNorm over C of x (B, C, L) [NCHW with L = H*W], eps inside the rsqrt, affine weight/bias (C) fp32 (bias may
  * be NULL).  y may be a narrower dtype than x (the consumer GEMM's).  mean / rstd: (B, L) fp32, written by fwd and

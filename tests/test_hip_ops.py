@@ -372,8 +372,8 @@ def test_dwconv3x3_silu_on_token_major_maps_matches_torch_fp32(shape, with_bias)
 
 # (B, H, W, C, O): the four layers of XFMamba-T at reduced batch, odd sizes (O and 9 C not whole 128-wide tiles, a token count
 # that is not a whole 128-token tile or 64-token weight-gradient stage), the smallest map
-CONV_S2_SHAPES = [(2, 112, 112, 48, 96), (2, 56, 56, 96, 192), (4, 28, 28, 192, 384), (8, 14, 14, 384, 768),
-                  (3, 6, 10, 8, 8), (1, 2, 2, 16, 24), (5, 12, 8, 40, 136), (64, 14, 14, 384, 768)]
+CONV_S2_SHAPES = [(2, 112, 112, 48, 96), (4, 56, 56, 96, 192), (4, 28, 28, 192, 384), (8, 14, 14, 384, 768),
+                  (3, 6, 10, 8, 8), (1, 2, 2, 16, 24), (5, 12, 8, 40, 136), (64, 14, 14, 384, 768), (16, 28, 28, 192, 384)]
 
 
 @pytest.mark.parametrize("shape", CONV_S2_SHAPES)
@@ -402,6 +402,14 @@ def test_conv3x3_stride2_on_token_major_maps_matches_torch_fp32(shape):
     assert_close(xd.grad.float().cpu(), xr.grad.permute(0, 2, 3, 1), tol, tol * float(xr.grad.abs().max()), "dx")
     assert wd.grad.shape == w.shape
     assert_close(wd.grad.cpu(), wr.grad, tol, tol * float(wr.grad.abs().max()), "dw")
+    # the weight gradient straight from the input map (the token x token kernel gathers the window taps itself), where covered
+    from xfmamba_amd.conv_tokens import conv3x3s2_wgrad_from_map
+    covered = bool(_lib.lib().xfm_conv3x3s2_tokens_bwd_weight_x_supported(B, H, W, C, O))
+    assert covered == (shape in [(2, 112, 112, 48, 96), (4, 56, 56, 96, 192), (16, 28, 28, 192, 384)])
+    if covered:
+        gw = conv3x3s2_wgrad_from_map(gy.to(DEV), x.to(DEV), wd.detach())
+        assert gw is not None and gw.shape == w.shape
+        assert_close(gw.float().cpu(), wr.grad, tol, tol * float(wr.grad.abs().max()), "dw from the map")
 
 
 @pytest.mark.parametrize("C", [48, 96, 192, 384, 768, 64, 1024])

@@ -52,6 +52,10 @@ def main():
         def bw():
             _lib.check(lib.xfm_conv3x3s2_tokens_bwd_weight(dy.data_ptr(), col.data_ptr(), dw.data_ptr(), B, H, H, C, O, s()), "w")
 
+        def bwx():
+            _lib.check(lib.xfm_conv3x3s2_tokens_bwd_weight_x(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, H, C, O, s()), "wx")
+
+        wx = lib.xfm_conv3x3s2_tokens_bwd_weight_x_supported(B, H, H, C, O)
         xn = x.permute(0, 3, 1, 2)                         # channels_last views
         wn = w.permute(0, 3, 1, 2)
         dyn = dy.permute(0, 3, 1, 2)
@@ -69,7 +73,7 @@ def main():
         r = lf()
         err = float((y.float() - r.permute(0, 2, 3, 1).float()).abs().max()) / float(r.float().abs().max())
         print(f"B {B} {H}x{H}x{C} -> {O}:  fwd own {timed(fwd):6.1f} lib {timed(lf):6.1f}   dgrad own {timed(bd):6.1f} lib {timed(lbd):6.1f}"
-              f"   wgrad own {timed(bw):6.1f} lib {timed(lbw):6.1f} us   max diff / max {err:.1e}")
+              f"   wgrad own {timed(bw):6.1f} from the map {(timed(bwx) if wx else 0.0):6.1f} lib {timed(lbw):6.1f} us   max diff / max {err:.1e}")
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ from . import _lib
 from .amp import cast_weight
 from .proj import wgrad_slot, zeros_f32
 
-__all__ = ["conv3x3s2_tokens_fn", "conv3x3s2_tokens_supported", "Conv3x3S2TokensHip"]
+__all__ = ["conv3x3s2_tokens_fn", "conv3x3s2_tokens_supported", "conv3x3s2_wgrad_from_map", "Conv3x3S2TokensHip"]
 
 # XFM_CONV_OWN=0: the strided convolutions stay on the convolution library (A/B switch, read once).
 # XFM_CONV_OWN_MIN_C: the fewest input channels the own path takes.  Measured per pass at batch 64 (tools/convprobe.py, us, own /
@@ -24,6 +24,8 @@ __all__ = ["conv3x3s2_tokens_fn", "conv3x3s2_tokens_supported", "Conv3x3S2Tokens
 # GEMM spends in total, so those two layers stay on it.
 _OWN = os.environ.get("XFM_CONV_OWN", "1") == "1"
 _OWN_MIN_C = int(os.environ.get("XFM_CONV_OWN_MIN_C", "192"))
+# XFM_CONV_WGRAD_X=0: the layers that stay on the convolution library also take their weight gradient from it
+_WGRAD_X = os.environ.get("XFM_CONV_WGRAD_X", "1") == "1"
 
 
 def conv3x3s2_tokens_supported(t: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
@@ -91,6 +93,28 @@ class Conv3x3S2TokensHip(torch.autograd.Function):
                 if dx.dtype != ctx.t_dtype:
                     dx = dx.to(ctx.t_dtype)
         return dx, dw
+
+
+def conv3x3s2_wgrad_from_map(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor):
+    """Weight gradient of the convolution from its token-major input map: dy (B, H/2, W/2, O), x (B, H, W, C) bf16 ->
+    the (O, C, 3, 3) gradient (a channels_last view of fp32 (O, 3, 3, C) sums) through ``xfm_conv3x3s2_tokens_bwd_weight_x``,
+    or None when the kernel does not cover the call (the caller then asks the convolution library)."""
+    if not (_OWN and _WGRAD_X and dy.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 4
+            and x.dim() == 4 and dy.is_contiguous() and x.is_contiguous()):
+        return None
+    B, H, W, C = x.shape
+    O = dy.shape[-1]
+    if dy.shape != (B, H // 2, W // 2, O) or weight.shape != (O, C, 3, 3):
+        return None
+    lib = _lib.lib()
+    if not lib.xfm_conv3x3s2_tokens_bwd_weight_x_supported(B, H, W, C, O):
+        return None
+    slot = wgrad_slot(weight, O, 9 * C)
+    acc = slot if slot is not None else zeros_f32(O * 9 * C, dy.device).view(O, 9 * C)
+    with torch.cuda.device(dy.device), _lib.timed("conv3x3s2_wgrad", (dy.numel() + x.numel() * 9 // 4) * 2):
+        _lib.check(lib.xfm_conv3x3s2_tokens_bwd_weight_x(dy.data_ptr(), x.data_ptr(), acc.data_ptr(), B, H, W, C, O,
+                                                         _lib.stream_ptr()), "conv3x3s2_tokens_bwd_weight_x")
+    return acc.view(O, 3, 3, C).permute(0, 3, 1, 2)
 
 
 def conv3x3s2_tokens_fn(t: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:

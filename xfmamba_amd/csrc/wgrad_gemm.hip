@@ -57,7 +57,13 @@ struct WgradArgs {
     // whose operand rows then meet in that XCD's L2 instead of being fetched once per tile (wgs = workgroups with work)
     int wgs, xcd_map;
     long long *prof;                    // debugging: 4 timestamps per workgroup (xfm_dbg_wgrad_prof), or null
+    // LDS-direct kernel, CONV instance: operand B is the token-major INPUT MAP x (batch, H, W, C) of a 3 x 3 stride-2 padding-1
+    // convolution and its N = 9 C columns are the taps (kh, kw, c) of the window of output token t -- the weight gradient
+    // dW (O, 3, 3, C) = dy^T . windows(x) without the windows ever being written (csrc/conv_tok.hip)
+    int cv_H, cv_W, cv_C, cv_OH, cv_OW;
 };
+
+__device__ uint4 wg_zero_page[4];     // what a tap in the padding reads
 
 static long long *g_wgrad_prof = nullptr;
 
@@ -589,7 +595,7 @@ template <int OFF> __device__ __forceinline__ void wg_tr_read(wg_bf16x4_t &d, co
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(OFF) : "memory");
 }
 
-template <bool DBG>
+template <bool DBG, bool CONV = false>
 __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a) {
     extern __shared__ __align__(16) uint8_t wg_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -613,6 +619,10 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
     // stage buffer b: A tile at 2 b kGlTile, B tile kGlTile behind it
     // this lane's share of a stage: instruction i (0..3) of this wave fills rows 4 (4 wave + i) .. + 3 of the tile
     int64_t offa[4], offb[4];                             // element offsets inside a 64-token stage of A / B
+    // CONV: the window of the token this lane's row of part i holds in the NEXT stage to request -- sample, output row / column
+    // -- and the lane's tap: element offset from the window's centre-row, left-column pixel (2 oh, 2 ow) of the sample, and whether
+    // the tap lies in the top / left padding for oh / ow = 0
+    int cvn[4], cvh[4], cvw[4], cvtap[4], cvpad[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 4 * (4 * wave + i) + (lane >> 4);
@@ -620,7 +630,18 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
         const int ca = min(m0 + 8 * ch, a.M - 8), cb = min(n0 + 8 * ch, a.N - 8);      // clamped: see above
         offa[i] = (int64_t)row * a.M + ca;
         offb[i] = (int64_t)row * a.N + cb;
+        if constexpr (CONV) {
+            const int tap = cb / a.cv_C, c = cb - tap * a.cv_C, kh = tap / 3, kw = tap - 3 * kh;
+            cvtap[i] = ((kh - 1) * a.cv_W + (kw - 1)) * a.cv_C + c;
+            cvpad[i] = (kh == 0 ? 1 : 0) | (kw == 0 ? 2 : 0);
+            const int t = st0 * kGlBK + row, per = a.cv_OH * a.cv_OW;
+            cvn[i] = t / per;
+            const int r = t - cvn[i] * per;
+            cvh[i] = r / a.cv_OW;
+            cvw[i] = r - cvh[i] * a.cv_OW;
+        }
     }
+    const int cv_qo = CONV ? kGlBK / a.cv_OW : 0, cv_ro = CONV ? kGlBK - cv_qo * a.cv_OW : 0;   // a stage further: 64 tokens
     // The loads of a stage are issued in FOUR parts, one per k16-step of the stage being multiplied: a 1 KB LDS-direct load
     // keeps the CU's address path busy for 16 cycles (64 B / clk) -- the 32 of a stage (32 KB) for as long as the stage's 16
     // MFMAs per wave take -- and a wave that issues its eight loads back to back sits in the issue queue for that long
@@ -633,7 +654,21 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
         uint8_t *dst = wg_lds + buf * 2 * kGlTile + (4 * wave + i) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa + offa[i]),
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb + offb[i]),
+        const uint16_t *src = pb + offb[i];
+        if constexpr (CONV) {
+            const bool pad = ((cvpad[i] & 1) && cvh[i] == 0) || ((cvpad[i] & 2) && cvw[i] == 0);
+            const int pix = ((cvn[i] * a.cv_H + 2 * cvh[i]) * a.cv_W + 2 * cvw[i]) * a.cv_C + cvtap[i];
+            src = pad ? reinterpret_cast<const uint16_t *>(wg_zero_page) : a.b + pix;
+            // this row's token one stage on (a stage is fewer than OH output rows: one wrap each at most)
+            cvw[i] += cv_ro;
+            const int c1 = cvw[i] >= a.cv_OW ? 1 : 0;
+            cvw[i] -= c1 * a.cv_OW;
+            cvh[i] += cv_qo + c1;
+            const int c2 = cvh[i] >= a.cv_OH ? 1 : 0;
+            cvh[i] -= c2 * a.cv_OH;
+            cvn[i] += c2;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(dst + kGlTile), 16, 0, 0);
     };
     const int64_t sa = (int64_t)kGlBK * a.M, sb = (int64_t)kGlBK * a.N;       // elements per stage (batch == 1: one token run)
@@ -870,6 +905,47 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     if (a_planes) return b_planes ? wgrad_launch<true, true, 64>(w, nsl, s) : wgrad_launch<true, false, 64>(w, nsl, s);
     if (b_planes) return wgrad_launch<false, true, 64>(w, nsl, s);
     return wgrad_launch<false, false, 64>(w, nsl, s);
+}
+
+/* Weight gradient of a 3 x 3, stride-2, padding-1 convolution on token-major maps straight from the input map (see
+ * xfm_conv3x3s2_tokens_* in include/xfm_hip.h): dweight (O, 3, 3, C) fp32, ZEROED by the caller, += dy^T . windows(x) with
+ * dy (B, H/2, W/2, O) and x (B, H, W, C) bf16 -- the LDS-direct token x token kernel with the rows of its second operand
+ * gathered from x (a tap in the padding reads a zero page), no (tokens, 9 C) workspace.  _supported: whole 64-token stages
+ * (B H/2 W/2 % 64 == 0, at least 2048 tokens), maps whose 64-token stage spans fewer than H/2 - 1 output rows, C, O % 8 == 0. */
+int xfm_conv3x3s2_tokens_bwd_weight_x_supported(int B, int H, int W, int C, int O) {
+    if (B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 8 || C % 8 || O < 8 || O % 8) return 0;
+    const long long T = (long long)B * (H / 2) * (W / 2);
+    if (T % xfm::kGlBK || T < 2048 || T > 0x7fffffffll || (long long)B * H * W * C >= 0x7fffffffll) return 0;
+    return (H / 2) >= xfm::kGlBK / (W / 2) + 2 ? 1 : 0;
+}
+
+int xfm_conv3x3s2_tokens_bwd_weight_x(const void *dy, const void *x, float *dweight, int B, int H, int W, int C, int O,
+                                      void *stream) {
+    using namespace xfm;
+    if (!dy || !x || !dweight) return XFM_EINVAL;
+    if (!xfm_conv3x3s2_tokens_bwd_weight_x_supported(B, H, W, C, O)) return XFM_ELIMIT;
+    if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return XFM_EINVAL;
+    WgradArgs w{};
+    w.a = (const uint16_t *)dy; w.b = (const uint16_t *)x; w.dw = dweight;
+    w.M = O; w.N = 9 * C; w.batch = 1; w.L = (int)((long long)B * (H / 2) * (W / 2));
+    w.lda = w.M; w.ldb = w.N; w.groups = 1;
+    w.cv_H = H; w.cv_W = W; w.cv_C = C; w.cv_OH = H / 2; w.cv_OW = W / 2;
+    w.steps_per_sample = w.L / kGlBK;
+    w.total_steps = w.steps_per_sample;
+    const int tiles = ((w.M + kWgTile - 1) / kWgTile) * ((w.N + kWgTile - 1) / kWgTile);
+    int nsl = std::max(1, std::min(256 / tiles, w.total_steps / 8));     // (as xfm_wgrad: one round of workgroups, >= 512 tokens each)
+    w.steps_per_slice = (w.total_steps + nsl - 1) / nsl;
+    nsl = (w.total_steps + w.steps_per_slice - 1) / w.steps_per_slice;
+    w.nslices = nsl;
+    w.stagger = nsl >= 4 ? (tiles >= 16 ? 0.5f : 0.2f) : 0.f;
+    const size_t lds = (size_t)kGlStages * 2 * kGlTile;
+    static xfm::LdsOptIn attr;
+    if (!xfm::lds_opt_in(attr, (const void *)wgrad_tt_glds_kernel<false, true>, lds)) return XFM_ELAUNCH;
+    w.wgs = tiles * nsl;
+    w.xcd_map = wg_xcd_map() ? 1 : 0;
+    const int grid = w.xcd_map ? (w.wgs + 7) / 8 * 8 : w.wgs;
+    hipLaunchKernelGGL((wgrad_tt_glds_kernel<false, true>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, w);
+    return check_launch();
 }
 
 }  // extern "C"

@@ -35,7 +35,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .csm import SwappingMerge_multiview, SwappingScan_multiview, SwappingScanStacked, cross_merge_fn, cross_scan_fn
-from .conv_tokens import conv3x3s2_tokens_fn, conv3x3s2_tokens_supported
+from .conv_tokens import conv3x3s2_tokens_fn, conv3x3s2_tokens_supported, conv3x3s2_wgrad_from_map
 from .csms6s import selective_scan_fn
 from .dwconv import dwconv3x3_silu_fn, dwconv3x3_silu_tokens_fn, dwconv_tokens_supported
 from .layernorm2d import layernorm2d_fn
@@ -638,6 +638,7 @@ class _ConvChannelsLast(torch.autograd.Function):
         x = x if x.dtype == cd else x.to(cd)
         w = cast_weight(weight, cd).contiguous(memory_format=torch.channels_last)
         ctx.conv = (tuple(stride), tuple(padding), tuple(dilation), groups)
+        ctx.weight = weight
         with torch.autocast("cuda", enabled=False):
             y = torch.ops.aten.convolution(x, w, None, ctx.conv[0], ctx.conv[1], ctx.conv[2], False, [0, 0], groups)
         ctx.save_for_backward(x, w)
@@ -649,10 +650,21 @@ class _ConvChannelsLast(torch.autograd.Function):
         stride, padding, dilation, groups = ctx.conv
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
-        gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, stride, padding, dilation, False, [0, 0], groups,
-                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
-        if gw is not None:
-            gw = gw.to(dtype=ctx.w_dtype, memory_format=torch.contiguous_format)
+        gw, need_w = None, ctx.needs_input_grad[1]
+        if need_w and stride == (2, 2) and padding == (1, 1) and dilation == (1, 1) and groups == 1 and w.shape[2:] == (3, 3):
+            # the weight gradient on this repository's token x token kernel, straight from the channels_last map (no rows
+            # written): 38 / 33 us against the library's 66 / 65 at the two large maps of the trunk
+            xt, gt = x.permute(0, 2, 3, 1), gy.permute(0, 2, 3, 1)
+            if xt.is_contiguous():
+                gw = conv3x3s2_wgrad_from_map(gt if gt.is_contiguous() else gt.contiguous(), xt, ctx.weight)
+                if gw is not None:
+                    need_w = False
+                    if gw.dtype != ctx.w_dtype:
+                        gw = gw.to(ctx.w_dtype)
+        gx, gwl, _ = torch.ops.aten.convolution_backward(gy, x, w, None, stride, padding, dilation, False, [0, 0], groups,
+                                                         [ctx.needs_input_grad[0], need_w, False])
+        if gwl is not None:
+            gw = gwl.to(dtype=ctx.w_dtype, memory_format=torch.contiguous_format)
         if gx is not None and gx.dtype != ctx.x_dtype:
             gx = gx.to(ctx.x_dtype)
         return gx, gw, None, None, None, None
