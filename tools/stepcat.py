@@ -21,6 +21,7 @@ for r in csv.DictReader(open(f)):
     elif 'partial_sums' in n: fam = 'deferred column sums (LayerNorm / bias gradients, folded per step)'
     elif 'rowln' in n or 'settle_' in n: fam = 'row LayerNorm (+residual)'
     elif 'ln2d' in n: fam = 'LayerNorm2d'
+    elif 'conv_im2col' in n or 'conv_col2im' in n: fam = 'own 3x3 stride-2 convolutions: neighbourhood rows (their GEMMs: the own MFMA families)'
     elif 'wgrad_kernel' in n or 'wgrad_tt' in n: fam = 'own MFMA weight-gradient GEMM'
     elif 'tokens_gemm3_kernel<0' in n or 'tokens_gemm2_kernel<' in n and ', 0, ' in n: fam = 'own MFMA GEMM'
     elif 'tokens_gemm2' in n or 'tokens_gemm3' in n: fam = 'own MFMA GEMM with GELU epilogue (Mlp fc1 / fc2 data gradient)'
