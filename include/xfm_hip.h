@@ -177,6 +177,17 @@ int xfm_conv3x3s2_tokens_bwd_weight(const void *dy, const void *col, float *dwei
  * elsewhere (csrc/wgrad_gemm.hip: the token x token kernel gathers the window taps itself).  _supported: B H/2 W/2 a multiple of 64
  * and at least 2048, H/2 >= 64 / (W/2) + 2. */
 int xfm_conv3x3s2_tokens_bwd_weight_x_supported(int B, int H, int W, int C, int O);
+/* The FIRST convolution of the patch embedding when its CI input channels are replicas of ONE channel (reference
+ * net_fusionmamba.py:88-104 `x.expand(-1, 3, -1, -1)` in front of models/fusion_vmamba.py:1504-1518): x (B, H, W) bf16 is that
+ * channel, weight (O, CI, 3, 3) bf16 the parameter's shadow (summed over CI inside), y / dy (B, H/2, W/2, O) bf16;
+ * dweight9 (O, 9) fp32 ZEROED by the caller -- the gradient of every one of the CI input-channel slices of the parameter --
+ * and ws: xfm_conv3x3s2_gray_ws_floats(O) fp32, ZEROED by the caller (replicas of the sums: adds to one address retire one by one).
+ * O % 8 == 0 with 192 % (O / 8) == 0, H, W even; no data gradient (the image is an input). */
+int xfm_conv3x3s2_gray_supported(int O, int H, int W);
+int xfm_conv3x3s2_gray_ws_floats(int O);
+int xfm_conv3x3s2_gray_fwd(const void *x, const void *weight, void *y, int B, int H, int W, int CI, int O, void *stream);
+int xfm_conv3x3s2_gray_bwd_weight(const void *dy, const void *x, float *dweight9, float *ws, int B, int H, int W, int O,
+                                  void *stream);
 int xfm_conv3x3s2_tokens_bwd_weight_x(const void *dy, const void *x, float *dweight, int B, int H, int W, int C, int O,
                                       void *stream);
 

@@ -412,6 +412,33 @@ def test_conv3x3_stride2_on_token_major_maps_matches_torch_fp32(shape):
         assert_close(gw.float().cpu(), wr.grad, tol, tol * float(wr.grad.abs().max()), "dw from the map")
 
 
+@pytest.mark.parametrize("shape", [(2, 224, 224, 3, 48), (3, 10, 6, 3, 48), (1, 2, 2, 1, 8), (5, 32, 48, 4, 96), (64, 224, 224, 3, 48)])
+def test_first_patch_embedding_convolution_on_a_replicated_channel_matches_torch_fp32(shape):
+    """The first convolution of the patch embedding (reference fusion_vmamba.py:1504-1518) when its input channels are replicas
+    of one channel (net_fusionmamba.py:88-104: x.expand(-1, 3, -1, -1)): xfm_conv3x3s2_gray_fwd / _bwd_weight (csrc/conv_tok.hip)
+    vs F.conv2d in fp32 on the expanded image with the bf16-rounded weight: output and every slice of the weight gradient."""
+    import torch.nn.functional as F
+    from xfmamba_amd import _lib
+    from xfmamba_amd.conv_tokens import conv3x3s2_gray_fn
+    B, H, W, CI, O = shape
+    g = torch.Generator().manual_seed(B + H + O)
+    x1 = torch.randn(B, H, W, generator=g).bfloat16()
+    w = (torch.randn(O, CI, 3, 3, generator=g) * (9 * CI) ** -0.5).bfloat16().float()
+    gy = torch.randn(B, H // 2, W // 2, O, generator=g).bfloat16()
+    wr = w.clone().requires_grad_()
+    yr = F.conv2d(x1.float().unsqueeze(1).expand(-1, CI, -1, -1), wr, None, stride=2, padding=1)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    assert _lib.lib().xfm_conv3x3s2_gray_supported(O, H, W)
+    wd = w.to(DEV).requires_grad_()
+    y = conv3x3s2_gray_fn(x1.to(DEV), wd)
+    y.backward(gy.to(DEV))
+    assert y.dtype == torch.bfloat16 and y.shape == (B, H // 2, W // 2, O)
+    tol = 1e-2
+    assert_close(y.float().cpu(), yr.detach().permute(0, 2, 3, 1), tol, tol * float(yr.abs().max()), "y")
+    assert wd.grad.shape == w.shape
+    assert_close(wd.grad.cpu(), wr.grad, tol, tol * float(wr.grad.abs().max()), "dw")
+
+
 @pytest.mark.parametrize("C", [48, 96, 192, 384, 768, 64, 1024])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["plain", "add", "add_scale"])

@@ -76,5 +76,39 @@ def main():
               f"   wgrad own {timed(bw):6.1f} from the map {(timed(bwx) if wx else 0.0):6.1f} lib {timed(lbw):6.1f} us   max diff / max {err:.1e}")
 
 
+def gray():
+    """the first convolution of the patch embedding on one replicated channel: own kernels vs the library on the 3-channel image"""
+    from xfmamba_amd import _lib
+    lib = _lib.lib()
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    g = torch.Generator().manual_seed(0)
+    H, CI, O = 224, 3, 48
+    x1 = torch.randn(B, H, H, generator=g).bfloat16().cuda()
+    w = (27 ** -0.5 * torch.randn(O, CI, 3, 3, generator=g)).bfloat16().cuda()
+    y = torch.empty(B, H // 2, H // 2, O, dtype=torch.bfloat16, device="cuda")
+    dy = torch.randn(B, H // 2, H // 2, O, generator=g).bfloat16().cuda()
+    dw9 = torch.zeros(O, 9, device="cuda")
+    ws = torch.zeros(lib.xfm_conv3x3s2_gray_ws_floats(O), device="cuda")
+    s = _lib.stream_ptr
+    x3 = x1.unsqueeze(-1).expand(-1, -1, -1, CI).contiguous().permute(0, 3, 1, 2)
+    wn = w.contiguous(memory_format=torch.channels_last)
+    dyn = dy.permute(0, 3, 1, 2)
+
+    def fwd():
+        _lib.check(lib.xfm_conv3x3s2_gray_fwd(x1.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, H, CI, O, s()), "f")
+
+    def bw():
+        _lib.check(lib.xfm_conv3x3s2_gray_bwd_weight(dy.data_ptr(), x1.data_ptr(), dw9.data_ptr(), ws.data_ptr(), B, H, H, O, s()), "w")
+
+    def lf():
+        return torch.ops.aten.convolution(x3, wn, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1)
+
+    def lbw():
+        return torch.ops.aten.convolution_backward(dyn, x3, wn, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])
+
+    print(f"B {B} gray 224x224 -> 48:  fwd own {timed(fwd):6.1f} lib {timed(lf):6.1f}   wgrad own {timed(bw):6.1f} lib {timed(lbw):6.1f} us")
+
+
 if __name__ == "__main__":
+    gray()
     main()

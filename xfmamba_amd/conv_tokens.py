@@ -14,7 +14,8 @@ from . import _lib
 from .amp import cast_weight
 from .proj import wgrad_slot, zeros_f32
 
-__all__ = ["conv3x3s2_tokens_fn", "conv3x3s2_tokens_supported", "conv3x3s2_wgrad_from_map", "Conv3x3S2TokensHip"]
+__all__ = ["conv3x3s2_tokens_fn", "conv3x3s2_tokens_supported", "conv3x3s2_wgrad_from_map", "Conv3x3S2TokensHip",
+           "conv3x3s2_gray_fn", "conv3x3s2_gray_supported", "Conv3x3S2GrayHip"]
 
 # XFM_CONV_OWN=0: the strided convolutions stay on the convolution library (A/B switch, read once).
 # XFM_CONV_OWN_MIN_C: the fewest input channels the own path takes.  Measured per pass at batch 64 (tools/convprobe.py, us, own /
@@ -26,6 +27,9 @@ _OWN = os.environ.get("XFM_CONV_OWN", "1") == "1"
 _OWN_MIN_C = int(os.environ.get("XFM_CONV_OWN_MIN_C", "192"))
 # XFM_CONV_WGRAD_X=0: the layers that stay on the convolution library also take their weight gradient from it
 _WGRAD_X = os.environ.get("XFM_CONV_WGRAD_X", "1") == "1"
+# XFM_CONV_GRAY=0: the first convolution of the patch embedding stays on the convolution library even when its input channels are
+# replicas of one channel
+_GRAY = os.environ.get("XFM_CONV_GRAY", "1") == "1"
 
 
 def conv3x3s2_tokens_supported(t: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
@@ -93,6 +97,62 @@ class Conv3x3S2TokensHip(torch.autograd.Function):
                 if dx.dtype != ctx.t_dtype:
                     dx = dx.to(ctx.t_dtype)
         return dx, dw
+
+
+class Conv3x3S2GrayHip(torch.autograd.Function):
+    """The first convolution of the patch embedding on ONE replicated channel: x1 (B, H, W) bf16, weight (O, CI, 3, 3) ->
+    (B, H/2, W/2, O) bf16 = conv2d(x1 expanded to CI channels, weight, stride 2, padding 1), no bias."""
+
+    @staticmethod
+    def forward(ctx, x1, weight):
+        _lib.require_cuda(x1, weight)
+        B, H, W = x1.shape
+        O, CI = weight.shape[0], weight.shape[1]
+        w = cast_weight(weight, torch.bfloat16).contiguous()
+        y = torch.empty(B, H // 2, W // 2, O, dtype=torch.bfloat16, device=x1.device)
+        with torch.cuda.device(x1.device), _lib.timed("conv3x3s2_gray_fwd", x1.numel() * 2 + y.numel() * 2):
+            _lib.check(_lib.lib().xfm_conv3x3s2_gray_fwd(x1.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, W, CI, O,
+                                                         _lib.stream_ptr()), "conv3x3s2_gray_fwd")
+        ctx.w_dtype, ctx.w_shape = weight.dtype, tuple(weight.shape)
+        ctx.save_for_backward(x1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x1,) = ctx.saved_tensors
+        B, H, W = x1.shape
+        O, CI = ctx.w_shape[0], ctx.w_shape[1]
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dy = dy.contiguous() if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16).contiguous()
+            nws = _lib.lib().xfm_conv3x3s2_gray_ws_floats(O)
+            acc = zeros_f32(O * 9 + nws, dy.device)                    # one fill: the sums and the kernel's replicas of them
+            dw9, ws = acc[:O * 9], acc[O * 9:]
+            with torch.cuda.device(dy.device), _lib.timed("conv3x3s2_gray_wgrad", x1.numel() * 2 + dy.numel() * 2):
+                _lib.check(_lib.lib().xfm_conv3x3s2_gray_bwd_weight(dy.data_ptr(), x1.data_ptr(), dw9.data_ptr(), ws.data_ptr(), B, H,
+                                                                    W, O, _lib.stream_ptr()), "conv3x3s2_gray_bwd_weight")
+            # every input-channel slice of the parameter saw the same image: the same gradient
+            dw = dw9.view(O, 1, 3, 3).expand(O, CI, 3, 3)
+            if dw.dtype != ctx.w_dtype:
+                dw = dw.to(ctx.w_dtype)
+        return None, dw
+
+
+def conv3x3s2_gray_supported(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
+    """x (B, CI, H, W) is a stride-0 broadcast of one channel, needs no gradient, and ``conv`` is a 3 x 3 stride-2 padding-1
+    convolution ``xfm_conv3x3s2_gray_*`` covers (bf16 compute)."""
+    if not (_OWN and _GRAY and x.is_cuda and x.dim() == 4 and x.shape[1] > 1 and x.stride(1) == 0 and not x.requires_grad
+            and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and conv.in_channels == x.shape[1]):
+        return False
+    cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else conv.weight.dtype
+    if cd != torch.bfloat16:
+        return False
+    return bool(_lib.lib().xfm_conv3x3s2_gray_supported(conv.out_channels, x.shape[2], x.shape[3]))
+
+
+def conv3x3s2_gray_fn(x1: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    return Conv3x3S2GrayHip.apply(x1, weight)
 
 
 def conv3x3s2_wgrad_from_map(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor):

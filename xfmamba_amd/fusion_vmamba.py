@@ -35,7 +35,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .csm import SwappingMerge_multiview, SwappingScan_multiview, SwappingScanStacked, cross_merge_fn, cross_scan_fn
-from .conv_tokens import conv3x3s2_tokens_fn, conv3x3s2_tokens_supported, conv3x3s2_wgrad_from_map
+from .conv_tokens import (conv3x3s2_gray_fn, conv3x3s2_gray_supported, conv3x3s2_tokens_fn, conv3x3s2_tokens_supported,
+                          conv3x3s2_wgrad_from_map)
 from .csms6s import selective_scan_fn
 from .dwconv import dwconv3x3_silu_fn, dwconv3x3_silu_tokens_fn, dwconv_tokens_supported
 from .layernorm2d import layernorm2d_fn
@@ -798,6 +799,14 @@ class VSSM(nn.Module):
         """patch_embed (conv s2 -> LN -> GELU -> conv s2 -> LN) -> fp32 tokens (B, H/4, W/4, C0)."""
         pe = self.patch_embed
         act_dtype = _tokens_dtype(pe[0].weight)
+        if act_dtype is not None and isinstance(pe[2], LayerNorm2d) and conv3x3s2_gray_supported(x, pe[0]):
+            # the image is ONE channel replicated (net_fusionmamba.py: x.expand(-1, 3, -1, -1)): the convolution of that channel
+            # with the weight summed over its input channels (csrc/conv_tok.hip: 9 taps, no replicated image, no library)
+            y = conv3x3s2_gray_fn(x[:, 0].to(torch.bfloat16).contiguous(), pe[0].weight)
+            t = layernorm_rows_fn(y, pe[2].weight, pe[2].bias, pe[2].eps, act_dtype, pe[0].bias)
+            t = bias_gelu_fn(t, None) if (isinstance(pe[4], nn.GELU) and getattr(pe[4], "approximate", "none") == "none"
+                                          and t.dtype in (torch.float32, torch.bfloat16) and t.shape[-1] % 8 == 0) else pe[4](t)
+            return _conv_ln_tokens(pe[5], pe[7], t, torch.float32)
         if x.shape[1] > 1 and x.stride(1) == 0 and act_dtype is not None and not x.requires_grad:
             # the image is a stride-0 broadcast of ONE channel (net_fusionmamba.py: x.expand(-1, 3, -1, -1)): cast the single
             # channel to the convolution's dtype first and replicate it as the LAST step -- 6 + 19 MB moved instead of a 77 MB
