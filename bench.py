@@ -180,8 +180,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend != "nccl" and not cuda_ok:
             # a machine without GPUs (the CPU test of the launcher): the host-side rendezvous still proves that the ranks came
-            # up; the assert below then stops them.  (With a GPU the group is created AFTER the device is set, as for RCCL:
-            # a gloo group created before the process touched the GPU returned NaN sums for device tensors.)
+            # up; the assert below then stops them.  (With a GPU the group is created after the device is set, as for RCCL.)
             dist.init_process_group(backend)
             if rank == 0:
                 print(f"[bench] ranks: {dist.get_world_size()} ({backend})", file=sys.stderr, flush=True)
@@ -267,6 +266,7 @@ def main():
     # wire bucket per piece (bf16 for the bf16 step), the late piece's all-reduce under the early piece's graph, Adam reading
     # the summed wire values in place (dp.PhasedGrads)
     phased = None
+    names = {id(p_): n_ for n_, p_ in model.named_parameters()}
     if use_phased:
         phased = PhasedGrads(model, wire_dtype=comm or torch.float32)
         model.mamba_feature_extrac.cut_after = a.dp_cut
@@ -301,6 +301,38 @@ def main():
             opt.step(grads=phased.grads(), grad_scale=phased.grad_scale)
 
     def phased_step():                               # eager form of the two-graph step (warm-up, kernel timing)
+        if os.environ.get("XFM_BENCH_NANCHECK"):     # development: the same step with a finiteness check behind every phase
+            st = phased_step.__dict__.setdefault("n", 0) + 1
+            phased_step.__dict__["n"] = st
+
+            def chk(tag, t):
+                torch.cuda.synchronize()
+                if not phased_step.__dict__.get("seen") and not bool(torch.isfinite(t.float()).all()):
+                    phased_step.__dict__["seen"] = True
+                    print(f"[bench] rank {rank} eager step {st}: first non-finite values in {tag} "
+                          f"({int((~torch.isfinite(t.float())).sum())} of {t.numel()})", file=sys.stderr)
+            loss = phase_a()
+            chk("loss", loss)
+            for pp, vv in zip(phased.pieces[0], phased.views[0]):
+                chk("bucket 0 slot of " + names[id(pp)], vv)
+            phased.reduce(0, overlap=False)
+            phased.wait()
+            chk("bucket 0 after its all-reduce", phased.flat[0])
+            phased.backward_early()
+            torch.cuda.synchronize()
+            bad1 = [names[id(pp)] for pp, vv in zip(phased.pieces[1], phased.views[1]) if not bool(torch.isfinite(vv.float()).all())]
+            if bad1 and not phased_step.__dict__.get("seen"):
+                order = [names[id(pp)] for pp in phased.pieces[1]]
+                print(f"[bench] rank {rank} eager step {st}: {len(bad1)} of {len(order)} early gradients non-finite; slots in bucket order: "
+                      + ", ".join(f"{i}:{n}" for i, n in enumerate(order) if n in bad1)[:3000], file=sys.stderr)
+            for pp, vv in zip(phased.pieces[1], phased.views[1]):
+                chk("bucket 1 slot of " + names[id(pp)], vv)
+            phased.reduce(1, overlap=False)
+            phased_update()
+            chk("bucket 1 after its all-reduce", phased.flat[1])
+            for n_, p_ in model.named_parameters():
+                chk("parameter " + n_ + " after the update", p_)
+            return loss
         loss = phase_a()
         phased.reduce(0)
         phased.backward_early()
@@ -396,7 +428,34 @@ def main():
                 print(f"[bench] graph capture failed, running eager: {type(e).__name__}: {e}", file=sys.stderr)
                 graph = graph_b = None
 
+    nan_check = bool(os.environ.get("XFM_BENCH_NANCHECK"))     # development: where a non-finite value first appears in the two-graph step
+    nan_state = {"step": 0, "seen": False}
+
+    def _finite(tag, t):
+        torch.cuda.synchronize()
+        if not nan_state["seen"] and not bool(torch.isfinite(t.float()).all()):
+            nan_state["seen"] = True
+            bad = int((~torch.isfinite(t.float())).sum())
+            print(f"[bench] rank {rank} step {nan_state['step']}: first non-finite values in {tag} ({bad} of {t.numel()})", file=sys.stderr)
+
     def run_step():
+        if graph_b is not None and nan_check:
+            nan_state["step"] += 1
+            graph.replay()
+            _finite("loss after graph A", loss_static)
+            _finite("bucket 0 after graph A (packed late gradients)", phased.flat[0])
+            phased.reduce(0, overlap=False)
+            phased.wait()
+            _finite("bucket 0 after its all-reduce", phased.flat[0])
+            graph_b.replay()
+            _finite("bucket 1 after graph B (packed early gradients)", phased.flat[1])
+            phased.reduce(1, overlap=False)
+            phased_update()
+            _finite("bucket 1 after its all-reduce", phased.flat[1])
+            for n_, p_ in model.named_parameters():
+                if not nan_state["seen"]:
+                    _finite("parameter " + n_ + " after the update", p_)
+            return loss_static
         if graph_b is not None:
             graph.replay()
             phased.reduce(0)                         # communication stream: runs under graph B

@@ -2,6 +2,8 @@
 behind the C ABI vs (i) golden vectors recorded from the real reference and (ii) the CPU oracle on
 seeded inputs.  Tolerances are BASELINE.json's: 1e-3 (fp32 I/O) / 1e-2 (16-bit I/O), relative to
 the tensor's magnitude."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -893,6 +895,22 @@ def test_dt_proj_backward_mfma_matches_torch_fp32(B, D, R, H):
                                              R, L, _lib.stream_ptr()), "dt_proj_bwd_mfma")
     assert_close(dxr.float().cpu(), dxr_ref, 1e-2, 1e-2 * float(dxr_ref.abs().max()), "dxr")
     assert_close(dw.cpu(), dw_ref, 1e-3, 1e-3 * float(dw_ref.abs().max()), "dw")
+
+
+def test_dt_proj_backward_under_a_second_process():
+    """tools/stress2.py in two processes at once: the merged dt_proj backward at the trunk's stage-0 and stage-1 shapes, every
+    result compared with the first.  Memory contention from the other process is what a too-short counted vmcnt wait needs to
+    show (round 5: trips 0 and 1 of the three-tile ring did not wait for their own tiles -- 31 of 300 launches wrong)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for op in ("dtbwd0", "dtbwd1"):
+        ps = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "stress2.py"), op, "150"], stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True) for _ in range(2)]
+        outs = [p.communicate(timeout=600)[0] for p in ps]
+        for p, o in zip(ps, outs):
+            assert p.returncode == 0, o[-2000:]
+            assert f"{op}: 0 of 150 runs differ" in o, o[-2000:]
 
 
 @pytest.mark.parametrize("C,dt", [(96, torch.float32), (384, torch.bfloat16), (768, torch.bfloat16)])

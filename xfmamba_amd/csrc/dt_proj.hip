@@ -347,7 +347,20 @@ __device__ __forceinline__ int dtm_off(const int row, const int ch) {      // 16
     return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-template <int DB>                                          // DB = D / 32
+// NSV: the d xr stores of a wave and tile that have a live lane.  Register v of the accumulator holds rank rows
+// (v & 3) + 8 (v >> 2) + 4 h: increasing in v, so the registers with a row below R are the first NSV = dtm_nsv(R).  The counted
+// vmcnt waits below are built on EXACTLY this many stores per tile: a store whose EXEC mask is empty is not a memory operation
+// and is not counted.  (Rounds 4-5 issued all 16 under lane masks and counted 16: with R = 6 twelve of them were empty, the
+// waits for a tile's LDS-direct loads returned with up to 24 of them still in flight, and under memory contention -- two
+// processes on one GPU -- the MFMAs read tiles that had not landed: NaN gradients in one run out of three of the two-rank
+// bench flow.)
+static int dtm_nsv(const int R) {
+    int n = 0;
+    for (int v = 0; v < 16; ++v) n += ((v & 3) + 8 * (v >> 2)) < R ? 1 : 0;
+    return n;
+}
+
+template <int DB, int NSV>                                 // DB = D / 32
 __global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProjBwdArgs a) {
     constexpr int D = 32 * DB;
     constexpr int TILE = D * 256, XT = 32 * 256;           // bytes: ddts tile, xr tile (32 rank rows)
@@ -416,8 +429,14 @@ __global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProj
         // this wave's share of tile t has landed.  Operations retire in issue order; younger than tile t's loads are, in a
         // three-tile ring, the 16 d xr stores of tiles t - 2 and t - 1 and the loads of tile t + 1 (none of which is waited for),
         // in a two-tile ring the 16 stores of tile t - 1.
-        if (NBUF == 3 && t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD + 32) : "memory");   // + the stores of two tiles
-        else if (NBUF == 2 && t > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                      // the previous tile's stores
+        // (The first two trips have fewer younger operations: no stores yet at t = 0, one tile's at t = 1.  Until round 5 they
+        //  used the steady-state count as well -- i.e. did not wait for tiles 0 and 1 at all: unnoticed on an idle GPU, where
+        //  the loads land during the prologue, wrong d xr in 1-10 % of the launches with a second process on the same GPU.)
+        if (NBUF == 3 && t + 1 < ntile) {
+            if (t >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD + 2 * NSV) : "memory");   // + the stores of two tiles
+            else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD + NSV) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        } else if (NBUF == 2 && t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSV) : "memory");                 // the previous tile's stores
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (first trip: W^T too) everyone's share landed, tile t - 1 is free.  A BARE barrier: __syncthreads() carries a fence
         // that the compiler turns into s_waitcnt vmcnt(0) for LDS-direct loads -- the ring would run with nothing in flight
@@ -450,11 +469,11 @@ __global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProj
             }
         }
         {
-            // 16 stores per tile, ALWAYS issued (lane mask in EXEC): the counted wait above needs a fixed number of
-            // vector-memory operations per tile
+            // NSV stores per tile, ALWAYS issued (lane mask in EXEC; every one of them has live lanes in every tile but the
+            // last): the counted wait above needs a fixed number of vector-memory operations per tile
             const int pos = t * kDtmTL + 32 * wave + c;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
+            for (int v = 0; v < NSV; ++v) {
                 const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
                 const bool live = pos < L && r < R;
                 const uint64_t m = __builtin_amdgcn_ballot_w64(live);
@@ -501,16 +520,28 @@ __global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProj
     for (int e = tid; e < D * R; e += 256) atomicAdd(dw + e, red[e]);
 }
 
-template <int DB> static int dt_proj_bwd_merged_launch(const DtProjBwdArgs &a, int B, hipStream_t s) {
+template <int DB, int NSV> static int dt_proj_bwd_merged_launch_nsv(const DtProjBwdArgs &a, int B, hipStream_t s) {
     constexpr int D = 32 * DB;
     const size_t lds = (size_t)(DB <= 4 ? 3 : 2) * (D * 256 + 32 * 256) + (size_t)32 * (D + 8) * 2;
-    auto fn = dt_proj_bwd_merged_kernel<DB>;
+    auto fn = dt_proj_bwd_merged_kernel<DB, NSV>;
     static xfm::LdsOptIn opted;
     if (lds > 64 * 1024) {
         if (!xfm::lds_opt_in(opted, (const void *)fn, lds)) return XFM_ELAUNCH;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)(B * 4)), dim3(256), lds, s, a);
     return check_launch();
+}
+
+// (built for the store counts of whole register groups: R in 4..8, 12..16, 20..24, 28..32; XFM_ELIMIT otherwise -- the caller
+//  then runs the two separate kernels)
+template <int DB> static int dt_proj_bwd_merged_launch(const DtProjBwdArgs &a, int B, hipStream_t s) {
+    switch (dtm_nsv(a.R)) {
+        case 4: return dt_proj_bwd_merged_launch_nsv<DB, 4>(a, B, s);
+        case 8: return dt_proj_bwd_merged_launch_nsv<DB, 8>(a, B, s);
+        case 12: return dt_proj_bwd_merged_launch_nsv<DB, 12>(a, B, s);
+        case 16: return dt_proj_bwd_merged_launch_nsv<DB, 16>(a, B, s);
+    }
+    return XFM_ELIMIT;
 }
 
 }  // namespace xfm
@@ -547,9 +578,11 @@ int xfm_ss2d_dt_proj_bwd_mfma(const void *ddts, const void *xr, const void *weig
     // one pass over ddts for both products where a (b, k) slab per workgroup fills the chip and the ring fits LDS
     static const bool merged_on = [] { const char *e = getenv("XFM_DTPROJ_MERGED"); return !e || atoi(e) != 0; }();
     if (merged_on && B * 4 >= 128 && L % 8 == 0 && (((uintptr_t)ddts | (uintptr_t)xr) & 15) == 0) {
-        if (D == 96) return dt_proj_bwd_merged_launch<3>(a, B, s);
-        if (D == 128) return dt_proj_bwd_merged_launch<4>(a, B, s);
-        if (D == 192) return dt_proj_bwd_merged_launch<6>(a, B, s);      // (256 channels: the two-tile ring is 164 KB)
+        int rc = XFM_ELIMIT;
+        if (D == 96) rc = dt_proj_bwd_merged_launch<3>(a, B, s);
+        else if (D == 128) rc = dt_proj_bwd_merged_launch<4>(a, B, s);
+        else if (D == 192) rc = dt_proj_bwd_merged_launch<6>(a, B, s);   // (256 channels: the two-tile ring is 164 KB)
+        if (rc != XFM_ELIMIT) return rc;
     }
     a.ltiles = ((L + 31) / 32 + 3) / 4;
     const size_t lds = (size_t)32 * (D + 8) * sizeof(uint16_t);
