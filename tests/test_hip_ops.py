@@ -876,7 +876,11 @@ def test_dt_proj_kernels_match_torch_fp32(B, D, R, H, with_bias):
 @pytest.mark.parametrize("B,D,R,H", [(2, 96, 6, 56), (2, 192, 12, 28), (3, 384, 24, 14), (2, 64, 5, 10),
                                      (1, 1024, 32, 24),       # XFMamba-B stage 2: 66 KB of LDS (opt-in above 64 KB)
                                      # one pass over ddts for both products (a (b, k) slab per workgroup, B * 4 >= 128):
-                                     (32, 96, 6, 56), (32, 192, 12, 28), (33, 128, 8, 12), (32, 256, 16, 12)])
+                                     (32, 96, 6, 56), (32, 192, 12, 28), (33, 128, 8, 12), (32, 256, 16, 12),
+                                     # XFMamba-S stage 0 (192 channels, rank 6: the two-tile ring with few live rank rows) and
+                                     # every store-count bucket of the three-tile ring
+                                     (32, 192, 6, 56), (32, 192, 8, 28), (32, 96, 12, 28), (32, 96, 24, 14), (32, 96, 32, 14),
+                                     (32, 96, 10, 14)])
 def test_dt_proj_backward_mfma_matches_torch_fp32(B, D, R, H):
     """Backward of dt_proj on MFMA (bf16): data gradient W^T.ddts and weight gradient sum_{b,l} ddts.xr^T vs fp32."""
     from xfmamba_amd import _lib
@@ -904,7 +908,7 @@ def test_dt_proj_backward_under_a_second_process():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for op in ("dtbwd0", "dtbwd1"):
+    for op in ("dtbwd0", "dtbwd1", "dtbwd2"):
         ps = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "stress2.py"), op, "150"], stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True) for _ in range(2)]
         outs = [p.communicate(timeout=600)[0] for p in ps]

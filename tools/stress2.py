@@ -17,7 +17,7 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 400
     g = torch.Generator().manual_seed(1)
     if op.startswith("dtbwd"):
-        B, D, R, L = (64, 96, 6, 3136) if op == "dtbwd0" else (64, 192, 12, 784)
+        B, D, R, L = {"dtbwd0": (64, 96, 6, 3136), "dtbwd1": (64, 192, 12, 784), "dtbwd2": (64, 192, 6, 3136)}[op]
         ddts = torch.randn(B, 4, D, L, generator=g).bfloat16().cuda()
         xr = torch.randn(B, 4, R, L, generator=g).bfloat16().cuda()
         w = (torch.randn(4, D, R, generator=g) * R ** -0.5).bfloat16().cuda()

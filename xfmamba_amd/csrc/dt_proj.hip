@@ -405,6 +405,10 @@ __global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProj
         }
     };
     constexpr int NLD = D / 16 + 2;                        // loads per wave and tile
+    // stores per wave and tile.  The two-tile ring (192 channels) keeps all sixteen under lane masks, as it has since round 4:
+    // its NSV = 4 instance wrote only the first two tiles of every slab on the GPU (not understood in the time left; the
+    // sixteen-store form passes tools/stress2.py dtbwd1 and is only ever built with NSV = 16)
+    constexpr int NST = NBUF == 2 ? 16 : NSV;
     static_assert(NLD < 32, "vmcnt budget");
     xfm_f32x16_t dwacc[DB];
 #pragma unroll
@@ -436,7 +440,7 @@ __global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProj
             if (t >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD + 2 * NSV) : "memory");   // + the stores of two tiles
             else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD + NSV) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-        } else if (NBUF == 2 && t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSV) : "memory");                 // the previous tile's stores
+        } else if (NBUF == 2 && t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");                 // the previous tile's stores
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (first trip: W^T too) everyone's share landed, tile t - 1 is free.  A BARE barrier: __syncthreads() carries a fence
         // that the compiler turns into s_waitcnt vmcnt(0) for LDS-direct loads -- the ring would run with nothing in flight
@@ -473,7 +477,7 @@ __global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProj
             // last): the counted wait above needs a fixed number of vector-memory operations per tile
             const int pos = t * kDtmTL + 32 * wave + c;
 #pragma unroll
-            for (int v = 0; v < NSV; ++v) {
+            for (int v = 0; v < NST; ++v) {
                 const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
                 const bool live = pos < L && r < R;
                 const uint64_t m = __builtin_amdgcn_ballot_w64(live);
@@ -535,6 +539,7 @@ template <int DB, int NSV> static int dt_proj_bwd_merged_launch_nsv(const DtProj
 // (built for the store counts of whole register groups: R in 4..8, 12..16, 20..24, 28..32; XFM_ELIMIT otherwise -- the caller
 //  then runs the two separate kernels)
 template <int DB> static int dt_proj_bwd_merged_launch(const DtProjBwdArgs &a, int B, hipStream_t s) {
+    if constexpr (DB > 4) return dt_proj_bwd_merged_launch_nsv<DB, 16>(a, B, s);      // (two-tile ring: see NST)
     switch (dtm_nsv(a.R)) {
         case 4: return dt_proj_bwd_merged_launch_nsv<DB, 4>(a, B, s);
         case 8: return dt_proj_bwd_merged_launch_nsv<DB, 8>(a, B, s);
