@@ -405,10 +405,11 @@ __global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProj
         }
     };
     constexpr int NLD = D / 16 + 2;                        // loads per wave and tile
-    // stores per wave and tile.  The two-tile ring (192 channels) keeps all sixteen under lane masks, as it has since round 4:
-    // its NSV = 4 instance wrote only the first two tiles of every slab on the GPU (not understood in the time left; the
-    // sixteen-store form passes tools/stress2.py dtbwd1 and is only ever built with NSV = 16)
-    constexpr int NST = NBUF == 2 ? 16 : NSV;
+    // stores per wave and tile.  (The asm block of a store ANDs the lane mask into EXEC -- s_and_b64 writes SCC -- and until
+    // round 5 did not say so: where the compiler had placed the loop's exit compare in front of the stores, the branch behind them
+    // took the store's SCC.  That was the NSV = 4 instance of the two-tile ring, which wrote two tiles per slab and left; every
+    // other instance happened to compare after the stores.)
+    constexpr int NST = NSV;
     static_assert(NLD < 32, "vmcnt budget");
     xfm_f32x16_t dwacc[DB];
 #pragma unroll
@@ -488,7 +489,7 @@ __global__ void __launch_bounds__(256, 1) dt_proj_bwd_merged_kernel(const DtProj
                              "s_and_b64 exec, exec, %[m]\n\t"
                              "global_store_short %[p], %[v], off\n\t"
                              "s_mov_b64 exec, %[sv]"
-                             : [sv] "=&s"(sv) : [m] "s"(m), [p] "v"(ptr), [v] "v"(val) : "memory");
+                             : [sv] "=&s"(sv) : [m] "s"(m), [p] "v"(ptr), [v] "v"(val) : "memory", "scc");
             }
         }
         // ---- dW[d][r] += sum over the tile's positions: wave w takes k16-steps 2 w, 2 w + 1 (positions 32 w .. + 31)
@@ -539,7 +540,6 @@ template <int DB, int NSV> static int dt_proj_bwd_merged_launch_nsv(const DtProj
 // (built for the store counts of whole register groups: R in 4..8, 12..16, 20..24, 28..32; XFM_ELIMIT otherwise -- the caller
 //  then runs the two separate kernels)
 template <int DB> static int dt_proj_bwd_merged_launch(const DtProjBwdArgs &a, int B, hipStream_t s) {
-    if constexpr (DB > 4) return dt_proj_bwd_merged_launch_nsv<DB, 16>(a, B, s);      // (two-tile ring: see NST)
     switch (dtm_nsv(a.R)) {
         case 4: return dt_proj_bwd_merged_launch_nsv<DB, 4>(a, B, s);
         case 8: return dt_proj_bwd_merged_launch_nsv<DB, 8>(a, B, s);

@@ -354,7 +354,7 @@ __device__ __forceinline__ void l3_merge_store(bf16_t *out, const bf16_t *P0, co
 // issue point is chosen so that it does not: right after the wave's operands of the tile's first chunk row have arrived.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void l3_dma16(const void *src, const uint32_t lds_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_base) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_base) : "memory", "m0");
 }
 
 template <int PL>
