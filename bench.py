@@ -71,8 +71,11 @@ def parse():
     ap.add_argument("--report-conv-kernels", action="store_true", help="development: after the JSON line's measurements, one extra "
                     "eager step under torch.profiler to list the MIOpen / CK convolution solvers the find pass chose (off by "
                     "default: it nests a profiler inside rocprofv3 runs and adds an eager step to their kernel statistics)")
-    ap.add_argument("--no-miopen-find", action="store_true", help="leave MIOpen's default solver heuristics (default: "
-                    "torch.backends.cudnn.benchmark = True, i.e. MIOpen's own find pass during warm-up; +5 %% measured)")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True: the convolution library's "
+                    "own solver search during warm-up.  Off by default since round 5: four convolution launches per step are left "
+                    "on the library (forward / data gradient of two layers) and the search moves nothing any more (13.46 vs 13.46 "
+                    "ms) -- no per-box solver choice, 8 s less start-up")
+    ap.add_argument("--no-miopen-find", action="store_true", help="(accepted for older scripts: the default now)")
     return ap.parse_args()
 
 
@@ -217,7 +220,7 @@ def main():
     if a.stream:
         fusion_vmamba.STREAM_LAYOUT = a.stream
 
-    if not a.no_miopen_find:
+    if a.miopen_find and not a.no_miopen_find:
         torch.backends.cudnn.benchmark = True
     torch.manual_seed(42)                                        # libs/config.py:22
     kw = dict(hidden_dim=1024) if a.model == "base" else {}
