@@ -247,6 +247,16 @@ int xfm_add_layernorm_rows_bwd(const void *x_new, const float *pre_bias, const f
                                void *dy, float *dweight, float *dbias, float *dpre_bias, float *workspace, int B, int rows_per_sample, int C,
                                int x_dtype, int dtype, void *stream);
 
+/* The same row LayerNorm without a residual branch and with the exact-erf GELU INSIDE: h = gelu(LayerNorm(x + pre_bias)) --
+ * norm -> GELU of the patch embedding (reference models/fusion_vmamba.py:1504-1518).  The backward pass recomputes the
+ * pre-activation from x, mean, rstd, weight and bias (so it takes `bias` too) and multiplies dh by gelu' first; workspace,
+ * dweight / dbias / dpre_bias (NULL: partial rows left for xfm_partial_sums_multi) as xfm_add_layernorm_rows_bwd. */
+int xfm_layernorm_rows_gelu_fwd(const void *x, const float *pre_bias, const float *weight, const float *bias, void *h, float *mean,
+                                float *rstd, int rows, int C, float eps, int x_dtype, int dtype, void *stream);
+int xfm_layernorm_rows_gelu_bwd(const void *x, const float *pre_bias, const float *weight, const float *bias, const void *dh,
+                                const float *mean, const float *rstd, void *dx, float *dweight, float *dbias, float *dpre_bias,
+                                float *workspace, int rows, int C, int x_dtype, int dtype, void *stream);
+
 /* Element-wise pieces of the Mlp (models/fusion_vmamba.py:135-153, fc1 -> GELU -> fc2) between the library GEMMs, on
  * (rows, C) row-major token-major activations in `dtype` (XFM_F32 / XFM_BF16; C % 4 resp. % 8 == 0, C <= 8192):
  *   xfm_bias_gelu_fwd: g = gelu(z + bias)  (exact erf GELU = nn.GELU(); bias (C) fp32 or NULL)

@@ -917,6 +917,42 @@ def test_dt_proj_backward_under_a_second_process():
             assert f"{op}: 0 of 150 runs differ" in o, o[-2000:]
 
 
+@pytest.mark.parametrize("C,xdt,odt", [(48, torch.bfloat16, torch.bfloat16), (48, torch.float32, torch.bfloat16),
+                                        (96, torch.float32, torch.float32), (384, torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("with_pre", [True, False])
+def test_layernorm_rows_with_gelu_inside_matches_torch_fp32(C, xdt, odt, with_pre):
+    """gelu(LayerNorm(x + pre_bias)) -- norm -> GELU of the patch embedding (reference fusion_vmamba.py:1504-1518) -- as one
+    kernel each way (xfm_layernorm_rows_gelu_fwd/_bwd) vs F.gelu(F.layer_norm(.)) in fp32: output, dx, dw, db, d pre_bias; and
+    against the two-kernel chain it replaces (layernorm_rows_fn + bias_gelu_fn)."""
+    import torch.nn.functional as F
+    from xfmamba_amd.rowln import layernorm_rows_fn, layernorm_rows_gelu_fn
+    from xfmamba_amd.mlp_tokens import bias_gelu_fn
+    g = torch.Generator().manual_seed(C + 11)
+    B, H, W = 3, 9, 7                                     # 189 rows: not a multiple of the rows a wave holds
+    x = (torch.randn(B, H, W, C, generator=g) * 1.5 + 0.3).to(xdt)
+    w = 1 + 0.2 * torch.randn(C, generator=g)
+    b = 0.3 * torch.randn(C, generator=g)
+    pre = 0.5 * torch.randn(C, generator=g) if with_pre else None
+    gh = torch.randn(B, H, W, C, generator=g).to(odt)
+    ref = [t.clone().requires_grad_() for t in (x.float(), w, b)] + ([pre.clone().requires_grad_()] if with_pre else [])
+    yr = F.gelu(F.layer_norm(ref[0] + (ref[3] if with_pre else 0.0), (C,), ref[1], ref[2], 1e-5))
+    yr.backward(gh.float())
+    dev = [t.to(DEV).requires_grad_() for t in (x, w, b)] + ([pre.to(DEV).requires_grad_()] if with_pre else [])
+    y = layernorm_rows_gelu_fn(dev[0], dev[1], dev[2], 1e-5, odt, dev[3] if with_pre else None)
+    y.backward(gh.to(DEV))
+    tol = 1e-2 if torch.bfloat16 in (xdt, odt) else 1e-4
+    assert y.dtype == odt
+    assert_close(y.float().cpu(), yr.detach(), tol, tol * float(yr.abs().max()), "y")
+    assert_close(dev[0].grad.float().cpu(), ref[0].grad, tol, tol * float(ref[0].grad.abs().max()), "dx")
+    assert_close(dev[1].grad.cpu(), ref[1].grad, tol, tol * float(ref[1].grad.abs().max()), "dw")
+    assert_close(dev[2].grad.cpu(), ref[2].grad, tol, tol * float(ref[2].grad.abs().max()), "db")
+    if with_pre:
+        assert_close(dev[3].grad.cpu(), ref[3].grad, tol, tol * float(ref[3].grad.abs().max()), "d pre_bias")
+    if odt == torch.bfloat16 and C % 8 == 0:
+        y2 = bias_gelu_fn(layernorm_rows_fn(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, odt, None if pre is None else pre.to(DEV)), None)
+        assert_close(y.float().cpu(), y2.float().cpu(), 1e-2, 1e-2 * float(yr.abs().max()), "y vs the two-kernel chain")
+
+
 @pytest.mark.parametrize("C,dt", [(96, torch.float32), (384, torch.bfloat16), (768, torch.bfloat16)])
 def test_add_layernorm_rows_with_deferred_linear_bias(C, dt):
     """x + drop_path(y + b2) followed by LayerNorm, with the bias of the linear layer that produced y (Mlp.fc2,

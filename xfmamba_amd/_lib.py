@@ -24,7 +24,7 @@ SYMBOLS = (
     "xfm_swap_scan", "xfm_ss2d_route_split", "xfm_ss2d_route_merge", "xfm_ss2d_dt_proj_supported", "xfm_ss2d_dt_proj_mfma_rp", "xfm_ss2d_dt_proj_fwd_mfma", "xfm_ss2d_dt_proj_bwd_mfma", "xfm_ss2d_dt_proj_fwd",
     "xfm_dwconv3x3_fwd", "xfm_dwconv3x3_bwd", "xfm_dwconv3x3_tokens_supported", "xfm_dwconv3x3_tokens_fwd", "xfm_dwconv3x3_tokens_bwd", "xfm_conv3x3s2_tokens_supported", "xfm_conv3x3s2_tokens_fwd", "xfm_conv3x3s2_tokens_bwd_data", "xfm_conv3x3s2_tokens_bwd_weight", "xfm_conv3x3s2_tokens_bwd_weight_x_supported", "xfm_conv3x3s2_tokens_bwd_weight_x", "xfm_conv3x3s2_gray_supported", "xfm_conv3x3s2_gray_ws_floats", "xfm_conv3x3s2_gray_fwd", "xfm_conv3x3s2_gray_bwd_weight", "xfm_layernorm2d_fwd", "xfm_layernorm2d_bwd", "xfm_layernorm2d_bwd_parts_blocks", "xfm_layernorm2d_bwd_parts", "xfm_layernorm2d_ws_floats", "xfm_layernorm2d_bwd_ws_floats", "xfm_layernorm2d_bwd_ws_blocks", "xfm_layernorm2d_fwd_ws", "xfm_layernorm2d_bwd_parts_ws",
     "xfm_add_layernorm_rows_supported", "xfm_add_layernorm_rows_bwd_blocks", "xfm_add_layernorm_rows_fwd",
-    "xfm_add_layernorm_rows_bwd", "xfm_colsum_blocks", "xfm_bias_gelu_fwd", "xfm_bias_gelu_bwd", "xfm_colsum", "xfm_partial_sums_multi", "xfm_pooled_transpose_fwd", "xfm_pooled_transpose_bwd", "xfm_gated_transpose_fwd", "xfm_gated_transpose_bwd", "xfm_views_avg_stack_fwd", "xfm_views_avg_stack_bwd", "xfm_bn_tokens_supported", "xfm_bn_tokens_ws_floats", "xfm_bn_tokens_fwd", "xfm_bn_tokens_bwd", "xfm_transpose_short_supported", "xfm_transpose_short", "xfm_transpose_short_add_bf16", "xfm_residual_settle_fwd", "xfm_residual_settle_bwd", "xfm_tokens_gemm_supported", "xfm_tokens_gemm", "xfm_tokens_gemm2_supported", "xfm_tokens_gemm2", "xfm_tokens_gemm2_parts_blocks", "xfm_tokens_gemm2_parts", "xfm_proj_gemm_supported", "xfm_proj_gemm", "xfm_proj_gemm_accumulate", "xfm_planes_gemm_supported", "xfm_planes_gemm",
+    "xfm_add_layernorm_rows_bwd", "xfm_layernorm_rows_gelu_fwd", "xfm_layernorm_rows_gelu_bwd", "xfm_colsum_blocks", "xfm_bias_gelu_fwd", "xfm_bias_gelu_bwd", "xfm_colsum", "xfm_partial_sums_multi", "xfm_pooled_transpose_fwd", "xfm_pooled_transpose_bwd", "xfm_gated_transpose_fwd", "xfm_gated_transpose_bwd", "xfm_views_avg_stack_fwd", "xfm_views_avg_stack_bwd", "xfm_bn_tokens_supported", "xfm_bn_tokens_ws_floats", "xfm_bn_tokens_fwd", "xfm_bn_tokens_bwd", "xfm_transpose_short_supported", "xfm_transpose_short", "xfm_transpose_short_add_bf16", "xfm_residual_settle_fwd", "xfm_residual_settle_bwd", "xfm_tokens_gemm_supported", "xfm_tokens_gemm", "xfm_tokens_gemm2_supported", "xfm_tokens_gemm2", "xfm_tokens_gemm2_parts_blocks", "xfm_tokens_gemm2_parts", "xfm_proj_gemm_supported", "xfm_proj_gemm", "xfm_proj_gemm_accumulate", "xfm_planes_gemm_supported", "xfm_planes_gemm",
     "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd", "xfm_ss2d_bwd_ws_bytes", "xfm_ss2d_bwd_ws", "xfm_ss2d_dtfused_rank", "xfm_ss2d_xr_rows",
     "xfm_ss2dc_supported", "xfm_ss2dc_ytokens_supported", "xfm_ss2dc_nsteps", "xfm_ss2dc_fwd", "xfm_ss2dc_bwd", "xfm_ss2dc_post",
     "xfm_fp8_planes_gemm_supported", "xfm_fp8_planes_gemm", "xfm_adam_multi", "xfm_adam_multi_scaled",
@@ -181,6 +181,8 @@ def lib() -> C.CDLL:
         l.xfm_conv3x3s2_gray_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]
         l.xfm_conv3x3s2_gray_ws_floats.argtypes = [C.c_int]
         l.xfm_conv3x3s2_gray_bwd_weight.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
+        l.xfm_layernorm_rows_gelu_fwd.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        l.xfm_layernorm_rows_gelu_bwd.argtypes = [C.c_void_p] * 12 + [C.c_int] * 4 + [C.c_void_p]
         l.xfm_colsum_blocks.argtypes = [C.c_longlong, C.c_int, C.c_int]
         l.xfm_bias_gelu_fwd.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]
         l.xfm_bias_gelu_bwd.argtypes = [C.c_void_p] * 6 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]

@@ -55,7 +55,33 @@ struct RowLnArgs {
     float *part;            // (nblk, 2, C) per-workgroup partial dw / db
     int rows, rows_per_sample, C;
     float eps;
+    int act;                // 1: h = gelu(LayerNorm(x)) (exact erf form) -- the patch embedding's norm -> GELU (reference
+                            // models/fusion_vmamba.py:1504-1518); the backward pass recomputes LayerNorm(x) from x, mean, rstd,
+                            // w and b (needs `b`) and multiplies dh by gelu' first
 };
+
+// erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7) on the hardware exp2 / rcp, E = exp(-x^2): as csrc/tokens_ops.hip
+__device__ __forceinline__ float rowln_erf(const float x, float &E) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    E = __builtin_amdgcn_exp2f(-(x * x) * 1.4426950408889634f);
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float r = fmaf(-(p * t), E, 1.0f);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float rowln_gelu(const float x) {
+    float E;
+    return 0.5f * x * (1.0f + rowln_erf(x * 0.70710678118654752f, E));
+}
+// gelu'(x) = Phi(x) + x phi(x)
+__device__ __forceinline__ float rowln_gelu_grad(const float x) {
+    float E;
+    const float cdf = 0.5f * (1.0f + rowln_erf(x * 0.70710678118654752f, E));
+    return fmaf(x, 0.3989422804014327f * E, cdf);
+}
 
 template <typename Tx, typename Ty, int G, int NV> __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
     constexpr int RPW = 64 / G;
@@ -118,6 +144,9 @@ template <typename Tx, typename Ty, int G, int NV> __global__ __launch_bounds__(
                 o.y = fmaf(v[k].y * rs, w[k].y, bb[k].y);
                 o.z = fmaf(v[k].z * rs, w[k].z, bb[k].z);
                 o.w = fmaf(v[k].w * rs, w[k].w, bb[k].w);
+                if (a.act) {
+                    o.x = rowln_gelu(o.x); o.y = rowln_gelu(o.y); o.z = rowln_gelu(o.z); o.w = rowln_gelu(o.w);
+                }
                 Vec4IO<Ty>::st(h + r * C + (k * G + sub) * 4, o);
             }
             if (sub == 0) {
@@ -169,6 +198,13 @@ template <typename Tx, typename Ty, int G, int NV> __global__ __launch_bounds__(
             if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
             xh[k] = make_float4((xv.x + pb[k].x - mu) * rs, (xv.y + pb[k].y - mu) * rs, (xv.z + pb[k].z - mu) * rs,
                                 (xv.w + pb[k].w - mu) * rs);
+            if (a.act) {                                 // dh arrives on gelu(LayerNorm(x)): through the activation first
+                const float4 bv = a.b ? Vec4IO<float>::ld(a.b + (k * G + sub) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                d.x *= rowln_gelu_grad(fmaf(xh[k].x, w[k].x, bv.x));
+                d.y *= rowln_gelu_grad(fmaf(xh[k].y, w[k].y, bv.y));
+                d.z *= rowln_gelu_grad(fmaf(xh[k].z, w[k].z, bv.z));
+                d.w *= rowln_gelu_grad(fmaf(xh[k].w, w[k].w, bv.w));
+            }
             aw[k].x = fmaf(d.x, xh[k].x, aw[k].x); aw[k].y = fmaf(d.y, xh[k].y, aw[k].y);
             aw[k].z = fmaf(d.z, xh[k].z, aw[k].z); aw[k].w = fmaf(d.w, xh[k].w, aw[k].w);
             ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
@@ -362,6 +398,42 @@ int xfm_add_layernorm_rows_bwd(const void *x_new, const float *pre_bias, const f
     if (!dweight) return XFM_OK;
     hipLaunchKernelGGL(rowln_wb_kernel, dim3((a.nparts * C + 63) / 64), dim3(1024), 0, s, workspace, dweight, dbias,
                        dpre_bias, nblk, C, a.nparts);
+    return check_launch();
+}
+
+/* h = gelu(LayerNorm(x + pre_bias)) and its backward pass on (rows, C) rows: xfm_add_layernorm_rows_fwd / _bwd without a residual
+ * branch and with the exact-erf GELU inside (reference models/fusion_vmamba.py:1504-1518: norm -> GELU of the patch embedding).
+ * The backward pass takes the LayerNorm bias as well (it recomputes the pre-activation); everything else as the plain entries. */
+int xfm_layernorm_rows_gelu_fwd(const void *x, const float *pre_bias, const float *weight, const float *bias, void *h, float *mean,
+                                float *rstd, int rows, int C, float eps, int x_dtype, int dtype, void *stream) {
+    using namespace xfm;
+    if (!x || !weight || !h || !mean || !rstd || rows <= 0 || C <= 0) return XFM_EINVAL;
+    int G, NV;
+    if (!pick_shape(C, G, NV)) return XFM_ELIMIT;
+    RowLnArgs a{};
+    a.x = x; a.pre_bias = pre_bias; a.w = weight; a.b = bias; a.h = h; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.rows_per_sample = rows; a.C = C; a.eps = eps; a.act = 1;
+    return launch_any(false, x_dtype, dtype, G, NV, a, fwd_blocks(a.rows, G), (hipStream_t)stream);
+}
+
+int xfm_layernorm_rows_gelu_bwd(const void *x, const float *pre_bias, const float *weight, const float *bias, const void *dh,
+                                const float *mean, const float *rstd, void *dx, float *dweight, float *dbias, float *dpre_bias,
+                                float *workspace, int rows, int C, int x_dtype, int dtype, void *stream) {
+    using namespace xfm;
+    if (!x || !weight || !dh || !mean || !rstd || !dx || !workspace || rows <= 0) return XFM_EINVAL;
+    int G, NV;
+    if (!pick_shape(C, G, NV)) return XFM_ELIMIT;
+    RowLnArgs a{};
+    a.x = x; a.pre_bias = pre_bias; a.nparts = (dpre_bias || (!dweight && pre_bias)) ? 3 : 2; a.w = weight; a.b = bias; a.dh = dh;
+    a.mean = const_cast<float *>(mean); a.rstd = const_cast<float *>(rstd); a.dx = dx; a.part = workspace;
+    a.rows = rows; a.rows_per_sample = rows; a.C = C; a.act = 1;
+    const int nblk = xfm_add_layernorm_rows_bwd_blocks(a.rows, C);
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = launch_any(true, x_dtype, dtype, G, NV, a, nblk, s);
+    if (rc != XFM_OK) return rc;
+    if (!dweight) return XFM_OK;
+    hipLaunchKernelGGL(rowln_wb_kernel, dim3((a.nparts * C + 63) / 64), dim3(1024), 0, s, workspace, dweight, dbias, dpre_bias, nblk,
+                       C, a.nparts);
     return check_launch();
 }
 

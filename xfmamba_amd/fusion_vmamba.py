@@ -42,7 +42,8 @@ from .dwconv import dwconv3x3_silu_fn, dwconv3x3_silu_tokens_fn, dwconv_tokens_s
 from .layernorm2d import layernorm2d_fn
 from .mlp_tokens import bias_gelu_fn, linear_tokens_fn, mlp_tokens_fn
 from .proj import batched_proj, gated_planes_to_tokens, planes_to_tokens, tokens_to_planes, tokens_to_planes_pooled
-from .rowln import residual_settle_fn, add_layernorm_rows_fn, layernorm_rows_fn, layernorm_rows_pass_fn, rows_supported
+from .rowln import (residual_settle_fn, add_layernorm_rows_fn, layernorm_rows_fn, layernorm_rows_gelu_fn, layernorm_rows_pass_fn,
+                    rows_supported)
 from .ss2d import ss2d_core_fn, ss2d_xproj_core_fn, to_route_order
 from .ss2d_chan import chan_supported, ss2d_chan_fn, ytokens_supported
 from . import fp8 as _fp8
@@ -621,6 +622,9 @@ def _run_blocks(blocks: nn.Sequential, x: torch.Tensor):
     return _blocks_tokens(blocks, t).permute(0, 3, 1, 2).contiguous()
 
 
+# XFM_LN_GELU=0: the patch embedding's norm -> GELU as two kernels each way (A/B switch, read once)
+_LN_GELU = os.environ.get("XFM_LN_GELU", "1") == "1"
+
 # XFM_CONV_CL=0: the strided convolutions through F.conv2d (A/B switch, read once)
 _CONV_CL = os.environ.get("XFM_CONV_CL", "1") == "1"
 
@@ -803,9 +807,14 @@ class VSSM(nn.Module):
             # the image is ONE channel replicated (net_fusionmamba.py: x.expand(-1, 3, -1, -1)): the convolution of that channel
             # with the weight summed over its input channels (csrc/conv_tok.hip: 9 taps, no replicated image, no library)
             y = conv3x3s2_gray_fn(x[:, 0].to(torch.bfloat16).contiguous(), pe[0].weight)
-            t = layernorm_rows_fn(y, pe[2].weight, pe[2].bias, pe[2].eps, act_dtype, pe[0].bias)
-            t = bias_gelu_fn(t, None) if (isinstance(pe[4], nn.GELU) and getattr(pe[4], "approximate", "none") == "none"
-                                          and t.dtype in (torch.float32, torch.bfloat16) and t.shape[-1] % 8 == 0) else pe[4](t)
+            if _LN_GELU and isinstance(pe[4], nn.GELU) and getattr(pe[4], "approximate", "none") == "none":
+                # norm -> GELU as ONE kernel each way (xfm_layernorm_rows_gelu_fwd/_bwd): the activation pass over the
+                # 112 x 112 x 48 map and its backward pass (154 + 231 MB per step) are gone
+                t = layernorm_rows_gelu_fn(y, pe[2].weight, pe[2].bias, pe[2].eps, act_dtype, pe[0].bias)
+            else:
+                t = layernorm_rows_fn(y, pe[2].weight, pe[2].bias, pe[2].eps, act_dtype, pe[0].bias)
+                t = bias_gelu_fn(t, None) if (isinstance(pe[4], nn.GELU) and getattr(pe[4], "approximate", "none") == "none"
+                                              and t.dtype in (torch.float32, torch.bfloat16) and t.shape[-1] % 8 == 0) else pe[4](t)
             return _conv_ln_tokens(pe[5], pe[7], t, torch.float32)
         if x.shape[1] > 1 and x.stride(1) == 0 and act_dtype is not None and not x.requires_grad:
             # the image is a stride-0 broadcast of ONE channel (net_fusionmamba.py: x.expand(-1, 3, -1, -1)): cast the single

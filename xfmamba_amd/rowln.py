@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from . import deferred as _deferred
 
-__all__ = ["residual_settle_fn", "add_layernorm_rows_fn", "layernorm_rows_fn", "rows_supported"]
+__all__ = ["residual_settle_fn", "add_layernorm_rows_fn", "layernorm_rows_fn", "layernorm_rows_gelu_fn", "rows_supported"]
 
 
 def rows_supported(C: int) -> bool:
@@ -97,6 +97,52 @@ class LayerNormRowsHip(torch.autograd.Function):
                 (None if dpre is None else dpre.to(pdtype)))
 
 
+class LayerNormRowsGeluHip(torch.autograd.Function):
+    """``gelu(LayerNorm(x + pre_bias))`` (exact erf GELU) in one pass each way: ``xfm_layernorm_rows_gelu_fwd/_bwd`` -- the
+    norm -> GELU pair of the patch embedding (reference ``models/fusion_vmamba.py:1504-1518``).  Nothing but x, mean, rstd is
+    kept: the backward kernel recomputes the pre-activation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype, pre_bias):
+        x, w, b, out_dtype = _prep(x, weight, bias, out_dtype)
+        pre = None if pre_bias is None else pre_bias.float().contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        h = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        with torch.cuda.device(x.device), _lib.timed("layernorm_rows_gelu_fwd", x.numel() * (x.element_size() + h.element_size())):
+            _lib.check(_lib.lib().xfm_layernorm_rows_gelu_fwd(
+                x.data_ptr(), _lib.ptr(pre), w.data_ptr(), _lib.ptr(b), h.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C,
+                float(eps), _lib.dtype_code(x.dtype), _lib.dtype_code(out_dtype), _lib.stream_ptr()), "layernorm_rows_gelu_fwd")
+        ctx.save_for_backward(x, w, b, mean, rstd, pre)
+        ctx.meta = (weight.dtype, out_dtype, None if pre_bias is None else pre_bias.dtype)
+        ctx.params = (weight, bias, pre_bias)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, w, b, mean, rstd, pre = ctx.saved_tensors
+        wdtype, dtype, pdtype = ctx.meta
+        dh = dh.contiguous() if dh.dtype == dtype else dh.to(dtype).contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        lib = _lib.lib()
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(w) if b is not None else None
+        dpre = torch.empty_like(w) if pre is not None else None
+        nblk = lib.xfm_add_layernorm_rows_bwd_blocks(rows, C)
+        ws = torch.empty(3 * C * nblk, dtype=torch.float32, device=x.device)
+        later = _deferred.add_job(ws, [dw, db, dpre], nblk, C, 3 if pre is not None else 2, params=ctx.params)
+        with torch.cuda.device(x.device), _lib.timed("layernorm_rows_gelu_bwd", x.numel() * (2 * x.element_size() + dh.element_size())):
+            _lib.check(lib.xfm_layernorm_rows_gelu_bwd(
+                x.data_ptr(), _lib.ptr(pre), w.data_ptr(), _lib.ptr(b), dh.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                None if later else dw.data_ptr(), _lib.ptr(db), _lib.ptr(dpre), ws.data_ptr(), rows, C, _lib.dtype_code(x.dtype),
+                _lib.dtype_code(dtype), _lib.stream_ptr()), "layernorm_rows_gelu_bwd")
+        return (dx, dw.to(wdtype), (None if db is None else db.to(wdtype)), None, None, (None if dpre is None else dpre.to(pdtype)))
+
+
 class AddLayerNormRowsHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, scale, weight, bias, eps, out_dtype, y_bias):
@@ -170,6 +216,11 @@ def layernorm_rows_fn(x, weight, bias, eps=1e-5, out_dtype=None, pre_bias=None):
     """LayerNorm over the last axis of a contiguous fp32 / bf16 (B, ..., C) tensor; output in ``out_dtype``.
     ``pre_bias`` (C,) is added to ``x`` first (the bias of the convolution that produced ``x``)."""
     return LayerNormRowsHip.apply(x, weight, bias, eps, out_dtype, pre_bias)
+
+
+def layernorm_rows_gelu_fn(x, weight, bias, eps=1e-5, out_dtype=None, pre_bias=None):
+    """``gelu(LayerNorm(x + pre_bias))`` over the last axis (exact erf GELU), one kernel each way."""
+    return LayerNormRowsGeluHip.apply(x, weight, bias, eps, out_dtype, pre_bias)
 
 
 def add_layernorm_rows_fn(x, y, scale, weight, bias, eps=1e-5, out_dtype=None, y_bias=None):
