@@ -71,11 +71,12 @@ def parse():
     ap.add_argument("--report-conv-kernels", action="store_true", help="development: after the JSON line's measurements, one extra "
                     "eager step under torch.profiler to list the MIOpen / CK convolution solvers the find pass chose (off by "
                     "default: it nests a profiler inside rocprofv3 runs and adds an eager step to their kernel statistics)")
-    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True: the convolution library's "
-                    "own solver search during warm-up.  Off by default since round 5: four convolution launches per step are left "
-                    "on the library (forward / data gradient of two layers) and the search moves nothing any more (13.46 vs 13.46 "
-                    "ms) -- no per-box solver choice, 8 s less start-up")
-    ap.add_argument("--no-miopen-find", action="store_true", help="(accepted for older scripts: the default now)")
+    ap.add_argument("--no-miopen-find", action="store_true", help="leave MIOpen's default solver heuristics (default: "
+                    "torch.backends.cudnn.benchmark = True, i.e. MIOpen's own find pass during warm-up).  Four convolution "
+                    "launches per step are left on the library since round 5 and the search still matters for them: on a fresh "
+                    "box the heuristics picked a 244 us forward solver where the search finds a 48 us one (0.54 vs 0.23 ms per "
+                    "step).  (A same-box A/B cannot show this: the first run's search result stays in the library's user "
+                    "database and the run without the search finds it there.)")
     return ap.parse_args()
 
 
@@ -220,7 +221,7 @@ def main():
     if a.stream:
         fusion_vmamba.STREAM_LAYOUT = a.stream
 
-    if a.miopen_find and not a.no_miopen_find:
+    if not a.no_miopen_find:
         torch.backends.cudnn.benchmark = True
     torch.manual_seed(42)                                        # libs/config.py:22
     kw = dict(hidden_dim=1024) if a.model == "base" else {}
