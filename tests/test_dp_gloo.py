@@ -404,7 +404,7 @@ def test_bench_two_ranks_on_one_gpu_run_the_two_graph_step_end_to_end():
     both on GPU 0 over gloo (XFM_BENCH_BACKEND, the development hook), the captured two-graph data-parallel step, bucket
     all-reduces between / after the replays, FusedAdam on the summed wire buckets -- one JSON line with a finite loss behind it.
     (Round 5 found this flow diverging in one run out of three: with two processes on one GPU the merged dt_proj backward read
-    LDS tiles its counted vmcnt wait had not covered -- tests/test_hip_ops.py::test_dt_proj_backward_under_a_second_process.)"""
+    LDS tiles its counted vmcnt wait had not covered -- tests/test_hip_ops.py::test_kernels_with_counted_waits_under_a_second_process.)"""
     import json
     import subprocess
     import sys

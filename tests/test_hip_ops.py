@@ -901,20 +901,24 @@ def test_dt_proj_backward_mfma_matches_torch_fp32(B, D, R, H):
     assert_close(dw.cpu(), dw_ref, 1e-3, 1e-3 * float(dw_ref.abs().max()), "dw")
 
 
-def test_dt_proj_backward_under_a_second_process():
-    """tools/stress2.py in two processes at once: the merged dt_proj backward at the trunk's stage-0 and stage-1 shapes, every
-    result compared with the first.  Memory contention from the other process is what a too-short counted vmcnt wait needs to
+def test_kernels_with_counted_waits_under_a_second_process():
+    """tools/stress2.py in two processes at once: the merged dt_proj backward at the trunk's stage-0 and stage-1 shapes (and the
+    other ring kernels), every result compared with the first.  Memory contention from the other process is what a too-short counted vmcnt wait needs to
     show (round 5: trips 0 and 1 of the three-tile ring did not wait for their own tiles -- 31 of 300 launches wrong)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for op in ("dtbwd0", "dtbwd1", "dtbwd2"):
-        ps = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "stress2.py"), op, "150"], stdout=subprocess.PIPE,
+    for op, n in (("dtbwd0", 150), ("dtbwd1", 150), ("dtbwd2", 150),
+                  # the other kernels with rings / counted waits / LDS-direct loads, at the trunk's shapes (fewer launches: they are
+                  # larger): the wide-map and channel-lane SS2D cores forward + backward, the tiled token GEMM, both token x token
+                  # weight-gradient forms
+                  ("l3_56", 40), ("l3_28", 40), ("chan14", 40), ("chan7", 40), ("gemm3", 40), ("wgrad", 40), ("wgradx", 40)):
+        ps = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "stress2.py"), op, str(n)], stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True) for _ in range(2)]
         outs = [p.communicate(timeout=600)[0] for p in ps]
         for p, o in zip(ps, outs):
             assert p.returncode == 0, o[-2000:]
-            assert f"{op}: 0 of 150 runs differ" in o, o[-2000:]
+            assert f"{op}: 0 of {n} runs differ" in o, o[-2000:]
 
 
 @pytest.mark.parametrize("C,xdt,odt", [(48, torch.bfloat16, torch.bfloat16), (48, torch.float32, torch.bfloat16),

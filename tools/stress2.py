@@ -30,8 +30,61 @@ def main():
             _lib.check(lib.xfm_ss2d_dt_proj_bwd_mfma(ddts.data_ptr(), xr.data_ptr(), w.data_ptr(), dxr.data_ptr(), dw.data_ptr(), B, D,
                                                      R, L, _lib.stream_ptr()), "dt_proj_bwd_mfma")
             return dxr.clone(), dw.clone()
+    elif op in ("l3_56", "l3_28", "chan14", "chan7"):
+        # the fused SS2D cores at the trunk's shapes, forward + backward through the autograd nodes: y / dx are exact (fixed-order
+        # sums), the parameter gradients come from atomics (tolerance)
+        from xfmamba_amd.ss2d import ss2d_xproj_core_fn
+        from xfmamba_amd.ss2d_chan import ss2d_chan_fn
+        B, D, HW, R = {"l3_56": (64, 96, 56, 6), "l3_28": (64, 192, 28, 12), "chan14": (64, 384, 14, 24), "chan7": (64, 768, 7, 48)}[op]
+        L = HW * HW
+        x = torch.randn(B, D, L, generator=g).bfloat16().cuda().requires_grad_()
+        xw = (torch.randn(4, R + 2, D, generator=g) * D ** -0.5).cuda().requires_grad_()
+        dtw = (torch.randn(4, D, R, generator=g) * R ** -0.5).cuda().requires_grad_()
+        A = (-torch.rand(4 * D, 1, generator=g) - 0.2).cuda().requires_grad_()
+        Dp = torch.randn(4 * D, generator=g).cuda().requires_grad_()
+        bias = (torch.randn(4 * D, generator=g) * 0.5).cuda().requires_grad_()
+        gy = torch.randn(B, D, L, generator=g).cuda()
+        fn = ss2d_xproj_core_fn if op.startswith("l3") else ss2d_chan_fn
+
+        def run():
+            for t in (x, xw, dtw, A, Dp, bias):
+                t.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = fn(x, xw, dtw, A, Dp, bias, HW, HW)
+            y.backward(gy)
+            return y.detach().clone(), x.grad.clone(), torch.cat([t.grad.float().flatten() for t in (xw, dtw, A, Dp, bias)])
+    elif op in ("gemm3", "wgrad", "wgradx"):
+        T, C, O = 12544, 1536, 384
+        xt = torch.randn(T, C, generator=g).bfloat16().cuda()
+        wt = (torch.randn(O, C, generator=g) * C ** -0.5).bfloat16().cuda()
+        yt = torch.empty(T, O, dtype=torch.bfloat16, device="cuda")
+        dyt = torch.randn(T, O, generator=g).bfloat16().cuda()
+        dwt = torch.zeros(O, C, device="cuda")
+        xm = torch.randn(64, 56, 56, 96, generator=g).bfloat16().cuda()
+        dym = torch.randn(64, 28, 28, 192, generator=g).bfloat16().cuda()
+        dwm = torch.zeros(192, 9 * 96, device="cuda")
+
+        def run():
+            if op == "gemm3":
+                _lib.check(lib.xfm_tokens_gemm2(xt.data_ptr(), wt.data_ptr(), None, yt.data_ptr(), None, None, T, C, O, 0, 0,
+                                                _lib.stream_ptr()), "gemm2")
+                return yt.clone(), yt.clone()[:1], torch.zeros(1, device="cuda")
+            if op == "wgrad":
+                dwt.zero_()
+                _lib.check(lib.xfm_wgrad(dyt.data_ptr(), xt.data_ptr(), dwt.data_ptr(), O, C, 1, T, 0, 0, 0, 0, _lib.stream_ptr()), "wgrad")
+                return yt[:1].clone(), yt[:1].clone(), dwt.clone().flatten()
+            dwm.zero_()
+            _lib.check(lib.xfm_conv3x3s2_tokens_bwd_weight_x(dym.data_ptr(), xm.data_ptr(), dwm.data_ptr(), 64, 56, 56, 96, 192,
+                                                             _lib.stream_ptr()), "wgradx")
+            return yt[:1].clone(), yt[:1].clone(), dwm.clone().flatten()
     else:
         raise SystemExit("unknown op")
+    if op.startswith("dtbwd"):
+        run0 = run
+
+        def run():
+            a, b = run0()
+            return a, a[:1], b.flatten()
     ref = run()
     torch.cuda.synchronize()
     bad = 0
@@ -39,14 +92,18 @@ def main():
     for i in range(n):
         out = run()
         torch.cuda.synchronize()
-        e0 = not bool(torch.equal(out[0], ref[0]))
-        e1 = float((out[1] - ref[1]).abs().max()) > 1e-3 * float(ref[1].abs().max()) or not bool(torch.isfinite(out[1]).all())
+        if op.startswith("chan"):                      # (their dx sums four routes with LDS float atomics: order-dependent rounding)
+            d1 = float((out[1].float() - ref[1].float()).abs().max())
+            e0 = not bool(torch.equal(out[0], ref[0])) or not (d1 <= 1.6e-2 * float(ref[1].float().abs().max()))
+        else:
+            e0 = not bool(torch.equal(out[0], ref[0])) or not bool(torch.equal(out[1], ref[1]))
+        e1 = float((out[2] - ref[2]).abs().max()) > 2e-3 * float(ref[2].abs().max()) + 1e-6 or not bool(torch.isfinite(out[2]).all())
         if e0 or e1:
             bad += 1
             if bad <= 3:
                 d = (out[0].float() - ref[0].float())
-                print(f"[{os.getpid()}] iteration {i}: dxr differs at {int((d != 0).sum() + torch.isnan(d).sum())} elements "
-                      f"(nan {int(torch.isnan(out[0].float()).sum())}), dw off {e1}", flush=True)
+                print(f"[{os.getpid()}] iteration {i}: exact outputs differ at {int((d != 0).sum() + torch.isnan(d).sum())} elements "
+                      f"(nan {int(torch.isnan(out[0].float()).sum())}), summed outputs off {e1}", flush=True)
     print(f"[{os.getpid()}] {op}: {bad} of {n} runs differ from the first ({time.time() - t0:.1f} s)", flush=True)
 
 
