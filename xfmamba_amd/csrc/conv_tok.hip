@@ -120,6 +120,21 @@ __device__ __forceinline__ void gray_window(const uint16_t *img, const int W, co
     }
 }
 
+// the six dwords of the window of output pixel (row r = (n, oh), column ow): clamped, unconditional loads (they stay in flight),
+// zeroed where the window leaves the image
+__device__ __forceinline__ void gray_win_load(const GrayArgs &a, const int r, const int ow, uint32_t (&d)[6]) {
+    const int n = r / a.OH, oh = r - n * a.OH;
+    const uint16_t *img = a.x + (long long)n * a.H * a.W;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = 2 * oh + kh - 1;
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(img + (ih < 0 ? 0 : ih) * a.W);
+        const uint32_t d1 = row[ow], d0 = row[ow > 0 ? ow - 1 : 0];
+        d[2 * kh] = (ih >= 0 && ow > 0) ? d0 : 0u;
+        d[2 * kh + 1] = ih >= 0 ? d1 : 0u;
+    }
+}
+
 // A workgroup walks output ROWS (n, oh); thread = (column slot, channel group): og = tid % OG, columns tid / OG + k (192 / OG) --
 // no division in the loops, and the 192 lanes' 16-byte pieces of a pass are 3 KB of consecutive bytes of the row.
 __global__ void __launch_bounds__(192) conv_gray_fwd_kernel(const GrayArgs a) {
@@ -140,24 +155,40 @@ __global__ void __launch_bounds__(192) conv_gray_fwd_kernel(const GrayArgs a) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) w[c][k] = w9[(og * 8 + c) * 9 + k];
     const int rows = a.B * a.OH;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-        const int n = r / a.OH, oh = r - n * a.OH;                   // (uniform)
-        const uint16_t *img = a.x + (long long)n * a.H * a.W;
-        uint4 *yrow = reinterpret_cast<uint4 *>(a.y) + (long long)r * a.OW * a.OG;
-        for (int ow = ow0; ow < a.OW; ow += step) {
-            float xv[9];
-            gray_window(img, a.W, oh, ow, xv);
-            float s[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float t = 0.f;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) t = fmaf(w[c][k], xv[k], t);
-                s[c] = t;
-            }
-            yrow[ow * a.OG + og] = make_uint4(pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3]), pack_bf16x2(s[4], s[5]),
-                                              pack_bf16x2(s[6], s[7]));
+    // one visit of look-ahead, as in the weight-gradient kernel below: the next window's six dwords are requested before this one
+    // is multiplied (a thread makes ~28 visits; without it every visit's loads were in the open: 37 us)
+    int r = blockIdx.x, ow = ow0;
+    uint32_t cur[6], nxt[6];
+    bool live = r < rows && ow < a.OW;
+    if (live) gray_win_load(a, r, ow, cur);
+    while (live) {
+        int r2 = r, ow2 = ow + step;
+        if (ow2 >= a.OW) {
+            ow2 = ow0;
+            r2 = r + gridDim.x;
         }
+        const bool live2 = r2 < rows;
+        if (live2) gray_win_load(a, r2, ow2, nxt);
+        float xv[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            xv[3 * kh] = __uint_as_float(cur[2 * kh] & 0xffff0000u);
+            xv[3 * kh + 1] = __uint_as_float(cur[2 * kh + 1] << 16);
+            xv[3 * kh + 2] = __uint_as_float(cur[2 * kh + 1] & 0xffff0000u);
+        }
+        float s[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) t = fmaf(w[c][k], xv[k], t);
+            s[c] = t;
+        }
+        (reinterpret_cast<uint4 *>(a.y) + (long long)r * a.OW * a.OG)[ow * a.OG + og] =
+            make_uint4(pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3]), pack_bf16x2(s[4], s[5]), pack_bf16x2(s[6], s[7]));
+#pragma unroll
+        for (int q = 0; q < 6; ++q) cur[q] = nxt[q];
+        r = r2; ow = ow2; live = live2;
     }
 }
 
@@ -325,7 +356,8 @@ int xfm_conv3x3s2_gray_fwd(const void *x, const void *weight, void *y, int B, in
     a.w = static_cast<const uint16_t *>(weight);
     a.CI = CI;
     a.y = static_cast<uint16_t *>(y);
-    const long long blocks = std::min<long long>((long long)B * a.OH, 256 * 4);
+    static const int env_fwgs = [] { const char *e = getenv("XFM_GRAY_FWD_WGS"); return e ? atoi(e) : 1024; }();   // tuning hook, read once
+    const long long blocks = std::min<long long>((long long)B * a.OH, env_fwgs);
     hipLaunchKernelGGL(conv_gray_fwd_kernel, dim3((unsigned)blocks), dim3(192), 0, (hipStream_t)stream, a);
     return check_launch();
 }
