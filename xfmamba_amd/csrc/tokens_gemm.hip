@@ -930,6 +930,7 @@ struct ProjTiledArgs {
     uint16_t *y;
     int B, L, CON, OUT, ltiles, ntn, ntiles;
     int accumulate;         // planes out: y += W x (the existing bf16 values are widened, added in fp32 and rounded once)
+    int img;                // planes out, not accumulating: leave through the LDS image (XFM_PROJ_IMG=0: A/B switch)
 };
 
 template <bool PIN, bool WT>
@@ -1083,7 +1084,34 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
     const int h = kb;
     if constexpr (!PIN) {
         // ---- planes out: D[n][position]: for one register 32 lanes hold 32 consecutive positions of one channel's plane row
-        __syncthreads();                                   // (bias)
+        __syncthreads();                                   // (bias; everyone is done with the stage buffers)
+        if (!a.accumulate && a.img) {
+            // through an image [128 channels][128 positions + 8] in the (now free) stage buffers: 2-byte LDS writes (consecutive
+            // lanes = consecutive addresses), then 8-byte stores -- four positions of a plane row per lane, a row's 32 pieces on
+            // consecutive lanes -- instead of 64 two-byte global stores per thread
+            constexpr int SP2 = 136;
+            uint16_t *img = reinterpret_cast<uint16_t *>(g3_lds);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pl = wn * 64 + j * 32 + c;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int nl = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                        img[nl * SP2 + pl] = (uint16_t)(pack_bf16x2(acc[i][j][v] + bl[nl], 0.f) & 0xffffu);
+                    }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int item = tid + 256 * it, row = item >> 5, ch = item & 31;
+                if (l0 + 4 * ch < L)                       // (L % 4 == 0)
+                    *reinterpret_cast<uint2 *>(a.y + ((int64_t)b * a.OUT + n0 + row) * L + l0 + 4 * ch) =
+                        *reinterpret_cast<const uint2 *>(img + row * SP2 + 4 * ch);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1154,6 +1182,8 @@ template <bool PIN, bool WT> static int proj_tiled_launch(ProjTiledArgs a, hipSt
     a.ltiles = (a.L + 127) / 128;
     a.ntn = a.OUT / 128;
     a.ntiles = a.B * a.ltiles * a.ntn;
+    static const int img_on = [] { const char *e = getenv("XFM_PROJ_IMG"); return (!e || atoi(e) != 0) ? 1 : 0; }();
+    a.img = img_on;
     hipLaunchKernelGGL(fn, dim3((unsigned)((a.ntiles + 7) / 8 * 8)), dim3(256), lds, s, a);
     return check_launch();
 }
