@@ -1112,6 +1112,36 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
             }
             return;
         }
+        if (a.accumulate && a.img) {
+            // y += W x: the fp32 tile through an image [128 channels][128 positions] (64 KB = the stage ring), then per lane four
+            // positions of a plane row: the existing bf16 values widened, added in fp32, rounded once, one 8-byte store
+            float *imgf = reinterpret_cast<float *>(g3_lds);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pl = wn * 64 + j * 32 + c;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int nl = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                        imgf[nl * 128 + (pl ^ ((nl & 7) << 2))] = acc[i][j][v] + bl[nl];      // (row-dependent column swizzle: see the reads)
+                    }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int item = tid + 256 * it, row = item >> 5, ch = item & 31;
+                if (l0 + 4 * ch < L) {
+                    uint2 *dst = reinterpret_cast<uint2 *>(a.y + ((int64_t)b * a.OUT + n0 + row) * L + l0 + 4 * ch);
+                    const uint2 old = *dst;
+                    const float4 t = *reinterpret_cast<const float4 *>(imgf + row * 128 + ((4 * ch) ^ ((row & 7) << 2)));
+                    const float o0 = t.x + __uint_as_float(old.x << 16), o1 = t.y + __uint_as_float(old.x & 0xffff0000u);
+                    const float o2 = t.z + __uint_as_float(old.y << 16), o3 = t.w + __uint_as_float(old.y & 0xffff0000u);
+                    *dst = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
