@@ -283,8 +283,8 @@ __global__ void __launch_bounds__(192) conv_gray_wgrad_kernel(const GrayArgs a) 
 }
 
 static int conv_gray_ok(int B, int H, int W, int O) {
-    return B > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && O >= 8 && O % 8 == 0 && 192 % (O / 8) == 0 &&
-           (long long)B * H * W < (1ll << 31);
+    return B > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && O >= 8 && O <= 192 && O % 8 == 0 && 192 % (O / 8) == 0 &&
+           (long long)B * H * W < (1ll << 31);            // (O <= 192: the forward stages O x 9 summed weights in w9[24 * 72])
 }
 
 static GrayArgs gray_args(const void *x, int B, int H, int W, int O) {

@@ -1277,8 +1277,10 @@ static int chan_run(const xfm_ss2dc_params_t *p, bool bwd, void *stream) {
         // (XFM_ELIMIT -- dt_rank beyond four k-steps, a ddts tensor of 4 GB -- is the same answer for both directions of a
         //  shape, so the generations never mix: their checkpoints differ at 7 x 7)
         const int rc1 = chan1_run(a, HW, bwd, s);
-        if (rc1 != XFM_ELIMIT) return rc1;
+        // (token-major y / dy / x / dx exist in the second generation only: such a request never reaches the kernels below)
+        if (rc1 != XFM_ELIMIT || a.ytok || a.xtok) return rc1;
     }
+    if (a.ytok || a.xtok) return XFM_ELIMIT;
     if (N == 1) {
         if (HW == 7) return chan_dispatch_ks<7, 1>(a, bwd, s);
         if (HW == 12) return chan_dispatch_ks<12, 1>(a, bwd, s);

@@ -1115,6 +1115,18 @@ __global__ void __launch_bounds__(256, L3_WPE) ss2d_l3_bwd_kernel(const LeanArgs
     else l3_bwd_body<HW, PPT, MODE, RP2, false>(a, smem, wave, lane);
 }
 
+}  // namespace xfm
+
+#include "ss2d_w.hpp"
+
+namespace xfm {
+
+// fourth-generation kernels (ss2d_w.hpp) for the activated-step-size mode; XFM_SS2D_W=0: the kernels of this file (A/B switch)
+static bool w_enabled() {
+    static const bool on = [] { const char *e = getenv("XFM_SS2D_W"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1183,6 +1195,8 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
         } else {
             return XFM_ELIMIT;
         }
+    } else if (p.delta_softplus == 2 && w_enabled()) {
+        fn = bwd ? (const void *)ss2d_w_bwd_kernel<HW, PPT> : (const void *)ss2d_w_fwd_kernel<HW, PPT>;
     } else if (bwd)
         fn = p.delta_softplus == 2 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 2>
                                    : (p.delta_softplus == 1 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 1>
@@ -1246,7 +1260,9 @@ int ss2d_l3_nseg(int batch, int D, int H, int W, int N, int in_dtype) {
     if ((e && e[0] == '0') || in_dtype != XFM_BF16 || N != 1 || H != W) return 0;
     const int ppt = l3_ppt(H);
     if (!ppt || D % ppt) return 0;
-    return (H * W + 511) / 512;
+    // ss2d_w.hpp keeps the state entering every LANE's chunk (64 per chunk row); the kernels of this file index the same
+    // buffer with one entry per chunk row
+    return (H * W + 511) / 512 * (w_enabled() ? 64 : 1);
 }
 
 // padded dt_rank for dt_proj inside the kernels of this file (0: no such kernel)

@@ -52,7 +52,7 @@ def _new_tables(device):
     return dict(jobs_h=torch.empty(6 * _MAX_JOBS, dtype=torch.int64).pin_memory(),
                 blocks_h=torch.empty(_MAX_BLOCKS, dtype=torch.int32).pin_memory(),
                 jobs_d=torch.empty(6 * _MAX_JOBS, dtype=torch.int64, device=device),
-                blocks_d=torch.empty(_MAX_BLOCKS, dtype=torch.int32, device=device), key=None, evt=None, nblocks=0)
+                blocks_d=torch.empty(_MAX_BLOCKS, dtype=torch.int32, device=device), key=None, evt=None, nblocks=0, nrows=0)
 
 
 def reserve_capture_tables(device, n: int = _CAP_POOL_MIN) -> None:
@@ -161,11 +161,18 @@ def flush(_end_of_pass: bool = True) -> None:
         bh[:len(blocks)] = torch.tensor(blocks, dtype=torch.int32)
         sl["jobs_d"][:len(rows)].copy_(jh[:len(rows)], non_blocking=True)
         sl["blocks_d"][:len(blocks)].copy_(bh[:len(blocks)], non_blocking=True)
-        sl["key"], sl["nblocks"] = key, len(blocks)
+        sl["key"], sl["nblocks"], sl["nrows"] = key, len(blocks), len(rows)
         if not capturing:
             if sl["evt"] is None:
                 sl["evt"] = torch.cuda.Event()
             sl["evt"].record()
+    elif capturing:
+        # a pair that an EARLIER capture recorded: its device tables are written only by that graph's memcpy nodes, i.e. only
+        # if that graph is replayed first.  Record the uploads in this graph too (same pinned contents, read-only): the new
+        # graph then never depends on another one having run.
+        nr, nb = sl["nrows"], sl["nblocks"]
+        sl["jobs_d"][:nr].copy_(sl["jobs_h"][:nr], non_blocking=True)
+        sl["blocks_d"][:nb].copy_(sl["blocks_h"][:nb], non_blocking=True)
     with torch.cuda.device(dev), _lib.timed("partial_sums", 0):
         _lib.check(_lib.lib().xfm_partial_sums_multi(sl["jobs_d"].data_ptr(), sl["blocks_d"].data_ptr(), sl["nblocks"],
                                                      _lib.stream_ptr()), "partial_sums_multi")
