@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XFM_ABI_VERSION 1
+#define XFM_ABI_VERSION 2      /* 2: xfm_ss2d_params_t.bc_f32 (round 6); layouts of round 5's y_tokens / x_tokens / xrt fields */
 
 enum { XFM_F32 = 0, XFM_F16 = 1, XFM_BF16 = 2 };
 
@@ -115,6 +115,9 @@ int xfm_swap_scan(const void *x, const void *x2, void *out, int B, int C, int L,
  * of xfm_ss2d_bwd. */
 int xfm_ss2d_route_split(const void *xd, void *xr, void *Bs, void *Cs, int B, int R, int N, int H, int W, int dtype,
                          void *stream);
+/* xfm_ss2d_route_split that writes the B / C rows a second time as fp32 (Bs32 / Cs32: (B, 4, N, H*W) fp32, per-route order) */
+int xfm_ss2d_route_split_bc32(const void *xd, void *xr, void *Bs, void *Cs, float *Bs32, float *Cs32, int B, int R, int N, int H,
+                              int W, int dtype, void *stream);
 int xfm_ss2d_route_merge(const void *dxr, const float *dBs, const float *dCs, void *dxd, int B, int R, int N, int H,
                          int W, int dtype, void *stream);
 
@@ -434,7 +437,17 @@ typedef struct {
                               (batch, 4, ceil(H*W / 512), dt_rank_p, 64, 8) in_dtype, per-route order */
     const void *dt_w;      /* (4, d_inner, dt_rank_p) in_dtype: dt_projs_weight rows, zero-padded to dt_rank_p */
     int dt_rank_p;         /* xfm_ss2d_dtfused_rank(...) */
+    int bc_f32;            /* 1: Bs32 / Cs32 below hold the B / C rows as fp32 too (xfm_ss2d_route_split_bc32); forward AND backward of
+                            * such a call are served by csrc/ss2d_w.hpp (xfm_ss2d_bc_f32() says for which shapes), whose
+                            * backward reads the fp32 rows; chk then holds one state per 8-position chunk (xfm_ss2d_plan) */
+    const float *Bs32, *Cs32;   /* (batch, 4, dstate, H*W) fp32, per-route order; read only when bc_f32 */
 } xfm_ss2d_params_t;
+
+/* 1 when the fused core wants the fp32 copies of the B / C rows for this shape in the activated-step-size mode
+ * (delta_softplus == 2): bf16 I/O, d_state 1, the wide square maps csrc/ss2d_w.hpp covers (56, 28, 48, 24).  The caller then
+ * produces the rows with xfm_ss2d_route_split_bc32 and sets bc_f32 / Bs32 / Cs32 in the forward and the backward call; with
+ * bc_f32 == 0 the same call is served by the kernels of csrc/ss2d_l3.hip. */
+int xfm_ss2d_bc_f32(int batch, int d_inner, int H, int W, int dstate, int in_dtype);
 
 /* dt_proj inside the fused SS2D core (delta_softplus == 3): the padded rank to lay xrt / dt_w out with (dt_rank rounded up
  * to even), or 0 when this shape / dtype has no such kernel (bf16 I/O, d_state 1, the wide square maps of csrc/ss2d_l3.hip,

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == declared
     for s in declared:
         assert hasattr(l, s), s
-    assert _lib.lib().xfm_abi_version() == 1
+    assert _lib.lib().xfm_abi_version() == 2
     assert _lib.lib().xfm_strerror(0) == b"ok" and b"dtype" in _lib.lib().xfm_strerror(-2)
 
 

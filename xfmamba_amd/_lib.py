@@ -25,7 +25,7 @@ SYMBOLS = (
     "xfm_dwconv3x3_fwd", "xfm_dwconv3x3_bwd", "xfm_dwconv3x3_tokens_supported", "xfm_dwconv3x3_tokens_fwd", "xfm_dwconv3x3_tokens_bwd", "xfm_conv3x3s2_tokens_supported", "xfm_conv3x3s2_tokens_fwd", "xfm_conv3x3s2_tokens_bwd_data", "xfm_conv3x3s2_tokens_bwd_weight", "xfm_conv3x3s2_tokens_bwd_weight_x_supported", "xfm_conv3x3s2_tokens_bwd_weight_x", "xfm_conv3x3s2_gray_supported", "xfm_conv3x3s2_gray_ws_floats", "xfm_conv3x3s2_gray_fwd", "xfm_conv3x3s2_gray_bwd_weight", "xfm_layernorm2d_fwd", "xfm_layernorm2d_bwd", "xfm_layernorm2d_bwd_parts_blocks", "xfm_layernorm2d_bwd_parts", "xfm_layernorm2d_ws_floats", "xfm_layernorm2d_bwd_ws_floats", "xfm_layernorm2d_bwd_ws_blocks", "xfm_layernorm2d_fwd_ws", "xfm_layernorm2d_bwd_parts_ws",
     "xfm_add_layernorm_rows_supported", "xfm_add_layernorm_rows_bwd_blocks", "xfm_add_layernorm_rows_fwd",
     "xfm_add_layernorm_rows_bwd", "xfm_layernorm_rows_gelu_fwd", "xfm_layernorm_rows_gelu_bwd", "xfm_colsum_blocks", "xfm_bias_gelu_fwd", "xfm_bias_gelu_bwd", "xfm_colsum", "xfm_partial_sums_multi", "xfm_pooled_transpose_fwd", "xfm_pooled_transpose_bwd", "xfm_gated_transpose_fwd", "xfm_gated_transpose_bwd", "xfm_views_avg_stack_fwd", "xfm_views_avg_stack_bwd", "xfm_bn_tokens_supported", "xfm_bn_tokens_ws_floats", "xfm_bn_tokens_fwd", "xfm_bn_tokens_bwd", "xfm_transpose_short_supported", "xfm_transpose_short", "xfm_transpose_short_add_bf16", "xfm_residual_settle_fwd", "xfm_residual_settle_bwd", "xfm_tokens_gemm_supported", "xfm_tokens_gemm", "xfm_tokens_gemm2_supported", "xfm_tokens_gemm2", "xfm_tokens_gemm2_parts_blocks", "xfm_tokens_gemm2_parts", "xfm_proj_gemm_supported", "xfm_proj_gemm", "xfm_proj_gemm_accumulate", "xfm_planes_gemm_supported", "xfm_planes_gemm",
-    "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd", "xfm_ss2d_bwd_ws_bytes", "xfm_ss2d_bwd_ws", "xfm_ss2d_dtfused_rank", "xfm_ss2d_xr_rows",
+    "xfm_ss2d_plan", "xfm_ss2d_fwd", "xfm_ss2d_bwd", "xfm_ss2d_bwd_ws_bytes", "xfm_ss2d_bwd_ws", "xfm_ss2d_dtfused_rank", "xfm_ss2d_xr_rows", "xfm_ss2d_bc_f32", "xfm_ss2d_route_split_bc32",
     "xfm_ss2dc_supported", "xfm_ss2dc_ytokens_supported", "xfm_ss2dc_nsteps", "xfm_ss2dc_fwd", "xfm_ss2dc_bwd", "xfm_ss2dc_post",
     "xfm_fp8_planes_gemm_supported", "xfm_fp8_planes_gemm", "xfm_adam_multi", "xfm_adam_multi_scaled",
     "xfm_wgrad_supported", "xfm_wgrad",
@@ -64,7 +64,8 @@ class SS2DParams(C.Structure):
         ("y", C.c_void_p), ("chk", C.c_void_p),
         ("dy", C.c_void_p), ("dx", C.c_void_p), ("ddts", C.c_void_p),
         ("dBs", C.c_void_p), ("dCs", C.c_void_p), ("dA", C.c_void_p), ("dD", C.c_void_p), ("ddelta_bias", C.c_void_p),
-        ("xrt", C.c_void_p), ("dt_w", C.c_void_p), ("dt_rank_p", C.c_int),
+        ("xrt", C.c_void_p), ("dt_w", C.c_void_p), ("dt_rank_p", C.c_int), ("bc_f32", C.c_int),
+        ("Bs32", C.c_void_p), ("Cs32", C.c_void_p),
     ]
 
 
@@ -165,6 +166,8 @@ def lib() -> C.CDLL:
         l.xfm_ss2d_route_split.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]
         l.xfm_ss2d_route_merge.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]
         l.xfm_ss2d_dtfused_rank.argtypes = [C.c_int] * 7
+        l.xfm_ss2d_bc_f32.argtypes = [C.c_int] * 6
+        l.xfm_ss2d_route_split_bc32.argtypes = [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p]
         l.xfm_ss2d_xr_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 4 + [C.c_void_p]
         l.xfm_ss2d_dt_proj_supported.argtypes = [C.c_int] * 3
         l.xfm_ss2d_dt_proj_mfma_rp.argtypes = [C.c_int] * 3
@@ -198,7 +201,7 @@ def lib() -> C.CDLL:
         l.xfm_proj_gemm.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]
         l.xfm_planes_gemm_supported.argtypes = [C.c_int] * 3
         l.xfm_planes_gemm.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]
-        if l.xfm_abi_version() != 1:
+        if l.xfm_abi_version() != 2:
             raise RuntimeError("xfmamba_amd: libxfm_hip.so ABI version mismatch")
         _lib = l
     return _lib

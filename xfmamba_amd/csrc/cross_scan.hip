@@ -151,15 +151,26 @@ __device__ __forceinline__ void plane_move(const Ts *src, Td *dst, int R0, int C
     }
 }
 
+// Bs32 / Cs32 (optional): the same B / C rows once more as fp32 -- the wide-map scan BACKWARD of ss2d_w.hpp reads them without
+// an unpack (its forward keeps the 16-bit rows: with five operand vectors per chunk row it is bound by the vector-memory path)
 template <typename T>
-__global__ void __launch_bounds__(256) route_split_kernel(const T *xd, T *xr, T *Bs, T *Cs, int R, int N, int H, int W) {
+__global__ void __launch_bounds__(256) route_split_kernel(const T *xd, T *xr, T *Bs, T *Cs, float *Bs32, float *Cs32, int R, int N,
+                                                          int H, int W) {
     extern __shared__ float tile[];
     const int C2 = R + 2 * N, L = H * W;
     const int c = blockIdx.x % C2, bk = blockIdx.x / C2, k = bk & 3;
     const T *src = xd + (int64_t)blockIdx.x * L;
-    T *dst = c < R ? xr + ((int64_t)bk * R + c) * L
-                   : (c < R + N ? Bs + ((int64_t)bk * N + (c - R)) * L : Cs + ((int64_t)bk * N + (c - R - N)) * L);
-    plane_move<T, T>(src, dst, H, W, (k & 1) != 0, tile);
+    const bool tr = (k & 1) != 0;
+    if (c < R) {
+        plane_move<T, T>(src, xr + ((int64_t)bk * R + c) * L, H, W, tr, tile);
+        return;
+    }
+    const int64_t off = c < R + N ? ((int64_t)bk * N + (c - R)) * L : ((int64_t)bk * N + (c - R - N)) * L;
+    plane_move<T, T>(src, (c < R + N ? Bs : Cs) + off, H, W, tr, tile);
+    if (Bs32) {
+        __syncthreads();
+        plane_move<T, float>(src, (c < R + N ? Bs32 : Cs32) + off, H, W, tr, tile);
+    }
 }
 
 // adjoint: gradients arrive as dt-input grad (T), dBs / dCs (fp32 accumulators of the scan backward)
@@ -178,7 +189,7 @@ __global__ void __launch_bounds__(256) route_merge_kernel(const T *dxr, const fl
 
 template <typename T>
 static int launch_route(bool merge, const void *a, const void *b, const void *c, void *d, void *e, void *f, int B, int R,
-                        int N, int H, int W, hipStream_t s) {
+                        int N, int H, int W, hipStream_t s, float *e32 = nullptr, float *f32 = nullptr) {
     const size_t lds = (size_t)(H > W ? H : W) * ((H > W ? W : H) + 1) * sizeof(float) + (size_t)(H + W) * sizeof(float);
     if (lds > 64 * 1024) return XFM_ELIMIT;
     const dim3 grid((unsigned)((int64_t)B * 4 * (R + 2 * N)));
@@ -186,7 +197,7 @@ static int launch_route(bool merge, const void *a, const void *b, const void *c,
         hipLaunchKernelGGL((route_merge_kernel<T>), grid, dim3(256), lds, s, (const T *)a, (const float *)b,
                            (const float *)c, (T *)d, R, N, H, W);
     else
-        hipLaunchKernelGGL((route_split_kernel<T>), grid, dim3(256), lds, s, (const T *)a, (T *)d, (T *)e, (T *)f, R, N, H, W);
+        hipLaunchKernelGGL((route_split_kernel<T>), grid, dim3(256), lds, s, (const T *)a, (T *)d, (T *)e, (T *)f, e32, f32, R, N, H, W);
     return check_launch();
 }
 
@@ -203,6 +214,19 @@ int xfm_ss2d_route_split(const void *xd, void *xr, void *Bs, void *Cs, int B, in
         case XFM_F32: return launch_route<float>(false, xd, nullptr, nullptr, xr, Bs, Cs, B, R, N, H, W, s);
         case XFM_F16: return launch_route<f16_t>(false, xd, nullptr, nullptr, xr, Bs, Cs, B, R, N, H, W, s);
         case XFM_BF16: return launch_route<bf16_t>(false, xd, nullptr, nullptr, xr, Bs, Cs, B, R, N, H, W, s);
+    }
+    return XFM_EDTYPE;
+}
+
+int xfm_ss2d_route_split_bc32(const void *xd, void *xr, void *Bs, void *Cs, float *Bs32, float *Cs32, int B, int R, int N, int H,
+                              int W, int dtype, void *stream) {
+    using namespace xfm;
+    if (!xd || !xr || !Bs || !Cs || !Bs32 || !Cs32 || B <= 0 || R <= 0 || N <= 0 || H <= 0 || W <= 0) return XFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case XFM_F32: return launch_route<float>(false, xd, nullptr, nullptr, xr, Bs, Cs, B, R, N, H, W, s, Bs32, Cs32);
+        case XFM_F16: return launch_route<f16_t>(false, xd, nullptr, nullptr, xr, Bs, Cs, B, R, N, H, W, s, Bs32, Cs32);
+        case XFM_BF16: return launch_route<bf16_t>(false, xd, nullptr, nullptr, xr, Bs, Cs, B, R, N, H, W, s, Bs32, Cs32);
     }
     return XFM_EDTYPE;
 }

@@ -242,6 +242,7 @@ int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, 
 size_t ss2d_l3_ws_bytes(const xfm_ss2d_params_t *p);
 int ss2d_l3_nseg(int batch, int D, int H, int W, int N, int in_dtype);
 int ss2d_l3_dtfused_rank(int batch, int D, int H, int W, int N, int R, int in_dtype);
+int ss2d_w_covers(int batch, int D, int H, int W, int N, int in_dtype);                                // ss2d_l3.hip / ss2d_w.hpp
 static bool ss2d_forced() {
     static const bool f = getenv("XFM_SS2D_FORCE") != nullptr;      // tuning hook, read once per process
     return f;
@@ -267,6 +268,7 @@ static int run2(const xfm_ss2d_params_t *p, bool bwd, void *stream, float *ws = 
         const int rc3 = ss2d_l3_run(p, bwd, (hipStream_t)stream, ws, ws_bytes);
         if (rc3 != XFM_ELIMIT) return rc3;
     }
+    if (p->bc_f32) return XFM_EINVAL;                        // fp32 B / C rows beside 16-bit planes: ss2d_w.hpp only (xfm_ss2d_bc_f32)
     Plan2 pl;
     int rc = plan_ss2d(p->batch, p->d_inner, p->H, p->W, p->dstate, p->in_dtype, &pl);
     if (rc) return rc;
@@ -317,6 +319,10 @@ int xfm_ss2d_plan(int batch, int d_inner, int H, int W, int dstate, int in_dtype
 int xfm_ss2d_dtfused_rank(int batch, int d_inner, int H, int W, int dstate, int dt_rank, int in_dtype) {
     if (xfm::ss2d_forced()) return 0;
     return xfm::ss2d_l3_dtfused_rank(batch, d_inner, H, W, dstate, dt_rank, in_dtype);
+}
+int xfm_ss2d_bc_f32(int batch, int d_inner, int H, int W, int dstate, int in_dtype) {
+    if (xfm::ss2d_forced()) return 0;
+    return xfm::ss2d_w_covers(batch, d_inner, H, W, dstate, in_dtype);
 }
 int xfm_ss2d_fwd(const xfm_ss2d_params_t *p, void *stream) { return xfm::run2(p, false, stream); }
 int xfm_ss2d_bwd(const xfm_ss2d_params_t *p, void *stream) { return xfm::run2(p, true, stream); }

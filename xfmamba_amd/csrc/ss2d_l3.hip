@@ -1155,13 +1155,23 @@ template <int HW, int PPT, int RP2> static const void *l3_fn3(const bool bwd) {
     return bwd ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 3, RP2> : (const void *)ss2d_l3_fwd_kernel<HW, PPT, 3, RP2>;
 }
 
+int ss2d_l3_nseg(int batch, int D, int H, int W, int N, int in_dtype);
+// ss2d_w.hpp serves this shape (activated step sizes, fp32 B / C rows): byte offsets inside every tensor fit its 32-bit
+// buffer addressing
+int ss2d_w_covers(int batch, int D, int H, int W, int N, int in_dtype) {
+    if (!w_enabled() || !ss2d_l3_nseg(batch, D, H, W, N, in_dtype)) return 0;
+    const long long planes = (long long)batch * 4 * D, L = (long long)H * W;
+    const long long chk = planes * ((L + 511) / 512) * 256;
+    return (planes * L * 2 < (1ll << 31) && chk < (1ll << 31)) ? 1 : 0;
+}
+
 template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool bwd, hipStream_t s, float *ws, size_t ws_bytes) {
     using G = L3Geom<HW>;
     constexpr int L = G::L, PL = PPT * L;
     const int D = p.d_inner;
     if (D % PPT) return XFM_ELIMIT;
     LeanArgs la{};
-    la.x = p.x; la.dts = p.dts; la.Bs = p.Bs; la.Cs = p.Cs;
+    la.x = p.x; la.dts = p.dts; la.Bs = p.Bs; la.Cs = p.Cs; la.Bs32 = p.Bs32; la.Cs32 = p.Cs32;
     la.A = p.A; la.D = p.D; la.bias = p.delta_bias;
     la.y = p.y; la.chk = p.chk; la.dy = p.dy; la.dx = p.dx; la.ddts = p.ddts;
     la.dBs = p.dBs; la.dCs = p.dCs; la.dA = p.dA; la.dD = p.dD; la.dbias = p.ddelta_bias;
@@ -1195,7 +1205,8 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
         } else {
             return XFM_ELIMIT;
         }
-    } else if (p.delta_softplus == 2 && w_enabled()) {
+    } else if (p.delta_softplus == 2 && p.bc_f32) {
+        if (!ss2d_w_covers(p.batch, D, HW, HW, 1, p.in_dtype) || !p.Bs32 || !p.Cs32) return XFM_EINVAL;
         fn = bwd ? (const void *)ss2d_w_bwd_kernel<HW, PPT> : (const void *)ss2d_w_fwd_kernel<HW, PPT>;
     } else if (bwd)
         fn = p.delta_softplus == 2 ? (const void *)ss2d_l3_bwd_kernel<HW, PPT, 2>
@@ -1237,6 +1248,7 @@ int ss2d_l3_run(const xfm_ss2d_params_t *p, bool bwd, hipStream_t s, float *ws, 
     }();
     if (!bwd && !fwd_enabled) return XFM_ELIMIT;
     if (p->in_dtype != XFM_BF16 || p->out_dtype != XFM_F32 || p->dstate != 1 || p->H != p->W) return XFM_ELIMIT;
+    if (p->bc_f32 && p->delta_softplus != 2) return XFM_EINVAL;
     if (p->delta_softplus < 0 || p->delta_softplus > 3) return XFM_ELIMIT;
     if (p->delta_softplus == 3 && !l3_rp2(p->H, p->dt_rank_p)) return XFM_ELIMIT;
     const int ppt = l3_ppt(p->H);

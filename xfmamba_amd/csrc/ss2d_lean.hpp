@@ -37,6 +37,7 @@ struct LeanArgs {
     int xmap;          // ss2d_l3.hip: 1 = XCD-local sample placement (batch % 8 == 0), see l3_block_map
     const void *xrt;   // ss2d_l3.hip, softplus mode 3: dt_proj input rows (batch, 4, L, Rp) bf16, position-major, route order
     const void *dtw;   //                               dt_proj weight (4, D, Rp) bf16
+    const float *Bs32, *Cs32;   // ss2d_w.hpp (backward): the B / C rows as fp32 (batch, 4, L)
 };
 
 // ---- DPP helpers -------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 // ss2d_w.hpp -- wide-map SS2D kernels, fourth generation (round 6): 56 x 56 / 28 x 28 (and 48 x 48 / 24 x 24), d_state 1, bf16
-// I/O, step sizes arriving activated (delta_softplus == 2: the production path).  Included by ss2d_l3.hip, whose tile staging,
+// I/O, step sizes arriving activated (delta_softplus == 2), fp32 copies of the B / C rows for the backward (bc_f32: the production path).  Included by ss2d_l3.hip, whose tile staging,
 // merge, LDS-direct prefetch and workgroup map it shares; same layout contract (include/xfm_hip.h), same algorithm (reference
 // models/fusion_vmamba.py:1145-1174; adjoint per selective_scan_bwd_kernel.cuh:141-273).  What changed against ss2d_l3.hip,
 // and the measurement behind each change (tools/ubench/valu_rate.hip on MI355X: at two waves per SIMD a plain fp32 FMA costs
@@ -19,7 +19,7 @@
 
 namespace xfm {
 
-struct WOps { uint4 d, b, c; float h; };
+struct WOps { uint4 d, b0, b1, c0, c1; float h; };      // step sizes (8 bf16), B and C (8 fp32 each), the entering state
 
 // Global operands through BUFFER descriptors: address = descriptor base (4 scalar registers per tensor) + scalar byte offset
 // (plane / route / chunk row: scalar adds or the instruction's immediate) + ONE 32-bit lane offset in a vector register for
@@ -46,15 +46,25 @@ __device__ __forceinline__ void w_st16(const __amdgpu_buffer_rsrc_t r, const uin
 __device__ __forceinline__ void w_st4(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff, const float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
 }
-__device__ __forceinline__ WBuf w_bufs(const LeanArgs &a, const int nseg) {
+__device__ __forceinline__ WBuf w_bufs(const LeanArgs &a, const int nseg, const bool bwd) {
     const uint32_t planes = (uint32_t)a.batch * 4u * (uint32_t)a.D_, L = (uint32_t)a.L;
     WBuf rs;
     rs.dts = w_rsrc(a.dts, planes * L * 2u);
     rs.ddts = w_rsrc(a.ddts, planes * L * 2u);
-    rs.Bs = w_rsrc(a.Bs, (uint32_t)a.batch * 4u * L * 2u);
-    rs.Cs = w_rsrc(a.Cs, (uint32_t)a.batch * 4u * L * 2u);
+    // the backward reads the fp32 copies of the B / C rows (xfm_ss2d_route_split_bc32), the forward the 16-bit rows: with five
+    // operand vectors per chunk row at four waves per SIMD the forward is bound by the vector-memory path (56 x 56: 105 vs 83 us)
+    rs.Bs = bwd ? w_rsrc(a.Bs32, (uint32_t)a.batch * 4u * L * 4u) : w_rsrc(a.Bs, (uint32_t)a.batch * 4u * L * 2u);
+    rs.Cs = bwd ? w_rsrc(a.Cs32, (uint32_t)a.batch * 4u * L * 4u) : w_rsrc(a.Cs, (uint32_t)a.batch * 4u * L * 2u);
     rs.chk = w_rsrc(a.chk, planes * (uint32_t)nseg * 256u);
     return rs;
+}
+
+// 8 fp32 of two 16-byte vectors -> four pairs in TRAVERSAL order (register renaming: no instruction)
+template <bool REV> __device__ __forceinline__ void w_pairs(const uint4 &v0, const uint4 &v1, l3f2 (&o)[4]) {
+    const float p[8] = {__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z), __uint_as_float(v0.w),
+                        __uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z), __uint_as_float(v1.w)};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = REV ? l3f2{p[7 - 2 * q], p[6 - 2 * q]} : l3f2{p[2 * q], p[2 * q + 1]};
 }
 
 // ascending inclusive scan of the affine maps (Q, R) with the state replay h[e] = a[e] h[e-1] + bb[e] of the lane's own chunk
@@ -98,6 +108,26 @@ __device__ __forceinline__ void w_scan_replay(float &Q, float &R, const l3f2 (&a
     h[3] = l3f2{h6, h7};
 }
 
+// sums of three values over the wave, left in lane 63 (row_shr steps, then the row totals handed up by row_bcast)
+__device__ __forceinline__ void w_wave_sum3(float &x, float &y, float &z) {
+#define W_SUM_STEP(CTRL, MASK)                     \
+    {                                              \
+        const float xs = dpp_mov<CTRL, MASK>(0.f, x); \
+        const float ys = dpp_mov<CTRL, MASK>(0.f, y); \
+        const float zs = dpp_mov<CTRL, MASK>(0.f, z); \
+        x += xs;                                   \
+        y += ys;                                   \
+        z += zs;                                   \
+    }
+    W_SUM_STEP(kRowShr1, 0xf)
+    W_SUM_STEP(kRowShr2, 0xf)
+    W_SUM_STEP(kRowShr4, 0xf)
+    W_SUM_STEP(kRowShr8, 0xf)
+    W_SUM_STEP(kRowBcast15, 0xa)
+    W_SUM_STEP(kRowBcast31, 0xc)
+#undef W_SUM_STEP
+}
+
 template <int N, typename F> __device__ __forceinline__ void w_static_for(F &&f) {
     if constexpr (N > 0) {
         w_static_for<N - 1>(f);
@@ -126,6 +156,7 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
     const uint32_t lo16 = (uint32_t)ci * 16u;         // its byte offset in a chunk row of bf16 operands
     const uint32_t lo4 = (uint32_t)(63 - lane) * 4u;  // ... and in a row of checkpoints (route-order chunk = the forward's lane)
     const uint32_t lo16t = tail_live ? lo16 : kWDead, lo4t = tail_live ? lo4 : kWDead;     // ... in the tail row
+    const uint32_t lo32 = 2u * lo16, lo32t = tail_live ? lo32 : kWDead;                     // ... of the fp32 B / C rows
     const bf16_t *xql = xq + ci * 8, *gql = gq + ci * 8;
     bf16_t *dxql = dxq + ci * 8;
     float Ec = 0.f;                                   // adjoint flowing in from the chunk row processed before
@@ -146,8 +177,8 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
         // ---- consume the raw vectors: everything the row needs from them is in fp32 registers below
         l3f2 v[4], u[4], g[4], Bq[4], Cq[4];
         l3_unpack<REV>(op.d, v);
-        l3_unpack<REV>(op.b, Bq);
-        l3_unpack<REV>(op.c, Cq);
+        w_pairs<REV>(op.b0, op.b1, Bq);
+        w_pairs<REV>(op.c0, op.c1, Cq);
         l3_unpack<REV>(lx, u);
         l3_unpack<REV>(lg, g);
         const float hin = op.h;
@@ -167,10 +198,12 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
         const int spn = has_next ? (REV ? NSEG - i : i - 1) : (REV ? 0 : NSEG - 1);
         const bool tail_n = G::HAS_TAIL && spn == NSEG - 1;
         if (has_next || chain) {
-            const uint32_t vo16 = tail_n ? lo16t : lo16, vo4 = tail_n ? lo4t : lo4;
+            const uint32_t vo16 = tail_n ? lo16t : lo16, vo4 = tail_n ? lo4t : lo4, vo32 = tail_n ? lo32t : lo32;
             op.d = w_ld16(rs.dts, vo16, dso + (has_next ? 0 : L * 2) + spn * (G::ROW * 2));
-            op.b = w_ld16(rs.Bs, vo16, bso + spn * (G::ROW * 2));
-            op.c = w_ld16(rs.Cs, vo16, bso + spn * (G::ROW * 2));
+            op.b0 = w_ld16(rs.Bs, vo32, bso + spn * (G::ROW * 4));
+            op.b1 = w_ld16(rs.Bs, vo32, bso + spn * (G::ROW * 4) + 16);
+            op.c0 = w_ld16(rs.Cs, vo32, bso + spn * (G::ROW * 4));
+            op.c1 = w_ld16(rs.Cs, vo32, bso + spn * (G::ROW * 4) + 16);
             op.h = w_ld4(rs.chk, vo4, cso + (has_next ? i - 1 : NSEG + NSEG - 1) * 256);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -304,9 +337,12 @@ __device__ __forceinline__ void w_bwd_first(WOps &op, const WBuf &rs, const int 
     const int ci = REV ? lane : 63 - lane;
     const bool live = !tail || ci < G::TAILV;
     const uint32_t lo16 = live ? (uint32_t)ci * 16u : kWDead, lo4 = live ? (uint32_t)(63 - lane) * 4u : kWDead;
+    const uint32_t lo32 = live ? (uint32_t)ci * 32u : kWDead;
     op.d = w_ld16(rs.dts, lo16, dso + sp * (G::ROW * 2));
-    op.b = w_ld16(rs.Bs, lo16, bso + sp * (G::ROW * 2));
-    op.c = w_ld16(rs.Cs, lo16, bso + sp * (G::ROW * 2));
+    op.b0 = w_ld16(rs.Bs, lo32, bso + sp * (G::ROW * 4));
+    op.b1 = w_ld16(rs.Bs, lo32, bso + sp * (G::ROW * 4) + 16);
+    op.c0 = w_ld16(rs.Cs, lo32, bso + sp * (G::ROW * 4));
+    op.c1 = w_ld16(rs.Cs, lo32, bso + sp * (G::ROW * 4) + 16);
     op.h = w_ld4(rs.chk, lo4, cso + (NSEG - 1) * 256);
 }
 
@@ -319,6 +355,10 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
     const int groups_pb = tiles_pb / a.pli;
     int b, tg;
     l3_block_map(a, groups_pb, b, tg);
+    // (uniform by construction, but formed on the vector ALU -- integer division -- and a vector register in a buffer
+    //  instruction's scalar-offset slot is legalised with a readfirstlane LOOP per access)
+    b = __builtin_amdgcn_readfirstlane(b);
+    tg = __builtin_amdgcn_readfirstlane(tg);
     bf16_t *xN = reinterpret_cast<bf16_t *>(smem), *xT = xN + PL, *gN = xT + PL, *gT = gN + PL, *DX = gT + PL;
     float *ldsacc = smem + (8 * (size_t)PL * 2) / 4 + wave * 2 * G::LSZ;
     // behind the strips: the second natural x image and the raw dy of the tile being fetched (l3_dma_tile)
@@ -335,8 +375,8 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
     const bf16_t *gq = col ? gT : gN;
     bf16_t *dxq = DX + (size_t)wave * PL;
     const int route = b * 4 + k;
-    const WBuf rs = w_bufs(a, NSEG);
-    const int bso = route * (L * 2);
+    const WBuf rs = w_bufs(a, NSEG, true);
+    const int bso = __builtin_amdgcn_readfirstlane(route * (L * 4));          // (fp32 rows)
     const int ci = REV ? lane : 63 - lane;
     {
         const int64_t po0 = ((int64_t)b * D + (int64_t)tg * a.pli * PPT) * L;
@@ -355,7 +395,8 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
         // tile `it` was sent for during tile it - 1 (or above): wait for this wave's pieces, then for everybody's
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // the operands of the tile's first row: in flight under the staging
-        w_bwd_first<HW, REV>(op, rs, (route * D + d0) * (L * 2), bso, (route * D + d0) * (NSEG * 256), lane);
+        w_bwd_first<HW, REV>(op, rs, __builtin_amdgcn_readfirstlane((route * D + d0) * (L * 2)), bso,
+                             __builtin_amdgcn_readfirstlane((route * D + d0) * (NSEG * 256)), lane);
         __syncthreads();                               // (also: the previous tile's merge has read the private planes)
         l3_stage_lds<HW, PPT>(xNc, xT, graw, gN, gT, tid);
         L3Next nx{};
@@ -371,18 +412,19 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
             const int d = d0 + pl, row = k * D + d;
             const float An = a.A[row], Dr = a.D[row];
             float dA_acc, dD_acc, dbias_acc;
-            w_bwd_plane<HW, REV, PL>(rs, (route * D + d) * (L * 2), bso, (route * D + d) * (NSEG * 256), pl + 1 < PPT, An, Dr, xq + pl * L, gq + pl * L, dxq + pl * L, ldsacc, rB, rC,
+            w_bwd_plane<HW, REV, PL>(rs, __builtin_amdgcn_readfirstlane((route * D + d) * (L * 2)), bso,
+                                     __builtin_amdgcn_readfirstlane((route * D + d) * (NSEG * 256)), pl + 1 < PPT, An, Dr, xq + pl * L, gq + pl * L, dxq + pl * L, ldsacc, rB, rC,
                                      dA_acc, dD_acc, dbias_acc, lane, op, nx);
             nx.go = false;
-            for (int o = 32; o > 0; o >>= 1) {
-                dA_acc += __shfl_xor(dA_acc, o, 64);
-                dD_acc += __shfl_xor(dD_acc, o, 64);
-                dbias_acc += __shfl_xor(dbias_acc, o, 64);
-            }
-            if (lane == 0) {
-                atomicAdd(a.dA + row, dA_acc);
-                atomicAdd(a.dD + row, dD_acc);
-                atomicAdd(a.dbias + row, dbias_acc);
+            // the plane's three parameter-gradient sums: DPP adds (no LDS round trips: a plane is 2 chunk rows at 28 x 28), and ONE
+            // atomic instruction of three lanes (the atomic unit retires instructions, not lanes)
+            w_wave_sum3(dA_acc, dD_acc, dbias_acc);
+            {
+                const float tA = bcast_lane<63>(dA_acc), tD = bcast_lane<63>(dD_acc), tb = bcast_lane<63>(dbias_acc);
+                if (lane < 3) {
+                    float *dst = (lane == 0 ? a.dA : (lane == 1 ? a.dD : a.dbias)) + row;
+                    atomicAdd(dst, lane == 0 ? tA : (lane == 1 ? tD : tb));
+                }
             }
         }
         __syncthreads();
@@ -542,6 +584,10 @@ __device__ __forceinline__ void w_fwd_body(const LeanArgs &a, float *smem, const
     const int groups_pb = tiles_pb / a.pli;
     int b, tg;
     l3_block_map(a, groups_pb, b, tg);
+    // (uniform by construction, but formed on the vector ALU -- integer division -- and a vector register in a buffer
+    //  instruction's scalar-offset slot is legalised with a readfirstlane LOOP per access)
+    b = __builtin_amdgcn_readfirstlane(b);
+    tg = __builtin_amdgcn_readfirstlane(tg);
     // LDS: xN | xT | 4 private y planes (bf16: the per-route partial sums are rounded to the I/O precision once, before
     // the fixed-order fp32 merge, as in the lean kernels)
     bf16_t *xN = reinterpret_cast<bf16_t *>(smem), *xT = xN + PL, *Y = xT + PL;
@@ -550,8 +596,8 @@ __device__ __forceinline__ void w_fwd_body(const LeanArgs &a, float *smem, const
     const bf16_t *xq = col ? xT : xN;
     bf16_t *yq = Y + (size_t)wave * PL;
     const int route = b * 4 + k;
-    const WBuf rs = w_bufs(a, NSEG);
-    const int bso = route * (L * 2);
+    const WBuf rs = w_bufs(a, NSEG, false);
+    const int bso = __builtin_amdgcn_readfirstlane(route * (L * 2));
     WFOps op;
     constexpr int NVX = 2;
     static_assert(PL <= 4096, "tile beyond the staging registers");
@@ -563,7 +609,7 @@ __device__ __forceinline__ void w_fwd_body(const LeanArgs &a, float *smem, const
         asm volatile("v_mov_b32 %0, 0" : "=v"(tz));
         const int tid = threadIdx.x + tz;
         // the operands of the tile's first row: in flight under the staging
-        w_fwd_first<HW, REV>(op, rs, (route * D + d0) * (L * 2), bso, lane);
+        w_fwd_first<HW, REV>(op, rs, __builtin_amdgcn_readfirstlane((route * D + d0) * (L * 2)), bso, lane);
         if constexpr (HW % 8 == 0) {
             constexpr int nvx = PL / 8;
             static_assert(NVX == 2, "staging registers are spelled out");
@@ -587,7 +633,8 @@ __device__ __forceinline__ void w_fwd_body(const LeanArgs &a, float *smem, const
         for (int pl = 0; pl < PPT; ++pl) {
             const int d = d0 + pl, row = k * D + d;
             const float A2 = a.A[row] * kLog2e, Dr = a.D[row];
-            w_fwd_plane<HW, REV>(rs, (route * D + d) * (L * 2), bso, (route * D + d) * (NSEG * 256), pl + 1 < PPT, A2, Dr, xq + pl * L, yq + pl * L, lane, op);
+            w_fwd_plane<HW, REV>(rs, __builtin_amdgcn_readfirstlane((route * D + d) * (L * 2)), bso,
+                                 __builtin_amdgcn_readfirstlane((route * D + d) * (NSEG * 256)), pl + 1 < PPT, A2, Dr, xq + pl * L, yq + pl * L, lane, op);
         }
         __syncthreads();
         int tz2;

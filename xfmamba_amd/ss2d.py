@@ -48,12 +48,14 @@ def _plan(Bt, Dm, H, W, N, dtype):
     return plan
 
 
-def _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, out_dtype, chk, softplus_mode=1, xrt=None, dt_w=None):
+def _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, out_dtype, chk, softplus_mode=1, xrt=None, dt_w=None, bc32=None):
     Bt, Dm, L = x.shape
     p.batch, p.d_inner, p.H, p.W, p.dstate = Bt, Dm, H, W, A.shape[1]
     p.delta_softplus = softplus_mode
     p.in_dtype, p.out_dtype = _lib.dtype_code(x.dtype), _lib.dtype_code(out_dtype)
     p.x, p.dts, p.Bs, p.Cs = x.data_ptr(), _lib.ptr(dts), Bs.data_ptr(), Cs.data_ptr()
+    if bc32 is not None:                        # fp32 copies of the B / C rows (ss2d_w.hpp: read by its backward)
+        p.bc_f32, p.Bs32, p.Cs32 = 1, bc32[0].data_ptr(), bc32[1].data_ptr()
     if softplus_mode == 3:                      # dt_proj inside the scan kernel: its input rows and weight instead of dts
         p.xrt, p.dt_w, p.dt_rank_p = xrt.data_ptr(), dt_w.data_ptr(), xrt.shape[3]
     p.A, p.D, p.delta_bias = A.data_ptr(), D.data_ptr(), bias.data_ptr()
@@ -115,15 +117,23 @@ class SS2DCoreHip(torch.autograd.Function):
         return dx, ddts, dA, dBs.to(Bs.dtype), dCs.to(Cs.dtype), dD, dbias, None, None
 
 
-def _route_split(xd, R, N, H, W):
+def _route_split(xd, R, N, H, W, bc32=False):
+    """x_proj rows (natural map) -> the dt_proj input rows, B and C in per-route order.  ``bc32``: B / C a second time as fp32
+    rows (the wide-map scan backward reads them without an unpack; same values -- the rows are widened, not recomputed)."""
     Bt, L = xd.shape[0], xd.shape[-1]
     xr = torch.empty((Bt, 4, R, L), dtype=xd.dtype, device=xd.device)
     Bs = torch.empty((Bt, 4, N, L), dtype=xd.dtype, device=xd.device)
     Cs = torch.empty_like(Bs)
+    b32 = torch.empty((2, Bt, 4, N, L), dtype=torch.float32, device=xd.device) if bc32 else None
     with torch.cuda.device(xd.device), _lib.timed("route_split", 2 * xd.numel() * xd.element_size()):
-        _lib.check(_lib.lib().xfm_ss2d_route_split(xd.data_ptr(), xr.data_ptr(), Bs.data_ptr(), Cs.data_ptr(), Bt, R, N,
-                                                   H, W, _lib.dtype_code(xd.dtype), _lib.stream_ptr()), "route_split")
-    return xr, Bs, Cs
+        if bc32:
+            _lib.check(_lib.lib().xfm_ss2d_route_split_bc32(xd.data_ptr(), xr.data_ptr(), Bs.data_ptr(), Cs.data_ptr(),
+                                                            b32[0].data_ptr(), b32[1].data_ptr(), Bt, R, N, H, W,
+                                                            _lib.dtype_code(xd.dtype), _lib.stream_ptr()), "route_split")
+        else:
+            _lib.check(_lib.lib().xfm_ss2d_route_split(xd.data_ptr(), xr.data_ptr(), Bs.data_ptr(), Cs.data_ptr(), Bt, R, N,
+                                                       H, W, _lib.dtype_code(xd.dtype), _lib.stream_ptr()), "route_split")
+    return xr, Bs, Cs, b32
 
 
 class SS2DProjCoreHip(torch.autograd.Function):
@@ -165,12 +175,14 @@ class SS2DProjCoreHip(torch.autograd.Function):
             raise RuntimeError("ss2d_proj_core: x (B,D,H*W), x_dbl (B,4*(R+2N),H*W) of one dtype, dt_w (4,D,R) expected")
         x, x_dbl = x.contiguous(), x_dbl.contiguous()
         A, D, bias = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
-        xr, Bs, Cs = _route_split(x_dbl, R, N, H, W)
-        w = cast_weight(dt_w, x.dtype)
         lib = _lib.lib()
+        Rp = lib.xfm_ss2d_dtfused_rank(Bt, Dm, H, W, N, R, _lib.dtype_code(x.dtype)) if _DT_FUSED else 0
+        mode2 = Rp <= 0 and x.dtype in (torch.float32, torch.bfloat16) and bool(lib.xfm_ss2d_dt_proj_supported(Dm, R, L))
+        bc32 = mode2 and x.dtype != torch.float32 and bool(lib.xfm_ss2d_bc_f32(Bt, Dm, H, W, N, _lib.dtype_code(x.dtype)))
+        xr, Bs, Cs, b32 = _route_split(x_dbl, R, N, H, W, bc32)
+        w = cast_weight(dt_w, x.dtype)
         mode = 1
         xrt = wp = None
-        Rp = lib.xfm_ss2d_dtfused_rank(Bt, Dm, H, W, N, R, _lib.dtype_code(x.dtype)) if _DT_FUSED else 0
         if Rp > 0:
             # SURVEY 8(f) rank 1 on the wide maps: dt_proj INSIDE the scan kernels (models/fusion_vmamba.py:1147-1150): they read
             # the position-major copy of the (small) dt_proj input rows; the (B, 4, D, L) step sizes never reach HBM
@@ -181,7 +193,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
                 _lib.check(lib.xfm_ss2d_xr_rows(xr.data_ptr(), xrt.data_ptr(), Bt * 4, R, Rp, L, _lib.dtype_code(x.dtype),
                                                 _lib.stream_ptr()), "xr_rows")
             wp = w.contiguous() if Rp == R else torch.nn.functional.pad(w, (0, Rp - R)).contiguous()
-        elif x.dtype in (torch.float32, torch.bfloat16) and lib.xfm_ss2d_dt_proj_supported(Dm, R, L):
+        elif mode2:
             # dt_proj kernel with the bias + softplus epilogue: the scan kernels then read the activated step size
             # (mode 2) instead of re-evaluating softplus per route element in the forward AND the backward pass
             mode = 2
@@ -203,7 +215,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
                if plan.n_chunks > 1 else None)
         y = torch.empty((Bt, Dm, L), dtype=torch.float32, device=x.device)
         p = _lib.SS2DParams()
-        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, mode, xrt, wp)
+        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, mode, xrt, wp, b32)
         p.y = y.data_ptr()
         isz = x.element_size()
         # SURVEY 8(d), "dt_proj also fused" boundary: x, y and the x_proj rows (2 B D L + 4 B (R + 2N) L elements)
@@ -216,14 +228,14 @@ class SS2DProjCoreHip(torch.autograd.Function):
         ctx.mode = mode
         ctx.wdtype = dt_w.dtype
         ctx.xw_meta = None if x_proj_w is None else (x_proj_w.dtype, tuple(x_proj_w.shape))
-        ctx.save_for_backward(x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw, xrt, wp)
+        ctx.save_for_backward(x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw, xrt, wp, b32)
         return y
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         from .proj import _bmm_f32, wgrad_mfma
-        x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw, xrt, wp = ctx.saved_tensors
+        x, xr, dts, w, A, Bs, Cs, D, bias, chk, xw, xrt, wp, b32 = ctx.saved_tensors
         H, W = ctx.hw
         dev = x.device
         Bt, Dm, L = x.shape
@@ -241,7 +253,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
         dA = acc[2 * nbc:2 * nbc + na].view(A.shape)
         dD, dbias = acc[2 * nbc + na:2 * nbc + na + nd], acc[2 * nbc + na + nd:2 * nbc + na + 2 * nd]
         p = _lib.SS2DParams()
-        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, ctx.mode, xrt, wp)
+        _fill(p, x, dts, A, Bs, Cs, D, bias, H, W, torch.float32, chk, ctx.mode, xrt, wp, b32)
         p.dy, p.dx, p.ddts = dy.data_ptr(), dx.data_ptr(), ddts.data_ptr()
         p.dBs, p.dCs, p.dA, p.dD, p.ddelta_bias = (dBs.data_ptr(), dCs.data_ptr(), dA.data_ptr(), dD.data_ptr(),
                                                    dbias.data_ptr())
