@@ -218,11 +218,14 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
         }
         // ---- the lane's adjoint map E_out = Q E_in + R over its chunk (walked against the route; E_t = a_t dh_t,
         // dh_t = C_t g_t + E_{t+1}), scanned over the lanes
+        l3f2 acg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acg[q] = a[q] * cg[q];
         float R = 0.f;
 #pragma unroll
         for (int q = 3; q >= 0; --q) {
-            R = a[q].y * (cg[q].y + R);
-            R = a[q].x * (cg[q].x + R);
+            R = fmaf(a[q].y, R, acg[q].y);
+            R = fmaf(a[q].x, R, acg[q].x);
         }
         float Q = (a[0].x * a[0].y) * (a[1].x * a[1].y) * ((a[2].x * a[2].y) * (a[3].x * a[3].y));
         l3f2 h[4], dh[4];
@@ -243,9 +246,9 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
 #pragma unroll
         for (int q = 3; q >= 0; --q) {
             dh[q].y = cg[q].y + E;
-            E = a[q].y * dh[q].y;
+            E = fmaf(a[q].y, E, acg[q].y);
             dh[q].x = cg[q].x + E;
-            E = a[q].x * dh[q].x;
+            E = fmaf(a[q].x, E, acg[q].x);
         }
         // ---- per position pair: the outputs, packed as they come
         uint32_t wd[4], wu[4];
