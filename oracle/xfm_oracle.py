@@ -230,13 +230,17 @@ def ss2d_v2_ref(sd: Dict[str, Tensor], p: str, x: Tensor, scan=selective_scan_re
 # --------------------------------------------------------------------------------------
 
 
-def vss_block_ref(sd, p, x, scan=selective_scan_ref):
+def vss_block_ref(sd, p, x, scan=selective_scan_ref, keep=None):
+    """``keep``: None (eval mode / drop_path 0), or the pair of per-sample DropPath factors (B,) of the block's two branches
+    as timm's ``drop_path`` forms them -- Bernoulli(1 - p) / (1 - p) per sample (fusion_vmamba.py:1327, 1335: ``x +
+    self.drop_path(...)``): train-mode parity feeds the factors the implementation under test sampled."""
     h = _ln2d(x, sd[p + "norm.weight"], sd[p + "norm.bias"])
-    x = x + ss2d_v2_ref(sd, p + "op.", h, scan)
+    y = ss2d_v2_ref(sd, p + "op.", h, scan)
+    x = x + (y if keep is None or keep[0] is None else y * keep[0].view(-1, 1, 1, 1).to(y.dtype))
     h = _ln2d(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
     h = _lin2d(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
     h = _lin2d(F.gelu(h), sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
-    return x + h
+    return x + (h if keep is None or keep[1] is None else h * keep[1].view(-1, 1, 1, 1).to(h.dtype))
 
 
 # --------------------------------------------------------------------------------------
@@ -244,7 +248,8 @@ def vss_block_ref(sd, p, x, scan=selective_scan_ref):
 # --------------------------------------------------------------------------------------
 
 
-def backbone_ref(sd, p, x, scan=selective_scan_ref, all_outs=False):
+def backbone_ref(sd, p, x, scan=selective_scan_ref, all_outs=False, drop=None):
+    """``drop``: None, or a mapping (stage, block) -> (keep1, keep2) of per-sample DropPath factors (vss_block_ref)."""
     x = F.conv2d(x, sd[p + "patch_embed.0.weight"], sd[p + "patch_embed.0.bias"], stride=2, padding=1)
     x = F.gelu(_ln2d(x, sd[p + "patch_embed.2.weight"], sd[p + "patch_embed.2.bias"]))
     x = F.conv2d(x, sd[p + "patch_embed.5.weight"], sd[p + "patch_embed.5.bias"], stride=2, padding=1)
@@ -254,7 +259,7 @@ def backbone_ref(sd, p, x, scan=selective_scan_ref, all_outs=False):
     while (p + f"layers.{i}.blocks.0.norm.weight") in sd:
         j = 0
         while (p + f"layers.{i}.blocks.{j}.norm.weight") in sd:
-            x = vss_block_ref(sd, p + f"layers.{i}.blocks.{j}.", x, scan)
+            x = vss_block_ref(sd, p + f"layers.{i}.blocks.{j}.", x, scan, None if drop is None else drop.get((i, j)))
             j += 1
         outs.append(_ln2d(x, sd[p + f"outnorm{i}.weight"], sd[p + f"outnorm{i}.bias"]))
         if (p + f"layers.{i}.downsample.1.weight") in sd:
@@ -369,13 +374,13 @@ def deep_block_ref(sd, p, x1, x2, scan=selective_scan_ref):
 # --------------------------------------------------------------------------------------
 
 
-def xfmamba_top_ref(sd, x_a, x_b, training=False, scan=selective_scan_ref):
-    """Whole model, eval-mode DropPath (identity).  ``training`` only switches the
-    BatchNorm of the shallow block to batch statistics."""
+def xfmamba_top_ref(sd, x_a, x_b, training=False, scan=selective_scan_ref, drop_a=None, drop_b=None):
+    """Whole model.  ``training`` switches the BatchNorm of the shallow block to batch statistics; DropPath is the
+    identity unless ``drop_a`` / ``drop_b`` hand the trunk its per-sample factors for the two views (backbone_ref)."""
     x_a = x_a.expand(-1, 3, -1, -1)
     x_b = x_b.expand(-1, 3, -1, -1)
-    z_a = backbone_ref(sd, "mamba_feature_extrac.", x_a, scan)
-    z_b = backbone_ref(sd, "mamba_feature_extrac.", x_b, scan)
+    z_a = backbone_ref(sd, "mamba_feature_extrac.", x_a, scan, drop=drop_a)
+    z_b = backbone_ref(sd, "mamba_feature_extrac.", x_b, scan, drop=drop_b)
     z_a, z_b = shallow_block_ref(sd, "shallow_mamba_fusion.", z_a, z_b, training, scan)
     z = deep_block_ref(sd, "fusemamba.blocks.0.", z_a, z_b, scan)
     z = F.conv2d(z, sd["final_conv.weight"], sd["final_conv.bias"])

@@ -915,3 +915,125 @@ def test_padded_x_proj_copy_follows_the_fused_optimizer():
         assert amp.padded_shadow(xw, C2p, torch.bfloat16) is None
     finally:
         wc.close()
+
+
+def test_model_tiny_bf16_bench_mode_step_matches_the_oracle(monkeypatch):
+    """BASELINE configs[1] in the MODE bench.py times: XFMamba-T, bf16 autocast, 32 two-view samples,
+    ``train()`` -- DropPath at the rates the trunk is constructed with (linspace(0, 0.2) over its 12 blocks, reference
+    models/fusion_vmamba.py:1390) and the shallow block's BatchNorm on batch statistics (reference :893, 906-907) -- forward and
+    backward of ONE step against the fp32 CPU oracle run on the same 32 samples.  Stochastic depth is made comparable by
+    handing the oracle the per-sample factors the implementation sampled (recorded at ``DropPath.sample_scale``: Bernoulli(1 - p)
+    / (1 - p), one row per block branch and stacked view); the oracle trunk runs in chunks of four samples under activation
+    checkpointing (memory of the CPU run), the two fusion blocks on the whole batch (BatchNorm couples the samples).
+    Checked: all 32 logits, the BatchNorm running buffers after the step, every parameter-gradient norm, fourteen sampled
+    gradient tensors in direction, the global gradient norm -- at the caps the eval-mode batch-32 and the gradient tests
+    hold the bf16 path to (the oracle's own bf16 run sits 1.1e-2 ... 1.7e-2 from its fp32 run on these weights)."""
+    from torch.utils.checkpoint import checkpoint
+    from oracle import c_scan
+    from xfmamba_amd import fusion_vmamba as fv
+    m = _tiny_with_synth_weights().train()
+    B, CH = 32, 4
+    g = torch.Generator().manual_seed(20261)
+    xa, xb = torch.randn(B, 1, 224, 224, generator=g), torch.randn(B, 1, 224, 224, generator=g)
+    lab = torch.randint(0, 2, (B,), generator=g)
+    names = {mod: name for name, mod in m.named_modules() if isinstance(mod, fv.DropPath)}
+    rates = [mod.drop_prob for mod in names]
+    assert max(rates) > 0.15 and sum(r > 0 for r in rates) >= 11, rates      # the constructed rates, not zeros
+    rec = {}
+    orig = fv.DropPath.sample_scale
+
+    def spy(self, batch, device):
+        r = orig(self, batch, device)
+        rec.setdefault(names[self], []).append(None if r is None else r.detach().float().cpu().clone())
+        return r
+
+    monkeypatch.setattr(fv.DropPath, "sample_scale", spy)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m(xa.to(DEV), xb.to(DEV))
+    monkeypatch.setattr(fv.DropPath, "sample_scale", orig)
+    assert torch.isfinite(out).all()
+    # the factors: two per trunk block (SS2D branch, then Mlp branch), 2 B rows ([view 1 | view 2]); some rows dropped
+    drop = {}
+    n_dropped = 0
+    for name, rows in rec.items():
+        parts = name.split(".")
+        if parts[0] != "mamba_feature_extrac":
+            continue
+        assert len(rows) == 2, (name, len(rows))
+        for r in rows:
+            if r is not None:
+                assert r.shape == (2 * B,)
+                n_dropped += int((r == 0).sum())
+        drop[(int(parts[2]), int(parts[4]))] = rows
+    assert len(drop) == 12 and n_dropped > 20, (len(drop), n_dropped)
+
+    sd = O.synth_state_dict(load_json("g5_state_shapes.json")["tiny"], seed=0)
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in sd.items()}
+    scan = c_scan.selective_scan_c
+
+    def trunk(x, view, c0):
+        dd = {ij: tuple(None if r is None else r[view * B + c0:view * B + c0 + CH] for r in rows) for ij, rows in drop.items()}
+        return checkpoint(lambda xx: O.backbone_ref(leaves, "mamba_feature_extrac.", xx.expand(-1, 3, -1, -1), scan, drop=dd),
+                          x[c0:c0 + CH], use_reentrant=False)
+
+    z_a = torch.cat([trunk(xa, 0, c0) for c0 in range(0, B, CH)])
+    z_b = torch.cat([trunk(xb, 1, c0) for c0 in range(0, B, CH)])
+    z_a, z_b = O.shallow_block_ref(leaves, "shallow_mamba_fusion.", z_a, z_b, True, scan)        # (batch statistics)
+    zz = O.deep_block_ref(leaves, "fusemamba.blocks.0.", z_a, z_b, scan)
+    zz = torch.nn.functional.conv2d(zz, leaves["final_conv.weight"], leaves["final_conv.bias"]).mean((2, 3))
+    lo = torch.nn.functional.linear(zz, leaves["classifier.head.weight"], leaves["classifier.head.bias"])
+    # d CE / d logits at the fp32 oracle's logits: ONE cotangent for both backward passes (saturated synthetic logits turn a
+    # 2e-2 logit difference into a 20 % difference of softmax - onehot: a property of the loss there, not of a kernel)
+    lg = lo.detach().clone().requires_grad_()
+    torch.nn.functional.cross_entropy(lg, lab).backward()
+    cot = lg.grad.clone()
+    lo.backward(cot)
+    ref = {k: v.grad.float() for k, v in leaves.items() if v.requires_grad and v.grad is not None}
+    out.float().backward(cot.to(DEV))
+    hip = {k: p.grad.float().cpu() for k, p in m.named_parameters() if p.grad is not None}
+
+    lo_ref = lo.detach().float()
+    d_log = float((out.detach().float().cpu() - lo_ref).abs().max()) / float(lo_ref.abs().max())
+    assert d_log < 3e-2, d_log
+    for k in ("running_mean", "running_var"):
+        got, want = m.state_dict()["shallow_mamba_fusion.norm." + k].float().cpu(), leaves["shallow_mamba_fusion.norm." + k].float()
+        assert_close(got, want, 3e-2, 3e-2 * float(want.abs().max()), k)
+    assert set(ref) == set(hip), set(ref) ^ set(hip)
+    tot_h = tot_r = 0.0
+    worst = (0.0, None)
+    for k, gr in ref.items():
+        rn = float(gr.double().norm())
+        eh = abs(float(hip[k].double().norm()) - rn) / (rn + 1e-12)
+        if gr.numel() >= 16:
+            assert eh <= 1e-1, (k, eh)
+            worst = max(worst, (eh, k))
+        tot_h += float(hip[k].double().pow(2).sum()); tot_r += rn * rn
+    assert abs(tot_h ** 0.5 - tot_r ** 0.5) / tot_r ** 0.5 < 3e-2, (tot_h, tot_r, worst)
+    sampled = [k for pat in ("patch_embed.0.weight", "layers.0.blocks.1.op.x_proj_weight", "layers.0.blocks.1.op.dt_projs_weight",
+                             "layers.1.blocks.0.op.A_logs", "layers.1.downsample", "layers.2.blocks.3.mlp.fc1.weight",
+                             "layers.2.blocks.7.op.out_proj.weight", "layers.3.blocks.1.op.in_proj.weight",
+                             "shallowfuseSS2D.x_proj_weight", "dt_projs_weight", "final_conv")
+               for k in sorted(ref) if pat in k][:14]
+    assert len(sampled) >= 10, sampled
+    for k in sampled:
+        cos = float(torch.nn.functional.cosine_similarity(hip[k].flatten().double(), ref[k].flatten().double(), dim=0))
+        assert cos > 0.97, (k, cos)
+
+
+def test_model_wrapper_eval_entry_matches_the_oracle():
+    """The inference entry (reference net_fusionmamba.py:10-26, 2_inference_chexpert.py:129-267):
+    ``ModelWrapper`` takes the two views concatenated along the channel axis, splits them, and returns the logits (or the
+    ``output_index``-th element of a tuple).  Eval mode, fp32, batch 2: against the CPU oracle on the same inputs."""
+    from oracle import c_scan
+    from xfmamba_amd.net_fusionmamba import ModelWrapper
+    m = _tiny_with_synth_weights().eval()
+    w = ModelWrapper(m).eval()
+    xa, xb, _ = g5_inputs()
+    with torch.no_grad():
+        got = w(torch.cat([xa, xb], dim=1).to(DEV)).float().cpu()
+        direct = m(xa.to(DEV), xb.to(DEV)).float().cpu()
+    assert torch.equal(got, direct)
+    sd = O.synth_state_dict(load_json("g5_state_shapes.json")["tiny"], seed=0)
+    with torch.no_grad():
+        ref = O.xfmamba_top_ref(sd, xa, xb, False, c_scan.selective_scan_c).float()
+    assert_close(got, ref, 1e-3, 1e-3 * float(ref.abs().max()), "ModelWrapper logits")

@@ -30,9 +30,30 @@ template <> struct Vec4IO<bf16_t> {
     }
 };
 
+// Sum over the G lanes of a row group, returned in all of them -- on the vector ALU only: quad permutes, the two mirrors inside a
+// row of 16 lanes, then gfx950's row / half swaps (v_permlane16_swap, v_permlane32_swap).  (As __shfl_xor every step is a
+// ds_bpermute round trip through the LDS pipeline: 2 log2(G) dependent round trips per row in the forward pass, with one
+// row group per wave in flight.)
+template <int CTRL> __device__ __forceinline__ float rowln_dpp(const float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 template <int G> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
+    static_assert(G >= 4 && G <= 64, "row groups of 4 ... 64 lanes");
+    v += rowln_dpp<0xB1>(v);                           // quad_perm [1, 0, 3, 2]
+    v += rowln_dpp<0x4E>(v);                           // quad_perm [2, 3, 0, 1]
+    if constexpr (G >= 8) v += rowln_dpp<0x141>(v);    // row_half_mirror: lane i <- lane 7 - i of its half row
+    if constexpr (G >= 16) v += rowln_dpp<0x140>(v);   // row_mirror: lane i <- lane 15 - i of its row
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    if constexpr (G >= 32) {                           // rows 0 <-> 1, 2 <-> 3
+        const uint32_t b = __float_as_uint(v);
+        const u32x2_t r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    if constexpr (G >= 64) {                           // halves
+        const uint32_t b = __float_as_uint(v);
+        const u32x2_t r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
     return v;
 }
 

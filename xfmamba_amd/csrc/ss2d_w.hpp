@@ -40,8 +40,15 @@ __device__ __forceinline__ uint4 w_ld16(const __amdgpu_buffer_rsrc_t r, const ui
 __device__ __forceinline__ float w_ld4(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// (A 16-byte buffer store reads its data registers over several cycles.  The compiler's hazard recognizer covers a vector
+//  instruction that overwrites them right behind the store only when the store's scalar-offset field is NOT a register; here
+//  it is one, and on gfx950 the hazard is there all the same: with a second workgroup on the CU, four lanes of every row of 16
+//  stored the LDS address that re-used the first data register instead of the packed step-size gradients -- seen at 48 x 48
+//  with 256 channels and more, found through the XFMamba-B gradient test.  Wait states behind the store, pinned, and the data registers kept allocated past the next few instructions.)
 __device__ __forceinline__ void w_st16(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff, const uint4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(w_u32x4{v.x, v.y, v.z, v.w}, r, voff, soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3");
 }
 __device__ __forceinline__ void w_st4(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff, const float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
@@ -270,6 +277,8 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
         w_st16(rs.ddts, is_tail ? lo16t : lo16, dso + sp * (G::ROW * 2), make_uint4(wd[0], wd[1], wd[2], wd[3]));
         if (!is_tail || tail_live)
             *reinterpret_cast<uint4 *>(dxql + sp * G::ROW) = make_uint4(wu[0], wu[1], wu[2], wu[3]);   // this route's private dx plane
+        // (the store's data registers stay allocated until here: nothing may be written into them right behind it -- w_st16)
+        asm volatile("" ::"v"(wd[0]), "v"(wd[1]), "v"(wd[2]), "v"(wd[3]));
         // ---- dB += dh (delta u), dC += g h, summed over the planes of this workgroup (traversal order; un-permuted at the flush)
         if (G::LSZ > 0 && sp >= G::NREG) {
             if (!is_tail || tail_live) {
