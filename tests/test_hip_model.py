@@ -919,7 +919,7 @@ def test_padded_x_proj_copy_follows_the_fused_optimizer():
 
 def test_model_tiny_bf16_bench_mode_step_matches_the_oracle(monkeypatch):
     """BASELINE configs[1] in the MODE bench.py times: XFMamba-T, bf16 autocast, 32 two-view samples,
-    ``train()`` -- DropPath at the rates the trunk is constructed with (linspace(0, 0.2) over its 12 blocks, reference
+    ``train()`` -- DropPath at the rates the trunk is constructed with (linspace(0, 0.2) over its 14 blocks, reference
     models/fusion_vmamba.py:1390) and the shallow block's BatchNorm on batch statistics (reference :893, 906-907) -- forward and
     backward of ONE step against the fp32 CPU oracle run on the same 32 samples.  Stochastic depth is made comparable by
     handing the oracle the per-sample factors the implementation sampled (recorded at ``DropPath.sample_scale``: Bernoulli(1 - p)
@@ -938,7 +938,7 @@ def test_model_tiny_bf16_bench_mode_step_matches_the_oracle(monkeypatch):
     lab = torch.randint(0, 2, (B,), generator=g)
     names = {mod: name for name, mod in m.named_modules() if isinstance(mod, fv.DropPath)}
     rates = [mod.drop_prob for mod in names]
-    assert max(rates) > 0.15 and sum(r > 0 for r in rates) >= 11, rates      # the constructed rates, not zeros
+    assert max(rates) > 0.15 and sum(r > 0 for r in rates) >= 13, rates      # the constructed rates, not zeros
     rec = {}
     orig = fv.DropPath.sample_scale
 
@@ -965,7 +965,7 @@ def test_model_tiny_bf16_bench_mode_step_matches_the_oracle(monkeypatch):
                 assert r.shape == (2 * B,)
                 n_dropped += int((r == 0).sum())
         drop[(int(parts[2]), int(parts[4]))] = rows
-    assert len(drop) == 12 and n_dropped > 20, (len(drop), n_dropped)
+    assert len(drop) == 14 and n_dropped > 20, (len(drop), n_dropped)
 
     sd = O.synth_state_dict(load_json("g5_state_shapes.json")["tiny"], seed=0)
     leaves = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in sd.items()}
@@ -1032,7 +1032,8 @@ def test_model_wrapper_eval_entry_matches_the_oracle():
     with torch.no_grad():
         got = w(torch.cat([xa, xb], dim=1).to(DEV)).float().cpu()
         direct = m(xa.to(DEV), xb.to(DEV)).float().cpu()
-    assert torch.equal(got, direct)
+    # (same kernels on channel slices of the concatenated tensor: equal up to the order of a few fp32 atomic sums)
+    assert_close(got, direct, 1e-5, 1e-5 * float(direct.abs().max()), "wrapper vs direct call")
     sd = O.synth_state_dict(load_json("g5_state_shapes.json")["tiny"], seed=0)
     with torch.no_grad():
         ref = O.xfmamba_top_ref(sd, xa, xb, False, c_scan.selective_scan_c).float()
