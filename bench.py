@@ -148,11 +148,62 @@ def _aten_profile(step):
         print(f"[aten-profile] {t:8.1f} us {n:4d}  {k:30s} {shp}  {where}", file=sys.stderr)
 
 
+# dense forward MACs per two-view sample (scan excluded): SURVEY.md section 6 / BASELINE.md section 2, measured on the reference
+_DENSE_GMAC = {("tiny", 224): 10.25, ("small", 224): 17.63, ("base", 224): 31.24, ("base", 384): 91.81}
+_SCAN_MELEM = {("tiny", 224): 13.698048, ("small", 224): 34.771968, ("base", 384): 136.249344}   # sum K D L per sample (x 1e6)
+
+
+def roofline_step(a, B, world, sec_per_step, kernels, ksteps):
+    """The whole step against both roofs: dense FLOPs of forward + backward (3 x the forward MACs x 2;
+    the reference's own count) against the bf16 matrix-core peak, and the bytes the hand-written kernels
+    report at their own boundaries (every launch of the eager re-run, HIP-event timed) against the HBM peak -- the latter a
+    LOWER bound of the step's traffic: library GEMMs / convolutions and framework element-wise kernels carry no byte count."""
+    gmac = _DENSE_GMAC.get((a.model, a.size))
+    out = {"ms_per_step": round(1e3 * sec_per_step, 3)}
+    if gmac is not None:
+        flops = 3 * 2 * gmac * 1e9 * B
+        scan = _SCAN_MELEM.get((a.model, a.size))
+        if scan is not None:
+            flops += 3 * (9 + 1) * scan * 1e6 * B      # 9 K D L N + K D L per scan call (N = 1 trunk; the N = 16 blocks are < 3 %)
+        out.update(dense_flops_per_step=int(flops), achieved_tflops=round(flops / sec_per_step / 1e12, 1), peak_tflops=2500.0,
+                   frac_mfma=round(flops / sec_per_step / 1e12 / 2500.0, 4))
+    if kernels:
+        nb = sum(k["bytes"] for k in kernels.values()) / max(ksteps, 1)
+        tk = sum(k["total_ms"] for k in kernels.values()) / max(ksteps, 1)
+        out.update(own_kernel_bytes_per_step=int(nb), own_kernel_ms_per_step=round(tk, 3),
+                   own_kernels_GBps=round(nb / (tk * 1e-3) / 1e9, 1) if tk > 0 else None,
+                   step_GBps_lower_bound=round(nb / sec_per_step / 1e9, 1), frac_hbm_lower_bound=round(nb / sec_per_step / 1e9 / HBM_PEAK_GBS, 4))
+    return out
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def _run_with_watchdog(cmd, env, limit, what="the child"):
+    """Run ``cmd`` as a fresh child process in its own process group and return its exit code; when it has not finished within
+    ``limit`` seconds -- a rendezvous that never completes because a rank died before init_process_group -- end the whole GROUP
+    (the launcher and its ranks; by id, never by pattern) and return 124."""
+    import signal
+    import subprocess
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] {what} did not finish within {limit:.0f} s: ending process group {proc.pid}", file=sys.stderr)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+                proc.wait(timeout=20)
+                break
+            except ProcessLookupError:
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
 
 
 def self_launch(a):
@@ -165,7 +216,7 @@ def self_launch(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.run(cmd, env=env).returncode
+    return _run_with_watchdog(cmd, env, float(os.environ.get("XFM_BENCH_LAUNCH_TIMEOUT", "1500")), f"the {a.gpus} ranks")
 
 
 def main():
@@ -535,7 +586,7 @@ def main():
                     pass
                 # timer name -> kernel key of tools/pmc_traffic.py (HBM bytes per launch from the PMC counters of this very
                 # command: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc passes; MI355X_MICROARCH.md "HBM")
-                pmc_key = {"ss2d_bwd": "ss2d_l3_bwd_kernel", "ss2d_fwd": "ss2d_l3_fwd_kernel",
+                pmc_key = {"ss2d_bwd": "ss2d_w_bwd_kernel", "ss2d_fwd": "ss2d_w_fwd_kernel",
                            "ss2dc_bwd": "chan1::bwd_kernel", "ss2dc_fwd": "chan1::fwd_kernel",
                            "ss2dc16_bwd": "deep_bwd_kernel<3, 4>", "ss2dc16_fwd": "ss2dc_fwd_kernel_n16",
                            "ss2dc16s_bwd": "deep_bwd_kernel<3, 1>", "ss2dc16s_fwd": "deep_fwd1_kernel"}
@@ -561,12 +612,16 @@ def main():
                                                            algorithmic_bytes_per_launch=int(k["bytes_alt"] / k["launches"]))
                     return r
 
-                # the north-star kernel family: the fused SS2D scans (lean chunk-scan kernels at 56x56 / 28x28, channel-lane
-                # kernels at 14x14 / 7x7, d_state 16 variant in the fusion block); `roofline` = the one costing most per step
+                # the north-star kernel family: the fused SS2D scans (wide-map kernels at 56x56 / 28x28, channel-lane kernels at
+                # 14x14 / 7x7, d_state 16 variants in the fusion blocks), all in `roofline_scan_kernels`.  `roofline` is the kernel
+                # VERDICT.md names -- the wide-map backward (csrc/ss2d_w.hpp; BASELINE.json's ">= 40 % in the scan kernel") --
+                # whichever scan family costs most per step (since round 6 the 14x14 channel-lane backward does, by a few
+                # percent: the rule "most ms per step" would flip between the two from box to box)
                 scan = [k for k in kernels if k.startswith("ss2d")]
                 roofs = {k: roof_of(k) for k in scan}
                 if scan:
-                    roof = roofs[max(scan, key=lambda k: kernels[k]["total_ms"])]
+                    roof = roofs["ss2d_bwd"] if "ss2d_bwd" in roofs else roofs[max(scan, key=lambda k: kernels[k]["total_ms"])]
+                    roof["costliest_scan_kernel_per_step"] = max(scan, key=lambda k: kernels[k]["total_ms"])
                 try:                                   # matrix-core utilisation of the GEMM kernels, offline PMC pass
                     mf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json")))[-1]
                     mj = json.load(open(mf))
@@ -594,6 +649,7 @@ def main():
                        "ss2d_mode": fusion_vmamba.SS2D_MODE, "fp8_proj": bool(a.fp8),
                        "single_view_images_per_s": round(2 * value, 2)},
             "roofline": roof,
+            "roofline_step": roofline_step(a, B, world, dt / a.steps, kernels, ksteps),
             "roofline_scan_kernels": roofs,
             "mfma_util": mfma,
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),

@@ -398,6 +398,27 @@ def test_bench_self_launches_its_ranks_when_typed_without_a_launcher():
         assert r.returncode != 0 and "needs MI355X GPUs" in err, err[-2000:]
 
 
+def test_bench_launch_watchdog_ends_a_hung_child_group():
+    """``bench.py``'s self-launch runs its ranks under a watchdog: a child that never finishes -- a rendezvous
+    waiting for a rank that died -- is ended as a process GROUP (a fresh session: the child and whatever it started) and the
+    caller gets a non-zero code instead of hanging; a child that finishes passes its own code through."""
+    import importlib.util
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("xfm_bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    marker = os.path.join("/tmp", f"xfm_watchdog_{os.getpid()}")
+    hung = [sys.executable, "-c", "import subprocess, sys, time; subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(120)']); "
+                                   f"open({marker!r}, 'w').write('up'); time.sleep(120)"]
+    t0 = time.time()
+    assert bench._run_with_watchdog(hung, dict(os.environ), 3.0, "the test child") == 124
+    assert time.time() - t0 < 60 and os.path.exists(marker)
+    os.remove(marker)
+    assert bench._run_with_watchdog([sys.executable, "-c", "import sys; sys.exit(7)"], dict(os.environ), 30.0) == 7
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_on_one_gpu_run_the_two_graph_step_end_to_end():
     """The whole N = 2 flow of bench.py as the driver types it (``python bench.py --gpus 2``, no launcher): self-launched ranks,

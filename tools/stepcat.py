@@ -14,7 +14,7 @@ for r in csv.DictReader(open(f)):
     elif 'xfm::deep' in n: fam = 'SS2D deep-fusion scan, backward (d_state 16)'
     elif 'ss2dc_fwd_kernel<7, 16' in n: fam = 'SS2D deep-fusion scan, forward (d_state 16)'
     elif 'xfm::ss2dc' in n or 'xfm::chan_' in n or 'xfm::chan1' in n: fam = 'SS2D channel-lane scan (+post)'
-    elif 'lean' in n or 'ss2d_l3' in n or 'dt_proj' in n or 'route_' in n: fam = 'SS2D wide-map scan + dt_proj + route split/merge'
+    elif 'lean' in n or 'ss2d_l3' in n or 'ss2d_w_' in n or 'dt_proj' in n or 'route_' in n: fam = 'SS2D wide-map scan + dt_proj + route split/merge'
     elif 'rowscan' in n or 'swap' in n or 'selective_scan' in n or 'xfm::scan_' in n: fam = 'shallow-fusion scan (single-route kernels, d_state 16)'
     elif 'at::native' in n: fam = 'framework reduce' if 'reduce_kernel' in n else 'framework elementwise / copy / fill'
     elif 'igemm' in n or 'miopen' in n.lower() or 'ck::' in n or '_ZN2ck' in n or 'batched_transpose' in n or 'SubTensor' in n or 'naive_conv' in n: fam = 'MIOpen convolution (+ its casts)'
