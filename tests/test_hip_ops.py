@@ -876,6 +876,41 @@ def test_dt_proj_kernels_match_torch_fp32(B, D, R, H, with_bias):
             assert_close(out2.float().cpu(), ref, tol, tol * float(ref.abs().max()), "MFMA bf16")
 
 
+def test_dt_proj_softplus_epilogue_over_the_whole_range():
+    """The softplus of the dt_proj epilogues (csrc/xfm_common.hpp softplus20_16bit; reference models/csms6s.py:49-50:
+    F.softplus with threshold 20) for pre-activations from -25 to 25 -- step sizes from 1e-11 up, the linear branch above 20 --
+    against torch fp32 at the RELATIVE bf16 bound: the form without a log1p series must keep e^x for tiny step sizes."""
+    import torch.nn.functional as F
+    from xfmamba_amd import _lib
+    lib = _lib.lib()
+    B, D, R, H = 1, 96, 6, 56
+    L = H * H
+    # one rank carries the value, weight 1: raw[d, l] = xr[0, l]; the sweep covers [-25, 25]
+    xr = torch.zeros(B, 4, R, L)
+    xr[:, :, 0] = torch.linspace(-25.0, 25.0, L)
+    w = torch.zeros(4, D, R)
+    w[:, :, 0] = 1.0
+    bias = torch.zeros(4 * D)
+    xd = xr.bfloat16().to(DEV)
+    ref = F.softplus(xd.float().cpu()[:, :, 0]).unsqueeze(2).expand(B, 4, D, L)            # (bf16-rounded arguments)
+    st = _lib.stream_ptr()
+    outs = {}
+    out = torch.empty(B, 4, D, L, dtype=torch.bfloat16, device=DEV)
+    wd, wb, bd = w.to(DEV).contiguous(), w.bfloat16().to(DEV).contiguous(), bias.to(DEV)
+    _lib.check(lib.xfm_ss2d_dt_proj_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, D, R, L,
+                                        _lib.dtype_code(torch.bfloat16), st), "dt_proj_fwd")
+    outs["VALU"] = out.float().cpu()
+    if lib.xfm_ss2d_dt_proj_mfma_rp(D, R, L):
+        out2 = torch.full_like(out, float("nan"))
+        _lib.check(lib.xfm_ss2d_dt_proj_fwd_mfma(xd.data_ptr(), wb.data_ptr(), bd.data_ptr(), out2.data_ptr(), B, D, R, L, st),
+                   "dt_proj_fwd_mfma")
+        outs["MFMA"] = out2.float().cpu()
+    for name, o in outs.items():
+        rel = ((o - ref).abs() / ref).max()
+        assert float(rel) < 8e-3, (name, float(rel))                                        # one bf16 ulp = 2^-8 relative
+        assert float(o.min()) > 0                                                           # never flushed to zero
+
+
 @pytest.mark.parametrize("B,D,R,H", [(2, 96, 6, 56), (2, 192, 12, 28), (3, 384, 24, 14), (2, 64, 5, 10),
                                      (1, 1024, 32, 24),       # XFMamba-B stage 2: 66 KB of LDS (opt-in above 64 KB)
                                      # one pass over ddts for both products (a (b, k) slab per workgroup, B * 4 >= 128):

@@ -109,9 +109,13 @@ __device__ __forceinline__ float softplus20(float x) {
 // by ~6e-8 / z relative: far inside half a bf16 ulp for every step size above 1e-4) and no selects -- with r = x log2(e),
 // log2(1 + 2^r) >= r and equals r in fp32 from r = 25 on, so max(log2(1 + 2^min(r, 64)), r) is the thresholded softplus
 // (log1p(e^x) - x < 2.1e-9 beyond the threshold of 20) and never overflows.  9 issue slots instead of ~16.
+// Below z = e^x = 2^-12 the sum 1 + z loses z's low bits (and all of z below 2^-24: the result would be 0 instead of e^x), so
+// there log2(1 + z) is taken as z log2(e) (the next term, z / 2, is below a quarter of a bf16 ulp): relative accuracy holds
+// for every step size, however far training drives it down.
 __device__ __forceinline__ float softplus20_16bit(float x) {
     const float r = x * kLog2e;
-    const float t = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(r, 64.f)));
+    const float z = __builtin_amdgcn_exp2f(fminf(r, 64.f));
+    const float t = z < 0.000244140625f ? z * kLog2e : __builtin_amdgcn_logf(1.0f + z);
     return fmaxf(t, r) * 0.6931471805599453f;
 }
 
