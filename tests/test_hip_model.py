@@ -94,17 +94,37 @@ def test_deep_fusion_block_golden_through_channel_lane_kernel():
         _lib.set_timer(None)
     names = set(timer.summary())
     assert {"ss2dc16_fwd", "ss2dc16_bwd"} <= names and not ({"cross_scan", "cross_merge", "selective_scan_fwd"} & names), names
+    # Yardstick: BASELINE's 1e-2 is a bound on ONE 16-bit operator; this block chains five bf16 GEMMs, three
+    # scans with bf16 operands and two LayerNorms under autocast.  What bf16 arithmetic itself does to it is measured by the CPU
+    # oracle of the same block under torch.autocast(bfloat16) (fp32 scan): every tensor of the HIP path must sit within 1.5 x
+    # the oracle's own distance from the fp32 record of the real reference (+ 5e-3 of the tensor scale), and never beyond the
+    # caps 1e-2 (output, input gradients) and 2e-2 (parameter gradients; measured: 1.2e-3, 2.1e-3, <= 1.7e-2 with the oracle's own bf16 run at 1.2e-2 on that tensor, A_logs).
+    sd = {k[len(f"{tag}/sd/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}/sd/")}
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    xin = [torch.from_numpy(z[f"{tag}/in{i}"]).clone().requires_grad_() for i in range(2)]
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        oo = O.deep_block_ref(leaves, "", xin[0], xin[1])
+    oo.float().backward(torch.from_numpy(z[f"{tag}/gout0"]))
+
+    def check(name, got, orc, ref, cap):
+        scale = float(ref.abs().max()) + 1e-12
+        d_hip, d_orc = float((got - ref).abs().max()) / scale, float((orc - ref).abs().max()) / scale
+        assert d_hip <= 1.5 * d_orc + 5e-3, (name, d_hip, d_orc)
+        assert d_hip <= cap, (name, d_hip)
+        return d_hip, d_orc
+
     ref = torch.from_numpy(z[f"{tag}/out0"])
-    assert_close(out.detach().float().cpu(), ref, 2e-2, 2e-2 * float(ref.abs().max()), "out")
+    rep = {"out": check("out", out.detach().float().cpu(), oo.detach().float(), ref, 1e-2)}
     for i, t in enumerate(ins):
-        ref = torch.from_numpy(z[f"{tag}/din{i}"])
-        assert_close(t.grad.float().cpu(), ref, 3e-2, 3e-2 * float(ref.abs().max()), f"din{i}")
+        rep[f"din{i}"] = check(f"din{i}", t.grad.float().cpu(), xin[i].grad.float(), torch.from_numpy(z[f"{tag}/din{i}"]), 1e-2)
     pre = f"{tag}/grad/"
     params = dict(m.named_parameters())
     for k in z.files:
         if k.startswith(pre):
-            ref = torch.from_numpy(z[k])
-            assert_close(params[k[len(pre):]].grad.float().cpu(), ref, 5e-2, 5e-2 * float(ref.abs().max()) + 1e-7, k)
+            n = k[len(pre):]
+            rep[n] = check(n, params[n].grad.float().cpu(), leaves[n].grad.float(), torch.from_numpy(z[k]), 2e-2)
+    print("deep block, bf16 autocast: (HIP error, oracle-autocast error) relative to each tensor's scale:",
+          {k: (round(a, 4), round(b, 4)) for k, (a, b) in rep.items()})
 
 
 def _lib_timer():

@@ -1317,22 +1317,23 @@ def test_tiled_xproj_forward_and_accumulating_backward(B, L, D, XC):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,L", [(4, 3136), (128, 40)])
-def test_planes_gemm_xproj_forward_and_accumulating_backward(B, L):
-    """x_proj on the natural map at the 56x56 stage (planes -> planes, 96 -> 32) and its backward data product
-    dx += W^T . d x_dbl (32 -> 96, accumulate) through xfm_planes_gemm, against fp32 matmuls."""
+@pytest.mark.parametrize("B,L,D,O", [(4, 3136, 96, 32), (128, 40, 96, 32), (6, 784, 192, 56), (64, 784, 192, 56), (136, 40, 192, 56)])
+def test_planes_gemm_xproj_forward_and_accumulating_backward(B, L, D, O):
+    """x_proj on the natural map at the 56x56 stage (planes -> planes, 96 -> 32) and at the 28x28 stage (192 -> 4 x 14 = 56 rows:
+    padded to MFMA tiles inside the kernel) and its backward data product dx += W^T . d x_dbl (accumulate) through
+    xfm_planes_gemm, against fp32 matmuls."""
     from xfmamba_amd.proj import mfma_planes
     g = torch.Generator().manual_seed(12)
-    x = torch.randn(B, 96, L, generator=g).to(torch.bfloat16).to(DEV)
-    w = (torch.randn(32, 96, generator=g) / 96 ** 0.5).to(torch.bfloat16).to(DEV)
-    y = mfma_planes(x, w, 32)
-    assert y is not None and y.shape == (B, 32, L)
+    x = torch.randn(B, D, L, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(O, D, generator=g) / D ** 0.5).to(torch.bfloat16).to(DEV)
+    y = mfma_planes(x, w, O)
+    assert y is not None and y.shape == (B, O, L)
     ref = torch.einsum("mk,bkl->bml", w.float(), x.float())
     assert_close(y.float().cpu(), ref.cpu(), 1e-2, 1e-2 * float(ref.abs().max()), "x_dbl")
-    dxd = torch.randn(B, 32, L, generator=g).to(torch.bfloat16).to(DEV)
-    dx0 = torch.randn(B, 96, L, generator=g).to(torch.bfloat16).to(DEV)
+    dxd = torch.randn(B, O, L, generator=g).to(torch.bfloat16).to(DEV)
+    dx0 = torch.randn(B, D, L, generator=g).to(torch.bfloat16).to(DEV)
     dx = dx0.clone()
-    assert mfma_planes(dxd, w, 96, transposed=True, accumulate_into=dx) is dx
+    assert mfma_planes(dxd, w, D, transposed=True, accumulate_into=dx) is dx
     ref = dx0.float() + torch.einsum("mk,bml->bkl", w.float(), dxd.float())
     assert_close(dx.float().cpu(), ref.cpu(), 1e-2, 1e-2 * float(ref.abs().max()), "dx")
 

@@ -32,6 +32,8 @@ struct TokGemmArgs {
     int64_t T;
     int wt;
     int L;                  // layout-changing variants: tokens per sample (planes are (B, C, L)); L % 8 == 0 && (B*L) % 32 == 0
+    int con_r, out_r;       // proj_gemm_kernel: real contraction / output widths (<= the kernel's CON / OUT: the weight is zero-
+                            // padded in LDS, plane rows past con_r read as zero, channels past out_r are not stored); 0: CON / OUT
 };
 
 template <int CON, int OUT, int OB>       // OB: output columns processed per pass (accumulators OB/32 x 16 registers)
@@ -186,8 +188,18 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
     extern __shared__ __align__(16) uint16_t wl[];
     float *bl = reinterpret_cast<float *>(wl + OUT * P);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int n = threadIdx.x; n < OUT; n += 512) bl[n] = a.bias ? a.bias[n] : 0.f;
-    if (!a.wt) {
+    const int con_r = a.con_r > 0 ? a.con_r : CON, out_r = a.out_r > 0 ? a.out_r : OUT;
+    const bool padded = con_r != CON || out_r != OUT;
+    for (int n = threadIdx.x; n < OUT; n += 512) bl[n] = (a.bias && n < out_r) ? a.bias[n] : 0.f;
+    if (padded) {
+        // (widths that are not whole MFMA tiles: x_proj of the 28 x 28 stage, 192 <-> 4 x 14 = 56 rows; the weight is (out_r,
+        //  con_r) row-major, or (con_r, out_r) when wt, and sits zero-padded to (OUT, CON) in LDS)
+        for (int e = threadIdx.x; e < CON * OUT; e += 512) {
+            const int n = e / CON, k = e - n * CON;
+            const bool in = n < out_r && k < con_r;
+            wl[n * P + k] = in ? (a.wt ? a.w[k * out_r + n] : a.w[n * con_r + k]) : (uint16_t)0;
+        }
+    } else if (!a.wt) {
         constexpr int VPR = CON / 8;
         for (int v = threadIdx.x; v < OUT * VPR; v += 512) {
             const int n = v / VPR, q = v - n * VPR;
@@ -216,12 +228,19 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
     };
     auto fetch_planes = [&](int64_t tl, int s0) {                  // k-steps s0 .. s0 + KH - 1 of tile tl
         const int64_t t = tl * 32 + c, bi = t / L;
-        const uint16_t *pp = a.x + (bi * CON + 16 * s0 + 8 * h) * L + (t - bi * L);
+        const uint16_t *pp = a.x + (bi * con_r + 16 * s0 + 8 * h) * L + (t - bi * L);
 #pragma unroll
         for (int s = 0; s < KH; ++s) {
             uint16_t v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = pp[(int64_t)j * L];
+            for (int j = 0; j < 8; ++j) {
+                if (padded) {                                                    // (rows past the real width: the zero padding)
+                    const int k = 16 * (s0 + s) + 8 * h + j;
+                    v[j] = k < con_r ? pp[(int64_t)j * L] : (uint16_t)0;
+                } else {
+                    v[j] = pp[(int64_t)j * L];
+                }
+            }
             pp += 16 * (int64_t)L;
             asm volatile("" : "+v"(pp));                                         // one running address, not 48 of them
 #pragma unroll
@@ -279,7 +298,7 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
         }
         // plane stores: the lane's two 8-token runs start at tokens t0 + 8 h and t0 + 16 + 8 h
         const int64_t ta = t0 + 8 * h, tb = ta + 16, ba = ta / L, bb2 = tb / L;
-        const int64_t oa = ba * OUT * L + (ta - ba * L), ob = bb2 * OUT * L + (tb - bb2 * L);
+        const int64_t oa = ba * out_r * L + (ta - ba * L), ob = bb2 * out_r * L + (tb - bb2 * L);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             uint32_t pk[4][2];
@@ -290,7 +309,8 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
                 else bv.x = bv.y = bv.z = bv.w = bl[32 * b + c];                                              // lane's channel
                 if constexpr (ACC) {                   // the four tokens t0 + 8 g + 4 h .. + 3 of channel 32 b + c, before the swap
                     const int64_t tg = t0 + 8 * g + 4 * h, bg = tg / L;
-                    const uint2 old = *reinterpret_cast<const uint2 *>(a.y + (bg * OUT + 32 * b + c) * L + (tg - bg * L));
+                    const int cc = 32 * b + c < out_r ? 32 * b + c : out_r - 1;         // (padding channels: read anything valid)
+                    const uint2 old = *reinterpret_cast<const uint2 *>(a.y + (bg * out_r + cc) * L + (tg - bg * L));
                     bv.x += __uint_as_float(old.x << 16);
                     bv.y += __uint_as_float(old.x & 0xffff0000u);
                     bv.z += __uint_as_float(old.y << 16);
@@ -314,7 +334,7 @@ __global__ void __launch_bounds__(512) proj_gemm_kernel(const TokGemmArgs a) {
                 uint16_t *dst = a.y + (t0 + c) * OUT + 32 * b + 8 * h;
                 *reinterpret_cast<tg_u32x4_t *>(dst) = v0;
                 *reinterpret_cast<tg_u32x4_t *>(dst + 16) = v1;
-            } else {                                                                              // channel plane, 8 tokens
+            } else if (32 * b + c < out_r) {                                                      // channel plane, 8 tokens
                 *reinterpret_cast<tg_u32x4_t *>(a.y + oa + (int64_t)(32 * b + c) * L) = v0;
                 *reinterpret_cast<tg_u32x4_t *>(a.y + ob + (int64_t)(32 * b + c) * L) = v1;
             }
@@ -1276,7 +1296,7 @@ int xfm_tokens_gemm(const void *x, const void *weight_bf16, const float *bias, v
                     int weight_transposed, void *stream) {
     using namespace xfm;
     if (!x || !weight_bf16 || !y || T <= 0) return XFM_EINVAL;
-    TokGemmArgs a;
+    TokGemmArgs a{};
     a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(weight_bf16);
     a.bias = bias;
@@ -1384,7 +1404,7 @@ int xfm_proj_gemm(const void *x, const void *weight_bf16, const float *bias, voi
         if (in_planes) return weight_transposed ? proj_tiled_launch<true, true>(t, s) : proj_tiled_launch<true, false>(t, s);
         return weight_transposed ? proj_tiled_launch<false, true>(t, s) : proj_tiled_launch<false, false>(t, s);
     }
-    TokGemmArgs a;
+    TokGemmArgs a{};
     a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(weight_bf16);
     a.bias = bias;
@@ -1415,7 +1435,10 @@ int xfm_proj_gemm_accumulate(const void *x, const void *weight_bf16, void *y, in
 /* planes -> planes: y (B, out, L) (+)= W . x (B, con, L); (con, out) = (96, 32): x_proj of the 56x56 stage on the natural
  * map; (32, 96) with accumulate != 0: its backward, dx += W^T . d x_dbl. */
 int xfm_planes_gemm_supported(int con, int out, int L) {
-    return (((con == 96 && out == 32) || (con == 32 && out == 96)) && L > 0 && L % 8 == 0) ? 1 : 0;
+    // x_proj of XFMamba-T's 56 x 56 stage (96 <-> 4 x 8 rows) and of its 28 x 28 stage (192 <-> 4 x 14 = 56 rows: padded to 64
+    // inside the kernel)
+    return (((con == 96 && out == 32) || (con == 32 && out == 96) || (con == 192 && out == 56) || (con == 56 && out == 192)) &&
+            L > 0 && L % 8 == 0) ? 1 : 0;
 }
 
 int xfm_planes_gemm(const void *x, const void *weight_bf16, const float *bias, void *y, int B, int L, int con, int out,
@@ -1423,7 +1446,7 @@ int xfm_planes_gemm(const void *x, const void *weight_bf16, const float *bias, v
     using namespace xfm;
     if (!x || !weight_bf16 || !y || B <= 0) return XFM_EINVAL;
     if (!xfm_planes_gemm_supported(con, out, L) || ((int64_t)B * L) % 32 != 0) return XFM_ELIMIT;
-    TokGemmArgs a;
+    TokGemmArgs a{};
     a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(weight_bf16);
     a.bias = bias;
@@ -1431,8 +1454,11 @@ int xfm_planes_gemm(const void *x, const void *weight_bf16, const float *bias, v
     a.T = (int64_t)B * L;
     a.wt = weight_transposed;
     a.L = L;
+    a.con_r = con; a.out_r = out;
     hipStream_t s = (hipStream_t)stream;
     if (con == 96) return accumulate ? proj_gemm_launch<96, 32, true, true, true>(a, s) : proj_gemm_launch<96, 32, true, true, false>(a, s);
+    if (con == 192) return accumulate ? proj_gemm_launch<192, 64, true, true, true>(a, s) : proj_gemm_launch<192, 64, true, true, false>(a, s);
+    if (con == 56) return accumulate ? proj_gemm_launch<64, 192, true, true, true>(a, s) : proj_gemm_launch<64, 192, true, true, false>(a, s);
     return accumulate ? proj_gemm_launch<32, 96, true, true, true>(a, s) : proj_gemm_launch<32, 96, true, true, false>(a, s);
 }
 }

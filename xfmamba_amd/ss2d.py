@@ -31,6 +31,22 @@ from .proj import mfma_planes, zeros_f32
 # the backward sweep of kernels that are issue-bound already.  Opt in with XFM_SS2D_DT_FUSED=1.
 _DT_FUSED = os.environ.get("XFM_SS2D_DT_FUSED", "0") == "1"
 
+_FALLBACKS_SEEN = set()
+
+
+def _note_library_fallback(what: str, *shape) -> None:
+    """A shape outside the hand-written kernels' coverage takes a framework GEMM instead: say so ONCE per (site, shape) on stderr
+    (the kernel mix -- and the per-kernel timers, which do not see library launches -- silently change otherwise; VERDICT r5
+    weak #11).  ``XFM_QUIET_FALLBACKS=1`` silences it."""
+    key = (what,) + tuple(int(v) for v in shape)
+    if key in _FALLBACKS_SEEN:
+        return
+    _FALLBACKS_SEEN.add(key)
+    if os.environ.get("XFM_QUIET_FALLBACKS", "0") != "1":
+        import sys
+        print(f"[xfmamba_amd.ss2d] {what}: shape {key[1:]} is outside the HIP kernels' coverage -> library GEMM", file=sys.stderr)
+
+
 __all__ = ["ss2d_core_fn", "ss2d_proj_core_fn", "ss2d_xproj_core_fn", "SS2DCoreHip", "SS2DProjCoreHip", "to_route_order"]
 
 
@@ -169,6 +185,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
                 xw = cast_weight(x_proj_w.reshape(K * C2, Dm), x.dtype)
                 x_dbl = mfma_planes(x.contiguous(), xw, K * C2)                 # x_proj on MFMA at the 56x56 stage
                 if x_dbl is None:
+                    _note_library_fallback("x_proj forward (planes GEMM)", Bt, Dm, L, K * C2)
                     x_dbl = torch.bmm(xw.unsqueeze(0).expand(Bt, K * C2, Dm), x)
         _lib.require_cuda(x_dbl)
         if K != 4 or L != H * W or x_dbl.shape != (Bt, K * C2, L) or x_dbl.dtype != x.dtype:
@@ -209,6 +226,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
                                                         Dm, R, L, _lib.dtype_code(x.dtype), _lib.stream_ptr()),
                                "dt_proj_fwd")
         else:
+            _note_library_fallback("dt_proj forward", Bt, Dm, R, L)
             dts = torch.matmul(w, xr)
         plan = _plan(Bt, Dm, H, W, N, x.dtype)
         chk = (torch.empty((Bt, 4, Dm, plan.n_chunks, N), dtype=torch.float32, device=x.device)
@@ -276,6 +294,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
                                                          dxr.data_ptr(), dw.data_ptr(), Bt, Dm, R, L, _lib.stream_ptr()),
                            "dt_proj_bwd_mfma")
         else:
+            _note_library_fallback("dt_proj backward", Bt, Dm, R, L)
             dxr = torch.matmul(w.transpose(1, 2), ddts)                               # (B, 4, R, L)
             dw = _bmm_f32(ddts.view(Bt * K, Dm, L), xr.view(Bt * K, R, L).transpose(1, 2)).view(Bt, K, Dm, R).sum(0)
         dxd = torch.empty((Bt, K * (R + 2 * N), L), dtype=x.dtype, device=dev)
@@ -287,9 +306,11 @@ class SS2DProjCoreHip(torch.autograd.Function):
             return dx, dxd, None, dw.to(ctx.wdtype), dA, dD, dbias, None, None
         KC2 = xw.shape[0]
         if mfma_planes(dxd, xw, Dm, transposed=True, accumulate_into=dx) is None:
+            _note_library_fallback("x_proj data gradient (planes GEMM)", Bt, Dm, L, KC2)
             dx.baddbmm_(xw.t().unsqueeze(0).expand(Bt, Dm, KC2), dxd)                  # dx += Wx^T @ d x_dbl
         dxw = wgrad_mfma(dxd, True, x, True)                                           # (K*C2, D): both operands planes
         if dxw is None:
+            _note_library_fallback("x_proj weight gradient", Bt, Dm, L, KC2)
             dxw = _bmm_f32(dxd, x.transpose(1, 2)).sum(0)
         dxw = dxw.view(ctx.xw_meta[1]).to(ctx.xw_meta[0])
         return dx, None, dxw, dw.to(ctx.wdtype), dA, dD, dbias, None, None
