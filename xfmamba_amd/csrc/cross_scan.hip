@@ -166,10 +166,32 @@ __global__ void __launch_bounds__(256) route_split_kernel(const T *xd, T *xr, T 
         return;
     }
     const int64_t off = c < R + N ? ((int64_t)bk * N + (c - R)) * L : ((int64_t)bk * N + (c - R - N)) * L;
-    plane_move<T, T>(src, (c < R + N ? Bs : Cs) + off, H, W, tr, tile);
-    if (Bs32) {
-        __syncthreads();
-        plane_move<T, float>(src, (c < R + N ? Bs32 : Cs32) + off, H, W, tr, tile);
+    T *dst = (c < R + N ? Bs : Cs) + off;
+    if (!Bs32) {
+        plane_move<T, T>(src, dst, H, W, tr, tile);
+        return;
+    }
+    // both copies of the row in one pass over the source
+    float *dst32 = (c < R + N ? Bs32 : Cs32) + off;
+    if (!tr) {
+        for (int e = threadIdx.x; e < L; e += blockDim.x) {
+            const float v = ldf<T>(src + e);
+            stf<T>(dst + e, v);
+            dst32[e] = v;
+        }
+        return;
+    }
+    const int pitch = W + 1;
+    for (int e = threadIdx.x; e < L; e += blockDim.x) {
+        const int r = e / W, cc = e - r * W;
+        tile[r * pitch + cc] = ldf<T>(src + e);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < L; e += blockDim.x) {     // (H x W) row-major -> (W x H) row-major
+        const int cc = e / H, r = e - cc * H;
+        const float v = tile[r * pitch + cc];
+        stf<T>(dst + e, v);
+        dst32[e] = v;
     }
 }
 
