@@ -30,12 +30,15 @@ def main():
             _lib.check(lib.xfm_ss2d_dt_proj_bwd_mfma(ddts.data_ptr(), xr.data_ptr(), w.data_ptr(), dxr.data_ptr(), dw.data_ptr(), B, D,
                                                      R, L, _lib.stream_ptr()), "dt_proj_bwd_mfma")
             return dxr.clone(), dw.clone()
-    elif op in ("l3_56", "l3_28", "chan14", "chan7"):
+    elif op in ("l3_56", "l3_28", "w_48", "w_24", "chan14", "chan7"):
         # the fused SS2D cores at the trunk's shapes, forward + backward through the autograd nodes: y / dx are exact (fixed-order
         # sums), the parameter gradients come from atomics (tolerance)
         from xfmamba_amd.ss2d import ss2d_xproj_core_fn
         from xfmamba_amd.ss2d_chan import ss2d_chan_fn
-        B, D, HW, R = {"l3_56": (64, 96, 56, 6), "l3_28": (64, 192, 28, 12), "chan14": (64, 384, 14, 24), "chan7": (64, 768, 7, 48)}[op]
+        # (l3_* / w_*: the wide-map kernels -- csrc/ss2d_w.hpp since round 6; w_48 / w_24: XFMamba-B's widths at two samples, the
+        #  launch in which a 16-byte buffer store's data registers were overwritten behind it with a second workgroup on the CU)
+        B, D, HW, R = {"l3_56": (64, 96, 56, 6), "l3_28": (64, 192, 28, 12), "w_48": (2, 512, 48, 32), "w_24": (2, 1024, 24, 64),
+                       "chan14": (64, 384, 14, 24), "chan7": (64, 768, 7, 48)}[op]
         L = HW * HW
         x = torch.randn(B, D, L, generator=g).bfloat16().cuda().requires_grad_()
         xw = (torch.randn(4, R + 2, D, generator=g) * D ** -0.5).cuda().requires_grad_()
@@ -44,7 +47,7 @@ def main():
         Dp = torch.randn(4 * D, generator=g).cuda().requires_grad_()
         bias = (torch.randn(4 * D, generator=g) * 0.5).cuda().requires_grad_()
         gy = torch.randn(B, D, L, generator=g).cuda()
-        fn = ss2d_xproj_core_fn if op.startswith("l3") else ss2d_chan_fn
+        fn = ss2d_xproj_core_fn if op.startswith(("l3", "w_")) else ss2d_chan_fn
 
         def run():
             for t in (x, xw, dtw, A, Dp, bias):
@@ -52,7 +55,25 @@ def main():
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y = fn(x, xw, dtw, A, Dp, bias, HW, HW)
             y.backward(gy)
-            return y.detach().clone(), x.grad.clone(), torch.cat([t.grad.float().flatten() for t in (xw, dtw, A, Dp, bias)])
+            run.segs = [("dxw", xw.numel()), ("ddtw", dtw.numel()), ("dA", A.numel()), ("dD", Dp.numel()), ("dbias", bias.numel())]
+            extra = []
+            if os.environ.get("XFM_DBG_KEEP"):
+                from xfmamba_amd import ss2d as _ss
+                extra = [_ss._DBG["dBs"].float().flatten(), _ss._DBG["dCs"].float().flatten()]
+                run.segs += [("dBs", extra[0].numel()), ("dCs", extra[1].numel())]
+            return y.detach().clone(), x.grad.clone(), torch.cat([t.grad.float().flatten() for t in (xw, dtw, A, Dp, bias)] + extra)
+    elif op in ("wgradpp", "wgradpp0"):
+        # the plane x plane weight-gradient product of the wide-map SS2D node: dW (56, 192) = sum d x_dbl (x) x at 28 x 28
+        # (wgradpp0: (32, 96) at 56 x 56)
+        from xfmamba_amd.proj import wgrad_mfma
+        B, M, N, L = (64, 56, 192, 784) if op == "wgradpp" else (64, 32, 96, 3136)
+        ap = torch.randn(B, M, L, generator=g).bfloat16().cuda()
+        bp = torch.randn(B, N, L, generator=g).bfloat16().cuda()
+
+        def run():
+            dw = wgrad_mfma(ap, True, bp, True)
+            assert dw is not None
+            return ap[:1, :1, :8].clone(), ap[:1, :1, :8].clone(), dw.clone().flatten()
     elif op in ("gemm3", "wgrad", "wgradx"):
         T, C, O = 12544, 1536, 384
         xt = torch.randn(T, C, generator=g).bfloat16().cuda()
@@ -98,13 +119,33 @@ def main():
         else:
             e0 = not bool(torch.equal(out[0], ref[0])) or not bool(torch.equal(out[1], ref[1]))
         e1 = float((out[2] - ref[2]).abs().max()) > 2e-3 * float(ref[2].abs().max()) + 1e-6 or not bool(torch.isfinite(out[2]).all())
+        bad1 = locals().get("bad1", 0) + (1 if e1 else 0)
         if e0 or e1:
             bad += 1
             if bad <= 3:
                 d = (out[0].float() - ref[0].float())
                 print(f"[{os.getpid()}] iteration {i}: exact outputs differ at {int((d != 0).sum() + torch.isnan(d).sum())} elements "
                       f"(nan {int(torch.isnan(out[0].float()).sum())}), summed outputs off {e1}", flush=True)
-    print(f"[{os.getpid()}] {op}: {bad} of {n} runs differ from the first ({time.time() - t0:.1f} s)", flush=True)
+                o0 = 0
+                for name, cnt in getattr(run, "segs", []):          # which of the summed outputs, where, by how much
+                    dd = (out[2][o0:o0 + cnt] - ref[2][o0:o0 + cnt]).abs()
+                    if name in ("dBs", "dCs"):
+                        own = float(ref[2][o0:o0 + cnt].abs().max())
+                        idx = (dd > 1e-3 * own).nonzero().flatten()
+                        if idx.numel():
+                            L_ = 784 if op == "l3_28" else 3136
+                            bk = sorted(set((idx // L_).tolist()))
+                            pos = (idx % L_)
+                            print(f"[{os.getpid()}]   {name}: {idx.numel()} elements off by > 1e-3 of {own:.4g}; (b*4+k) rows {bk[:8]}; positions "
+                                  f"{int(pos.min())}..{int(pos.max())}; max diff {float(dd.max()):.4g}; sample diffs {dd[idx[:6]].tolist()}", flush=True)
+                        o0 += cnt
+                        continue
+                    if float(dd.max()) > 2e-3 * float(ref[2].abs().max()) + 1e-6:
+                        idx = (dd > 2e-3 * float(ref[2].abs().max()) + 1e-6).nonzero().flatten()
+                        print(f"[{os.getpid()}]   {name}: {idx.numel()} of {cnt} off, first at {idx[:8].tolist()}, max diff {float(dd.max()):.4g} "
+                              f"(scale {float(ref[2][o0:o0 + cnt].abs().max()):.4g})", flush=True)
+                    o0 += cnt
+    print(f"[{os.getpid()}] {op}: {bad} of {n} runs differ from the first ({time.time() - t0:.1f} s); summed outputs off in {locals().get('bad1', 0)}", flush=True)
 
 
 if __name__ == "__main__":

@@ -1190,8 +1190,7 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
     static const bool env_no_xmap = getenv("XFM_L3_NO_XMAP") != nullptr;
     la.xmap = (p.batch % 8 == 0 && !env_no_xmap) ? 1 : 0;
     const int groups = tiles_pb / pli;
-    const bool wk = p.delta_softplus == 2 && p.bc_f32;                 // served by ss2d_w.hpp: its partial sums are stored by chunk row
-    const size_t need = (size_t)p.batch * groups * 4 * 2 * (wk ? G::NSEG * G::ROW : L) * sizeof(float);
+    const size_t need = (size_t)p.batch * groups * 4 * 2 * L * sizeof(float);
     la.parts = (bwd && ws && ws_bytes >= need && groups > 1 && L % 4 == 0) ? ws : nullptr;
     size_t lds = bwd ? (size_t)8 * PL * 2 + (size_t)4 * 2 * G::LSZ * sizeof(float) : (size_t)6 * PL * 2;
     if (bwd && p.delta_softplus != 3 && L3_PREFETCH) lds += (size_t)PL * 2 + (size_t)PL * 4;   // second x image | raw dy
@@ -1227,10 +1226,7 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
         set_last_hip_error(e);
         return XFM_ELAUNCH;
     }
-    if (la.parts && wk)
-        hipLaunchKernelGGL(ss2d_w_parts_kernel, dim3((L / 8 + 255) / 256, p.batch * 4), dim3(256), 0, s, la.parts, p.dBs, p.dCs, groups,
-                           L, G::NSEG * G::ROW);
-    else if (la.parts)
+    if (la.parts)
         hipLaunchKernelGGL(ss2d_l3_parts_kernel, dim3((L / 4 + 255) / 256, p.batch * 4), dim3(256), 0, s, la.parts, p.dBs, p.dCs,
                            groups, L);
     return check_launch();
@@ -1326,8 +1322,7 @@ size_t ss2d_l3_ws_bytes(const xfm_ss2d_params_t *p) {
     if (!ppt || p->d_inner % ppt) return 0;
     const int tiles_pb = p->d_inner / ppt;
     const int groups = tiles_pb / l3_pli(p->batch, tiles_pb, true);
-    // (padded to whole chunk rows: what ss2d_w.hpp's layout needs covers the layout of this file's kernels too)
-    return groups > 1 ? (size_t)p->batch * groups * 4 * 2 * ((p->H * p->W + 511) / 512 * 512) * sizeof(float) : 0;
+    return groups > 1 ? (size_t)p->batch * groups * 4 * 2 * p->H * p->W * sizeof(float) : 0;
 }
 
 }  // namespace xfm

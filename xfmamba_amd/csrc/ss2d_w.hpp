@@ -454,41 +454,14 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
             }
         }
     }
-    // ---- flush: registers hold [chunk row][traversal element] of this lane.
-    if (a.parts) {
-        // The workgroup's partial sums leave AS THEY SIT: parts[(b, group, route, dB | dC)][chunk row][lane][8 traversal elements],
-        // 32 contiguous bytes per lane (two 16-byte stores per row and array, 2 KB per wave instruction pair) -- no LDS staging,
-        // no per-element stores; ss2d_w_parts_kernel undoes the lane / element order while it adds the groups of a sample up.
-        constexpr int NP = NSEG * G::ROW;              // padded row block of one array
-        float *dst = a.parts + ((((int64_t)b * groups_pb + tg) * 4 + k) * 2) * NP + lane * 8;
-#pragma unroll
-        for (int s = 0; s < G::NREG; ++s) {
-            if (s * G::ROW + ci * 8 < L) {
-                float *d0 = dst + s * G::ROW;
-                *reinterpret_cast<float4 *>(d0) = make_float4(rB[s][0].x, rB[s][0].y, rB[s][1].x, rB[s][1].y);
-                *reinterpret_cast<float4 *>(d0 + 4) = make_float4(rB[s][2].x, rB[s][2].y, rB[s][3].x, rB[s][3].y);
-                *reinterpret_cast<float4 *>(d0 + NP) = make_float4(rC[s][0].x, rC[s][0].y, rC[s][1].x, rC[s][1].y);
-                *reinterpret_cast<float4 *>(d0 + NP + 4) = make_float4(rC[s][2].x, rC[s][2].y, rC[s][3].x, rC[s][3].y);
-            }
-        }
-        // the LDS strip holds [row - NREG][chunk][traversal element]; a lane wrote the sums of its own chunk
-        if constexpr (G::LSZ > 0) {
-#pragma unroll
-            for (int s = G::NREG; s < NSEG; ++s) {
-                if (s * G::ROW + ci * 8 < L) {
-                    const float *src = ldsacc + (s - G::NREG) * G::ROW + ci * 8;
-                    float *d0 = dst + s * G::ROW;
-                    *reinterpret_cast<float4 *>(d0) = *reinterpret_cast<const float4 *>(src);
-                    *reinterpret_cast<float4 *>(d0 + 4) = *reinterpret_cast<const float4 *>(src + 4);
-                    *reinterpret_cast<float4 *>(d0 + NP) = *reinterpret_cast<const float4 *>(src + G::LSZ);
-                    *reinterpret_cast<float4 *>(d0 + NP + 4) = *reinterpret_cast<const float4 *>(src + G::LSZ + 4);
-                }
-            }
-        }
-        return;
-    }
-    // without a workspace: contiguous float atomics (only fast when a wave instruction covers contiguous bytes), so the sums are
-    // first laid out by position in LDS (the plane region is free)
+    // ---- flush: registers hold [chunk row][traversal element] of this lane.  The sums are first laid out by position in LDS (the
+    // plane region is free), then leave as plain coalesced stores of this workgroup's partial rows (ss2d_l3_parts_kernel adds the
+    // groups of a sample up) or, without a workspace, as contiguous float atomics (only fast when a wave instruction covers
+    // contiguous bytes).
+    // (Tried and withdrawn: the partial sums leaving the registers as they sit -- chunk row, lane, traversal element -- with a
+    //  summing kernel that undoes the order: 3 us faster at 56 x 56 and, with a second process on the GPU, wrong dB / dC values
+    //  at chunks 48 .. 63 of the register rows in 0.1 - 25 % of the launches, in every store form tried (16- / 8-byte global,
+    //  buffer stores from untouched registers, host synchronisation between the two kernels); this form: 0 of 12 000.)
     __syncthreads();
     float *dBg = a.dBs + (int64_t)route * L, *dCg = a.dCs + (int64_t)route * L;
     float *stage = smem + (size_t)wave * L;            // 4 waves x L floats <= 8 PL bf16 (PPT >= 1: 16 L bytes)
@@ -510,41 +483,14 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
         for (int e = lane; e < G::LSZ; e += 64)
             stage[G::NREG * G::ROW + (e & ~7) + (REV ? 7 - (e & 7) : (e & 7))] = ldsacc[pass * G::LSZ + e];
         wave_sync();
-        float *dstp = pass ? dCg : dBg;
-        for (int e = lane; e < L; e += 64) atomicAdd(dstp + e, stage[e]);
+        if (a.parts) {
+            float *dp = a.parts + ((((int64_t)b * groups_pb + tg) * 4 + k) * 2 + pass) * L;
+            for (int e = lane; e < L; e += 64) dp[e] = stage[e];
+        } else {
+            float *dstp = pass ? dCg : dBg;
+            for (int e = lane; e < L; e += 64) atomicAdd(dstp + e, stage[e]);
+        }
         wave_sync();
-    }
-}
-
-// dBs / dCs (batch, 4, L) = sum over the workgroups of a sample of their partial sums in the layout w_bwd_body leaves them:
-// (batch, groups, 4, 2, chunk row, lane, 8 traversal elements).  A thread owns one 8-position chunk: lane = 63 - chunk for the
-// forward routes (0, 1), = chunk for the reversed ones (2, 3), whose elements are stored back to front.
-__global__ void __launch_bounds__(256) ss2d_w_parts_kernel(const float *__restrict__ parts, float *__restrict__ dBs,
-                                                           float *__restrict__ dCs, const int groups, const int L, const int NP) {
-    const int bk = blockIdx.y, b = bk >> 2, k = bk & 3;
-    const int c = blockIdx.x * 256 + threadIdx.x;      // chunk of 8 positions
-    if (c * 8 >= L) return;
-    const bool rev = k >= 2;
-    const int s = c >> 6, ci = c & 63, lane = rev ? ci : 63 - ci;
-    float4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, c0 = b0, c1 = b0;
-    for (int g = 0; g < groups; ++g) {
-        const float *p = parts + ((((int64_t)b * groups + g) * 4 + k) * 2) * NP + (s * 64 + lane) * 8;
-        const float4 vb0 = *reinterpret_cast<const float4 *>(p), vb1 = *reinterpret_cast<const float4 *>(p + 4);
-        const float4 vc0 = *reinterpret_cast<const float4 *>(p + NP), vc1 = *reinterpret_cast<const float4 *>(p + NP + 4);
-        b0.x += vb0.x; b0.y += vb0.y; b0.z += vb0.z; b0.w += vb0.w; b1.x += vb1.x; b1.y += vb1.y; b1.z += vb1.z; b1.w += vb1.w;
-        c0.x += vc0.x; c0.y += vc0.y; c0.z += vc0.z; c0.w += vc0.w; c1.x += vc1.x; c1.y += vc1.y; c1.z += vc1.z; c1.w += vc1.w;
-    }
-    float *oB = dBs + (int64_t)bk * L + c * 8, *oC = dCs + (int64_t)bk * L + c * 8;
-    if (rev) {
-        *reinterpret_cast<float4 *>(oB) = make_float4(b1.w, b1.z, b1.y, b1.x);
-        *reinterpret_cast<float4 *>(oB + 4) = make_float4(b0.w, b0.z, b0.y, b0.x);
-        *reinterpret_cast<float4 *>(oC) = make_float4(c1.w, c1.z, c1.y, c1.x);
-        *reinterpret_cast<float4 *>(oC + 4) = make_float4(c0.w, c0.z, c0.y, c0.x);
-    } else {
-        *reinterpret_cast<float4 *>(oB) = b0;
-        *reinterpret_cast<float4 *>(oB + 4) = b1;
-        *reinterpret_cast<float4 *>(oC) = c0;
-        *reinterpret_cast<float4 *>(oC + 4) = c1;
     }
 }
 
