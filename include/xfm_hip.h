@@ -92,6 +92,12 @@ typedef struct {
 int xfm_abi_version(void);
 const char *xfm_strerror(int code);
 const char *xfm_last_hip_error(void);
+/* Profiling hook (no reference counterpart; bench.py's per-kernel timer uses it): hands two hipEvent_t to the library.  The next
+ * entry point of THIS thread that launches a main kernel followed by a small finishing kernel (xfm_ss2d_bwd_ws on the wide-map
+ * kernels: the scan, then the sum of the workgroups' partial dB / dC rows) records `start_event` right before and `stop_event`
+ * right after the main kernel on its stream and forgets the pair.  Returns 1 if a pair handed over earlier was still pending (no
+ * such launch happened since) -- pass NULL, NULL to ask and clear. */
+int xfm_prof_main_kernel(void *start_event, void *stop_event);
 
 int xfm_scan_plan(int batch, int dim, int seqlen, int dstate, int n_groups, xfm_scan_plan_t *plan);
 int xfm_selective_scan_fwd(const xfm_scan_params_t *p, void *stream);

@@ -708,6 +708,34 @@ def test_ss2d_proj_core_matches_operator_chain(shape, dt):
         assert_close(a.float().cpu(), b.float().cpu(), tol, tol * float(b.float().abs().max()) + 1e-7, name)
 
 
+def test_kernel_timer_brackets_the_wide_map_scan_itself():
+    """xfm_prof_main_kernel: the per-kernel timer of bench.py hands its event pair to the library, which records it around the
+    wide-map backward scan only; the sum of the workgroups' partial dB / dC rows behind it is a record of its own.  Paths without
+    the hook (a short map: no finishing kernel) keep the whole-call bracket, and no pair stays pending."""
+    from xfmamba_amd import _lib
+    from xfmamba_amd.ss2d import ss2d_proj_core_fn
+    g = torch.Generator().manual_seed(5)
+    got = {}
+    for (B, D, H) in ((8, 96, 56), (2, 64, 10)):
+        L, K, N, R = H * H, 4, 1, max(1, D // 16)
+        t = [v.to(DEV).requires_grad_() for v in (torch.randn(B, D, L, generator=g).bfloat16(), (0.5 * torch.randn(B, K * (R + 2 * N), L, generator=g)).bfloat16(),
+                                                  torch.randn(K, D, R, generator=g) * R ** -0.5, -torch.rand(K * D, N, generator=g) - 0.1,
+                                                  torch.randn(K * D, generator=g), 0.1 * torch.rand(K * D, generator=g))]
+        timer = _lib.KernelTimer()
+        _lib.set_timer(timer)
+        try:
+            for _ in range(3):
+                ss2d_proj_core_fn(*t, H, H).float().sum().backward()
+        finally:
+            _lib.set_timer(None)
+        got[H] = timer.summary()
+        assert _lib.lib().xfm_prof_main_kernel(None, None) == 0
+    wide, short = got[56], got[10]
+    assert "ss2d_bwd_finish" in wide and wide["ss2d_bwd"]["launches"] == wide["ss2d_bwd_finish"]["launches"] == 3
+    assert 0 < wide["ss2d_bwd_finish"]["avg_us"] < wide["ss2d_bwd"]["avg_us"]
+    assert "ss2d_bwd" in short and "ss2d_bwd_finish" not in short and short["ss2d_bwd"]["avg_us"] > 0
+
+
 @pytest.mark.parametrize("shape", [(2, 96, 56, 56, 1), (2, 384, 14, 14, 1), (2, 64, 10, 6, 2), (1, 32, 96, 96, 1)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_ss2d_xproj_core_matches_operator_chain(shape, dt):

@@ -1221,7 +1221,9 @@ template <int HW, int PPT> static int l3_launch(const xfm_ss2d_params_t &p, bool
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const unsigned grid = (unsigned)((int64_t)p.batch * (tiles_pb / pli));
     void *kargs[] = {&la};
+    prof_before_main(s);
     const hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, lds, s);
+    prof_after_main(s);
     if (e != hipSuccess) {
         set_last_hip_error(e);
         return XFM_ELAUNCH;

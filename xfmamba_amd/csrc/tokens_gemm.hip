@@ -394,7 +394,8 @@ __device__ __forceinline__ float tg_erf(float x, float &E) {
 }
 
 // timing-only switches (build with -DXFM_GEMM2_TIMING, then XFM_GEMM2_DBG=<bits>: 2 every tile reads the same rows, 4 no
-// epilogue, 8 no MFMA, 16 no token-row loads, 32 staging only); the production build compiles them away.  Measured with them
+// epilogue, 8 no MFMA, 16 no token-row loads, 32 staging only; the tiled form: XFM_G3_DBG=<bits> 4 no epilogue stores, 8 no MFMA,
+// 16 no operand loads, 64 no GELU arithmetic, 128 no epilogue); the production build compiles them away.  Measured with them
 // at 12544 x 384 -> 1536 (45 us): staging 4.5 us, the tile loop without MFMAs / loads / stores another 10, MFMAs + token rows
 // +9, the GELU epilogue and its two 38.5 MB stores +20.
 __device__ __forceinline__ bool tg2_dbg(const TokGemm2Args &a, const int bit) {
@@ -707,6 +708,7 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
     const bool ragged = (CON & 63) != 0;                   // (uniform)
     const uint16_t *zp = reinterpret_cast<const uint16_t *>(g3_zero_page);
     auto issue_part = [&](const int st, const int i) {
+        if (tg2_dbg(a, 16 << 8)) return;                   // (timing switch: no operand loads)
         uint8_t *dst = g3_lds + (st & 1) * kG3Stage + (4 * wave + i) * 1024;
         const bool last = ragged && st == NST - 1;
         const uint16_t *px = (last && 64 * st + kch[i] >= CON) ? zp : gx[i] + 64 * st;
@@ -793,6 +795,10 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
                 wop[0] = __builtin_shufflevector(wlo[r][0], whi[r][0], 0, 1, 2, 3, 4, 5, 6, 7);
                 wop[1] = __builtin_shufflevector(wlo[r][1], whi[r][1], 0, 1, 2, 3, 4, 5, 6, 7);
             }
+            if (tg2_dbg(a, 8 << 8)) {                         // (timing switch: no matrix instruction)
+                asm volatile("" ::"v"(wop[0]), "v"(wop[1]), "v"(xf[r][0]), "v"(xf[r][1]));
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -806,6 +812,10 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
         k16(std::integral_constant<int, 3>{});
     }
     __builtin_amdgcn_s_barrier();                          // the stage buffers become the output image
+    if (tg2_dbg(a, 128 << 8)) {                            // (timing switch: no epilogue at all)
+        if (acc[0][0][0] + acc[1][1][3] == 123.456f) a.y[tid] = 1;
+        return;
+    }
     // ---- epilogue: D[n][t] -> image [128 tokens][136] (bf16), then whole rows
     constexpr int SP = 136;
     uint16_t *img = reinterpret_cast<uint16_t *>(g3_lds);
@@ -865,6 +875,11 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
         const tg_u32x4_t v = *reinterpret_cast<const tg_u32x4_t *>(img + r * SP + 8 * ck);
         if (row >= a.T || !col_ok) continue;
         const int64_t off = row * a.OUT + n0 + 8 * ck;
+        if (tg2_dbg(a, 64 << 8)) {                         // (timing switch: stores without the GELU arithmetic)
+            *reinterpret_cast<tg_u32x4_t *>(a.y + off) = v;
+            if constexpr (EPI == 1) *reinterpret_cast<tg_u32x4_t *>(a.y2 + off) = v;
+            continue;
+        }
         if constexpr (EPI == 0) {
             *reinterpret_cast<tg_u32x4_t *>(a.y + off) = v;
         } else {
@@ -886,6 +901,10 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
                     }
                 }
                 o[q] = pack_bf16x2(r2[0], r2[1]);
+            }
+            if (tg2_dbg(a, 4 << 8)) {                          // (timing switch: the arithmetic without the stores)
+                if (o[0] == 0x12345678u) a.y[off] = 1;
+                continue;
             }
             if constexpr (EPI == 1) {
                 *reinterpret_cast<tg_u32x4_t *>(a.y + off) = v;          // z
@@ -1339,6 +1358,8 @@ int xfm_tokens_gemm2(const void *x, const void *weight_bf16, const float *bias, 
 #ifdef XFM_GEMM2_TIMING
     static const int dbg = [] { const char *e = getenv("XFM_GEMM2_DBG"); return e ? atoi(e) : 0; }();   // timing switches: 2, 4
     a.wt |= dbg & 62;
+    static const int dbg3 = [] { const char *e = getenv("XFM_G3_DBG"); return e ? atoi(e) : 0; }();   // tiled form: bits << 8
+    a.wt |= dbg3 << 8;
 #else
     constexpr int dbg = 0;                                        // (the timing switches exist in -DXFM_GEMM2_TIMING builds only)
 #endif

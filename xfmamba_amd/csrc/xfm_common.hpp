@@ -133,5 +133,7 @@ __device__ __forceinline__ void wave_sync() {
 // ---- host-side error plumbing ------------------------------------------------------------------
 void set_last_hip_error(hipError_t e);
 int check_launch();
+void prof_before_main(hipStream_t s);      // xfm_prof_main_kernel: events around an entry point's main kernel
+void prof_after_main(hipStream_t s);
 
 }  // namespace xfm

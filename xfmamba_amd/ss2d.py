@@ -283,7 +283,7 @@ class SS2DProjCoreHip(torch.autograd.Function):
         # scratch for the workgroups' partial dB / dC sums (wide-map kernels: stores + one summing pass instead of atomics)
         wsb = lib.xfm_ss2d_bwd_ws_bytes(ctypes.byref(p))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
-        with torch.cuda.device(dev), _lib.timed("ss2d_bwd", nbytes, nbytes_f):
+        with torch.cuda.device(dev), _lib.timed("ss2d_bwd", nbytes, nbytes_f, main_kernel=True):
             _lib.check(lib.xfm_ss2d_bwd_ws(ctypes.byref(p), _lib.ptr(ws), wsb, _lib.stream_ptr()), "ss2d_bwd")
         if mfma_bwd:
             # dt_proj backward on MFMA: ddts is read once for the data gradient and once for the weight gradient
