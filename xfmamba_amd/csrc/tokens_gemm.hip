@@ -671,26 +671,36 @@ template <int OFF> __device__ __forceinline__ void g3_read_tr(g3_bf16x4_t &d, co
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(OFF) : "memory");
 }
 
-template <int EPI, bool WT>
-__global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args a, const int CON, const int ntn, const int ntiles) {
+// NW waves per workgroup: 4 (a wave owns 64 outputs x 64 tokens) or 8 (32 outputs x 64 tokens: twice the waves per SIMD behind the
+// same 64 KB ring, half the accumulators per wave)
+template <int EPI, bool WT, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) tokens_gemm3_kernel(const TokGemm2Args a, const int CON, const int ntn, const int ntiles) {
     extern __shared__ __align__(16) uint8_t g3_lds[];      // 2 stages (64 KB) | bias (512 B); the output image overlays the stages
     float *bl = reinterpret_cast<float *>(g3_lds + 2 * kG3Stage);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-major order with the output tile fastest: the n-tiles of one token tile are neighbours on one XCD (its x rows are
     // fetched from HBM once and re-read from that L2)
-    const int vid = (blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    if (vid >= ntiles) return;
+    // A workgroup walks the tiles slot, slot + nslot, .. of its XCD's range (grid <= 2 workgroups per CU: the stores of one tile
+    // drain under the next tile's k-loop instead of holding a finished workgroup's LDS and registers until they are acknowledged).
+    const int per_x = (ntiles + 7) >> 3, nslot = (int)(gridDim.x >> 3), slot0 = (int)(blockIdx.x >> 3);
+    for (int slot = slot0; slot < per_x; slot += nslot) {
+    const int vid = (blockIdx.x & 7) * per_x + slot;
+    if (vid >= ntiles) break;
+    if (slot != slot0) __syncthreads();                    // the previous tile's image / bias / column-sum reads are done
     const int tn = vid % ntn, tm = vid / ntn;
     const int64_t t0 = (int64_t)tm * 128;
     const int n0 = tn * 128;
     if (tid < 128) bl[tid] = (a.bias && n0 + tid < a.OUT) ? a.bias[n0 + tid] : 0.f;
-    const int wm = wave >> 1, wn = wave & 1;               // wave -> outputs 64 wm .., tokens 64 wn ..
+    constexpr int NI = NW == 4 ? 2 : 1;                    // 32-output blocks of a wave
+    constexpr int NP = 16 / NW;                            // 1 KB pieces of a stage (per operand) a wave requests
+    const int wm = wave >> 1, wn = wave & 1;               // wave -> outputs 32 NI wm .., tokens 64 wn ..
+    const int ow = 32 * NI * wm;
     // ---- global side of the LDS-direct loads (lane constants; k0 is added per stage through the scalar base)
-    const uint16_t *gx[4], *gw[4];
-    int kch[4];                                            // first k of this lane's chunk inside a stage (k-contiguous images)
+    const uint16_t *gx[NP], *gw[NP];
+    int kch[NP];                                           // first k of this lane's chunk inside a stage (k-contiguous images)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 8 * (4 * wave + i) + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+    for (int i = 0; i < NP; ++i) {
+        const int row = 8 * (NP * wave + i) + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
         kch[i] = 8 * ch;
         int64_t tr = t0 + row;
         if (tr >= a.T) tr = a.T - 1;
@@ -699,7 +709,7 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
         if constexpr (!WT) {
             gw[i] = a.w + (int64_t)min(n0 + row, a.OUT - 1) * CON + 8 * ch;
         } else {                                           // (CON, OUT): rows 4 (4 wave + i) .. + 3 of the k-major image
-            const int kr = 4 * (4 * wave + i) + (lane >> 4);
+            const int kr = 4 * (NP * wave + i) + (lane >> 4);
             const int cw = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
             gw[i] = a.w + (int64_t)kr * a.OUT + min(n0 + 8 * cw, a.OUT - 8);
         }
@@ -709,7 +719,7 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
     const uint16_t *zp = reinterpret_cast<const uint16_t *>(g3_zero_page);
     auto issue_part = [&](const int st, const int i) {
         if (tg2_dbg(a, 16 << 8)) return;                   // (timing switch: no operand loads)
-        uint8_t *dst = g3_lds + (st & 1) * kG3Stage + (4 * wave + i) * 1024;
+        uint8_t *dst = g3_lds + (st & 1) * kG3Stage + (NP * wave + i) * 1024;
         const bool last = ragged && st == NST - 1;
         const uint16_t *px = (last && 64 * st + kch[i] >= CON) ? zp : gx[i] + 64 * st;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)px,
@@ -719,7 +729,7 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
             if constexpr (!WT) {
                 if (64 * st + kch[i] >= CON) pw = zp;
             } else {                                       // k-major weight: whole rows past CON
-                if (64 * st + 4 * (4 * wave + i) + (lane >> 4) >= CON) pw = zp;
+                if (64 * st + 4 * (NP * wave + i) + (lane >> 4) >= CON) pw = zp;
             }
         }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pw,
@@ -728,79 +738,87 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
     // ---- fragment addresses (stage 0; stage s & 1 adds kG3Stage)
     const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)g3_lds;
     const int c = lane & 31, kb = lane >> 5;
-    uint32_t ax[2][4], aw[2][4];                           // [32-row block][k16-step]; WT: aw[i][0 / 1] = lo / hi of step 0
+    uint32_t ax[2][4], aw[NI][4];                          // [32-row block][k16-step]; WT: aw[i][0 / 1] = lo / hi of step 0
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             ax[j][s4] = base + g3_off(wn * 64 + j * 32 + c, 2 * s4 + kb);
-            if constexpr (!WT) aw[j][s4] = base + kG3Half + g3_off(wm * 64 + j * 32 + c, 2 * s4 + kb);
+            if constexpr (!WT) {
+                if (j < NI) aw[j % NI][s4] = base + kG3Half + g3_off(ow + j * 32 + c, 2 * s4 + kb);
+            }
         }
     if constexpr (WT) {
         const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
         const int r0 = 8 * (g >> 1);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ct = wm * 64 + i * 32, c0 = (ct + 16 * (g & 1)) >> 3;
+        for (int i = 0; i < NI; ++i) {
+            const int ct = ow + i * 32, c0 = (ct + 16 * (g & 1)) >> 3;
             aw[i][0] = base + kG3Half + g3_tok_off(r0 + q, c0 + (p >> 1)) + 8 * (p & 1);
             aw[i][1] = base + kG3Half + g3_tok_off(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1);
             aw[i][2] = aw[i][3] = 0;
         }
     }
-    tg_f32x16_t acc[2][2];
+    tg_f32x16_t acc[NI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_part(0, i);
+    for (int i = 0; i < NP; ++i) issue_part(0, i);
     for (int st = 0; st < NST; ++st) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage st (nothing else is in flight)
         __builtin_amdgcn_s_barrier();                      // everyone's share landed; everyone is done with stage st - 1
         const bool more = st + 1 < NST;
         const uint32_t so = (st & 1) * kG3Stage;
-        tg_u32x4_t xf[2][2], wf[2][2];                     // [ring][block]
-        g3_bf16x4_t wlo[2][2], whi[2][2];                  // (k-major weight: the two transposed halves of a fragment)
+        tg_u32x4_t xf[2][2], wf[2][NI];                    // [ring][block]
+        g3_bf16x4_t wlo[2][NI], whi[2][NI];                // (k-major weight: the two transposed halves of a fragment)
         auto frags = [&](const int ring, auto sc) {
             constexpr int S = decltype(sc)::value;
             g3_read16<0>(xf[ring][0], ax[0][S] + so);
             g3_read16<0>(xf[ring][1], ax[1][S] + so);
             if constexpr (!WT) {
-                g3_read16<0>(wf[ring][0], aw[0][S] + so);
-                g3_read16<0>(wf[ring][1], aw[1][S] + so);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) g3_read16<0>(wf[ring][i], aw[i][S] + so);
             } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NI; ++i) {
                     g3_read_tr<4096 * S>(wlo[ring][i], aw[i][0] + so);
                     g3_read_tr<4096 * S>(whi[ring][i], aw[i][1] + so);
                 }
             }
         };
-        constexpr int NRD = WT ? 6 : 4;                    // LDS reads of one k16-step
+        constexpr int NRD = 2 + (WT ? 2 * NI : NI);        // LDS reads of one k16-step
         auto k16 = [&](auto sc) {
             constexpr int S = decltype(sc)::value, r = S & 1;
             if constexpr (S + 1 < 4) frags(r ^ 1, std::integral_constant<int, S + 1>{});
-            if (more) issue_part(st + 1, S);
+            if constexpr (S < NP) {
+                if (more) issue_part(st + 1, S);
+            }
             if constexpr (S + 1 < 4) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            tg_bf16x8_t wop[2];
-            if constexpr (!WT) {
-                asm volatile("" : "+v"(xf[r][0]), "+v"(xf[r][1]), "+v"(wf[r][0]), "+v"(wf[r][1]));
-                wop[0] = __builtin_bit_cast(tg_bf16x8_t, wf[r][0]);
-                wop[1] = __builtin_bit_cast(tg_bf16x8_t, wf[r][1]);
-            } else {
-                asm volatile("" : "+v"(xf[r][0]), "+v"(xf[r][1]), "+v"(wlo[r][0]), "+v"(whi[r][0]), "+v"(wlo[r][1]), "+v"(whi[r][1]));
-                wop[0] = __builtin_shufflevector(wlo[r][0], whi[r][0], 0, 1, 2, 3, 4, 5, 6, 7);
-                wop[1] = __builtin_shufflevector(wlo[r][1], whi[r][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            tg_bf16x8_t wop[NI];
+            asm volatile("" : "+v"(xf[r][0]), "+v"(xf[r][1]));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if constexpr (!WT) {
+                    asm volatile("" : "+v"(wf[r][i]));
+                    wop[i] = __builtin_bit_cast(tg_bf16x8_t, wf[r][i]);
+                } else {
+                    asm volatile("" : "+v"(wlo[r][i]), "+v"(whi[r][i]));
+                    wop[i] = __builtin_shufflevector(wlo[r][i], whi[r][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
             }
             if (tg2_dbg(a, 8 << 8)) {                         // (timing switch: no matrix instruction)
-                asm volatile("" ::"v"(wop[0]), "v"(wop[1]), "v"(xf[r][0]), "v"(xf[r][1]));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wop[i]));
+                asm volatile("" ::"v"(xf[r][0]), "v"(xf[r][1]));
                 return;
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop[i], __builtin_bit_cast(tg_bf16x8_t, xf[r][j]), acc[i][j], 0, 0, 0);
@@ -813,8 +831,8 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
     }
     __builtin_amdgcn_s_barrier();                          // the stage buffers become the output image
     if (tg2_dbg(a, 128 << 8)) {                            // (timing switch: no epilogue at all)
-        if (acc[0][0][0] + acc[1][1][3] == 123.456f) a.y[tid] = 1;
-        return;
+        if (acc[0][0][0] + acc[NI - 1][1][3] == 123.456f) a.y[tid] = 1;
+        continue;
     }
     // ---- epilogue: D[n][t] -> image [128 tokens][136] (bf16), then whole rows
     constexpr int SP = 136;
@@ -822,14 +840,14 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     const int h = kb;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             uint32_t pk[4][2];                             // group g: channels 8 g + 4 h .. + 3 of the 32-block, token c
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 bv = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (EPI == 0) bv = *reinterpret_cast<const float4 *>(bl + wm * 64 + i * 32 + 8 * g + 4 * h);
+                if constexpr (EPI == 0) bv = *reinterpret_cast<const float4 *>(bl + ow + i * 32 + 8 * g + 4 * h);
                 pk[g][0] = pack_bf16x2(acc[i][j][4 * g] + bv.x, acc[i][j][4 * g + 1] + bv.y);
                 pk[g][1] = pack_bf16x2(acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w);
             }
@@ -844,23 +862,24 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
             tg_u32x4_t v0, v1;
             v0[0] = pk[0][0]; v0[1] = pk[0][1]; v0[2] = pk[1][0]; v0[3] = pk[1][1];      // channels 8 h .. + 7
             v1[0] = pk[2][0]; v1[1] = pk[2][1]; v1[2] = pk[3][0]; v1[3] = pk[3][1];      // channels 16 + 8 h .. + 7
-            uint16_t *row = img + (wn * 64 + j * 32 + c) * SP + wm * 64 + i * 32;
+            uint16_t *row = img + (wn * 64 + j * 32 + c) * SP + ow + i * 32;
             *reinterpret_cast<tg_u32x4_t *>(row + 8 * h) = v0;
             *reinterpret_cast<tg_u32x4_t *>(row + 16 + 8 * h) = v1;
         }
     __syncthreads();
-    const int ck = tid & 15, rl = tid >> 4;                // 16 chunks of 8 channels per row, 16 rows per pass
+    const int ck = tid & 15, rl = tid >> 4;                // 16 chunks of 8 channels per row, RP rows per pass
+    constexpr int RP = 4 * NW, NPS = 128 / RP;
     float bbv[8];
     if constexpr (EPI != 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) bbv[e] = bl[8 * ck + e];
     }
-    tg_u32x4_t zi[EPI == 2 ? 8 : 1];
+    tg_u32x4_t zi[EPI == 2 ? NPS : 1];
     const bool col_ok = n0 + 8 * ck < a.OUT;               // (OUT % 8 == 0)
     if constexpr (EPI == 2) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int64_t row = t0 + 16 * i + rl;
+        for (int i = 0; i < NPS; ++i) {
+            int64_t row = t0 + RP * i + rl;
             if (row >= a.T) row = a.T - 1;
             zi[i] = *reinterpret_cast<const tg_u32x4_t *>(a.zin + row * a.OUT + min(n0 + 8 * ck, a.OUT - 8));
         }
@@ -869,8 +888,8 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
 #pragma unroll
     for (int e = 0; e < 8; ++e) csum[e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = 16 * i + rl;
+    for (int i = 0; i < NPS; ++i) {
+        const int r = RP * i + rl;
         const int64_t row = t0 + r;
         const tg_u32x4_t v = *reinterpret_cast<const tg_u32x4_t *>(img + r * SP + 8 * ck);
         if (row >= a.T || !col_ok) continue;
@@ -922,33 +941,49 @@ __global__ void __launch_bounds__(256, 2) tokens_gemm3_kernel(const TokGemm2Args
     if constexpr (EPI == 2) {
         // the bias gradient's partial row of this tile: the 16 row-lanes of a column chunk meet in LDS (past the image)
         if (a.colpart) {
-            float *red = reinterpret_cast<float *>(g3_lds + 40960);          // [16][128]
+            float *red = reinterpret_cast<float *>(g3_lds + 40960);          // [RP][128]
             *reinterpret_cast<float4 *>(red + rl * 128 + 8 * ck) = make_float4(csum[0], csum[1], csum[2], csum[3]);
             *reinterpret_cast<float4 *>(red + rl * 128 + 8 * ck + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
             __syncthreads();
             if (tid < 128 && n0 + tid < a.OUT) {
                 float s = 0.f;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) s += red[q * 128 + tid];
+                for (int q = 0; q < RP; ++q) s += red[q * 128 + tid];
                 a.colpart[(int64_t)tm * a.OUT + n0 + tid] = s;
             }
         }
     }
+    }   // tiles of this workgroup
 }
 
-template <int EPI, bool WT>
-static int tokens_gemm3_launch(const TokGemm2Args &a, int con, hipStream_t s) {
+template <int EPI, bool WT, int NW>
+static int tokens_gemm3_launch_nw(const TokGemm2Args &a, int con, hipStream_t s) {
     const size_t lds = 2 * kG3Stage + 512;
-    auto fn = tokens_gemm3_kernel<EPI, WT>;
+    auto fn = tokens_gemm3_kernel<EPI, WT, NW>;
     static LdsOptIn opted;
     if (!lds_opt_in(opted, reinterpret_cast<const void *>(fn), lds)) return XFM_ELAUNCH;
     const int ntn = (a.OUT + 127) / 128;
     const int64_t ntm = (a.T + 127) / 128;
     const int64_t ntiles = ntm * ntn;
     if (ntiles > (1 << 30)) return XFM_ELIMIT;
-    const unsigned grid = (unsigned)((ntiles + 7) / 8 * 8);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, a, con, ntn, (int)ntiles);
+    // (measured, 12544 x 384 -> 1536 with the GELU epilogue: 37.6 us one tile per workgroup, 36.0 walking, 33.6 walking with eight
+    //  waves; with three k-stages per tile -- 50176 x 192 -> 768 -- walking costs 2 us: there the epilogues are most of a tile and
+    //  a fresh workgroup's k-loop overlaps them better)
+    static const int env_persist = [] { const char *e = getenv("XFM_G3_PERSIST"); return e ? atoi(e) : -1; }();
+    const bool persist = env_persist >= 0 ? env_persist != 0 : con >= 384;
+    unsigned grid = (unsigned)((ntiles + 7) / 8 * 8);
+    if (persist && grid > 512u) grid = 512u;                        // two workgroups per CU, each walks its share of the tiles
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * NW), lds, s, a, con, ntn, (int)ntiles);
     return check_launch();
+}
+
+template <int EPI, bool WT>
+static int tokens_gemm3_launch(const TokGemm2Args &a, int con, hipStream_t s) {
+    // eight waves (32 outputs x 64 tokens each, ~90 registers: four waves per SIMD behind the same two 64 KB rings) pay where the
+    // output side is wide -- 5 ... 10 % at out >= 768 --, not for the narrow products (768 -> 384: 16.7 vs 17.5 us)
+    static const int env_nw = [] { const char *e = getenv("XFM_G3_NW"); return e ? atoi(e) : 0; }();
+    const int nw = env_nw ? env_nw : (a.OUT >= 768 ? 8 : 4);
+    return nw == 8 ? tokens_gemm3_launch_nw<EPI, WT, 8>(a, con, s) : tokens_gemm3_launch_nw<EPI, WT, 4>(a, con, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
