@@ -595,8 +595,29 @@ template <int OFF> __device__ __forceinline__ void wg_tr_read(wg_bf16x4_t &d, co
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(OFF) : "memory");
 }
 
-template <bool DBG, bool CONV = false>
-__global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a) {
+// NW waves per workgroup: 4 (a wave owns 64 x 64 of the tile) or 8 (32 A-channels x 64 B-channels: two waves per SIMD behind the same
+// four-stage ring).  Eight is an experiment switch (XFM_WGRAD_NW=8), not the default: 12544 x 1536 x 384 28.0 -> 29.9 us, the
+// fusion blocks' 9408 x 1536 x 1536 81.6 -> 88.7, the small products unchanged -- a wave's 64 x 64 block already reads 1 KB of
+// fragments per MFMA, i.e. LDS reads take as long as the MFMAs, and a 32 x 64 block reads 1.5 KB.  (Timing switches at
+// 1536 x 384: no operand loads and no atomics 25.4 us, no fragment reads / MFMAs 24.6, everything 28 -- the two halves are equally
+// long and overlap; the atomics cost 0.7 us there and 6 ... 7 us of the 18 ... 25 us small products.)
+template <int NW> __device__ __forceinline__ void wg_wait_next(wg_bf16x4_t (&lo)[4], wg_bf16x4_t (&hi)[4]) {
+    if constexpr (NW == 4)
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lo[0]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[2]), "+v"(hi[3]));
+}
+template <int NW> __device__ __forceinline__ void wg_wait_all(wg_bf16x4_t (&lo)[4], wg_bf16x4_t (&hi)[4]) {
+    if constexpr (NW == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[2]), "+v"(hi[3]));
+}
+
+template <bool DBG, bool CONV = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, 1) wgrad_tt_glds_kernel(const WgradArgs a) {
     extern __shared__ __align__(16) uint8_t wg_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dbg = DBG ? a.dbg : 0;                       // timing switches only in the debugging instance
@@ -608,24 +629,26 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
     const int m0 = (tile_id / nbn) * kWgTile, n0 = (tile_id % nbn) * kWgTile;
     const int st0 = wg_slice_start(a, slice), st1 = wg_slice_start(a, slice + 1);
     if (st0 >= st1) return;
+    constexpr int NI = NW == 4 ? 2 : 1;                    // 32-channel A blocks of a wave
+    constexpr int NP = 16 / NW;                            // 1 KB pieces of a stage (per operand) a wave requests
     const int wm = wave >> 1, wn = wave & 1;
-    wg_f32x16_t acc[2][2];
+    wg_f32x16_t acc[NI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
     // stage buffer b: A tile at 2 b kGlTile, B tile kGlTile behind it
     // this lane's share of a stage: instruction i (0..3) of this wave fills rows 4 (4 wave + i) .. + 3 of the tile
-    int64_t offa[4], offb[4];                             // element offsets inside a 64-token stage of A / B
+    int64_t offa[NP], offb[NP];                           // element offsets inside a 64-token stage of A / B
     // CONV: the window of the token this lane's row of part i holds in the NEXT stage to request -- sample, output row / column
     // -- and the lane's tap: element offset from the window's centre-row, left-column pixel (2 oh, 2 ow) of the sample, and whether
     // the tap lies in the top / left padding for oh / ow = 0
-    int cvn[4], cvh[4], cvw[4], cvtap[4], cvpad[4];
+    int cvn[NP], cvh[NP], cvw[NP], cvtap[NP], cvpad[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 4 * (4 * wave + i) + (lane >> 4);
+    for (int i = 0; i < NP; ++i) {
+        const int row = 4 * (NP * wave + i) + (lane >> 4);
         const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
         const int ca = min(m0 + 8 * ch, a.M - 8), cb = min(n0 + 8 * ch, a.N - 8);      // clamped: see above
         offa[i] = (int64_t)row * a.M + ca;
@@ -651,7 +674,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
     //  an MFMA covers 8 of them)
     auto issue_part = [&](const uint16_t *pa, const uint16_t *pb, const int buf, const int i) {
         if (dbg & 4) return;
-        uint8_t *dst = wg_lds + buf * 2 * kGlTile + (4 * wave + i) * 1024;
+        uint8_t *dst = wg_lds + buf * 2 * kGlTile + (NP * wave + i) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa + offa[i]),
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         const uint16_t *src = pb + offb[i];
@@ -678,7 +701,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
     for (int q = 0; q < kGlStages - 1; ++q)
         if (st0 + q < st1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) issue_part(pan, pbn, bufn, i);
+            for (int i = 0; i < NP; ++i) issue_part(pan, pbn, bufn, i);
             pan += sa; pbn += sb; bufn = (bufn + 1) & (kGlStages - 1);
         }
     if (DBG && a.prof && tid == 0) a.prof[4 * blockIdx.x + 1] = wall_clock64();
@@ -691,7 +714,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
         const int r0 = 8 * (g >> 1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int ct = (t < 2 ? wm : wn) * 64 + (t & 1) * 32;
+            const int ct = t < 2 ? wm * 32 * NI + (t & 1) * 32 : wn * 64 + (t & 1) * 32;
             const int c0 = (ct + 16 * (g & 1)) >> 3;
             fr[t][0] = base + wg_tok_off(r0 + q, c0 + (p >> 1)) + 8 * (p & 1);
             fr[t][1] = base + wg_tok_off(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1);
@@ -700,10 +723,10 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
     static_assert((kGlStages & (kGlStages - 1)) == 0, "stage ring is a power of two");
     int buf = 0;
     for (int st = st0; st < st1; ++st) {
-        // stage st has landed when at most the 8 loads of each later stage in flight remain outstanding
+        // stage st has landed when at most the 2 NP loads of each later stage in flight remain outstanding
         const int later = min(st1 - 1 - st, kGlStages - 2);
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NP) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // everyone's share of stage st is in LDS; everyone is done with st - 1.  A BARE barrier: __syncthreads() carries a
         // workgroup fence, and for LDS-direct loads the compiler turns that into s_waitcnt vmcnt(0) -- every stage would wait
@@ -713,7 +736,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
         const bool more = st + kGlStages - 1 < st1;       // stage st + 3 refills the buffer stage st - 1 used
         if (dbg & 2) {
             if (more)
-                for (int i = 0; i < 4; ++i) issue_part(pan, pbn, bufn, i);
+                for (int i = 0; i < NP; ++i) issue_part(pan, pbn, bufn, i);
         } else {
             uint32_t ad[4][2];
 #pragma unroll
@@ -728,8 +751,10 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
                 wg_tr_read<4096 * S>(hi[ring][0], ad[0][1]);
                 wg_tr_read<4096 * S + kGlTile>(lo[ring][2], ad[2][0]);
                 wg_tr_read<4096 * S + kGlTile>(hi[ring][2], ad[2][1]);
-                wg_tr_read<4096 * S>(lo[ring][1], ad[1][0]);
-                wg_tr_read<4096 * S>(hi[ring][1], ad[1][1]);
+                if constexpr (NI == 2) {
+                    wg_tr_read<4096 * S>(lo[ring][1], ad[1][0]);
+                    wg_tr_read<4096 * S>(hi[ring][1], ad[1][1]);
+                }
                 wg_tr_read<4096 * S + kGlTile>(lo[ring][3], ad[3][0]);
                 wg_tr_read<4096 * S + kGlTile>(hi[ring][3], ad[3][1]);
             };
@@ -737,20 +762,23 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
                 constexpr int S = decltype(sc)::value, r = S & 1;
                 if constexpr (S + 1 < kGlBK / 16) {
                     frags(r ^ 1, std::integral_constant<int, S + 1>{});
-                    if (more) issue_part(pan, pbn, bufn, S);
-                    wg_wait<8>(lo[r], hi[r]);
+                    if constexpr (S < NP) {
+                        if (more) issue_part(pan, pbn, bufn, S);
+                    }
+                    wg_wait_next<NW>(lo[r], hi[r]);
                 } else {
-                    if (more) issue_part(pan, pbn, bufn, S);
-                    wg_wait<0>(lo[r], hi[r]);
+                    if constexpr (S < NP) {
+                        if (more) issue_part(pan, pbn, bufn, S);
+                    }
+                    wg_wait_all<NW>(lo[r], hi[r]);
                 }
-                wg_bf16x8_t af[2], bf[2];
+                wg_bf16x8_t af[NI], bf[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = __builtin_shufflevector(lo[r][i], hi[r][i], 0, 1, 2, 3, 4, 5, 6, 7);
-                    bf[i] = __builtin_shufflevector(lo[r][2 + i], hi[r][2 + i], 0, 1, 2, 3, 4, 5, 6, 7);
-                }
+                for (int i = 0; i < NI; ++i) af[i] = __builtin_shufflevector(lo[r][i], hi[r][i], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) bf[i] = __builtin_shufflevector(lo[r][2 + i], hi[r][2 + i], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             };
@@ -767,13 +795,13 @@ __global__ void __launch_bounds__(256, 1) wgrad_tt_glds_kernel(const WgradArgs a
     if (DBG && a.prof && tid == 0) a.prof[4 * blockIdx.x + 2] = wall_clock64();
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + c;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const int m = m0 + wm * 32 * NI + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
                 if (m < a.M && n < a.N && !(dbg & 1)) atomicAdd(a.dw + (int64_t)m * a.N + n, acc[i][j][v]);
             }
         }
@@ -887,14 +915,17 @@ int xfm_wgrad(const void *a, const void *b, float *dw, int M, int N, int batch, 
     hipStream_t s = (hipStream_t)stream;
     if (glds) {
         const size_t lds = (size_t)kGlStages * 2 * kGlTile;
-        static xfm::LdsOptIn attr[2];
+        static xfm::LdsOptIn attr[3];
         if (!xfm::lds_opt_in(attr[0], (const void *)wgrad_tt_glds_kernel<false>, lds) ||
-            !xfm::lds_opt_in(attr[1], (const void *)wgrad_tt_glds_kernel<true>, lds))
+            !xfm::lds_opt_in(attr[1], (const void *)wgrad_tt_glds_kernel<true>, lds) ||
+            !xfm::lds_opt_in(attr[2], (const void *)wgrad_tt_glds_kernel<false, false, 8>, lds))
             return XFM_ELAUNCH;
         w.wgs = tiles * nsl;
         w.xcd_map = wg_xcd_map() ? 1 : 0;
         const int grid = w.xcd_map ? (w.wgs + 7) / 8 * 8 : w.wgs;
+        static const int env_nw = [] { const char *e = getenv("XFM_WGRAD_NW"); return e ? atoi(e) : 4; }();
         if (w.dbg || w.prof) hipLaunchKernelGGL(wgrad_tt_glds_kernel<true>, dim3((unsigned)grid), dim3(256), lds, s, w);
+        else if (env_nw == 8) hipLaunchKernelGGL((wgrad_tt_glds_kernel<false, false, 8>), dim3((unsigned)grid), dim3(512), lds, s, w);
         else hipLaunchKernelGGL(wgrad_tt_glds_kernel<false>, dim3((unsigned)grid), dim3(256), lds, s, w);
         return check_launch();
     }
@@ -939,12 +970,16 @@ int xfm_conv3x3s2_tokens_bwd_weight_x(const void *dy, const void *x, float *dwei
     w.nslices = nsl;
     w.stagger = nsl >= 4 ? (tiles >= 16 ? 0.5f : 0.2f) : 0.f;
     const size_t lds = (size_t)kGlStages * 2 * kGlTile;
-    static xfm::LdsOptIn attr;
-    if (!xfm::lds_opt_in(attr, (const void *)wgrad_tt_glds_kernel<false, true>, lds)) return XFM_ELAUNCH;
+    static xfm::LdsOptIn attr[2];
+    if (!xfm::lds_opt_in(attr[0], (const void *)wgrad_tt_glds_kernel<false, true>, lds) ||
+        !xfm::lds_opt_in(attr[1], (const void *)wgrad_tt_glds_kernel<false, true, 8>, lds))
+        return XFM_ELAUNCH;
     w.wgs = tiles * nsl;
     w.xcd_map = wg_xcd_map() ? 1 : 0;
     const int grid = w.xcd_map ? (w.wgs + 7) / 8 * 8 : w.wgs;
-    hipLaunchKernelGGL((wgrad_tt_glds_kernel<false, true>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, w);
+    static const int env_nw = [] { const char *e = getenv("XFM_WGRAD_NW"); return e ? atoi(e) : 4; }();
+    if (env_nw == 8) hipLaunchKernelGGL((wgrad_tt_glds_kernel<false, true, 8>), dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, w);
+    else hipLaunchKernelGGL((wgrad_tt_glds_kernel<false, true>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, w);
     return check_launch();
 }
 
