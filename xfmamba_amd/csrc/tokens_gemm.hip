@@ -1007,8 +1007,8 @@ struct ProjTiledArgs {
     int img;                // planes out, not accumulating: leave through the LDS image (XFM_PROJ_IMG=0: A/B switch)
 };
 
-template <bool PIN, bool WT>
-__global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs a) {
+template <bool PIN, bool WT, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) proj_tiled_kernel(const ProjTiledArgs a) {
     extern __shared__ __align__(16) uint8_t g3_lds[];      // 2 stages (64 KB) | bias (512 B); the token-major output image overlays
     float *bl = reinterpret_cast<float *>(g3_lds + 2 * kG3Stage);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1018,18 +1018,21 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
     const int b = tm / a.ltiles, l0 = (tm - b * a.ltiles) * 128;
     const int n0 = tn * 128, L = a.L, CON = a.CON;
     if (tid < 128) bl[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
-    const int wm = wave >> 1, wn = wave & 1;               // wave -> outputs 64 wm .., positions 64 wn ..
+    constexpr int NI = NW == 4 ? 2 : 1;                    // 32-output blocks of a wave (NW: as tokens_gemm3_kernel)
+    constexpr int NP = 16 / NW;                            // 1 KB pieces of a stage (per operand) a wave requests
+    const int wm = wave >> 1, wn = wave & 1;               // wave -> outputs 32 NI wm .., positions 64 wn ..
+    const int ow = 32 * NI * wm;
     const uint16_t *zp = reinterpret_cast<const uint16_t *>(g3_zero_page);
     // ---- global side of the LDS-direct loads
-    const uint16_t *gx[4], *gw[4];
+    const uint16_t *gx[NP], *gw[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NP; ++i) {
         if constexpr (!PIN) {                              // x tile [128 positions][64 k]
-            const int row = 8 * (4 * wave + i) + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+            const int row = 8 * (NP * wave + i) + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
             const int l = min(l0 + row, L - 1);
             gx[i] = a.x + ((int64_t)b * L + l) * CON + 8 * ch;
         } else {                                           // x tile [64 k][128 positions]: rows 4 (4 wave + i) .. + 3
-            const int kr = 4 * (4 * wave + i) + (lane >> 4);
+            const int kr = 4 * (NP * wave + i) + (lane >> 4);
             const int cw = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
             // a chunk that straddles L is read 8 - Lrem % 8 positions EARLIER (inside the row: nothing is read past the tensor);
             // its columns then hold positions Lrem - 8 .. Lrem - 1, which the epilogue's row map undoes
@@ -1038,17 +1041,17 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
             gx[i] = lc < lrem ? a.x + ((int64_t)b * CON + kr) * L + l0 + ls : nullptr;
         }
         if constexpr (!WT) {
-            const int row = 8 * (4 * wave + i) + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+            const int row = 8 * (NP * wave + i) + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
             gw[i] = a.w + (int64_t)(n0 + row) * CON + 8 * ch;
         } else {
-            const int kr = 4 * (4 * wave + i) + (lane >> 4);
+            const int kr = 4 * (NP * wave + i) + (lane >> 4);
             const int cw = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
             gw[i] = a.w + (int64_t)kr * a.OUT + n0 + 8 * cw;
         }
     }
     const int NST = CON / 64;
     auto issue_part = [&](const int st, const int i) {
-        uint8_t *dst = g3_lds + (st & 1) * kG3Stage + (4 * wave + i) * 1024;
+        uint8_t *dst = g3_lds + (st & 1) * kG3Stage + (NP * wave + i) * 1024;
         const uint16_t *px;
         if constexpr (!PIN) px = gx[i] + 64 * st;
         else px = gx[i] ? gx[i] + (int64_t)64 * st * L : zp;
@@ -1061,7 +1064,7 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
     // ---- fragment addresses (stage buffer 0)
     const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)g3_lds;
     const int c = lane & 31, kb = lane >> 5;
-    uint32_t ax[2][4], aw[2][4];                           // k-contiguous images: [32-row block][k16-step]; k-major: [block][lo, hi]
+    uint32_t ax[2][4], aw[NI][4];                          // k-contiguous images: [32-row block][k16-step]; k-major: [block][lo, hi]
     {
         const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
         const int r0 = 8 * (g >> 1);
@@ -1076,33 +1079,36 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
                 ax[j][1] = base + g3_tok_off(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1);
                 ax[j][2] = ax[j][3] = 0;
             }
-            if constexpr (!WT) {
+            if (j < NI) {
+                const int jw = j % NI;
+                if constexpr (!WT) {
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) aw[j][s4] = base + kG3Half + g3_off(wm * 64 + j * 32 + c, 2 * s4 + kb);
-            } else {
-                const int ct = wm * 64 + j * 32, c0 = (ct + 16 * (g & 1)) >> 3;
-                aw[j][0] = base + kG3Half + g3_tok_off(r0 + q, c0 + (p >> 1)) + 8 * (p & 1);
-                aw[j][1] = base + kG3Half + g3_tok_off(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1);
-                aw[j][2] = aw[j][3] = 0;
+                    for (int s4 = 0; s4 < 4; ++s4) aw[jw][s4] = base + kG3Half + g3_off(ow + j * 32 + c, 2 * s4 + kb);
+                } else {
+                    const int ct = ow + j * 32, c0 = (ct + 16 * (g & 1)) >> 3;
+                    aw[jw][0] = base + kG3Half + g3_tok_off(r0 + q, c0 + (p >> 1)) + 8 * (p & 1);
+                    aw[jw][1] = base + kG3Half + g3_tok_off(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1);
+                    aw[jw][2] = aw[jw][3] = 0;
+                }
             }
         }
     }
-    tg_f32x16_t acc[2][2];
+    tg_f32x16_t acc[NI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_part(0, i);
+    for (int i = 0; i < NP; ++i) issue_part(0, i);
     for (int st = 0; st < NST; ++st) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const bool more = st + 1 < NST;
         const uint32_t so = (st & 1) * kG3Stage;
-        tg_u32x4_t xf[2][2], wf[2][2];
-        g3_bf16x4_t xlo[2][2], xhi[2][2], wlo[2][2], whi[2][2];
+        tg_u32x4_t xf[2][2], wf[2][NI];
+        g3_bf16x4_t xlo[2][2], xhi[2][2], wlo[2][NI], whi[2][NI];
         auto frags = [&](const int ring, auto sc) {
             constexpr int S = decltype(sc)::value;
 #pragma unroll
@@ -1112,21 +1118,25 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
                     g3_read_tr<4096 * S>(xlo[ring][j], ax[j][0] + so);
                     g3_read_tr<4096 * S>(xhi[ring][j], ax[j][1] + so);
                 }
-                if constexpr (!WT) g3_read16<0>(wf[ring][j], aw[j][S] + so);
-                else {
-                    g3_read_tr<4096 * S>(wlo[ring][j], aw[j][0] + so);
-                    g3_read_tr<4096 * S>(whi[ring][j], aw[j][1] + so);
+                if (j < NI) {
+                    if constexpr (!WT) g3_read16<0>(wf[ring][j % NI], aw[j % NI][S] + so);
+                    else {
+                        g3_read_tr<4096 * S>(wlo[ring][j % NI], aw[j % NI][0] + so);
+                        g3_read_tr<4096 * S>(whi[ring][j % NI], aw[j % NI][1] + so);
+                    }
                 }
             }
         };
-        constexpr int NRD = (PIN ? 4 : 2) + (WT ? 4 : 2);  // LDS reads of one k16-step
+        constexpr int NRD = (PIN ? 4 : 2) + (WT ? 2 * NI : NI);  // LDS reads of one k16-step
         auto k16 = [&](auto sc) {
             constexpr int S = decltype(sc)::value, r = S & 1;
             if constexpr (S + 1 < 4) frags(r ^ 1, std::integral_constant<int, S + 1>{});
-            if (more) issue_part(st + 1, S);
+            if constexpr (S < NP) {
+                if (more) issue_part(st + 1, S);
+            }
             if constexpr (S + 1 < 4) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            tg_bf16x8_t wop[2], xop[2];
+            tg_bf16x8_t wop[NI], xop[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if constexpr (!PIN) {
@@ -1136,16 +1146,18 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
                     asm volatile("" : "+v"(xlo[r][j]), "+v"(xhi[r][j]));
                     xop[j] = __builtin_shufflevector(xlo[r][j], xhi[r][j], 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-                if constexpr (!WT) {
-                    asm volatile("" : "+v"(wf[r][j]));
-                    wop[j] = __builtin_bit_cast(tg_bf16x8_t, wf[r][j]);
-                } else {
-                    asm volatile("" : "+v"(wlo[r][j]), "+v"(whi[r][j]));
-                    wop[j] = __builtin_shufflevector(wlo[r][j], whi[r][j], 0, 1, 2, 3, 4, 5, 6, 7);
+                if (j < NI) {
+                    if constexpr (!WT) {
+                        asm volatile("" : "+v"(wf[r][j % NI]));
+                        wop[j % NI] = __builtin_bit_cast(tg_bf16x8_t, wf[r][j % NI]);
+                    } else {
+                        asm volatile("" : "+v"(wlo[r][j % NI]), "+v"(whi[r][j % NI]));
+                        wop[j % NI] = __builtin_shufflevector(wlo[r][j % NI], whi[r][j % NI], 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop[i], xop[j], acc[i][j], 0, 0, 0);
         };
@@ -1166,20 +1178,20 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
             constexpr int SP2 = 136;
             uint16_t *img = reinterpret_cast<uint16_t *>(g3_lds);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int pl = wn * 64 + j * 32 + c;
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
-                        const int nl = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                        const int nl = ow + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
                         img[nl * SP2 + pl] = (uint16_t)(pack_bf16x2(acc[i][j][v] + bl[nl], 0.f) & 0xffffu);
                     }
                 }
             __syncthreads();
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int item = tid + 256 * it, row = item >> 5, ch = item & 31;
+            for (int it = 0; it < 64 / NW; ++it) {
+                const int item = tid + 64 * NW * it, row = item >> 5, ch = item & 31;
                 if (l0 + 4 * ch < L)                       // (L % 4 == 0)
                     *reinterpret_cast<uint2 *>(a.y + ((int64_t)b * a.OUT + n0 + row) * L + l0 + 4 * ch) =
                         *reinterpret_cast<const uint2 *>(img + row * SP2 + 4 * ch);
@@ -1191,20 +1203,20 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
             // positions of a plane row: the existing bf16 values widened, added in fp32, rounded once, one 8-byte store
             float *imgf = reinterpret_cast<float *>(g3_lds);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int pl = wn * 64 + j * 32 + c;
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
-                        const int nl = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                        const int nl = ow + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
                         imgf[nl * 128 + (pl ^ ((nl & 7) << 2))] = acc[i][j][v] + bl[nl];      // (row-dependent column swizzle: see the reads)
                     }
                 }
             __syncthreads();
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int item = tid + 256 * it, row = item >> 5, ch = item & 31;
+            for (int it = 0; it < 64 / NW; ++it) {
+                const int item = tid + 64 * NW * it, row = item >> 5, ch = item & 31;
                 if (l0 + 4 * ch < L) {
                     uint2 *dst = reinterpret_cast<uint2 *>(a.y + ((int64_t)b * a.OUT + n0 + row) * L + l0 + 4 * ch);
                     const uint2 old = *dst;
@@ -1217,13 +1229,13 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int l = l0 + wn * 64 + j * 32 + c;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    const int nl = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    const int nl = ow + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
                     if (l < L) {
                         uint16_t *dst = a.y + ((int64_t)b * a.OUT + n0 + nl) * L + l;
                         float val = acc[i][j][v] + bl[nl];
@@ -1239,13 +1251,13 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
         uint16_t *img = reinterpret_cast<uint16_t *>(g3_lds);
         typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 uint32_t pk[4][2];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(bl + wm * 64 + i * 32 + 8 * g + 4 * h);
+                    const float4 bv = *reinterpret_cast<const float4 *>(bl + ow + i * 32 + 8 * g + 4 * h);
                     pk[g][0] = pack_bf16x2(acc[i][j][4 * g] + bv.x, acc[i][j][4 * g + 1] + bv.y);
                     pk[g][1] = pack_bf16x2(acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w);
                 }
@@ -1260,7 +1272,7 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
                 tg_u32x4_t v0, v1;
                 v0[0] = pk[0][0]; v0[1] = pk[0][1]; v0[2] = pk[1][0]; v0[3] = pk[1][1];
                 v1[0] = pk[2][0]; v1[1] = pk[2][1]; v1[2] = pk[3][0]; v1[3] = pk[3][1];
-                uint16_t *row = img + (wn * 64 + j * 32 + c) * SP + wm * 64 + i * 32;
+                uint16_t *row = img + (wn * 64 + j * 32 + c) * SP + ow + i * 32;
                 *reinterpret_cast<tg_u32x4_t *>(row + 8 * h) = v0;
                 *reinterpret_cast<tg_u32x4_t *>(row + 16 + 8 * h) = v1;
             }
@@ -1268,8 +1280,8 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
         const int ck = tid & 15, rl = tid >> 4;
         const int lrem = L - l0, tail0 = lrem & ~7, shift = (8 - (lrem & 7)) & 7;     // (see the straddling chunk above)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = 16 * i + rl;
+        for (int i = 0; i < 32 / NW; ++i) {
+            const int r = 4 * NW * i + rl;
             const int lr = (shift && r >= tail0) ? r - shift : r;               // position this image row holds
             if (lr < 0 || lr >= lrem || r >= tail0 + 8) continue;
             const tg_u32x4_t v = *reinterpret_cast<const tg_u32x4_t *>(img + r * SP + 8 * ck);
@@ -1278,9 +1290,9 @@ __global__ void __launch_bounds__(256, 2) proj_tiled_kernel(const ProjTiledArgs 
     }
 }
 
-template <bool PIN, bool WT> static int proj_tiled_launch(ProjTiledArgs a, hipStream_t s) {
+template <bool PIN, bool WT, int NW> static int proj_tiled_launch_nw(ProjTiledArgs a, hipStream_t s) {
     const size_t lds = 2 * kG3Stage + 512;
-    auto fn = proj_tiled_kernel<PIN, WT>;
+    auto fn = proj_tiled_kernel<PIN, WT, NW>;
     static LdsOptIn opted;
     if (!lds_opt_in(opted, reinterpret_cast<const void *>(fn), lds)) return XFM_ELAUNCH;
     a.ltiles = (a.L + 127) / 128;
@@ -1288,8 +1300,15 @@ template <bool PIN, bool WT> static int proj_tiled_launch(ProjTiledArgs a, hipSt
     a.ntiles = a.B * a.ltiles * a.ntn;
     static const int img_on = [] { const char *e = getenv("XFM_PROJ_IMG"); return (!e || atoi(e) != 0) ? 1 : 0; }();
     a.img = img_on;
-    hipLaunchKernelGGL(fn, dim3((unsigned)((a.ntiles + 7) / 8 * 8)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((a.ntiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
     return check_launch();
+}
+
+template <bool PIN, bool WT> static int proj_tiled_launch(ProjTiledArgs a, hipStream_t s) {
+    // eight waves (as tokens_gemm3_kernel): the 14 x 14 projections are 384 tiles -- one or two workgroups per CU --, so four-wave
+    // workgroups leave most SIMDs with a single wave; step 13.29 -> 13.25 ms same-box
+    static const int nw = [] { const char *e = getenv("XFM_PROJ_NW"); return e ? atoi(e) : 8; }();
+    return nw == 8 ? proj_tiled_launch_nw<PIN, WT, 8>(a, s) : proj_tiled_launch_nw<PIN, WT, 4>(a, s);
 }
 
 int tokens_gemm2_form() {
