@@ -97,3 +97,10 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
                 assert "scan_oracle" not in src, f
+
+
+def test_graft_entry_build_checks_the_headers_abi_version():
+    """``__graft_entry__.build()`` (the driver's build check) compiles the library and the oracle's C restatement and compares the
+    library's ABI version with the one ``include/xfm_hip.h`` declares -- not with a literal that a struct change leaves behind."""
+    import __graft_entry__ as entry
+    entry.build()
