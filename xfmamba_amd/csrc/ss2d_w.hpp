@@ -53,6 +53,25 @@ __device__ __forceinline__ void w_st16(const __amdgpu_buffer_rsrc_t r, const uin
 __device__ __forceinline__ void w_st4(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff, const float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
 }
+__device__ __forceinline__ uint32_t w_ld2(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
+    return (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+}
+__device__ __forceinline__ void w_st2(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff, const uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b16((short)v, r, voff, soff, 0);
+}
+// ONE POSITION PER LANE in the last chunk row where it holds exactly 64 positions (56 x 56: 3136 = 6 x 512 + 64): as a row of
+// 8-position chunks it keeps 8 of 64 lanes busy for the price of a full row -- a seventh of the sweeps' instructions.  Per lane
+// one step size, one B, one C (2- / 4-byte loads), the forward stores the state entering every POSITION of that row in the row's
+// 256 checkpoint bytes (as many as a row of per-chunk checkpoints), so the backward needs no state scan there either: one FMA
+// replays the state, one ascending DPP scan of (a, a C g) carries the adjoint.  Needs the row's dB / dC sums in the LDS strip.
+template <int HW> struct WTail1 {
+    using G = L3Geom<HW>;
+    static constexpr bool on = G::HAS_TAIL && G::TAILV == 8 && G::LSZ == 64 && G::NREG == G::NSEG - 1;
+};
+// (forward: that row's operands travel in the first dword of the vectors a full row uses, WFOps d.x / b.x / c.x.  Backward: in
+//  registers of their own, W1Ops -- the short row does not cover the latency of the requests a row issues for its successor, so the
+//  row BEFORE it requests both its operands and its successor's)
+struct W1Ops { uint32_t d; float b, c, h; };
 __device__ __forceinline__ WBuf w_bufs(const LeanArgs &a, const int nseg, const bool bwd) {
     const uint32_t planes = (uint32_t)a.batch * 4u * (uint32_t)a.D_, L = (uint32_t)a.L;
     WBuf rs;
@@ -154,9 +173,10 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
                                             const float An, const float Dr,
                                             const bf16_t *xq, const bf16_t *gq, bf16_t *dxq, float *ldsacc,
                                             l3f2 (&rB)[L3Geom<HW>::NACC][4], l3f2 (&rC)[L3Geom<HW>::NACC][4], float &dA_acc,
-                                            float &dD_acc, float &dbias_acc, const int lane, WOps &op, const L3Next &nx) {
+                                            float &dD_acc, float &dbias_acc, const int lane, WOps &op, W1Ops &op1, const L3Next &nx) {
     using G = L3Geom<HW>;
     constexpr int L = G::L, NSEG = G::NSEG;
+    constexpr bool T1 = WTail1<HW>::on;
     const float A2 = An * kLog2e;
     const int ci = REV ? lane : 63 - lane;            // physical chunk of this lane: the lanes run AGAINST the route
     const bool tail_live = !G::HAS_TAIL || ci < G::TAILV;
@@ -171,14 +191,125 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
     uint4 lx, lg;                                     // x / dy of the row to process, read from LDS one row ahead
     {
         constexpr int sp0 = REV ? 0 : NSEG - 1;
-        if (G::HAS_TAIL && sp0 == NSEG - 1 && !tail_live) {
+        if (T1 && sp0 == NSEG - 1) {
+            lx = lg = make_uint4(0, 0, 0, 0);
+            lx.x = reinterpret_cast<const uint16_t *>(xq)[sp0 * G::ROW + ci];
+            lg.x = reinterpret_cast<const uint16_t *>(gq)[sp0 * G::ROW + ci];
+        } else if (G::HAS_TAIL && sp0 == NSEG - 1 && !tail_live) {
             lx = lg = make_uint4(0, 0, 0, 0);
         } else {
             lx = *reinterpret_cast<const uint4 *>(xql + sp0 * G::ROW);
             lg = *reinterpret_cast<const uint4 *>(gql + sp0 * G::ROW);
         }
     }
-    auto row = [&](auto tail_tag, const int i) {      // i: route-order chunk row
+    // the next tile's planes by LDS-direct loads: sent for once the operands of the tile's first row are here (nothing of
+    // this wave is in flight behind the explicit wait, so the asm loads cannot make a compiler-counted wait unsafe)
+    auto dma_next_tile = [&](const int i) {
+        if constexpr (PFPL > 0) {
+            if (nx.go && i == NSEG - 1) {
+                int lz;
+                asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0" : "=v"(lz)::"memory");
+                l3_dma_tile<PFPL>(nx.x, nx.g, nx.xdst, nx.gdst, nx.wave, lane + lz);
+            }
+        }
+    };
+    // ---- request the next row to process (row i - 1 of this plane, or the first row of the next plane): global operands
+    // now, its x / dy from LDS behind the scan (a short round trip: 8 registers less at the row's register peak)
+    // (next1: the row requested is the one-position-per-lane tail -- known at compile time at every call site, so that the rolled
+    //  loop over the full rows stays free of branches: with a run-time test there the 56 x 56 launch took 182 us instead of 157)
+    auto request_full = [&](const int spn, const int dsn, const int csn) {
+        const bool tail_n = G::HAS_TAIL && spn == NSEG - 1;
+        const uint32_t vo16 = tail_n ? lo16t : lo16, vo4 = tail_n ? lo4t : lo4, vo32 = tail_n ? lo32t : lo32;
+        op.d = w_ld16(rs.dts, vo16, dsn);
+        op.b0 = w_ld16(rs.Bs, vo32, bso + spn * (G::ROW * 4));
+        op.b1 = w_ld16(rs.Bs, vo32, bso + spn * (G::ROW * 4) + 16);
+        op.c0 = w_ld16(rs.Cs, vo32, bso + spn * (G::ROW * 4));
+        op.c1 = w_ld16(rs.Cs, vo32, bso + spn * (G::ROW * 4) + 16);
+        op.h = w_ld4(rs.chk, vo4, csn);
+    };
+    auto request_next = [&](auto next1_tag, const int i) {
+        constexpr bool next1 = decltype(next1_tag)::value;
+        if constexpr (next1) {
+            // the row after this one is the one-position tail (of this plane: REV, i == 1; of the next plane: !REV, i == 0): its
+            // operands, and those of the full row behind it (REV: the next plane's first row; !REV: the next plane's row NSEG - 2)
+            constexpr int spt = NSEG - 1;
+            const bool same = REV;                    // the tail belongs to this plane
+            if (same || chain) {
+                const int dst_ = dso + (same ? 0 : L * 2) + spt * (G::ROW * 2);
+                const int cst_ = cso + (same ? 0 : (NSEG + NSEG - 1)) * 256;
+                op1.d = w_ld2(rs.dts, (uint32_t)ci * 2u, dst_);
+                op1.b = w_ld4(rs.Bs, (uint32_t)ci * 4u, bso + spt * (G::ROW * 4));
+                op1.c = w_ld4(rs.Cs, (uint32_t)ci * 4u, bso + spt * (G::ROW * 4));
+                op1.h = w_ld4(rs.chk, lo4, cst_);
+            }
+            if (chain) {
+                constexpr int spf = REV ? 0 : NSEG - 2;       // physical row of the full row behind the tail, in the NEXT plane
+                constexpr int rf = REV ? NSEG - 1 : NSEG - 2; // ... its route-order index
+                request_full(spf, dso + L * 2 + spf * (G::ROW * 2), cso + (NSEG + rf) * 256);
+            }
+        } else {
+            const bool has_next = i > 0;
+            const int spn = has_next ? (REV ? NSEG - i : i - 1) : (REV ? 0 : NSEG - 1);
+            if (has_next || chain)
+                request_full(spn, dso + (has_next ? 0 : L * 2) + spn * (G::ROW * 2), cso + (has_next ? i - 1 : NSEG + NSEG - 1) * 256);
+        }
+    };
+    auto lds_next = [&](auto next1_tag, const int i) {
+        constexpr bool next1 = decltype(next1_tag)::value;
+        const bool has_next = i > 0;
+        const int spn = has_next ? (REV ? NSEG - i : i - 1) : (REV ? 0 : NSEG - 1);
+        const bool tail_n = G::HAS_TAIL && spn == NSEG - 1;
+        if (has_next) {
+            if constexpr (next1) {
+                lx.x = reinterpret_cast<const uint16_t *>(xq)[spn * G::ROW + ci];
+                lg.x = reinterpret_cast<const uint16_t *>(gq)[spn * G::ROW + ci];
+            } else if (!tail_n || tail_live) {
+                lx = *reinterpret_cast<const uint4 *>(xql + spn * G::ROW);
+                lg = *reinterpret_cast<const uint4 *>(gql + spn * G::ROW);
+            } else {
+                lx = lg = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    // ---- the tail row with one position per lane (WTail1)
+    auto row1 = [&](const int i) {
+        constexpr int sp = NSEG - 1;
+        // (a real branch in front of the row: as straight-line code the compiler schedules it into its neighbours, and the
+        //  56 x 56 launch takes 168 us instead of 158)
+        int skip;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(skip));
+        if (skip) return;
+        const float v = __uint_as_float(op1.d << 16), u = __uint_as_float(lx.x << 16), g = __uint_as_float(lg.x << 16);
+        const float Bq = op1.b, Cq = op1.c, hin = op1.h;
+        __builtin_amdgcn_sched_barrier(0);
+        dma_next_tile(i);
+        __builtin_amdgcn_sched_barrier(0);
+        const float a = exp2_fast(v * A2);
+        const float vu = v * u, bb = vu * Bq, cg = Cq * g, acg = a * cg;
+        float Q = a, R = acg;
+        l3_scan_up(Q, R);                             // the lanes run against the route: ascending = the adjoint's direction
+        const float h = fmaf(a, hin, bb);             // state after this position (the forward stored the one entering it)
+        const float tE = fmaf(Q, Ec, R);
+        const float E = dpp_mov<kWaveShr1>(Ec, tE);   // adjoint entering this position
+        Ec = bcast_lane<63>(tE);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_next(std::false_type{}, i);
+        __builtin_amdgcn_sched_barrier(0);
+        const float dh = cg + E;
+        const float sg = 1.f - exp2_fast(v * (-kLog2e));
+        const float ah = h - bb, s1 = dh * Bq, dhah = dh * ah;
+        dA2.x = fmaf(v, dhah, dA2.x);
+        const float du = fmaf(v, s1, g * Dr);
+        const float dd = fmaf(u, s1, dhah * An) * sg;
+        dD2.x = fmaf(g, u, dD2.x);
+        db2.x += dd;
+        w_st2(rs.ddts, (uint32_t)ci * 2u, dso + sp * (G::ROW * 2), l3_cvt_pk(dd, 0.f));
+        reinterpret_cast<uint16_t *>(dxq)[sp * G::ROW + ci] = (uint16_t)(l3_cvt_pk(du, 0.f) & 0xffffu);
+        float *tb = ldsacc + ci;                      // the strip holds the tail row by position
+        tb[0] = fmaf(dh, vu, tb[0]);
+        tb[G::LSZ] = fmaf(g, h, tb[G::LSZ]);
+    };
+    auto row = [&](auto tail_tag, auto next1_tag, const int i) {      // i: route-order chunk row
         constexpr bool is_tail = decltype(tail_tag)::value;
         const int sp = REV ? NSEG - 1 - i : i;        // physical chunk row
         // ---- consume the raw vectors: everything the row needs from them is in fp32 registers below
@@ -190,29 +321,8 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
         l3_unpack<REV>(lg, g);
         const float hin = op.h;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PFPL > 0) {
-            // the next tile's planes by LDS-direct loads: sent for once the operands of the tile's first row are here (nothing of
-            // this wave is in flight behind the explicit wait, so the asm loads cannot make a compiler-counted wait unsafe)
-            if (nx.go && i == NSEG - 1) {
-                int lz;
-                asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0" : "=v"(lz)::"memory");
-                l3_dma_tile<PFPL>(nx.x, nx.g, nx.xdst, nx.gdst, nx.wave, lane + lz);
-            }
-        }
-        // ---- request the next row to process (row i - 1 of this plane, or the first row of the next plane): global operands
-        // now, its x / dy from LDS behind the scan (a short round trip: 8 registers less at the row's register peak)
-        const bool has_next = i > 0;
-        const int spn = has_next ? (REV ? NSEG - i : i - 1) : (REV ? 0 : NSEG - 1);
-        const bool tail_n = G::HAS_TAIL && spn == NSEG - 1;
-        if (has_next || chain) {
-            const uint32_t vo16 = tail_n ? lo16t : lo16, vo4 = tail_n ? lo4t : lo4, vo32 = tail_n ? lo32t : lo32;
-            op.d = w_ld16(rs.dts, vo16, dso + (has_next ? 0 : L * 2) + spn * (G::ROW * 2));
-            op.b0 = w_ld16(rs.Bs, vo32, bso + spn * (G::ROW * 4));
-            op.b1 = w_ld16(rs.Bs, vo32, bso + spn * (G::ROW * 4) + 16);
-            op.c0 = w_ld16(rs.Cs, vo32, bso + spn * (G::ROW * 4));
-            op.c1 = w_ld16(rs.Cs, vo32, bso + spn * (G::ROW * 4) + 16);
-            op.h = w_ld4(rs.chk, vo4, cso + (has_next ? i - 1 : NSEG + NSEG - 1) * 256);
-        }
+        dma_next_tile(i);
+        request_next(next1_tag, i);
         __builtin_amdgcn_sched_barrier(0);
         // ---- element-wise part
         l3f2 a[4], vu[4], bb[4], cg[4];
@@ -241,14 +351,7 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
         float E = dpp_mov<kWaveShr1>(Ec, tE);         // adjoint entering this lane's chunk = the map of the lanes below on the carry
         Ec = bcast_lane<63>(tE);
         __builtin_amdgcn_sched_barrier(0);
-        if (has_next) {
-            if (!tail_n || tail_live) {
-                lx = *reinterpret_cast<const uint4 *>(xql + spn * G::ROW);
-                lg = *reinterpret_cast<const uint4 *>(gql + spn * G::ROW);
-            } else {
-                lx = lg = make_uint4(0, 0, 0, 0);
-            }
-        }
+        lds_next(next1_tag, i);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 3; q >= 0; --q) {
@@ -323,17 +426,31 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
 #undef W_ACC_ROW
         }
     };
+    constexpr std::false_type no{};
+    constexpr std::true_type yes{};
     if constexpr (!G::HAS_TAIL) {
 #pragma unroll 1
-        for (int i = NSEG - 1; i >= 0; --i) row(std::false_type{}, i);
-    } else if constexpr (!REV) {
-        row(std::true_type{}, NSEG - 1);
+        for (int i = NSEG - 1; i >= 0; --i) row(no, no, i);
+    } else if constexpr (T1 && !REV) {
+        // the tail first; the plane's last row (i = 0) requests the next plane's tail
+        row1(NSEG - 1);
 #pragma unroll 1
-        for (int i = NSEG - 2; i >= 0; --i) row(std::false_type{}, i);
+        for (int i = NSEG - 2; i >= 1; --i) row(no, no, i);
+        row(no, yes, 0);
+    } else if constexpr (T1) {
+        // the tail last, requested by row 1
+#pragma unroll 1
+        for (int i = NSEG - 1; i >= 2; --i) row(no, no, i);
+        row(no, yes, 1);
+        row1(0);
+    } else if constexpr (!REV) {
+        row(yes, no, NSEG - 1);
+#pragma unroll 1
+        for (int i = NSEG - 2; i >= 0; --i) row(no, no, i);
     } else {
 #pragma unroll 1
-        for (int i = NSEG - 1; i >= 1; --i) row(std::false_type{}, i);
-        row(std::true_type{}, 0);
+        for (int i = NSEG - 1; i >= 1; --i) row(no, no, i);
+        row(yes, no, 0);
     }
     dA_acc = dA2.x + dA2.y;
     dD_acc = dD2.x + dD2.y;
@@ -342,11 +459,26 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
 
 // first operands of a plane (route-order row NSEG - 1), requested ahead of the tile's staging
 template <int HW, bool REV>
-__device__ __forceinline__ void w_bwd_first(WOps &op, const WBuf &rs, const int dso, const int bso, const int cso, const int lane) {
+__device__ __forceinline__ void w_bwd_first(WOps &op, W1Ops &op1, const WBuf &rs, const int dso, const int bso, const int cso, const int lane) {
     using G = L3Geom<HW>;
     constexpr int NSEG = G::NSEG, sp = REV ? 0 : NSEG - 1;
     constexpr bool tail = G::HAS_TAIL && sp == NSEG - 1;
     const int ci = REV ? lane : 63 - lane;
+    if constexpr (tail && WTail1<HW>::on) {
+        // the one-position tail is the plane's first row: its operands, and those of the full row behind it
+        op1.d = w_ld2(rs.dts, (uint32_t)ci * 2u, dso + sp * (G::ROW * 2));
+        op1.b = w_ld4(rs.Bs, (uint32_t)ci * 4u, bso + sp * (G::ROW * 4));
+        op1.c = w_ld4(rs.Cs, (uint32_t)ci * 4u, bso + sp * (G::ROW * 4));
+        op1.h = w_ld4(rs.chk, (uint32_t)(63 - lane) * 4u, cso + (NSEG - 1) * 256);
+        constexpr int spf = NSEG - 2;
+        op.d = w_ld16(rs.dts, (uint32_t)ci * 16u, dso + spf * (G::ROW * 2));
+        op.b0 = w_ld16(rs.Bs, (uint32_t)ci * 32u, bso + spf * (G::ROW * 4));
+        op.b1 = w_ld16(rs.Bs, (uint32_t)ci * 32u, bso + spf * (G::ROW * 4) + 16);
+        op.c0 = w_ld16(rs.Cs, (uint32_t)ci * 32u, bso + spf * (G::ROW * 4));
+        op.c1 = w_ld16(rs.Cs, (uint32_t)ci * 32u, bso + spf * (G::ROW * 4) + 16);
+        op.h = w_ld4(rs.chk, (uint32_t)(63 - lane) * 4u, cso + (NSEG - 2) * 256);
+        return;
+    }
     const bool live = !tail || ci < G::TAILV;
     const uint32_t lo16 = live ? (uint32_t)ci * 16u : kWDead, lo4 = live ? (uint32_t)(63 - lane) * 4u : kWDead;
     const uint32_t lo32 = live ? (uint32_t)ci * 32u : kWDead;
@@ -395,6 +527,7 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
         l3_dma_tile<PL>((const bf16_t *)a.x + po0, (const float *)a.dy + po0, l3_lds_addr(xN), l3_lds_addr(graw), wave, lane);
     }
     WOps op;
+    W1Ops op1;
 #pragma unroll 1
     for (int it = 0; it < a.pli; ++it) {
         const int d0 = (tg * a.pli + it) * PPT;
@@ -407,7 +540,7 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
         // tile `it` was sent for during tile it - 1 (or above): wait for this wave's pieces, then for everybody's
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // the operands of the tile's first row: in flight under the staging
-        w_bwd_first<HW, REV>(op, rs, __builtin_amdgcn_readfirstlane((route * D + d0) * (L * 2)), bso,
+        w_bwd_first<HW, REV>(op, op1, rs, __builtin_amdgcn_readfirstlane((route * D + d0) * (L * 2)), bso,
                              __builtin_amdgcn_readfirstlane((route * D + d0) * (NSEG * 256)), lane);
         __syncthreads();                               // (also: the previous tile's merge has read the private planes)
         l3_stage_lds<HW, PPT>(xNc, xT, graw, gN, gT, tid);
@@ -426,7 +559,7 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
             float dA_acc, dD_acc, dbias_acc;
             w_bwd_plane<HW, REV, PL>(rs, __builtin_amdgcn_readfirstlane((route * D + d) * (L * 2)), bso,
                                      __builtin_amdgcn_readfirstlane((route * D + d) * (NSEG * 256)), pl + 1 < PPT, An, Dr, xq + pl * L, gq + pl * L, dxq + pl * L, ldsacc, rB, rC,
-                                     dA_acc, dD_acc, dbias_acc, lane, op, nx);
+                                     dA_acc, dD_acc, dbias_acc, lane, op, op1, nx);
             nx.go = false;
             // the plane's three parameter-gradient sums: DPP adds (no LDS round trips: a plane is 2 chunk rows at 28 x 28), and ONE
             // atomic instruction of three lanes (the atomic unit retires instructions, not lanes)
@@ -479,9 +612,9 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
                 }
             }
         }
-        // the LDS strip holds [chunk][traversal element]
+        // the LDS strip holds [chunk][traversal element] -- or, one position per lane (WTail1), the tail row by position
         for (int e = lane; e < G::LSZ; e += 64)
-            stage[G::NREG * G::ROW + (e & ~7) + (REV ? 7 - (e & 7) : (e & 7))] = ldsacc[pass * G::LSZ + e];
+            stage[G::NREG * G::ROW + (WTail1<HW>::on ? e : (e & ~7) + (REV ? 7 - (e & 7) : (e & 7)))] = ldsacc[pass * G::LSZ + e];
         wave_sync();
         if (a.parts) {
             float *dp = a.parts + ((((int64_t)b * groups_pb + tg) * 4 + k) * 2 + pass) * L;
@@ -515,6 +648,12 @@ __device__ __forceinline__ void w_fwd_first(WFOps &op, const WBuf &rs, const int
     constexpr int NSEG = G::NSEG, sp = REV ? NSEG - 1 : 0;
     constexpr bool tail = G::HAS_TAIL && sp == NSEG - 1;
     const int ci = REV ? 63 - lane : lane;
+    if constexpr (tail && WTail1<HW>::on) {
+        op.d.x = w_ld2(rs.dts, (uint32_t)ci * 2u, dso + sp * (G::ROW * 2));
+        op.b.x = w_ld2(rs.Bs, (uint32_t)ci * 2u, bso + sp * (G::ROW * 2));
+        op.c.x = w_ld2(rs.Cs, (uint32_t)ci * 2u, bso + sp * (G::ROW * 2));
+        return;
+    }
     const uint32_t lo16 = (!tail || ci < G::TAILV) ? (uint32_t)ci * 16u : kWDead;
     op.d = w_ld16(rs.dts, lo16, dso + sp * (G::ROW * 2));
     op.b = w_ld16(rs.Bs, lo16, bso + sp * (G::ROW * 2));
@@ -527,6 +666,9 @@ __device__ __forceinline__ void w_fwd_plane(const WBuf &rs, const int dso, const
                                             WFOps &op) {
     using G = L3Geom<HW>;
     constexpr int L = G::L, NSEG = G::NSEG;
+    constexpr bool T1 = WTail1<HW>::on;
+    const uint16_t *xq16 = reinterpret_cast<const uint16_t *>(xq);
+    uint16_t *yq16 = reinterpret_cast<uint16_t *>(yq);
     const int ci = REV ? 63 - lane : lane;            // the lanes run WITH the route
     const bool tail_live = !G::HAS_TAIL || ci < G::TAILV;
     const uint32_t lo16 = (uint32_t)ci * 16u, lo4 = (uint32_t)lane * 4u;
@@ -537,31 +679,65 @@ __device__ __forceinline__ void w_fwd_plane(const WBuf &rs, const int dso, const
     uint4 lx;
     {
         constexpr int sp0 = REV ? NSEG - 1 : 0;
-        lx = (G::HAS_TAIL && sp0 == NSEG - 1 && !tail_live) ? make_uint4(0, 0, 0, 0)
-                                                            : *reinterpret_cast<const uint4 *>(xql + sp0 * G::ROW);
+        if constexpr (T1 && sp0 == NSEG - 1) {
+            lx = make_uint4(0, 0, 0, 0);
+            lx.x = xq16[sp0 * G::ROW + ci];
+        } else {
+            lx = (G::HAS_TAIL && sp0 == NSEG - 1 && !tail_live) ? make_uint4(0, 0, 0, 0)
+                                                                : *reinterpret_cast<const uint4 *>(xql + sp0 * G::ROW);
+        }
     }
     w_static_for<NSEG>([&](auto ic) {
         constexpr int i = decltype(ic)::value;        // route-order chunk row
         constexpr int sp = REV ? NSEG - 1 - i : i;
         constexpr bool is_tail = G::HAS_TAIL && sp == NSEG - 1;
+        constexpr bool one = T1 && is_tail;           // this row runs one position per lane
         l3f2 v[4], u[4], Bq[4], Cq[4];
-        l3_unpack<REV>(op.d, v);
-        l3_unpack<REV>(op.b, Bq);
-        l3_unpack<REV>(op.c, Cq);
-        l3_unpack<REV>(lx, u);
+        float v1 = 0.f, u1 = 0.f, B1 = 0.f, C1 = 0.f;
+        if constexpr (one) {
+            v1 = __uint_as_float(op.d.x << 16);
+            B1 = __uint_as_float(op.b.x << 16);
+            C1 = __uint_as_float(op.c.x << 16);
+            u1 = __uint_as_float(lx.x << 16);
+        } else {
+            l3_unpack<REV>(op.d, v);
+            l3_unpack<REV>(op.b, Bq);
+            l3_unpack<REV>(op.c, Cq);
+            l3_unpack<REV>(lx, u);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (i + 1 < NSEG) {
             constexpr int spn = REV ? NSEG - 2 - i : i + 1;
             constexpr bool tail_n = G::HAS_TAIL && spn == NSEG - 1;
-            op.d = w_ld16(rs.dts, tail_n ? lo16t : lo16, dso + spn * (G::ROW * 2));
-            op.b = w_ld16(rs.Bs, tail_n ? lo16t : lo16, bso + spn * (G::ROW * 2));
-            op.c = w_ld16(rs.Cs, tail_n ? lo16t : lo16, bso + spn * (G::ROW * 2));
-            if (!tail_n || tail_live) lx = *reinterpret_cast<const uint4 *>(xql + spn * G::ROW);
-            else lx = make_uint4(0, 0, 0, 0);
+            if constexpr (T1 && tail_n) {
+                op.d.x = w_ld2(rs.dts, (uint32_t)ci * 2u, dso + spn * (G::ROW * 2));
+                op.b.x = w_ld2(rs.Bs, (uint32_t)ci * 2u, bso + spn * (G::ROW * 2));
+                op.c.x = w_ld2(rs.Cs, (uint32_t)ci * 2u, bso + spn * (G::ROW * 2));
+                lx.x = xq16[spn * G::ROW + ci];
+            } else {
+                op.d = w_ld16(rs.dts, tail_n ? lo16t : lo16, dso + spn * (G::ROW * 2));
+                op.b = w_ld16(rs.Bs, tail_n ? lo16t : lo16, bso + spn * (G::ROW * 2));
+                op.c = w_ld16(rs.Cs, tail_n ? lo16t : lo16, bso + spn * (G::ROW * 2));
+                if (!tail_n || tail_live) lx = *reinterpret_cast<const uint4 *>(xql + spn * G::ROW);
+                else lx = make_uint4(0, 0, 0, 0);
+            }
         } else {
             if (chain) w_fwd_first<HW, REV>(op, rs, dso + L * 2, bso, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (one) {
+            const float a1 = exp2_fast(v1 * A2), bb1 = v1 * u1 * B1;
+            float P = a1, S = bb1;
+            l3_scan_up(P, S);
+            const float th = fmaf(P, hc, S);          // state after this position
+            const float hh = dpp_mov<kWaveShr1>(hc, th);
+            hc = bcast_lane<63>(th);
+            w_st4(rs.chk, lo4, cso + i * 256, hh);    // the state ENTERING every position of the row
+            const float y1 = fmaf(C1, th, u1 * Dr);
+            yq16[sp * G::ROW + ci] = (uint16_t)(l3_cvt_pk(y1, 0.f) & 0xffffu);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         l3f2 a[4], bb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
