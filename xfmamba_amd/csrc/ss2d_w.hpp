@@ -66,7 +66,8 @@ __device__ __forceinline__ void w_st2(const __amdgpu_buffer_rsrc_t r, const uint
 // replays the state, one ascending DPP scan of (a, a C g) carries the adjoint.  Needs the row's dB / dC sums in the LDS strip.
 template <int HW> struct WTail1 {
     using G = L3Geom<HW>;
-    static constexpr bool on = G::HAS_TAIL && G::TAILV == 8 && G::LSZ == 64 && G::NREG == G::NSEG - 1;
+    // (56 x 56 and 24 x 24; the row's dB / dC sums are a register pair, so the LDS strip -- if there is one -- must hold nothing else)
+    static constexpr bool on = G::HAS_TAIL && G::TAILV == 8 && G::NREG >= G::NSEG - 1;
 };
 // (forward: that row's operands travel in the first dword of the vectors a full row uses, WFOps d.x / b.x / c.x.  Backward: in
 //  registers of their own, W1Ops -- the short row does not cover the latency of the requests a row issues for its successor, so the
@@ -172,7 +173,7 @@ template <int HW, bool REV, int PFPL>
 __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const int bso, const int cso, const bool chain,
                                             const float An, const float Dr,
                                             const bf16_t *xq, const bf16_t *gq, bf16_t *dxq, float *ldsacc,
-                                            l3f2 (&rB)[L3Geom<HW>::NACC][4], l3f2 (&rC)[L3Geom<HW>::NACC][4], float &dA_acc,
+                                            l3f2 (&rB)[L3Geom<HW>::NACC][4], l3f2 (&rC)[L3Geom<HW>::NACC][4], l3f2 &rT, float &dA_acc,
                                             float &dD_acc, float &dbias_acc, const int lane, WOps &op, W1Ops &op1, const L3Next &nx) {
     using G = L3Geom<HW>;
     constexpr int L = G::L, NSEG = G::NSEG;
@@ -305,9 +306,8 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
         db2.x += dd;
         w_st2(rs.ddts, (uint32_t)ci * 2u, dso + sp * (G::ROW * 2), l3_cvt_pk(dd, 0.f));
         reinterpret_cast<uint16_t *>(dxq)[sp * G::ROW + ci] = (uint16_t)(l3_cvt_pk(du, 0.f) & 0xffffu);
-        float *tb = ldsacc + ci;                      // the strip holds the tail row by position
-        tb[0] = fmaf(dh, vu, tb[0]);
-        tb[G::LSZ] = fmaf(g, h, tb[G::LSZ]);
+        rT.x = fmaf(dh, vu, rT.x);                    // the row's dB / dC sums: one pair of registers (not the LDS strip: two
+        rT.y = fmaf(g, h, rT.y);                      // read-modify-write round trips in the row's dependent chain)
     };
     auto row = [&](auto tail_tag, auto next1_tag, const int i) {      // i: route-order chunk row
         constexpr bool is_tail = decltype(tail_tag)::value;
@@ -510,6 +510,7 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
     float *graw = reinterpret_cast<float *>(xN1 + PL);
     for (int e = lane; e < 2 * G::LSZ; e += 64) ldsacc[e] = 0.f;
     l3f2 rB[G::NACC][4], rC[G::NACC][4];
+    l3f2 rT = {0.f, 0.f};                              // WTail1: dB / dC sums of this lane's position of the tail row
 #pragma unroll
     for (int s = 0; s < G::NACC; ++s)
 #pragma unroll
@@ -558,7 +559,7 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
             const float An = a.A[row], Dr = a.D[row];
             float dA_acc, dD_acc, dbias_acc;
             w_bwd_plane<HW, REV, PL>(rs, __builtin_amdgcn_readfirstlane((route * D + d) * (L * 2)), bso,
-                                     __builtin_amdgcn_readfirstlane((route * D + d) * (NSEG * 256)), pl + 1 < PPT, An, Dr, xq + pl * L, gq + pl * L, dxq + pl * L, ldsacc, rB, rC,
+                                     __builtin_amdgcn_readfirstlane((route * D + d) * (NSEG * 256)), pl + 1 < PPT, An, Dr, xq + pl * L, gq + pl * L, dxq + pl * L, ldsacc, rB, rC, rT,
                                      dA_acc, dD_acc, dbias_acc, lane, op, op1, nx);
             nx.go = false;
             // the plane's three parameter-gradient sums: DPP adds (no LDS round trips: a plane is 2 chunk rows at 28 x 28), and ONE
@@ -603,6 +604,7 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
 #pragma unroll
         for (int s = 0; s < G::NREG; ++s) {
             const int tp0 = s * G::ROW + ci * 8;
+            if (WTail1<HW>::on && s == NSEG - 1) continue;      // (that row's sums: rT, below)
             if (tp0 < L) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -612,9 +614,13 @@ __device__ __forceinline__ void w_bwd_body(const LeanArgs &a, float *smem, const
                 }
             }
         }
-        // the LDS strip holds [chunk][traversal element] -- or, one position per lane (WTail1), the tail row by position
-        for (int e = lane; e < G::LSZ; e += 64)
-            stage[G::NREG * G::ROW + (WTail1<HW>::on ? e : (e & ~7) + (REV ? 7 - (e & 7) : (e & 7)))] = ldsacc[pass * G::LSZ + e];
+        // the LDS strip holds [chunk][traversal element]; one position per lane (WTail1): the tail row's sums are a register pair
+        if constexpr (WTail1<HW>::on) {
+            stage[(NSEG - 1) * G::ROW + ci] = pass ? rT.y : rT.x;
+        } else {
+            for (int e = lane; e < G::LSZ; e += 64)
+                stage[G::NREG * G::ROW + (e & ~7) + (REV ? 7 - (e & 7) : (e & 7))] = ldsacc[pass * G::LSZ + e];
+        }
         wave_sync();
         if (a.parts) {
             float *dp = a.parts + ((((int64_t)b * groups_pb + tg) * 4 + k) * 2 + pass) * L;
