@@ -14,6 +14,8 @@
 //   * chunk rows are unrolled STATICALLY (7 / 2 per plane): tail handling, accumulator row and operand addresses are compile-time,
 //     the raw operand vectors are unpacked before the next row's requests are issued (scheduling barrier), so the requests land
 //     in the registers just freed: the ~23 v_mov_b64 per chunk row that rotated the prefetch buffers are gone.
+//   * the 64-position LAST chunk row of a 56 x 56 (24 x 24) plane runs ONE POSITION PER LANE (WTail1 below): as a row of 8-position
+//     chunks it kept 8 of 64 lanes busy for the price of a full row.  56 x 56 backward 159.5 -> 152 us, 24 x 24 233 -> 209 us.
 // Roofline: HBM (24 B per (b,d,p) element backward, 14 B forward at this boundary; + 2 B each way for the checkpoints).
 #pragma once
 
