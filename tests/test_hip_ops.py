@@ -672,8 +672,11 @@ def test_layernorm_rows_with_conv_bias_and_bf16_input(C, xdt, hdt):
 
 # (the 48 x 48 / 24 x 24 shapes at XFMamba-B's channel counts fill every CU with two workgroups at batch 2: the configuration in
 #  which a 16-byte buffer store's data registers were overwritten behind it -- csrc/ss2d_w.hpp, w_st16)
+# (56 x 56 and 24 x 24 run their last chunk row one position per lane -- csrc/ss2d_w.hpp, WTail1 --: one sample, an odd batch, the
+#  widths of XFMamba-S, a single tile per workgroup)
 @pytest.mark.parametrize("shape", [(2, 96, 56, 56, 1), (3, 192, 28, 28, 1), (2, 384, 14, 14, 1), (2, 64, 10, 6, 2),
-                                   (2, 256, 48, 48, 1), (2, 1024, 24, 24, 1), (8, 192, 28, 28, 1)])
+                                   (2, 256, 48, 48, 1), (2, 1024, 24, 24, 1), (8, 192, 28, 28, 1), (1, 96, 56, 56, 1),
+                                   (3, 192, 56, 56, 1), (5, 64, 24, 24, 1), (16, 16, 56, 56, 1)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_ss2d_proj_core_matches_operator_chain(shape, dt):
     """Route split + dt_proj + fused scan as one node (xfm_ss2d_route_split/_merge inside) vs the same maths spelled
