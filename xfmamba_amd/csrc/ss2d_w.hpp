@@ -311,8 +311,12 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
         rT.x = fmaf(dh, vu, rT.x);                    // the row's dB / dC sums: one pair of registers (not the LDS strip: two
         rT.y = fmaf(g, h, rT.y);                      // read-modify-write round trips in the row's dependent chain)
     };
-    auto row = [&](auto tail_tag, auto next1_tag, const int i) {      // i: route-order chunk row
+    // i: route-order chunk row -- an int in the rolled loops, a std::integral_constant for the peeled rows and for maps of two chunk
+    // rows (28 x 28, 24 x 24): there every test on the row index folds away, and so does the compare-and-skip of the accumulate chain
+    auto row = [&](auto tail_tag, auto next1_tag, auto iv) {
         constexpr bool is_tail = decltype(tail_tag)::value;
+        constexpr bool is_static = !std::is_same<decltype(iv), int>::value;
+        const int i = iv;
         const int sp = REV ? NSEG - 1 - i : i;        // physical chunk row
         // ---- consume the raw vectors: everything the row needs from them is in fp32 registers below
         l3f2 v[4], u[4], g[4], Bq[4], Cq[4];
@@ -402,19 +406,7 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
         {
             // One statement per register row: a scalar compare-and-skip around eight packed FMAs INSIDE the statement, so that the
             // compiler sees a plain read-modify-write of the row's sums (as a switch over the rows it double-buffers all of them)
-#define W_ACC_ROW(SS)                                                                                           \
-    if constexpr (SS < G::NREG)                                                                                 \
-        asm volatile("s_cmp_lg_u32 %[sp], " #SS "\n\t"                                                          \
-                     "s_cbranch_scc1 1f\n\t"                                                                    \
-                     "v_pk_fma_f32 %[b0], %[d0], %[u0], %[b0]\n\t"                                              \
-                     "v_pk_fma_f32 %[c0], %[g0], %[h0], %[c0]\n\t"                                              \
-                     "v_pk_fma_f32 %[b1], %[d1], %[u1], %[b1]\n\t"                                              \
-                     "v_pk_fma_f32 %[c1], %[g1], %[h1], %[c1]\n\t"                                              \
-                     "v_pk_fma_f32 %[b2], %[d2], %[u2], %[b2]\n\t"                                              \
-                     "v_pk_fma_f32 %[c2], %[g2], %[h2], %[c2]\n\t"                                              \
-                     "v_pk_fma_f32 %[b3], %[d3], %[u3], %[b3]\n\t"                                              \
-                     "v_pk_fma_f32 %[c3], %[g3], %[h3], %[c3]\n\t"                                              \
-                     "1:\n\t"                                                                                   \
+#define W_ACC_OPS(SS)                                                                                           \
                      : [b0] "+v"(rB[SS < G::NREG ? SS : 0][0]), [b1] "+v"(rB[SS < G::NREG ? SS : 0][1]),        \
                        [b2] "+v"(rB[SS < G::NREG ? SS : 0][2]), [b3] "+v"(rB[SS < G::NREG ? SS : 0][3]),        \
                        [c0] "+v"(rC[SS < G::NREG ? SS : 0][0]), [c1] "+v"(rC[SS < G::NREG ? SS : 0][1]),        \
@@ -422,14 +414,37 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
                      : [d0] "v"(dh[0]), [d1] "v"(dh[1]), [d2] "v"(dh[2]), [d3] "v"(dh[3]), [u0] "v"(vu[0]),     \
                        [u1] "v"(vu[1]), [u2] "v"(vu[2]), [u3] "v"(vu[3]), [g0] "v"(g[0]), [g1] "v"(g[1]),       \
                        [g2] "v"(g[2]), [g3] "v"(g[3]), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]),          \
-                       [h3] "v"(h[3]), [sp] "s"(sp)                                                             \
-                     : "scc");
+                       [h3] "v"(h[3])
+#define W_ACC_FMAS                                                                                              \
+                     "v_pk_fma_f32 %[b0], %[d0], %[u0], %[b0]\n\t"                                              \
+                     "v_pk_fma_f32 %[c0], %[g0], %[h0], %[c0]\n\t"                                              \
+                     "v_pk_fma_f32 %[b1], %[d1], %[u1], %[b1]\n\t"                                              \
+                     "v_pk_fma_f32 %[c1], %[g1], %[h1], %[c1]\n\t"                                              \
+                     "v_pk_fma_f32 %[b2], %[d2], %[u2], %[b2]\n\t"                                              \
+                     "v_pk_fma_f32 %[c2], %[g2], %[h2], %[c2]\n\t"                                              \
+                     "v_pk_fma_f32 %[b3], %[d3], %[u3], %[b3]\n\t"                                              \
+                     "v_pk_fma_f32 %[c3], %[g3], %[h3], %[c3]\n\t"
+#define W_ACC_ROW(SS)                                                                                           \
+    if constexpr (SS < G::NREG) {                                                                               \
+        if constexpr (is_static) {                                                                              \
+            if (sp == SS) asm volatile(W_ACC_FMAS W_ACC_OPS(SS));                                               \
+        } else {                                                                                                \
+            asm volatile("s_cmp_lg_u32 %[sp], " #SS "\n\t"                                                      \
+                         "s_cbranch_scc1 1f\n\t" W_ACC_FMAS "1:\n\t" W_ACC_OPS(SS), [sp] "s"(sp)                \
+                         : "scc");                                                                              \
+        }                                                                                                       \
+    }
             W_ACC_ROW(0) W_ACC_ROW(1) W_ACC_ROW(2) W_ACC_ROW(3) W_ACC_ROW(4) W_ACC_ROW(5) W_ACC_ROW(6) W_ACC_ROW(7)
 #undef W_ACC_ROW
+#undef W_ACC_FMAS
+#undef W_ACC_OPS
         }
     };
     constexpr std::false_type no{};
     constexpr std::true_type yes{};
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using IL = std::integral_constant<int, NSEG - 1>;
     if constexpr (!G::HAS_TAIL) {
 #pragma unroll 1
         for (int i = NSEG - 1; i >= 0; --i) row(no, no, i);
@@ -438,21 +453,30 @@ __device__ __forceinline__ void w_bwd_plane(const WBuf &rs, const int dso, const
         row1(NSEG - 1);
 #pragma unroll 1
         for (int i = NSEG - 2; i >= 1; --i) row(no, no, i);
-        row(no, yes, 0);
+        row(no, yes, I0{});
     } else if constexpr (T1) {
         // the tail last, requested by row 1
 #pragma unroll 1
         for (int i = NSEG - 1; i >= 2; --i) row(no, no, i);
-        row(no, yes, 1);
+        row(no, yes, I1{});
         row1(0);
+    } else if constexpr (NSEG == 2) {
+        // two chunk rows per plane (28 x 28): both spelled out
+        if constexpr (!REV) {
+            row(yes, no, I1{});
+            row(no, no, I0{});
+        } else {
+            row(no, no, I1{});
+            row(yes, no, I0{});
+        }
     } else if constexpr (!REV) {
-        row(yes, no, NSEG - 1);
+        row(yes, no, IL{});
 #pragma unroll 1
         for (int i = NSEG - 2; i >= 0; --i) row(no, no, i);
     } else {
 #pragma unroll 1
         for (int i = NSEG - 1; i >= 1; --i) row(no, no, i);
-        row(yes, no, 0);
+        row(yes, no, I0{});
     }
     dA_acc = dA2.x + dA2.y;
     dD_acc = dD2.x + dD2.y;
